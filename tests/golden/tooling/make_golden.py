@@ -1,0 +1,360 @@
+#!/usr/bin/env python3
+"""Capture golden vectors by IMPORTING THE REFERENCE (InSilicoSeq v2.0.1 at /root/reference).
+
+Runs only in the build container (the reference cannot travel to the GPU box).  Biopython is
+not installed there, so the reference is imported on top of the stand-in ``Bio`` package in
+tests/golden/tooling/bio_shim; with it the reference's own 17 hot-path
+golden tests pass, which this script re-checks before capturing anything.
+
+Outputs (all pickle-free ``.npz`` / text, committed under tests/golden/):
+  models/<name>.dense.npz     dense tables of the shipped profiles (insilicoseq_amd.model.DenseModel)
+  pairs/<case>.npz            simulate_read outputs under random.seed(s); np.random.seed(s),
+                              plus the next doubles of both MT streams (pins stream consumption)
+  units.json                  function-level goldens (reference unit tests re-expressed + extra)
+  worker/<case>.npz           worker_iterator FASTQ text for multi-record work lists
+  generate/<case>.npz         `iss generate` end-to-end outputs (FASTQ + abundance file)
+  mt_taps.npz                 first words of both MT streams for several seeds
+
+Usage:  python tests/golden/tooling/make_golden.py   (from the repo root)
+"""
+import hashlib
+import io
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.dirname(HERE)
+REPO = os.path.dirname(os.path.dirname(GOLDEN))
+SHIM = os.path.join(HERE, "bio_shim")
+REF = "/root/reference"
+
+work = tempfile.mkdtemp(prefix="iss_ref_")
+REFCOPY = os.path.join(work, "refcopy")
+shutil.copytree(REF, REFCOPY)
+subprocess.check_call(["chmod", "-R", "u+w", REFCOPY])
+sys.path.insert(0, REFCOPY)
+sys.path.insert(0, SHIM)
+sys.path.insert(0, REPO)
+os.chdir(REFCOPY)
+
+# 0. the reference's own golden tests must pass on the shim
+env = dict(os.environ, PYTHONPATH=SHIM + ":" + REFCOPY)
+subprocess.check_call([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "iss/test/test_error_model.py",
+                       "iss/test/test_generator.py"], env=env, cwd=REFCOPY)
+
+from Bio.Seq import Seq  # noqa: E402
+from Bio.SeqRecord import SeqRecord  # noqa: E402
+
+from iss import generator  # noqa: E402
+from iss.error_models import basic, kde  # noqa: E402
+from iss.util import rev_comp  # noqa: E402
+
+from insilicoseq_amd.model import DenseModel  # noqa: E402
+
+PROFILES = {
+    "novaseq": "iss/profiles/NovaSeq", "hiseq": "iss/profiles/HiSeq", "miseq": "iss/profiles/miSeq_0.npz",
+    "miseq-20": "iss/profiles/miSeq_20.npz", "miseq-24": "iss/profiles/miSeq_24.npz",
+    "miseq-28": "iss/profiles/miSeq_28.npz", "miseq-32": "iss/profiles/miSeq_32.npz",
+    "miseq-36": "iss/profiles/miSeq_36.npz", "nextseq": "iss/profiles/nextSeq.npz",
+    "miseq-legacy": "iss/profiles/MiSeq", "ecoli": "data/ecoli.npz",
+}
+
+for sub in ("models", "pairs", "worker", "generate"):
+    os.makedirs(os.path.join(GOLDEN, sub), exist_ok=True)
+
+# 1. dense tables ------------------------------------------------------------------------
+for name, path in PROFILES.items():
+    DenseModel.from_reference_npz(os.path.join(REFCOPY, path)).save(os.path.join(GOLDEN, "models", name + ".dense.npz"))
+
+
+# 2. genomes -----------------------------------------------------------------------------
+def random_genome(seed, n, alphabet="ACGT"):
+    rnd = random.Random(seed)
+    return "".join(rnd.choice(alphabet) for _ in range(n))
+
+
+def mixed_genome(seed, n):
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n):
+        x = rnd.random()
+        if x < 0.80:
+            out.append(rnd.choice("ACGT"))
+        elif x < 0.92:
+            out.append(rnd.choice("acgt"))
+        elif x < 0.97:
+            out.append(rnd.choice("NRYWSMKHBVD"))
+        else:
+            out.append(rnd.choice("nrywsmkhbvd"))
+    return "".join(out)
+
+
+GENOMES = {
+    "acgt20k": random_genome(1, 20000),
+    "mixed5k": mixed_genome(2, 5000),
+    "short420": random_genome(3, 420),
+    "short200": random_genome(4, 200),
+    "short700": random_genome(5, 700),
+    "amplicon700": random_genome(6, 700),
+    "acgt3k": random_genome(7, 3000),
+}
+
+
+def make_indel_heavy(err_mod, p_ins, p_del):
+    for tab, p in ((err_mod.ins_for, p_ins), (err_mod.ins_rev, p_ins), (err_mod.del_for, p_del),
+                   (err_mod.del_rev, p_del)):
+        for row in tab:
+            for k in list(row.keys()):
+                row[k] = p
+
+
+def load_model(name, frag=None, sd=None, indel=None):
+    em = kde.KDErrorModel(os.path.join(REFCOPY, PROFILES[name]), frag, sd)
+    if indel is not None:
+        make_indel_heavy(em, indel[0], indel[1])
+    return em
+
+
+# (case name, model, genome, seed, n_pairs, seq_type, frag, sd, gc_bias, indel)
+CASES = [
+    ("novaseq_acgt", "novaseq", "acgt20k", 42, 96, "metagenomics", None, None, False, None),
+    ("novaseq_mixed", "novaseq", "mixed5k", 43, 96, "metagenomics", None, None, False, None),
+    ("novaseq_short200", "novaseq", "short200", 44, 64, "metagenomics", None, None, False, None),
+    ("novaseq_amplicon", "novaseq", "amplicon700", 45, 48, "amplicon", None, None, False, None),
+    ("novaseq_frag160", "novaseq", "acgt3k", 46, 96, "metagenomics", 160, 40, False, None),
+    ("novaseq_frag450", "novaseq", "acgt20k", 47, 64, "metagenomics", 450, 30, False, None),
+    ("novaseq_gcbias", "novaseq", "acgt20k", 48, 96, "metagenomics", None, None, True, None),
+    ("novaseq_indel_heavy", "novaseq", "acgt20k", 49, 96, "metagenomics", None, None, False, (0.01, 0.03)),
+    ("novaseq_indel_heavy_mixed", "novaseq", "mixed5k", 50, 64, "metagenomics", None, None, False, (0.01, 0.03)),
+    ("novaseq_indel_mild", "novaseq", "acgt20k", 51, 96, "metagenomics", None, None, False, (0.001, 0.003)),
+    ("novaseq_indel_extreme", "novaseq", "short700", 52, 32, "metagenomics", None, None, False, (0.2, 0.35)),
+    ("hiseq_acgt", "hiseq", "acgt20k", 53, 96, "metagenomics", None, None, False, None),
+    ("hiseq_mixed", "hiseq", "mixed5k", 54, 64, "metagenomics", None, None, False, None),
+    ("miseq_acgt", "miseq", "acgt20k", 55, 64, "metagenomics", None, None, False, None),
+    ("miseq_short420", "miseq", "short420", 56, 48, "metagenomics", None, None, False, None),
+    ("miseq_legacy_acgt", "miseq-legacy", "acgt20k", 57, 64, "metagenomics", None, None, False, None),
+    ("miseq_legacy_amplicon", "miseq-legacy", "amplicon700", 58, 32, "amplicon", 1000, 10, False, None),
+    ("nextseq_acgt", "nextseq", "acgt20k", 59, 48, "metagenomics", None, None, False, None),
+    ("miseq36_acgt", "miseq-36", "acgt20k", 60, 32, "metagenomics", None, None, False, None),
+    ("ecoli_acgt", "ecoli", "acgt3k", 61, 128, "metagenomics", None, None, False, None),
+    ("ecoli_gcbias_frag", "ecoli", "acgt3k", 62, 128, "metagenomics", 300, 25, True, None),
+]
+
+
+def to_u8(s):
+    return np.frombuffer(s.encode("ascii"), dtype=np.uint8)
+
+
+def run_pairs(em, genome, seed, n_pairs, seq_type, gc_bias):
+    random.seed(seed)
+    np.random.seed(seed)
+    rec = SeqRecord(Seq(genome), id="g", description="")
+    RL = int(em.read_length)
+    out = [np.zeros((n_pairs, RL), dtype=np.uint8) for _ in range(4)]
+    n = 0
+    for fwd, rev, _ in generator.reads_generator(n_pairs, rec, em, 0, gc_bias, seq_type):
+        out[0][n] = to_u8(str(fwd.seq))
+        out[1][n] = fwd.letter_annotations["phred_quality"]
+        out[2][n] = to_u8(str(rev.seq))
+        out[3][n] = rev.letter_annotations["phred_quality"]
+        n += 1
+    tail_py = np.array([random.random() for _ in range(4)])
+    tail_np = np.array([np.random.random_sample() for _ in range(4)])
+    return out, n, tail_py, tail_np
+
+
+for (case, model, gkey, seed, n_pairs, seq_type, frag, sd, gc_bias, indel) in CASES:
+    em = load_model(model, frag, sd, indel)
+    out, n, tail_py, tail_np = run_pairs(em, GENOMES[gkey], seed, n_pairs, seq_type, gc_bias)
+    meta = dict(case=case, model=model, genome=gkey, seed=seed, n_pairs=n_pairs, n_done=n, sequence_type=seq_type,
+                fragment_length=frag, fragment_sd=sd, gc_bias=gc_bias, indel=indel)
+    np.savez_compressed(os.path.join(GOLDEN, "pairs", case + ".npz"), r1_base=out[0], r1_qual=out[1], r2_base=out[2],
+                        r2_qual=out[3], tail_py=tail_py, tail_np=tail_np, genome=to_u8(GENOMES[gkey]),
+                        meta=np.array(json.dumps(meta)))
+    print("pairs", case, n)
+
+# 3. function-level goldens -----------------------------------------------------------------
+units = {}
+# 3a. the reference's unit goldens, re-run here so the expected values come from the reference itself
+np.random.seed(42)
+em = kde.KDErrorModel("data/ecoli.npz")
+units["kde_phred_reverse_seed42"] = [int(x) for x in em.gen_phred_scores(em.quality_reverse, "reverse")]
+
+random.seed(42)
+np.random.seed(42)
+bm = basic.BasicErrorModel()
+read = SeqRecord(Seq("AAAAA" * 25), id="read_1", description="test read")
+read.letter_annotations["phred_quality"] = [5] * 125
+read.annotations["original"] = str(read.seq)
+read.annotations["mutations"] = []
+units["basic_mut_sequence_seed42"] = str(bm.mut_sequence(read, "forward").seq)
+
+random.seed(42)
+np.random.seed(42)
+bm = basic.BasicErrorModel()
+bm.ins_for[1]["G"] = 1.0
+bm.del_for[0]["A"] = 1.0
+read = SeqRecord(Seq("ATATA" * 25), id="read_1", description="test read")
+read.annotations["mutations"] = []
+ref_genome = SeqRecord(Seq("ATATA" * 100), id="ref_genome", description="test reference")
+units["basic_introduce_indels_seed42"] = str(bm.introduce_indels(read, "forward", ref_genome, (5, 130)).seq)
+
+random.seed(12)
+np.random.seed(12)
+em = kde.KDErrorModel("data/ecoli.npz")
+em.del_for[0]["A"] = 1.0
+em.del_for[1]["T"] = 1.0
+read = SeqRecord(Seq("ATTTA" * 4), id="read_1", description="test read")
+read.annotations["mutations"] = []
+ref_genome = SeqRecord(Seq("ATTTA" * 100), id="ref_genome", description="test reference")
+units["ecoli_adjust_extend_seed12"] = str(em.introduce_indels(read, "forward", ref_genome, (480, 500)).seq)
+
+random.seed(87)
+np.random.seed(87)
+em = kde.KDErrorModel("data/ecoli.npz")
+em.del_rev[0]["C"] = 1.0
+em.del_rev[1]["G"] = 1.0
+ref_genome = SeqRecord(Seq("GG" + "GTACC" * 100 + "GG"), id="ref_genome", description="test reference")
+read = SeqRecord(Seq(rev_comp(str(ref_genome.seq[484:504]))), id="read_1", description="test read")
+read.annotations["mutations"] = []
+units["ecoli_indels_rev_seed87"] = str(em.introduce_indels(read, "reverse", ref_genome, (484, 504)).seq)
+
+# simulate_read goldens of test_generator.py
+random.seed(42)
+np.random.seed(42)
+bm = basic.BasicErrorModel(450, 0)
+g = SeqRecord(Seq("AAAAACCCCC" * 100), id="my_genome", description="test genome")
+t = generator.simulate_read(g, bm, 1, 0, "metagenomics")
+units["basic_simulate_read_seed42"] = [str(t[0].seq), [int(x) for x in t[0].letter_annotations["phred_quality"]],
+                                        str(t[1].seq), [int(x) for x in t[1].letter_annotations["phred_quality"]]]
+random.seed(42)
+np.random.seed(42)
+em = kde.KDErrorModel("data/ecoli.npz")
+g = SeqRecord(Seq("CGTTTCAACC" * 400), id="my_genome", description="test genome")
+t = generator.simulate_read(g, em, 1, 0, "metagenomics")
+units["kde_simulate_read_seed42"] = [str(t[0].seq), [int(x) for x in t[0].letter_annotations["phred_quality"]],
+                                      str(t[1].seq), [int(x) for x in t[1].letter_annotations["phred_quality"]]]
+random.seed(42)
+np.random.seed(42)
+em = kde.KDErrorModel("data/ecoli.npz", 1000, 10)
+g = SeqRecord(Seq("AAACC" * 100), id="my_genome", description="test genome")
+t = generator.simulate_read(g, em, 1, 0, "metagenomics")
+units["kde_short_simulate_read_seed42"] = [str(t[0].seq), [int(x) for x in t[0].letter_annotations["phred_quality"]],
+                                            str(t[1].seq), [int(x) for x in t[1].letter_annotations["phred_quality"]]]
+random.seed(42)
+np.random.seed(42)
+bm = basic.BasicErrorModel()
+units["basic_phred_seed42"] = [int(x) for x in bm.gen_phred_scores(20, "forward")]
+
+# 3b. extra: forced indel patterns on an editable model (exercise ordering / stacking rules)
+extra = []
+rnd = random.Random(99)
+for k in range(24):
+    seed = 1000 + k
+    em = kde.KDErrorModel("data/ecoli.npz")
+    genome = random_genome(200 + k, 300, "ACGTN" if k % 3 == 0 else "ACGT")
+    start = rnd.randrange(0, 250)
+    orientation = "forward" if k % 2 == 0 else "reverse"
+    ins_tab = em.ins_for if orientation == "forward" else em.ins_rev
+    del_tab = em.del_for if orientation == "forward" else em.del_rev
+    edits = []
+    for _ in range(rnd.randrange(1, 7)):
+        pos, base, p = rnd.randrange(0, 20), rnd.choice("ATCG"), rnd.choice([1.0, 0.5, 0.25])
+        if rnd.random() < 0.5:
+            ins_tab[pos][base] = p
+            edits.append(["ins", pos, base, p])
+        else:
+            del_tab[pos][base] = p
+            edits.append(["del", pos, base, p])
+    end = start + 20
+    tmpl = genome[start:end] if orientation == "forward" else rev_comp(genome[start:end])
+    random.seed(seed)
+    np.random.seed(seed)
+    read = SeqRecord(Seq(tmpl), id="r", description="")
+    read.annotations["mutations"] = []
+    res = str(em.introduce_indels(read, orientation, Seq(genome), (start, end)).seq)
+    extra.append(dict(seed=seed, genome=genome, start=start, end=end, orientation=orientation, edits=edits,
+                      template=tmpl, result=res, tail_py=random.random()))
+units["forced_indels_ecoli"] = extra
+
+# 3c. rev_comp and phred_to_prob tables
+from iss import util  # noqa: E402
+
+units["rev_comp_iupac"] = util.rev_comp("ACGTRYWSKMNBVDHacgtrywskmnbvdh")
+units["phred_to_prob"] = [float(util.phred_to_prob(np.int64(q))) for q in range(0, 42)]
+with open(os.path.join(GOLDEN, "units.json"), "w") as fh:
+    json.dump(units, fh, indent=0)
+print("units", len(units))
+
+
+# 4. worker_iterator goldens (multi-record work lists, FASTQ text + optional VCF) ------------
+def fasta_records(path):
+    from Bio import SeqIO
+
+    return list(SeqIO.parse(path, "fasta"))
+
+
+def run_worker(case, model, records, counts, cpu_number, seed, seq_type, gc_bias, store_mutations=False,
+               frag=None, sd=None):
+    em = kde.KDErrorModel(os.path.join(REFCOPY, PROFILES[model]), frag, sd, store_mutations)
+    prefix = os.path.join(work, case)
+    wl = [(r, n, "default") for r, n in zip(records, counts)]
+    generator.worker_iterator(wl, em, cpu_number, prefix, seed, seq_type, gc_bias)
+    blobs = {}
+    for suffix in ("_R1.fastq", "_R2.fastq", ".vcf"):
+        with open(prefix + suffix, "rb") as fh:
+            blobs[suffix] = np.frombuffer(fh.read(), dtype=np.uint8)
+    meta = dict(case=case, model=model, ids=[r.id for r in records], counts=counts, cpu_number=cpu_number, seed=seed,
+                sequence_type=seq_type, gc_bias=gc_bias, store_mutations=store_mutations, fragment_length=frag,
+                fragment_sd=sd)
+    np.savez_compressed(os.path.join(GOLDEN, "worker", case + ".npz"), r1=blobs["_R1.fastq"], r2=blobs["_R2.fastq"],
+                        vcf=blobs[".vcf"], meta=np.array(json.dumps(meta)),
+                        **{"genome_%d" % i: to_u8(str(r.seq)) for i, r in enumerate(records)})
+    print("worker", case)
+
+
+genomes5 = fasta_records("data/genomes.fasta")
+run_worker("genomes_hiseq_cpu0", "hiseq", genomes5, [30, 17, 25, 12, 9], 0, 42, "metagenomics", False)
+run_worker("genomes_miseq_cpu1", "miseq", genomes5, [12, 7, 9, 8, 5], 1, 42, "metagenomics", False)
+big = [SeqRecord(Seq(random_genome(70 + i, 4000 + 500 * i)), id="syn%d" % i, description="") for i in range(3)]
+run_worker("syn_novaseq_cpu3_gc", "novaseq", big, [40, 1, 23], 3, 7, "metagenomics", True)
+run_worker("syn_novaseq_vcf", "novaseq", big, [300, 200, 100], 0, 11, "metagenomics", False, store_mutations=True)
+
+# 5. `iss generate` end to end -------------------------------------------------------------------
+for cpus in (1, 2, 3):
+    outp = os.path.join(work, "gen_c%d" % cpus)
+    subprocess.check_call([sys.executable, "-m", "iss", "generate", "--genomes", "data/genomes.fasta", "--model",
+                           "hiseq", "-n", "600", "--seed", "42", "--cpus", str(cpus), "-o", outp, "--quiet"],
+                          env=env, cwd=REFCOPY)
+    blobs = {}
+    for suffix in ("_R1.fastq", "_R2.fastq", "_abundance.txt"):
+        with open(outp + suffix, "rb") as fh:
+            blobs[suffix] = np.frombuffer(fh.read(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLDEN, "generate", "genomes_hiseq_n600_seed42_cpus%d.npz" % cpus),
+                        r1=blobs["_R1.fastq"], r2=blobs["_R2.fastq"], abundance=blobs["_abundance.txt"],
+                        sha_r1=np.array(hashlib.sha256(blobs["_R1.fastq"].tobytes()).hexdigest()))
+    print("generate cpus", cpus, len(blobs["_R1.fastq"]))
+shutil.copy(os.path.join(REFCOPY, "data/genomes.fasta"), os.path.join(GOLDEN, "genomes.fasta"))
+shutil.copy(os.path.join(REFCOPY, "data/ecoli.npz"), os.path.join(GOLDEN, "ecoli.npz"))
+
+# 6. raw MT stream taps -----------------------------------------------------------------------------
+taps = {}
+for s in (0, 1, 42, 43, 2**31, 2**32 - 1):
+    random.seed(s)
+    np.random.seed(s)
+    taps["py_%d" % s] = np.array([random.getrandbits(32) for _ in range(1300)], dtype=np.uint32)
+    taps["np_%d" % s] = np.random.randint(0, 2**32, size=1300, dtype=np.uint64).astype(np.uint32) * 0
+    # legacy raw words: random_sample consumes (a>>5, b>>6); record doubles instead (exact in f64)
+    np.random.seed(s)
+    taps["npd_%d" % s] = np.array([np.random.random_sample() for _ in range(650)])
+    del taps["np_%d" % s]
+np.savez_compressed(os.path.join(GOLDEN, "mt_taps.npz"), **taps)
+shutil.rmtree(work, ignore_errors=True)
+print("done")

@@ -1,0 +1,197 @@
+"""Pin the CPU oracle (oracle/iss_oracle.c, MT mode) to the reference.
+
+Golden vectors were captured by importing the reference (tests/golden/tooling/make_golden.py);
+expected values of the reference's own unit tests (iss/test/test_error_model.py:30-105,
+iss/test/test_generator.py:70-116) are re-asserted here literally as well."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, dense_model, load_pairs_case, pairs_cases
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def units():
+    with open(os.path.join(GOLDEN, "units.json")) as fh:
+        return json.load(fh)
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32-10
+    assert [hex(x) for x in O.philox4x32_10([0] * 4, [0] * 2)] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in O.philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)] == [
+        "0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(x) for x in O.philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344],
+                                            [0xA4093822, 0x299F31D0])] == [
+        "0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_mt_streams_match_cpython_and_numpy_taps():
+    z = np.load(os.path.join(GOLDEN, "mt_taps.npz"))
+    for s in (0, 1, 42, 43, 2**31, 2**32 - 1):
+        r = O.Rng().seed_mt(s)
+        words = np.array([r.py_word() for _ in range(1300)], dtype=np.uint32)
+        assert (words == z["py_%d" % s]).all()
+        dbl = np.array([r.np_random() for _ in range(650)])
+        assert (dbl == z["npd_%d" % s]).all()
+
+
+def test_first_doubles_seed42():
+    r = O.Rng().seed_mt(42)
+    assert r.py_random() == 0.6394267984578837  # random.seed(42); random.random()
+    assert r.np_random() == 0.3745401188473625  # np.random.seed(42); np.random.rand()
+
+
+@pytest.mark.parametrize("case", pairs_cases())
+def test_pairs_match_reference(case):
+    z, meta = load_pairs_case(case)
+    d = dense_model(meta["model"], meta["indel"])
+    orc = O.Oracle(d)
+    rng = O.Rng().seed_mt(meta["seed"])
+    genome = z["genome"].tobytes()
+    res = orc.simulate(rng, genome, meta["n_pairs"], sequence_type=meta["sequence_type"],
+                       fragment_length=meta["fragment_length"], fragment_sd=meta["fragment_sd"],
+                       gc_bias=meta["gc_bias"])
+    assert res["status"] == 0 and res["n_done"] == meta["n_done"]
+    for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+        assert (res[k] == z[k]).all(), k
+    # stream consumption: the next doubles of both streams equal the reference's
+    assert [rng.py_random() for _ in range(4)] == list(z["tail_py"])
+    assert [rng.np_random() for _ in range(4)] == list(z["tail_np"])
+
+
+def test_kde_phred_golden(units):
+    # iss/test/test_error_model.py:30-34
+    orc = O.Oracle(dense_model("ecoli"))
+    rng = O.Rng().seed_np(42)
+    q = orc.gen_phred_scores(rng, 1)
+    assert list(q[10:]) == [40, 40, 40, 40, 40, 40, 40, 40, 10, 10]
+    assert list(q) == units["kde_phred_reverse_seed42"]
+
+
+def _basic_dense():
+    from insilicoseq_amd.model import DenseModel, phred_to_prob
+
+    RL = 125
+    third = np.array([1 / 3, 1 / 3, 1 / 3])
+    cdf = third.cumsum()
+    cdf /= cdf[-1]
+    alts = {"A": "TCG", "T": "ACG", "C": "ATG", "G": "ATC"}
+    subst_cdf = np.tile(cdf, (2, RL, 4, 1))
+    subst_alt = np.zeros((2, RL, 4, 3), dtype=np.uint8)
+    for bi, b in enumerate("ATCG"):
+        subst_alt[:, :, bi, :] = [ord(c) for c in alts[b]]
+    return DenseModel(RL, np.array([1.0]), np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (2, 1)),
+                      np.tile(np.array([0, 0, 0, 1], dtype=np.uint8), (2, 1)), np.ones((2, 4, RL, 41)), subst_cdf,
+                      subst_alt, np.zeros((2, RL, 4)), np.tile(np.frombuffer(b"ATCG", dtype=np.uint8), (2, RL, 1)),
+                      np.zeros((2, RL, 4)), np.array([phred_to_prob(q) for q in range(42)]))
+
+
+def test_basic_phred_golden(units):
+    # iss/test/test_error_model.py:22-27
+    orc = O.Oracle(_basic_dense(), quality_mode=1, basic_mean_quality=20)  # gen_phred_scores(20, "forward")
+    q = orc.gen_phred_scores(O.Rng().seed_np(42), 0)
+    assert list(q[:10]) == [23, 19, 25, 40, 19, 19, 40, 26, 18, 23]
+    assert list(q) == units["basic_phred_seed42"]
+
+
+def test_mut_sequence_golden(units):
+    # iss/test/test_error_model.py:47-56
+    orc = O.Oracle(_basic_dense(), quality_mode=1)
+    rc, s = orc.mut_sequence(O.Rng().seed_mt(42), "AAAAA" * 25, [5] * 125, 0)
+    assert rc == 0 and s[:10] == "AAAACAGAAA"
+    assert s == units["basic_mut_sequence_seed42"]
+
+
+def test_introduce_indels_golden(units):
+    # iss/test/test_error_model.py:59-71
+    d = _basic_dense()
+    # BasicErrorModel aliases ONE list of dicts as ins_for/ins_rev/del_for/del_rev (basic.py:36-38),
+    # so the test's two assignments set both the insertion and the deletion probability.
+    d.ins[:, 1, 3] = d.dele[:, 1, 3] = 1.0  # ins_for[1]["G"] = 1.0
+    d.ins[:, 0, 0] = d.dele[:, 0, 0] = 1.0  # del_for[0]["A"] = 1.0
+    orc = O.Oracle(d, quality_mode=1)
+    rc, s = orc.introduce_indels(O.Rng().seed_mt(42), "ATATA" * 25, 0, "ATATA" * 100, (5, 130))
+    assert rc == 0 and len(s) == 125 and s[:10] == "ATGATAATAT"
+    assert s == units["basic_introduce_indels_seed42"]
+
+
+def test_adjust_seq_length_extend_golden(units):
+    # iss/test/test_error_model.py:74-87
+    d = dense_model("ecoli")
+    d.dele[0, 0, 0] = 1.0  # del_for[0]["A"]
+    d.dele[0, 1, 1] = 1.0  # del_for[1]["T"]
+    orc = O.Oracle(d)
+    rc, s = orc.introduce_indels(O.Rng().seed_mt(12), "ATTTA" * 4, 0, "ATTTA" * 100, (480, 500))
+    assert rc == 0 and s[:10] == "TTAATTTAAT" and s[10:] == "TTAATTTAAA"
+    assert s == units["ecoli_adjust_extend_seed12"]
+
+
+def test_introduce_indels_rev_golden(units):
+    # iss/test/test_error_model.py:90-105
+    d = dense_model("ecoli")
+    d.dele[1, 0, 2] = 1.0  # del_rev[0]["C"]
+    d.dele[1, 1, 3] = 1.0  # del_rev[1]["G"]
+    orc = O.Oracle(d)
+    ref = "GG" + "GTACC" * 100 + "GG"
+    read = O.rev_comp(ref[484:504])
+    rc, s = orc.introduce_indels(O.Rng().seed_mt(87), read, 1, ref, (484, 504))
+    assert rc == 0 and s == "CGTACGGTACGGTACGGTAC"
+    assert s == units["ecoli_indels_rev_seed87"]
+
+
+def _sim_one(orc, seed, genome, **kw):
+    res = orc.simulate(O.Rng().seed_mt(seed), genome, 1, **kw)
+    assert res["status"] == 0
+    return [res["r1_base"][0].tobytes().decode(), list(map(int, res["r1_qual"][0])),
+            res["r2_base"][0].tobytes().decode(), list(map(int, res["r2_qual"][0]))]
+
+
+def test_simulate_read_basic_golden(units):
+    # iss/test/test_generator.py:70-75
+    orc = O.Oracle(_basic_dense(), quality_mode=1)
+    got = _sim_one(orc, 42, "AAAAACCCCC" * 100, fragment_length=450, fragment_sd=0)
+    assert (got[0] + got[2])[-15:] == "TTTTGGGGGTTTTTG"
+    assert got == units["basic_simulate_read_seed42"]
+
+
+def test_simulate_read_kde_golden(units):
+    # iss/test/test_generator.py:78-83
+    got = _sim_one(O.Oracle(dense_model("ecoli")), 42, "CGTTTCAACC" * 400)
+    assert (got[0] + got[2])[:15] == "CCGTTTCAACCCGTT"
+    assert got == units["kde_simulate_read_seed42"]
+
+
+def test_simulate_read_kde_short_golden(units):
+    # iss/test/test_generator.py:86-91
+    got = _sim_one(O.Oracle(dense_model("ecoli")), 42, "AAACC" * 100, fragment_length=1000, fragment_sd=10)
+    assert got[0] + got[2] == "ACCAAACCAAACCAAACCAAGGTTTGGTTTGGTTTGGTAT"
+    assert got == units["kde_short_simulate_read_seed42"]
+
+
+def test_small_input_is_skipped():
+    # iss/test/test_generator.py:62-67 (AssertionError) -> ISS_SKIP_RECORD
+    res = O.Oracle(dense_model("ecoli")).simulate(O.Rng().seed_mt(1), "AAAAACCCCC", 3)
+    assert res["status"] == O.SKIP_RECORD and res["n_done"] == 0
+
+
+def test_forced_indel_patterns(units):
+    for c in units["forced_indels_ecoli"]:
+        d = dense_model("ecoli")
+        o = 0 if c["orientation"] == "forward" else 1
+        for kind, pos, base, p in c["edits"]:
+            bi = "ATCG".index(base)
+            (d.ins if kind == "ins" else d.dele)[o, pos, bi] = p
+        rng = O.Rng().seed_mt(c["seed"])
+        rc, s = O.Oracle(d).introduce_indels(rng, c["template"], o, c["genome"], (c["start"], c["end"]))
+        assert rc == 0 and s == c["result"], c
+        assert rng.py_random() == c["tail_py"]
+
+
+def test_rev_comp_and_phred_table(units):
+    assert O.rev_comp("ACGTRYWSKMNBVDHacgtrywskmnbvdh") == units["rev_comp_iupac"]
+    d = dense_model("novaseq")
+    assert list(d.phred_thr) == units["phred_to_prob"]
