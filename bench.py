@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- read-pairs/s of the MI355X read-generation path on BASELINE.json's headline config.
+
+A "step" = one pass of the hot path over one batch of synthetic input: 10 M reads (5 M pairs) of
+the NovaSeq KDE model (read_length 151) over 5 synthetic 5 Mbp genomes with log-normal abundances
+(BASELINE.json configs[2]; SURVEY.md 8d "cfg 3").  Genomes, model tables and work list are resident
+in HBM before the timed region; outputs stay in HBM (R1/R2 base + phred buffers).
+
+N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling -- every rank is one
+reference worker (cpu_number = rank, worker seed = seed + rank) generating its own 5 M pairs;
+the only collective is ONE RCCL broadcast of the model tables + packed genomes from rank 0 before
+the timed region (the path itself has no exchange step).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+READS_PER_STEP = 10_000_000
+N_GENOMES = 5
+GENOME_LEN = 5_000_000
+SEED = 42
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def synthetic_genomes(n, length, seed):
+    rng = np.random.RandomState(seed)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    return [letters[rng.randint(0, 4, size=length)] for _ in range(n)]
+
+
+def algorithmic_bytes_per_pair(read_length):
+    # 4*RL output bytes (R1+R2 bases and phreds) + two RL-base windows of the 2-bit genome
+    return 4 * read_length + 2 * ((read_length + 3) // 4)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=READS_PER_STEP, help="reads per step per GPU")
+    ap.add_argument("--model", default="novaseq")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=400_000)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+
+    from insilicoseq_amd.engine import ReadEngine
+    from insilicoseq_amd.generator import Record, generate_work_divider, lognormal_abundance
+    from insilicoseq_amd.model import DenseModel
+
+    # ---- inputs: rank 0 builds them, RCCL broadcast to the other ranks (only when N > 1)
+    model_path = os.path.join(ROOT, "tests", "golden", "models", args.model + ".dense.npz")
+    if rank == 0:
+        dense = DenseModel.load(model_path)
+        genomes = synthetic_genomes(N_GENOMES, GENOME_LEN, 123)
+    if dist is not None:
+        t_b = time.time()
+        if rank == 0:
+            fields = [np.ascontiguousarray(getattr(dense, k)) for k in DenseModel.FIELDS]
+            meta = [dense.read_length] + [list(f.shape) for f in fields]
+        else:
+            meta = None
+        box = [meta]
+        dist.broadcast_object_list(box, src=0)
+        meta = box[0]
+        dtypes = {"bin_nonempty": np.uint8, "subst_alt": np.uint8, "ins_letter": np.uint8}
+        recv = []
+        for k, shape in zip(DenseModel.FIELDS, meta[1:]):
+            dt = dtypes.get(k, np.float64)
+            if rank == 0:
+                t = torch.from_numpy(np.ascontiguousarray(getattr(dense, k)).view(np.uint8).reshape(-1)).cuda()
+            else:
+                t = torch.empty(int(np.prod(shape)) * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
+            dist.broadcast(t, src=0)
+            recv.append(t.cpu().numpy().view(dt).reshape(shape))
+        if rank != 0:
+            dense = DenseModel(meta[0], *recv)
+        gt = torch.empty(N_GENOMES * GENOME_LEN, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            gt.copy_(torch.from_numpy(np.concatenate(genomes)))
+        dist.broadcast(gt, src=0)
+        if rank != 0:
+            flat = gt.cpu().numpy()
+            genomes = [flat[i * GENOME_LEN:(i + 1) * GENOME_LEN] for i in range(N_GENOMES)]
+        torch.cuda.synchronize()
+        bcast_s = time.time() - t_b
+    else:
+        bcast_s = 0.0
+
+    records = [Record(g, id="genome_%d" % i) for i, g in enumerate(genomes)]
+    abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(123))
+    n_pairs_step = args.reads // 2
+    work = []
+    for chunk in generate_work_divider(records, None, abundance, args.reads, None, None, dense, "bench",
+                                       chunk_size=n_pairs_step):
+        work.extend(chunk)
+    work = [(r, n) for r, n, _ in work]
+    total_pairs_step = sum(n for _, n in work)
+
+    eng = ReadEngine(local_rank)
+    eng.load_model(dense)
+    gids = {id(r): eng.add_genome(r.seq) for r in records}
+    eng.reserve(total_pairs_step)
+    worker_seed = SEED + rank
+    ordinal = [0]
+
+    def step():
+        row = 0
+        for rec, n in work:
+            eng.generate(gids[id(rec)], n, first_ordinal=ordinal[0], seed=worker_seed, out_first_pair=row)
+            ordinal[0] += n
+            row += n
+
+    def sync_all():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    eng.timing_read()
+    eng.timing_enable(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    tm = eng.timing_read()
+    eng.timing_enable(False)
+    stats = eng.stats_read()
+    if dist is not None:
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    if rank == 0:
+        RL = dense.read_length
+        pairs_total = total_pairs_step * args.steps * world
+        value = pairs_total / elapsed
+        b_pair = algorithmic_bytes_per_pair(RL)
+        main_s = tm["main_ms"] / 1e3
+        n_main_launches = len(work) * args.steps
+        achieved = (total_pairs_step * args.steps * b_pair) / main_s / 1e9 if main_s > 0 else 0.0
+        all_kernels_s = (tm["setup_ms"] + tm["main_ms"] + tm["indel_scan_ms"] + tm["indel_fixup_ms"]) / 1e3
+        out = {
+            "metric": "read_pairs_per_sec", "value": value, "unit": "read-pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: %d reads/step/GPU, %s KDE model (read_length %d), %d x %d bp "
+                            "uniform ACGT genomes, log-normal abundance, seed %d; outputs left in HBM" % (
+                                args.reads, args.model, RL, N_GENOMES, GENOME_LEN, SEED),
+                "pairs_per_step_per_gpu": total_pairs_step, "read_length": RL, "work_items": len(work),
+                "rng": "philox4x32-10", "parallelism": "1 worker/GPU, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_main", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "algorithmic_bytes_per_pair": b_pair, "avg_launch_ms": tm["main_ms"] / max(n_main_launches, 1),
+                "launches": n_main_launches,
+            },
+            "kernel_ms_per_step": {k: tm[k] / args.steps for k in ("setup_ms", "main_ms", "indel_scan_ms",
+                                                                    "indel_fixup_ms")},
+            "all_kernels_GBps": (total_pairs_step * args.steps * b_pair) / all_kernels_s / 1e9 if all_kernels_s else 0,
+            "indel_fixup_reads_per_step": stats["fixup_reads"] / max(args.steps, 1),
+            "model_broadcast_s": bcast_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dense, work, args.cpu_sample_pairs)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def cpu_baseline(dense, work, sample_pairs):
+    """The CPU oracle (oracle/iss_oracle.c, the reference's algorithm restated in C with the reference's
+    two MT19937 streams) timed on ONE host core on a bounded sample of the same workload."""
+    from oracle import oracle as O
+
+    orc = O.Oracle(dense)
+    rng = O.Rng().seed_mt(SEED)
+    todo = sample_pairs
+    t0 = time.perf_counter()
+    done = 0
+    for rec, n in work:
+        k = min(n, max(1, int(round(sample_pairs * n / sum(x for _, x in work)))), todo)
+        if k <= 0:
+            continue
+        res = orc.simulate(rng, rec.seq, k)
+        assert res["status"] == 0
+        done += res["n_done"]
+        todo -= k
+    dt = time.perf_counter() - t0
+    return {
+        "value": done / dt, "unit": "read-pairs/s", "cores": 1, "kind": "port",
+        "sample": "%d pairs of the same work list (proportional per genome), MT19937 streams, %.1f s" % (done, dt),
+        "note": "the Python reference itself measured 873 (1 process) / 3376 (8 processes) read-pairs/s "
+                "end-to-end in the build container (BASELINE.md); it cannot run on the GPU box",
+    }
+
+
+if __name__ == "__main__":
+    main()

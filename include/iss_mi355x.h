@@ -1,0 +1,144 @@
+/*
+ * iss_mi355x.h -- C ABI of the MI355X (gfx950) read-generation engine.
+ *
+ * Drop-in boundary for ONE hot path of InSilicoSeq v2.0.1: the per-read loop of
+ * `iss generate`.  Every entry point names the reference
+ * interface it replaces (file:line into the reference tree).  Plain pointers and
+ * sizes only; no torch / numpy types.  All functions return 0 on success and a
+ * negative ISS_E_* code on failure (never exit()); iss_last_error() returns the
+ * message of the last failure on that context (or the global one when ctx == NULL).
+ *
+ * Threading: one context per GPU; calls on one context are serialised by the
+ * caller; contexts are independent across threads / processes (the reference's
+ * workers share nothing either, iss/app.py:99-106).
+ *
+ * Arithmetic contract: every f64 comparison of the reference is carried out as an
+ * exact integer comparison on 53-bit uniforms m = (w0>>5)*2^26 + (w1>>6) against
+ * thresholds prepared on the host (floor/ceil of table*2^53, exact), see DESIGN.md.
+ * Uniform words come from Philox4x32-10 addressed by
+ * (seed, pair ordinal, attempt, kind, index, sub) -- the address map is part of the
+ * contract and is documented in DESIGN.md ("RNG address map").
+ */
+#ifndef ISS_MI355X_H
+#define ISS_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISS_ABI_VERSION 1
+
+#define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
+#define ISS_E_HIP (-2)         /* HIP runtime failure (message has the hip error)  */
+#define ISS_E_NOMEM (-3)
+#define ISS_E_SHORT_RECORD (-4) /* read_length >= len(record): the reference's AssertionError,
+                                   iss/generator.py:130 -> record skipped at :77-80 */
+#define ISS_E_IO (-5)
+
+#define ISS_SEQ_METAGENOMICS 0 /* iss/generator.py:134-135, 164-166 */
+#define ISS_SEQ_AMPLICON 1     /* iss/generator.py:136-137, 167-169 */
+
+typedef struct iss_ctx iss_ctx;
+
+int iss_abi_version(void);
+
+/* One context = one GPU = one reference worker (`cpu_number`), iss/generator.py:223. */
+int iss_ctx_create(int device_ordinal, iss_ctx **out);
+void iss_ctx_destroy(iss_ctx *ctx);
+const char *iss_last_error(const iss_ctx *ctx);
+
+/* Optional: launch on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the context's own stream.  NULL restores the context stream. */
+int iss_ctx_set_stream(iss_ctx *ctx, void *hip_stream);
+
+/*
+ * Model tables, replaces KDErrorModel.__init__ / load_npz (iss/error_models/kde.py:24-50,
+ * iss/error_models/__init__.py:27-50): the 13-key .npz flattened on the host
+ * (insilicoseq_amd/model.py) and uploaded once to HBM.  All thresholds are integers in
+ * [0, 2^53] (see header comment); orientation 0 = forward, 1 = reverse; base order A,T,C,G.
+ */
+typedef struct {
+    int32_t read_length;
+    int32_t n_isize;
+    int32_t n_q;                 /* entries per per-position quality CDF (41)              */
+    const uint64_t *isize_thr;   /* [n_isize]        floor(cdf*2^53): insert = #(thr <  m)  kde.py:97   */
+    const uint64_t *bin_thr;     /* [2][4]           ceil (cdf*2^53): bin    = #(thr <= m)  kde.py:74   */
+    const uint8_t *bin_nonempty; /* [2][4]                                                  kde.py:80   */
+    const uint64_t *q_thr;       /* [2][4][RL][n_q]  floor: phred = #(thr < m)              kde.py:84   */
+    const uint64_t *subst_thr;   /* [2][RL][4][3]    ceil : alt index = #(thr <= m)  __init__.py:95-97 */
+    const uint8_t *subst_alt;    /* [2][RL][4][3]    ASCII alternatives                                */
+    const uint64_t *ins_thr;     /* [2][RL][4]       ceil : insert iff m < thr       __init__.py:194   */
+    const uint8_t *ins_letter;   /* [2][RL][4]       ASCII, in the dict's iteration order              */
+    const uint64_t *del_thr;     /* [2][RL][4]       ceil : delete iff m < thr       __init__.py:209   */
+    const uint64_t *mut_thr;     /* [n_q+1]          floor(phred_to_prob(q)*2^53): error iff m > thr   */
+} iss_model_tables;
+
+int iss_model_upload(iss_ctx *ctx, const iss_model_tables *tables);
+
+/*
+ * Genome upload, replaces handing `record.seq` to the worker (iss/generator.py:116,
+ * pickled through iss/app.py:99-106).  ASCII in, validated against the reference's
+ * rev_comp alphabet (iss/util.py:57-88; any other letter is the reference's KeyError and is
+ * rejected here with ISS_E_INVALID); stored in HBM as 2-bit codes (A,T,C,G = 0..3) + a
+ * 1-bit "exception" mask (IUPAC / lower case) + the ASCII copy the exceptions are read from.
+ */
+int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_t *genome_id);
+int iss_genome_clear(iss_ctx *ctx);
+
+/* Device output buffers: four arrays [capacity_pairs][pitch] (R1 bases, R1 phred, R2 bases,
+ * R2 phred), pitch = 4*ceil(read_length/4).  Reserve before generating. */
+int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs);
+int iss_output_pitch(const iss_ctx *ctx);
+/* raw device pointers (for a caller that consumes the reads on the GPU / benchmarks) */
+int iss_output_device_ptrs(const iss_ctx *ctx, void **r1_base, void **r1_qual, void **r2_base, void **r2_qual);
+
+/*
+ * The hot path: n_pairs read pairs from one record, replaces
+ *   reads_generator + simulate_read            iss/generator.py:69-95, 98-192
+ *   ErrorModel.introduce_indels / adjust_seq_length / introduce_error_scores / mut_sequence
+ *                                              iss/error_models/__init__.py:158-228, 114-156, 52-67, 69-112
+ *   KDErrorModel.gen_phred_scores / random_insert_size   iss/error_models/kde.py:52-98
+ * Asynchronous on the context stream.  Pair k of the call is written to row
+ * (out_first_pair + k) and draws its uniforms at Philox address (seed, first_ordinal + k).
+ * `seed` is the worker seed (reference: seed + cpu_number, iss/generator.py:234-236).
+ * Returns ISS_E_SHORT_RECORD (nothing launched) when read_length >= genome length.
+ */
+int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
+                 int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair);
+
+int iss_synchronize(iss_ctx *ctx);
+
+/* Copy rows [first_pair, first_pair + n_pairs) to host arrays of pitch iss_output_pitch(). */
+int iss_output_download(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, uint8_t *r1_base, uint8_t *r1_qual,
+                        uint8_t *r2_base, uint8_t *r2_qual);
+
+/* Per-pair coordinates (forward_start, reverse_start, reverse_end, insert_size) of rows
+ * [first_pair, first_pair+n_pairs) as int64[n][4] -- iss/generator.py:135, 165-176. */
+int iss_output_download_coords(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, int64_t *coords);
+
+/* HIP-event timing of the kernels launched by iss_generate (on the launch stream).
+ * enable: 1/0.  iss_timing_read synchronises, returns accumulated milliseconds per kernel
+ * (setup, main, indel-scan, indel-fixup) and the number of iss_generate launches, then
+ * resets the accumulators. */
+int iss_timing_enable(iss_ctx *ctx, int enable);
+int iss_timing_read(iss_ctx *ctx, double ms[4], int64_t *n_launches);
+
+/* Counters of the last iss_generate call(s): reads re-done by the indel fix-up kernel. */
+int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads);
+
+/*
+ * FASTQ emission, replaces SeqIO.write(record, handle, "fastq-sanger") in
+ * simulate_reads (iss/generator.py:64-65): records "@{record_id}_{i}_{cpu_number}/{1|2}\n
+ * SEQ\n+\nQUAL\n" with QUAL = chr(33+q), ids per iss/generator.py:150, 181; i runs from
+ * first_i.  Host-side formatter (multi-threaded) appending to two file descriptors.
+ */
+int iss_fastq_write(int fd_r1, int fd_r2, const char *record_id, int64_t first_i, int32_t cpu_number,
+                    int64_t n_pairs, int32_t read_length, int32_t pitch, const uint8_t *r1_base,
+                    const uint8_t *r1_qual, const uint8_t *r2_base, const uint8_t *r2_qual, int32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISS_MI355X_H */

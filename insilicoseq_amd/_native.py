@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI in include/iss_mi355x.h (libiss_mi355x.so, built in-tree).
+
+There is NO fallback: if the HIP library is missing or no MI355X is visible, the product
+raises (``NativeLibraryError`` / ``EngineError``) instead of computing anything on the CPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libiss_mi355x.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+E_INVALID, E_HIP, E_NOMEM, E_SHORT_RECORD, E_IO = -1, -2, -3, -4, -5
+SEQ_TYPES = {"metagenomics": 0, "amplicon": 1}
+
+# every symbol include/iss_mi355x.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "iss_abi_version", "iss_ctx_create", "iss_ctx_destroy", "iss_last_error", "iss_ctx_set_stream",
+    "iss_model_upload", "iss_genome_upload", "iss_genome_clear", "iss_output_reserve", "iss_output_pitch",
+    "iss_output_device_ptrs", "iss_generate", "iss_synchronize", "iss_output_download",
+    "iss_output_download_coords", "iss_timing_enable", "iss_timing_read", "iss_stats_read", "iss_fastq_write",
+)
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "%s (iss error %d)" % (message, code))
+        self.code = code
+
+
+class ModelTables(C.Structure):
+    _fields_ = [
+        ("read_length", C.c_int32), ("n_isize", C.c_int32), ("n_q", C.c_int32),
+        ("isize_thr", C.c_void_p), ("bin_thr", C.c_void_p), ("bin_nonempty", C.c_void_p), ("q_thr", C.c_void_p),
+        ("subst_thr", C.c_void_p), ("subst_alt", C.c_void_p), ("ins_thr", C.c_void_p), ("ins_letter", C.c_void_p),
+        ("del_thr", C.c_void_p), ("mut_thr", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises NativeLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    L.iss_abi_version.restype = C.c_int
+    L.iss_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.iss_ctx_destroy.argtypes = [vp]
+    L.iss_ctx_destroy.restype = None
+    L.iss_last_error.argtypes = [vp]
+    L.iss_last_error.restype = C.c_char_p
+    L.iss_ctx_set_stream.argtypes = [vp, vp]
+    L.iss_model_upload.argtypes = [vp, C.POINTER(ModelTables)]
+    L.iss_genome_upload.argtypes = [vp, vp, i64, C.POINTER(i32)]
+    L.iss_genome_clear.argtypes = [vp]
+    L.iss_output_reserve.argtypes = [vp, i64]
+    L.iss_output_pitch.argtypes = [vp]
+    L.iss_output_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.iss_generate.argtypes = [vp, i32, i64, u64, u64, i32, i32, i64]
+    L.iss_synchronize.argtypes = [vp]
+    L.iss_output_download.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    L.iss_output_download_coords.argtypes = [vp, i64, i64, vp]
+    L.iss_timing_enable.argtypes = [vp, C.c_int]
+    L.iss_timing_read.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(i64)]
+    L.iss_stats_read.argtypes = [vp, C.POINTER(i64)]
+    L.iss_fastq_write.argtypes = [C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i32, i32, vp, vp, vp, vp, i32]
+    for name in EXPORTS:
+        if name not in ("iss_ctx_destroy", "iss_last_error"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(ctx, rc):
+    if rc < 0:
+        msg = lib().iss_last_error(ctx)
+        raise EngineError(rc, msg.decode("utf-8", "replace") if msg else "unknown error")
+    return rc

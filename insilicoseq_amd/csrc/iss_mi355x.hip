@@ -1,0 +1,544 @@
+// iss_mi355x.hip -- C-ABI shared library of the MI355X read-generation engine (see include/iss_mi355x.h).
+// Host side: context, HBM uploads (model tables, genomes), launch sequencing on one HIP stream,
+// HIP-event timing, downloads, FASTQ formatting.  Device side: iss_kernels.hip.h.
+#include "iss_mi355x.h"
+
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "iss_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Genome {
+    uint32_t *packed = nullptr;
+    uint32_t *mask = nullptr;
+    uint8_t *ascii = nullptr;
+    int64_t L = 0;
+};
+
+struct TimedLaunch {
+    hipEvent_t ev[5];  // boundaries: setup | main | scan | fixup
+    bool has_scan;
+};
+
+}  // namespace
+
+struct iss_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // model
+    bool have_model = false;
+    iss::DevModel M{};
+    std::vector<void *> model_allocs;
+    // genomes
+    std::vector<Genome> genomes;
+    // outputs
+    int64_t capacity = 0;
+    uint8_t *out[4] = {nullptr, nullptr, nullptr, nullptr};
+    iss::PairDesc *desc = nullptr;
+    uint32_t *flags = nullptr;
+    uint32_t *fix_list = nullptr;
+    uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
+    uint64_t *stats = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    double ms_acc[4] = {0, 0, 0, 0};
+    int64_t n_launches = 0;
+};
+
+namespace {
+
+int fail(iss_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->last_error = msg;
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(ctx, ISS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+template <typename T>
+int upload(iss_ctx *ctx, const T *host, size_t n, T **dev, std::vector<void *> *track) {
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    if (track) track->push_back(p);
+    if (n) HIP_TRY(ctx, hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<T *>(p);
+    return 0;
+}
+
+void free_model(iss_ctx *ctx) {
+    for (void *p : ctx->model_allocs) (void)hipFree(p);
+    ctx->model_allocs.clear();
+    ctx->have_model = false;
+}
+
+void free_outputs(iss_ctx *ctx) {
+    for (auto &p : ctx->out) { if (p) (void)hipFree(p); p = nullptr; }
+    if (ctx->desc) (void)hipFree(ctx->desc);
+    if (ctx->flags) (void)hipFree(ctx->flags);
+    if (ctx->fix_list) (void)hipFree(ctx->fix_list);
+    ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
+    ctx->capacity = 0;
+}
+
+// letters util.rev_comp accepts (iss/util.py:57-88)
+bool valid_letter(uint8_t c) {
+    switch (c & ~0x20) {
+        case 'A': case 'C': case 'G': case 'T': case 'Y': case 'R': case 'W': case 'S': case 'K': case 'M':
+        case 'N': case 'B': case 'V': case 'D': case 'H':
+            return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+        default: return false;
+    }
+}
+
+int settle_timing(iss_ctx *ctx) {
+    for (auto &t : ctx->timed) {
+        HIP_TRY(ctx, hipEventSynchronize(t.ev[4]));
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, t.ev[k], t.ev[k + 1]));
+            ctx->ms_acc[k] += ms;
+        }
+        for (auto &e : t.ev) (void)hipEventDestroy(e);
+    }
+    ctx->timed.clear();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iss_abi_version(void) { return ISS_ABI_VERSION; }
+
+const char *iss_last_error(const iss_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+
+int iss_ctx_create(int device_ordinal, iss_ctx **out) {
+    if (!out) return fail(nullptr, ISS_E_INVALID, "iss_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, ISS_E_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, ISS_E_INVALID, "device ordinal out of range");
+    iss_ctx *ctx = new iss_ctx();
+    ctx->device = device_ordinal;
+    HIP_TRY(ctx, hipSetDevice(device_ordinal));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, 64));
+    ctx->fix_count = static_cast<uint32_t *>(p);
+    ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 16);
+    HIP_TRY(ctx, hipMemset(p, 0, 64));
+    *out = ctx;
+    return 0;
+}
+
+void iss_ctx_destroy(iss_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->timed) for (auto &e : t.ev) (void)hipEventDestroy(e);
+    free_model(ctx);
+    free_outputs(ctx);
+    iss_genome_clear(ctx);
+    if (ctx->fix_count) (void)hipFree(ctx->fix_count);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int iss_ctx_set_stream(iss_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return 0;
+}
+
+int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
+    if (!ctx || !t) return fail(ctx, ISS_E_INVALID, "iss_model_upload: NULL argument");
+    if (t->read_length < 2 || t->read_length > iss::FIX_STACK)
+        return fail(ctx, ISS_E_INVALID, "read_length must be in [2, 1024]");
+    if (t->n_isize < 1 || t->n_q < 1 || t->n_q > 255) return fail(ctx, ISS_E_INVALID, "bad table sizes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_model(ctx);
+    const int RL = t->read_length, nq = t->n_q;
+    const uint64_t two53 = 1ull << 53;
+    auto check = [&](const uint64_t *p, size_t n) { for (size_t i = 0; i < n; ++i) if (p[i] > two53) return false; return true; };
+    const size_t n_qthr = (size_t)2 * 4 * RL * nq;
+    if (!check(t->isize_thr, t->n_isize) || !check(t->bin_thr, 8) || !check(t->q_thr, n_qthr) ||
+        !check(t->subst_thr, (size_t)2 * RL * 12) || !check(t->ins_thr, (size_t)2 * RL * 4) ||
+        !check(t->del_thr, (size_t)2 * RL * 4) || !check(t->mut_thr, nq + 1))
+        return fail(ctx, ISS_E_INVALID, "threshold above 2^53");
+    for (int i = 1; i < t->n_isize; ++i)
+        if (t->isize_thr[i] < t->isize_thr[i - 1]) return fail(ctx, ISS_E_INVALID, "insert-size thresholds not monotone");
+    for (int o = 0; o < 2; ++o)
+        for (int b = 0; b < 4; ++b) {
+            if (!t->bin_nonempty[o * 4 + b]) {
+                const uint64_t prev = b ? t->bin_thr[o * 4 + b - 1] : 0;
+                if (t->bin_thr[o * 4 + b] != prev)
+                    return fail(ctx, ISS_E_INVALID, "a mean-quality bin with non-zero probability has no histograms");
+                continue;
+            }
+            for (int p = 0; p < RL; ++p) {
+                const uint64_t *row = t->q_thr + ((size_t)(o * 4 + b) * RL + p) * nq;
+                for (int k = 1; k < nq; ++k)
+                    if (row[k] < row[k - 1]) return fail(ctx, ISS_E_INVALID, "quality thresholds not monotone");
+            }
+        }
+    iss::DevModel &M = ctx->M;
+    M = iss::DevModel{};
+    M.RL = RL; M.n_isize = t->n_isize; M.n_q = nq;
+    M.G = (RL + 3) / 4; M.pitch = M.G * 4;
+    std::vector<uint32_t> q_hi(n_qthr), mut_hi(nq + 1);
+    for (size_t i = 0; i < n_qthr; ++i) q_hi[i] = (uint32_t)(t->q_thr[i] >> 26);
+    for (int i = 0; i <= nq; ++i) mut_hi[i] = (uint32_t)(t->mut_thr[i] >> 26);
+    std::vector<uint64_t> del_max((size_t)2 * RL);
+    std::vector<uint8_t> ins_any((size_t)2 * RL), amask(M.G, 0);
+    std::vector<int32_t> agroups;
+    for (int o = 0; o < 2; ++o)
+        for (int n = 0; n < RL; ++n) {
+            const size_t e = (size_t)o * RL + n;
+            uint64_t dm = 0, im = 0;
+            for (int x = 0; x < 4; ++x) { dm = std::max(dm, t->del_thr[e * 4 + x]); im = std::max(im, t->ins_thr[e * 4 + x]); }
+            del_max[e] = dm;
+            ins_any[e] = im ? 1 : 0;
+            if ((dm || im) && n <= RL - 2) amask[n / 4] |= (uint8_t)(1u << (o * 4 + (n & 3)));
+        }
+    for (int gI = 0; gI < M.G; ++gI) if (amask[gI]) agroups.push_back(gI);
+    M.n_active_groups = (int32_t)agroups.size();
+    int rc = 0;
+    auto *tr = &ctx->model_allocs;
+#define UP(field, src, n, T) if ((rc = upload<T>(ctx, src, n, const_cast<T **>(&M.field), tr))) return rc
+    UP(isize_thr, t->isize_thr, (size_t)t->n_isize, uint64_t);
+    UP(bin_thr, t->bin_thr, 8, uint64_t);
+    UP(q_thr, t->q_thr, n_qthr, uint64_t);
+    UP(q_thr_hi, q_hi.data(), n_qthr, uint32_t);
+    UP(subst_thr, t->subst_thr, (size_t)2 * RL * 12, uint64_t);
+    UP(subst_alt, t->subst_alt, (size_t)2 * RL * 12, uint8_t);
+    UP(ins_thr, t->ins_thr, (size_t)2 * RL * 4, uint64_t);
+    UP(ins_letter, t->ins_letter, (size_t)2 * RL * 4, uint8_t);
+    UP(del_thr, t->del_thr, (size_t)2 * RL * 4, uint64_t);
+    UP(del_thr_max, del_max.data(), del_max.size(), uint64_t);
+    UP(mut_thr, t->mut_thr, (size_t)nq + 1, uint64_t);
+    UP(mut_thr_hi, mut_hi.data(), mut_hi.size(), uint32_t);
+    UP(ins_any, ins_any.data(), ins_any.size(), uint8_t);
+    UP(active_groups, agroups.data(), agroups.size(), int32_t);
+    UP(active_mask, amask.data(), amask.size(), uint8_t);
+#undef UP
+    ctx->have_model = true;
+    free_outputs(ctx);  // pitch may have changed
+    return 0;
+}
+
+int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_t *genome_id) {
+    if (!ctx || !ascii || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload: NULL argument");
+    if (length < 1 || length >= (int64_t)0x7fffffff) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^31-2]");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n_pk = (size_t)(length + 15) / 16 + 2, n_mk = (size_t)(length + 31) / 32 + 2;
+    std::vector<uint32_t> pk(n_pk, 0), mk(n_mk, 0);
+    for (int64_t i = 0; i < length; ++i) {
+        const uint8_t c = ascii[i];
+        uint32_t code;
+        switch (c) {
+            case 'A': code = 0; break; case 'T': code = 1; break; case 'C': code = 2; break; case 'G': code = 3; break;
+            default:
+                if (!valid_letter(c)) {
+                    char buf[160];
+                    snprintf(buf, sizeof buf, "genome letter 0x%02x at offset %lld is outside the rev_comp alphabet "
+                             "(the reference raises KeyError, iss/util.py:90)", c, (long long)i);
+                    return fail(ctx, ISS_E_INVALID, buf);
+                }
+                code = 0;
+                mk[i >> 5] |= 1u << (i & 31);
+        }
+        pk[i >> 4] |= code << ((i & 15) * 2);
+    }
+    Genome G;
+    G.L = length;
+    int rc;
+    if ((rc = upload<uint32_t>(ctx, pk.data(), n_pk, &G.packed, nullptr))) return rc;
+    if ((rc = upload<uint32_t>(ctx, mk.data(), n_mk, &G.mask, nullptr))) return rc;
+    if ((rc = upload<uint8_t>(ctx, ascii, (size_t)length, &G.ascii, nullptr))) return rc;
+    ctx->genomes.push_back(G);
+    *genome_id = (int32_t)ctx->genomes.size() - 1;
+    return 0;
+}
+
+int iss_genome_clear(iss_ctx *ctx) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &G : ctx->genomes) { (void)hipFree(G.packed); (void)hipFree(G.mask); (void)hipFree(G.ascii); }
+    ctx->genomes.clear();
+    return 0;
+}
+
+int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
+    if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_output_reserve: upload a model first");
+    if (capacity_pairs < 1) return fail(ctx, ISS_E_INVALID, "capacity must be >= 1");
+    if (capacity_pairs <= ctx->capacity) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_outputs(ctx);
+    const size_t row = (size_t)ctx->M.pitch;
+    for (auto &p : ctx->out) {
+        void *q = nullptr;
+        HIP_TRY(ctx, hipMalloc(&q, row * (size_t)capacity_pairs));
+        p = static_cast<uint8_t *>(q);
+    }
+    void *q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));
+    ctx->desc = static_cast<iss::PairDesc *>(q);
+    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * (size_t)capacity_pairs));
+    ctx->flags = static_cast<uint32_t *>(q);
+    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
+    ctx->fix_list = static_cast<uint32_t *>(q);
+    ctx->capacity = capacity_pairs;
+    return 0;
+}
+
+int iss_output_pitch(const iss_ctx *ctx) { return (ctx && ctx->have_model) ? ctx->M.pitch : ISS_E_INVALID; }
+
+int iss_output_device_ptrs(const iss_ctx *ctx, void **a, void **b, void **c, void **d) {
+    if (!ctx || !ctx->capacity) return ISS_E_INVALID;
+    if (a) *a = ctx->out[0];
+    if (b) *b = ctx->out[1];
+    if (c) *c = ctx->out[2];
+    if (d) *d = ctx->out[3];
+    return 0;
+}
+
+int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
+                 int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
+    if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_generate: upload a model first");
+    if (genome_id < 0 || genome_id >= (int32_t)ctx->genomes.size()) return fail(ctx, ISS_E_INVALID, "unknown genome id");
+    if (sequence_type != ISS_SEQ_METAGENOMICS && sequence_type != ISS_SEQ_AMPLICON)
+        return fail(ctx, ISS_E_INVALID, "sequence type is not supported");  // generator.py:139, 171
+    if (n_pairs < 0 || out_first_pair < 0 || out_first_pair + n_pairs > ctx->capacity)
+        return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
+    const Genome &G = ctx->genomes[genome_id];
+    const iss::DevModel &M = ctx->M;
+    if (!(M.RL < G.L)) return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
+    if (n_pairs == 0) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L};
+    const int64_t max_chunk = std::max<int64_t>(1, (int64_t)0x7fffffff / std::max(M.G, std::max(M.n_active_groups, 1)) / 2);
+    for (int64_t done = 0; done < n_pairs;) {
+        const int64_t n = std::min(max_chunk, n_pairs - done);
+        const int64_t row0 = out_first_pair + done;
+        iss::RunArgs A{};
+        A.n_pairs = n;
+        A.first_ordinal = first_ordinal + (uint64_t)done;
+        A.seed = seed;
+        A.sequence_type = sequence_type;
+        A.gc_bias = gc_bias ? 1 : 0;
+        A.gc_thr = 8106479329266893ull;  // ceil(0.90 * 2^53), 0.90 being the f64 nearest to 0.9
+        for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
+        iss::PairDesc *desc = ctx->desc + row0;
+        uint32_t *flags = ctx->flags + row0;
+        uint32_t *fix_list = ctx->fix_list + 2 * row0;
+        TimedLaunch tl{};
+        tl.has_scan = M.n_active_groups > 0;
+        auto mark = [&](int k) -> hipError_t {
+            if (!ctx->timing) return hipSuccess;
+            hipError_t e = hipEventCreate(&tl.ev[k]);
+            if (e != hipSuccess) return e;
+            return hipEventRecord(tl.ev[k], ctx->stream);
+        };
+        HIP_TRY(ctx, mark(0));
+        {
+            const unsigned blocks = (unsigned)((n + 255) / 256);
+            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), 0, ctx->stream, M, dg, A, desc);
+        }
+        HIP_TRY(ctx, mark(1));
+        {
+            const uint64_t items = (uint64_t)n * M.G;
+            const unsigned blocks = (unsigned)((items + 255) / 256);
+            hipLaunchKernelGGL(iss::k_main, dim3(blocks), dim3(256), 0, ctx->stream, M, dg, A, desc);
+        }
+        HIP_TRY(ctx, mark(2));
+        if (M.n_active_groups > 0) {
+            HIP_TRY(ctx, hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t), ctx->stream));
+            const uint64_t items = (uint64_t)n * M.n_active_groups;
+            const unsigned blocks = (unsigned)((items + 255) / 256);
+            hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(256), 0, ctx->stream, M, A, desc, flags, fix_list,
+                               ctx->fix_count);
+        }
+        HIP_TRY(ctx, mark(3));
+        if (M.n_active_groups > 0) {
+            const unsigned blocks = (unsigned)std::min<int64_t>(4096, (2 * n + 63) / 64);
+            hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64), 0, ctx->stream, M, dg, A, desc, fix_list,
+                               ctx->fix_count, ctx->stats);
+        }
+        HIP_TRY(ctx, mark(4));
+        HIP_TRY(ctx, hipGetLastError());
+        if (ctx->timing) ctx->timed.push_back(tl);
+        done += n;
+    }
+    ctx->n_launches += 1;
+    return 0;
+}
+
+int iss_synchronize(iss_ctx *ctx) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int iss_output_download(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, uint8_t *r1_base, uint8_t *r1_qual,
+                        uint8_t *r2_base, uint8_t *r2_qual) {
+    if (!ctx || first_pair < 0 || n_pairs < 0 || first_pair + n_pairs > ctx->capacity)
+        return fail(ctx, ISS_E_INVALID, "iss_output_download: rows out of range");
+    uint8_t *host[4] = {r1_base, r1_qual, r2_base, r2_qual};
+    const size_t pitch = (size_t)ctx->M.pitch;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < 4; ++k)
+        if (host[k] && n_pairs)
+            HIP_TRY(ctx, hipMemcpyAsync(host[k], ctx->out[k] + (size_t)first_pair * pitch, pitch * (size_t)n_pairs,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int iss_output_download_coords(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, int64_t *coords) {
+    if (!ctx || !coords || first_pair < 0 || n_pairs < 0 || first_pair + n_pairs > ctx->capacity)
+        return fail(ctx, ISS_E_INVALID, "iss_output_download_coords: rows out of range");
+    std::vector<iss::PairDesc> tmp((size_t)n_pairs);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n_pairs)
+        HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->desc + first_pair, sizeof(iss::PairDesc) * (size_t)n_pairs,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        coords[4 * i + 0] = tmp[i].fs;
+        coords[4 * i + 1] = (int64_t)tmp[i].re - ctx->M.RL;
+        coords[4 * i + 2] = tmp[i].re;
+        coords[4 * i + 3] = tmp[i].isz;
+    }
+    return 0;
+}
+
+int iss_timing_enable(iss_ctx *ctx, int enable) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    int rc = settle_timing(ctx);
+    ctx->timing = enable != 0;
+    return rc;
+}
+
+int iss_timing_read(iss_ctx *ctx, double ms[4], int64_t *n_launches) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = settle_timing(ctx);
+    if (rc) return rc;
+    for (int k = 0; k < 4; ++k) { if (ms) ms[k] = ctx->ms_acc[k]; ctx->ms_acc[k] = 0; }
+    if (n_launches) *n_launches = ctx->n_launches;
+    ctx->n_launches = 0;
+    return 0;
+}
+
+int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t v = 0;
+    HIP_TRY(ctx, hipMemcpy(&v, ctx->stats, sizeof v, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof v));
+    if (n_fixup_reads) *n_fixup_reads = (int64_t)v;
+    return 0;
+}
+
+// ------------------------------------------------------------------ FASTQ formatting (host)
+static int write_all(int fd, const char *p, size_t n) {
+    while (n) {
+        ssize_t w = write(fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; return -1; }
+        p += w; n -= (size_t)w;
+    }
+    return 0;
+}
+
+static size_t fmt_u64(char *dst, uint64_t v) {
+    char tmp[24];
+    size_t n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    for (size_t i = 0; i < n; ++i) dst[i] = tmp[n - 1 - i];
+    return n;
+}
+
+int iss_fastq_write(int fd_r1, int fd_r2, const char *record_id, int64_t first_i, int32_t cpu_number, int64_t n_pairs,
+                    int32_t read_length, int32_t pitch, const uint8_t *r1_base, const uint8_t *r1_qual,
+                    const uint8_t *r2_base, const uint8_t *r2_qual, int32_t n_threads) {
+    if (!record_id || n_pairs < 0 || read_length < 1 || pitch < read_length || cpu_number < 0 || first_i < 0)
+        return fail(nullptr, ISS_E_INVALID, "iss_fastq_write: bad argument");
+    const size_t idlen = strlen(record_id);
+    const size_t max_rec = 1 + idlen + 1 + 20 + 1 + 11 + 2 + 1 + (size_t)read_length + 3 + (size_t)read_length + 1;
+    const int64_t chunk = 1 << 14;
+    n_threads = std::max(1, std::min<int32_t>(n_threads, 64));
+    char cpu_txt[16];
+    const size_t cpu_len = fmt_u64(cpu_txt, (uint64_t)cpu_number);
+    for (int64_t base = 0; base < n_pairs; base += chunk * n_threads) {
+        const int nt = (int)std::min<int64_t>(n_threads, (n_pairs - base + chunk - 1) / chunk);
+        std::vector<std::vector<char>> buf(2 * nt);
+        std::vector<size_t> used(2 * nt, 0);
+        auto work = [&](int t) {
+            const int64_t lo = base + (int64_t)t * chunk, hi = std::min(n_pairs, lo + chunk);
+            for (int mate = 0; mate < 2; ++mate) {
+                std::vector<char> &b = buf[2 * t + mate];
+                b.resize((size_t)(hi - lo) * max_rec);
+                char *w = b.data();
+                const uint8_t *bases = mate ? r2_base : r1_base, *quals = mate ? r2_qual : r1_qual;
+                for (int64_t i = lo; i < hi; ++i) {
+                    *w++ = '@';
+                    memcpy(w, record_id, idlen); w += idlen;
+                    *w++ = '_';
+                    w += fmt_u64(w, (uint64_t)(first_i + i));
+                    *w++ = '_';
+                    memcpy(w, cpu_txt, cpu_len); w += cpu_len;
+                    *w++ = '/'; *w++ = (char)('1' + mate); *w++ = '\n';
+                    memcpy(w, bases + (size_t)i * pitch, (size_t)read_length); w += read_length;
+                    *w++ = '\n'; *w++ = '+'; *w++ = '\n';
+                    const uint8_t *q = quals + (size_t)i * pitch;
+                    for (int k = 0; k < read_length; ++k) w[k] = (char)(33 + q[k]);
+                    w += read_length;
+                    *w++ = '\n';
+                }
+                used[2 * t + mate] = (size_t)(w - b.data());
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (int t = 0; t < nt; ++t) {
+            if (write_all(fd_r1, buf[2 * t].data(), used[2 * t]) || write_all(fd_r2, buf[2 * t + 1].data(), used[2 * t + 1]))
+                return fail(nullptr, ISS_E_IO, std::string("write failed: ") + strerror(errno));
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

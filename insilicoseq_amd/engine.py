@@ -1,0 +1,164 @@
+"""ReadEngine: one MI355X context = one reference worker (host-side driver over the C ABI).
+
+Uploads the model tables and genomes once to HBM, launches the read-generation kernels for
+(record, n_pairs) work items and brings the R1/R2 base + phred buffers back (or leaves them in
+HBM for a device-side consumer).  Everything numeric happens in the HIP library; this file is
+plumbing.  Reference counterparts: the body of ``worker_iterator`` / ``simulate_reads`` /
+``reads_generator`` (iss/generator.py:223-251, 21-66, 69-95)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import EngineError, SEQ_TYPES, check
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class ReadEngine(object):
+    def __init__(self, device=0):
+        self._lib = _native.lib()
+        self._ctx = C.c_void_p()
+        check(None, self._lib.iss_ctx_create(int(device), C.byref(self._ctx)))
+        self.device = int(device)
+        self.read_length = None
+        self.pitch = None
+        self._capacity = 0
+        self._genome_lengths = []
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.iss_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        return check(self._ctx, rc)
+
+    # ------------------------------------------------------------------ uploads
+    def load_model(self, dense):
+        """Upload a DenseModel (insilicoseq_amd.model) -- replaces pickling the ErrorModel to the worker."""
+        t = dense.device_tables()
+        keep = {
+            "isize_thr": _u64(t["isize_thr"]), "bin_thr": _u64(t["bin_thr"]), "q_thr": _u64(t["q_thr"]),
+            "subst_thr": _u64(t["subst_thr"]), "ins_thr": _u64(t["ins_thr"]), "del_thr": _u64(t["del_thr"]),
+            "mut_thr": _u64(t["mut_thr"]),
+            "bin_nonempty": np.ascontiguousarray(dense.bin_nonempty, dtype=np.uint8),
+            "subst_alt": np.ascontiguousarray(dense.subst_alt, dtype=np.uint8),
+            "ins_letter": np.ascontiguousarray(dense.ins_letter, dtype=np.uint8),
+        }
+        mt = _native.ModelTables()
+        mt.read_length = dense.read_length
+        mt.n_isize = dense.n_isize
+        mt.n_q = dense.n_q
+        for k, v in keep.items():
+            setattr(mt, k, v.ctypes.data)
+        self._check(self._lib.iss_model_upload(self._ctx, C.byref(mt)))
+        self.read_length = dense.read_length
+        self.pitch = self._lib.iss_output_pitch(self._ctx)
+        self._capacity = 0
+        return self
+
+    def add_genome(self, seq):
+        """Upload one record's sequence (str / bytes / uint8 array); returns its genome id."""
+        if isinstance(seq, str):
+            seq = seq.encode("ascii")
+        a = np.frombuffer(seq, dtype=np.uint8) if isinstance(seq, (bytes, bytearray)) else np.ascontiguousarray(
+            seq, dtype=np.uint8)
+        gid = C.c_int32(-1)
+        self._check(self._lib.iss_genome_upload(self._ctx, a.ctypes.data, a.size, C.byref(gid)))
+        self._genome_lengths.append(int(a.size))
+        return gid.value
+
+    def clear_genomes(self):
+        self._check(self._lib.iss_genome_clear(self._ctx))
+        self._genome_lengths = []
+
+    def genome_length(self, gid):
+        return self._genome_lengths[gid]
+
+    def reserve(self, n_pairs):
+        if n_pairs > self._capacity:
+            self._check(self._lib.iss_output_reserve(self._ctx, int(n_pairs)))
+            self._capacity = int(n_pairs)
+
+    # ------------------------------------------------------------------ the hot path
+    def generate(self, genome_id, n_pairs, first_ordinal=0, seed=0, sequence_type="metagenomics", gc_bias=False,
+                 out_first_pair=0):
+        """Asynchronously generate n_pairs pairs into rows [out_first_pair, +n_pairs).  Raises
+        EngineError(code=E_SHORT_RECORD) when read_length >= len(record) (the reference's
+        AssertionError, iss/generator.py:130)."""
+        if sequence_type not in SEQ_TYPES:
+            raise ValueError("Sequence type %s not known" % sequence_type)  # generator.py:171
+        self.reserve(out_first_pair + n_pairs)
+        self._check(self._lib.iss_generate(self._ctx, int(genome_id), int(n_pairs), int(first_ordinal) & (2**64 - 1),
+                                           int(seed) & (2**64 - 1), SEQ_TYPES[sequence_type], int(bool(gc_bias)),
+                                           int(out_first_pair)))
+
+    def synchronize(self):
+        self._check(self._lib.iss_synchronize(self._ctx))
+
+    def download(self, first_pair, n_pairs):
+        """Rows [first_pair, +n_pairs) as four uint8 arrays [n_pairs, read_length] (views on pitch-wide rows)."""
+        outs = [np.empty((n_pairs, self.pitch), dtype=np.uint8) for _ in range(4)]
+        self._check(self._lib.iss_output_download(self._ctx, int(first_pair), int(n_pairs),
+                                                  *[o.ctypes.data for o in outs]))
+        RL = self.read_length
+        return {"r1_base": outs[0][:, :RL], "r1_qual": outs[1][:, :RL], "r2_base": outs[2][:, :RL],
+                "r2_qual": outs[3][:, :RL], "_pitched": outs}
+
+    def coords(self, first_pair, n_pairs):
+        c = np.empty((n_pairs, 4), dtype=np.int64)
+        self._check(self._lib.iss_output_download_coords(self._ctx, int(first_pair), int(n_pairs), c.ctypes.data))
+        return c
+
+    def device_ptrs(self):
+        p = [C.c_void_p() for _ in range(4)]
+        self._check(self._lib.iss_output_device_ptrs(self._ctx, *[C.byref(x) for x in p]))
+        return [x.value for x in p]
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.iss_ctx_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
+
+    # ------------------------------------------------------------------ measurement
+    def timing_enable(self, on=True):
+        self._check(self._lib.iss_timing_enable(self._ctx, int(bool(on))))
+
+    def timing_read(self):
+        ms = (C.c_double * 4)()
+        n = C.c_int64(0)
+        self._check(self._lib.iss_timing_read(self._ctx, C.byref(ms), C.byref(n)))
+        return {"setup_ms": ms[0], "main_ms": ms[1], "indel_scan_ms": ms[2], "indel_fixup_ms": ms[3],
+                "launches": n.value}
+
+    def stats_read(self):
+        n = C.c_int64(0)
+        self._check(self._lib.iss_stats_read(self._ctx, C.byref(n)))
+        return {"fixup_reads": n.value}
+
+
+def fastq_write(fd_r1, fd_r2, record_id, first_i, cpu_number, n_pairs, read_length, pitch, r1_base, r1_qual, r2_base,
+                r2_qual, n_threads=4):
+    """FASTQ text for rows of pitched uint8 arrays (SeqIO.write(..., 'fastq-sanger'), generator.py:64-65)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (r1_base, r1_qual, r2_base, r2_qual)]
+    rc = _native.lib().iss_fastq_write(int(fd_r1), int(fd_r2), str(record_id).encode(), int(first_i), int(cpu_number),
+                                       int(n_pairs), int(read_length), int(pitch), *[a.ctypes.data for a in arrs],
+                                       int(n_threads))
+    check(None, rc)
+
+
+__all__ = ["ReadEngine", "EngineError", "fastq_write"]

@@ -1,0 +1,237 @@
+"""Host-side mirror of the reference's per-worker driver, on top of the HIP engine.
+
+Same function names, argument order and error behaviour as iss/generator.py so the parity
+tests read like the reference's:
+
+* ``worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence_type, gc_bias)``
+  -- iss/generator.py:223-251: creates ``{prefix}_R1.fastq``, ``{prefix}_R2.fastq``,
+  ``{prefix}.vcf``; worker seed = ``seed + cpu_number`` when ``seed is not None``; work items in
+  order; pair ids restart at 0 for every work item (:72-75); read ids
+  ``{record.id}_{i}_{cpu_number}/1|2`` (:150, 181).
+* ``simulate_reads`` -- iss/generator.py:21-66.
+* ``generate_work_divider`` -- iss/generator.py:254-356 (rounding correction :299-306, chunking
+  :333-356); ``to_coverage`` -- iss/abundance.py:178-193.
+
+One worker == one GPU (``cpu_number`` == rank).  The uniforms come from Philox addressed by
+(worker seed, running pair ordinal within the worker), so the output is a pure function of
+(seed, cpu_number, work list) -- independent of launch geometry.  It is bit-identical to the
+CPU oracle in Philox mode, which in MT mode is bit-identical to the reference.
+"""
+import logging
+import os
+import sys
+
+import numpy as np
+
+from . import _native
+from .engine import ReadEngine, fastq_write
+from .model import DenseModel
+
+
+class Record(object):
+    """The two attributes of a Bio.SeqRecord the hot path reads: ``id`` and ``seq``."""
+
+    def __init__(self, seq, id="<unknown id>", description=""):
+        self.seq = seq
+        self.id = id
+        self.description = description
+
+    def __len__(self):
+        return len(self.seq)
+
+
+def parse_fasta(path_or_handle):
+    """FASTA -> Records; id = first whitespace-separated token of the header, sequence case-preserved
+    (what Bio.SeqIO.parse(..., 'fasta') yields; pinned by iss/test/test_util.py:41-45)."""
+    fh = open(path_or_handle, "r") if isinstance(path_or_handle, (str, bytes, os.PathLike)) else path_or_handle
+    own = fh is not path_or_handle
+    try:
+        header, chunks = None, []
+        for line in fh:
+            line = line.rstrip("\r\n")
+            if line.startswith(">"):
+                if header is not None:
+                    yield Record("".join(chunks), id=(header.split(None, 1) or [""])[0], description=header)
+                header, chunks = line[1:], []
+            elif header is not None:
+                chunks.append(line.strip())
+        if header is not None:
+            yield Record("".join(chunks), id=(header.split(None, 1) or [""])[0], description=header)
+    finally:
+        if own:
+            fh.close()
+
+
+def to_coverage(total_n_reads, species_abundance, read_length, genome_size):
+    """iss/abundance.py:178-193"""
+    n_reads = total_n_reads * species_abundance
+    coverage = (n_reads * read_length) / genome_size
+    return coverage
+
+
+def generate_work_divider(fasta_file, readcount_dic, abundance_dic, n_reads, coverage, coverage_file, error_model,
+                          output, chunk_size):
+    """Yield lists of (record, n_pairs, mode) -- iss/generator.py:254-356.  ``mode`` is always
+    "default": the >2 GiB pickle spill (:313-331) is a transport workaround of the reference's
+    process pool and has no counterpart here (genomes are uploaded to HBM, not pickled)."""
+    logger = logging.getLogger(__name__)
+    current_chunk = 0
+    total_reads_generated = 0
+    total_reads_generated_unrounded = 0
+    chunk_work = []
+    for record in fasta_file:
+        if readcount_dic is not None:
+            if record.id not in readcount_dic:
+                logger.warning("Record %s not found in readcount file" % record.id)
+                continue
+            n_pairs_unrounded = readcount_dic[record.id] / 2
+        elif abundance_dic is not None:
+            if record.id not in abundance_dic:
+                logger.warning("Record %s not found in abundance file" % record.id)
+                continue
+            record_abundance = abundance_dic[record.id]
+            genome_size = len(record.seq)
+            if coverage or coverage_file:
+                record_coverage = record_abundance
+            else:
+                record_coverage = to_coverage(n_reads, record_abundance, error_model.read_length, genome_size)
+            n_pairs_unrounded = ((record_coverage * len(record.seq)) / error_model.read_length) / 2
+        else:
+            raise RuntimeError("No readcount or abundance file provided")
+        n_pairs = round(n_pairs_unrounded)
+        total_reads_generated_unrounded += n_pairs_unrounded
+        total_reads_generated += n_pairs
+        if round(total_reads_generated_unrounded) > total_reads_generated:
+            logger.debug("Adding a pair to correct rounding error")
+            n_pairs += 1
+            total_reads_generated += 1
+        logger.debug("Will generate %s read pairs for %s" % (n_pairs, record.id))
+        if n_pairs == 0:
+            continue
+        mode = "default"
+        n_pairs_remaining = n_pairs
+        while n_pairs_remaining > 0:
+            chunk_remaining = chunk_size - current_chunk
+            if n_pairs_remaining <= chunk_remaining:
+                chunk_work.append((record, n_pairs_remaining, mode))
+                n_pairs_added = n_pairs_remaining
+            else:
+                chunk_work.append((record, chunk_remaining, mode))
+                n_pairs_added = chunk_remaining
+            n_pairs_remaining -= n_pairs_added
+            current_chunk += n_pairs_added
+            if current_chunk == chunk_size:
+                yield chunk_work
+                chunk_work = []
+                current_chunk = 0
+    if chunk_work:
+        yield chunk_work
+
+
+def _dense_of(error_model):
+    if isinstance(error_model, DenseModel):
+        return error_model
+    if hasattr(error_model, "dense"):
+        return error_model.dense()
+    raise TypeError("error_model must be an insilicoseq_amd KDErrorModel or DenseModel")
+
+
+def worker_seed(seed, cpu_number):
+    """``seed + cpu_number`` when seeded (iss/generator.py:234-236); OS entropy otherwise."""
+    if seed is not None:
+        return (int(seed) + int(cpu_number)) & (2**64 - 1)
+    return int.from_bytes(os.urandom(8), "little")
+
+
+class Worker(object):
+    """State of one reference worker on one GPU: engine + uploaded genomes + running ordinal."""
+
+    BATCH_PAIRS = 1 << 20  # rows generated / downloaded / formatted per step of the streaming loop
+
+    def __init__(self, error_model, cpu_number, seed, device=None):
+        self.cpu_number = int(cpu_number)
+        self.seed = worker_seed(seed, cpu_number)
+        self.engine = ReadEngine(self.cpu_number if device is None else device)
+        self.dense = _dense_of(error_model)
+        self.engine.load_model(self.dense)
+        self.ordinal = 0
+        self._gids = {}
+
+    def close(self):
+        self.engine.close()
+
+    def genome_id(self, record):
+        key = id(record)
+        if key not in self._gids:
+            self._gids[key] = self.engine.add_genome(str(record.seq))
+        return self._gids[key]
+
+    def simulate_reads(self, record, n_pairs, forward_handle, reverse_handle, mutations_handle, sequence_type,
+                       gc_bias=False, writer_threads=4):
+        """iss/generator.py:21-66 for one work item, streamed in batches: generate on the GPU, copy
+        back, format FASTQ on host threads."""
+        logger = logging.getLogger(__name__)
+        logger.debug("Cpu #%s: Generating %s read pairs" % (self.cpu_number, n_pairs))
+        eng = self.engine
+        if not (eng.read_length < len(record.seq)):
+            # AssertionError in simulate_read -> warning + record skipped (generator.py:77-80)
+            logger.warning("%s shorter than read length for this ErrorModel" % record.id)
+            logger.warning("Skipping %s. You will have less reads than specified" % record.id)
+            return 0
+        gid = self.genome_id(record)
+        for fh in (forward_handle, reverse_handle):
+            fh.flush()
+        done = 0
+        while done < n_pairs:
+            n = min(self.BATCH_PAIRS, n_pairs - done)
+            eng.generate(gid, n, first_ordinal=self.ordinal, seed=self.seed, sequence_type=sequence_type,
+                         gc_bias=gc_bias, out_first_pair=0)
+            eng.synchronize()
+            rows = eng.download(0, n)["_pitched"]
+            fastq_write(forward_handle.fileno(), reverse_handle.fileno(), record.id, done, self.cpu_number, n,
+                        eng.read_length, eng.pitch, rows[0], rows[1], rows[2], rows[3], n_threads=writer_threads)
+            self.ordinal += n
+            done += n
+        return done
+
+
+def simulate_reads(record, error_model, n_pairs, cpu_number, forward_handle, reverse_handle, mutations_handle,
+                   sequence_type, gc_bias=False, mode="default", seed=None):
+    """Signature of iss/generator.py:21-32 (+ ``seed``: the reference reads the global RNG state)."""
+    w = Worker(error_model, cpu_number, seed, device=0)
+    try:
+        return w.simulate_reads(record, n_pairs, forward_handle, reverse_handle, mutations_handle, sequence_type,
+                                gc_bias)
+    finally:
+        w.close()
+
+
+def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence_type, gc_bias, device=None):
+    """iss/generator.py:223-251 on GPU ``device`` (default: ``cpu_number``)."""
+    logger = logging.getLogger(__name__)
+    if getattr(error_model, "store_mutations", False):
+        raise NotImplementedError("--store_mutations (VCF rows) is not on the device path yet (SURVEY.md 8 f3)")
+    if sequence_type not in _native.SEQ_TYPES:
+        raise RuntimeError("sequence type '%s' is not supported" % sequence_type)  # generator.py:139
+    try:
+        forward_handle = open("%s_R1.fastq" % worker_prefix, "w")
+        reverse_handle = open("%s_R2.fastq" % worker_prefix, "w")
+        mutation_handle = open("%s.vcf" % worker_prefix, "w")
+    except PermissionError as e:
+        logger.error("Failed to write temporary output file(s): %s" % e)
+        sys.exit(1)
+    w = Worker(error_model, cpu_number, seed, device=device)
+    try:
+        with forward_handle, reverse_handle, mutation_handle:
+            for record, n_pairs, _mode in work:
+                w.simulate_reads(record, n_pairs, forward_handle, reverse_handle, mutation_handle, sequence_type,
+                                 gc_bias)
+    finally:
+        w.close()
+
+
+def lognormal_abundance(record_ids, rng):
+    """iss/abundance.py:137-154 with an explicit RandomState."""
+    dist = rng.lognormal(size=len(record_ids))
+    dist_scaled = dist / sum(dist)
+    return {r: a for r, a in zip(record_ids, dist_scaled)}

@@ -1,0 +1,113 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle in Philox mode, bit-exact.
+
+The oracle itself is pinned to the reference in MT mode (tests/test_oracle_golden.py); both
+providers feed the same semantic function, so HIP == oracle(Philox) closes the chain."""
+import numpy as np
+import pytest
+
+from helpers import dense_model, mixed_genome, random_genome
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from insilicoseq_amd.engine import ReadEngine
+
+    eng = ReadEngine(0)
+    yield eng
+    eng.close()
+
+
+def _compare(engine, dense, genome, n_pairs, seed, first_ordinal=0, sequence_type="metagenomics", gc_bias=False):
+    from oracle import oracle as O
+
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.generate(gid, n_pairs, first_ordinal=first_ordinal, seed=seed, sequence_type=sequence_type,
+                    gc_bias=gc_bias)
+    engine.synchronize()
+    got = engine.download(0, n_pairs)
+    coords = engine.coords(0, n_pairs)
+    rng = O.Rng().seed_philox(seed)
+    exp = O.Oracle(dense).simulate(rng, genome, n_pairs, first_ordinal=first_ordinal, sequence_type=sequence_type,
+                                   gc_bias=gc_bias, want_coords=True)
+    assert exp["status"] == 0 and exp["n_done"] == n_pairs
+    assert (coords == exp["coords"]).all(), "pair coordinates differ"
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        bad = np.argwhere(got[k] != exp[k])
+        assert bad.size == 0, "%s differs at (pair, pos) %s ... (%d cells)" % (k, bad[:5].tolist(), len(bad))
+    return got, engine.stats_read()
+
+
+CASES = [
+    # (model, indel override, genome builder, n_pairs, seed, first_ordinal, seq_type, gc_bias)
+    ("novaseq", None, lambda: random_genome(11, 200000), 6000, 42, 0, "metagenomics", False),
+    ("novaseq", None, lambda: mixed_genome(12, 50000), 3000, 2**40 + 17, 2**33 + 5, "metagenomics", False),
+    ("novaseq", None, lambda: random_genome(13, 200), 1500, 7, 100, "metagenomics", False),
+    ("novaseq", None, lambda: random_genome(14, 700), 1500, 8, 0, "amplicon", False),
+    ("novaseq", None, lambda: random_genome(15, 100000), 3000, 9, 12345, "metagenomics", True),
+    ("hiseq", None, lambda: random_genome(16, 300000), 5000, 10, 0, "metagenomics", False),
+    ("hiseq", None, lambda: mixed_genome(17, 20000), 3000, 11, 0, "metagenomics", True),
+    ("miseq", None, lambda: random_genome(18, 100000), 3000, 12, 0, "metagenomics", False),
+    ("miseq", None, lambda: random_genome(19, 420), 1000, 13, 0, "metagenomics", False),
+    ("miseq-legacy", None, lambda: random_genome(20, 50000), 2500, 14, 0, "metagenomics", False),
+    ("miseq-legacy", None, lambda: mixed_genome(21, 30000), 1500, 15, 0, "metagenomics", False),
+    ("nextseq", None, lambda: random_genome(22, 50000), 1500, 16, 0, "metagenomics", False),
+    ("miseq-36", None, lambda: random_genome(23, 50000), 1000, 17, 0, "metagenomics", False),
+    ("ecoli", None, lambda: random_genome(24, 3000), 4000, 18, 0, "metagenomics", False),
+    ("novaseq", (0.001, 0.003), lambda: random_genome(25, 100000), 3000, 19, 0, "metagenomics", False),
+    ("novaseq", (0.01, 0.03), lambda: mixed_genome(26, 30000), 2000, 20, 0, "metagenomics", False),
+    ("novaseq", (0.2, 0.35), lambda: random_genome(27, 5000), 600, 21, 0, "metagenomics", False),
+    ("novaseq", (1.0, 0.0), lambda: random_genome(28, 5000), 200, 22, 0, "metagenomics", False),
+    ("novaseq", (0.0, 1.0), lambda: random_genome(29, 5000), 200, 23, 0, "metagenomics", False),
+    ("novaseq", (1.0, 1.0), lambda: mixed_genome(30, 5000), 200, 24, 0, "amplicon", False),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_hip_matches_oracle(engine, case):
+    model, indel, mk_genome, n_pairs, seed, first, seq_type, gc_bias = CASES[case]
+    _, stats = _compare(engine, dense_model(model, indel), mk_genome(), n_pairs, seed, first, seq_type, gc_bias)
+    if indel is not None and indel[0] + indel[1] >= 0.01:
+        assert stats["fixup_reads"] > 0  # the indel fix-up path really ran
+
+
+def test_rows_and_ordinals_compose(engine):
+    """Two calls writing adjacent rows with consecutive ordinals == one call (work items of a worker)."""
+    dense = dense_model("hiseq")
+    genome = random_genome(31, 80000)
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.generate(gid, 3000, first_ordinal=50, seed=99)
+    engine.synchronize()
+    whole = engine.download(0, 3000)
+    whole = {k: v.copy() for k, v in whole.items() if not k.startswith("_")}
+    engine.generate(gid, 1234, first_ordinal=50, seed=99, out_first_pair=0)
+    engine.generate(gid, 3000 - 1234, first_ordinal=50 + 1234, seed=99, out_first_pair=1234)
+    engine.synchronize()
+    parts = engine.download(0, 3000)
+    for k in whole:
+        assert (whole[k] == parts[k]).all()
+
+
+def test_short_record_is_reported(engine):
+    from insilicoseq_amd import _native
+
+    engine.load_model(dense_model("novaseq"))
+    engine.clear_genomes()
+    gid = engine.add_genome("ACGT" * 30)  # 120 <= read_length 151
+    with pytest.raises(_native.EngineError) as e:
+        engine.generate(gid, 10)
+    assert e.value.code == _native.E_SHORT_RECORD
+
+
+def test_invalid_letter_is_rejected(engine):
+    from insilicoseq_amd import _native
+
+    engine.load_model(dense_model("ecoli"))
+    with pytest.raises(_native.EngineError) as e:
+        engine.add_genome("ACGTXACGT" * 10)
+    assert e.value.code == _native.E_INVALID
