@@ -22,6 +22,7 @@ namespace {
 thread_local std::string g_last_error;
 
 struct Genome {
+    uint32_t *packed_alloc = nullptr, *mask_alloc = nullptr;  // allocations (one leading pad word)
     uint32_t *packed = nullptr;
     uint32_t *mask = nullptr;
     uint8_t *ascii = nullptr;
@@ -37,6 +38,7 @@ struct TimedLaunch {
 
 struct iss_ctx {
     int device = 0;
+    int n_cu = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string last_error;
@@ -145,6 +147,13 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     iss_ctx *ctx = new iss_ctx();
     ctx->device = device_ordinal;
     HIP_TRY(ctx, hipSetDevice(device_ordinal));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, device_ordinal));
+        ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_main),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     void *p = nullptr;
@@ -178,7 +187,7 @@ int iss_ctx_set_stream(iss_ctx *ctx, void *hip_stream) {
 
 int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     if (!ctx || !t) return fail(ctx, ISS_E_INVALID, "iss_model_upload: NULL argument");
-    if (t->read_length < 2 || t->read_length > iss::FIX_STACK)
+    if (t->read_length < 2 || t->read_length > iss::FIX_MAX_RL)
         return fail(ctx, ISS_E_INVALID, "read_length must be in [2, 1024]");
     if (t->n_isize < 1 || t->n_q < 1 || t->n_q > 255) return fail(ctx, ISS_E_INVALID, "bad table sizes");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -212,9 +221,74 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     M = iss::DevModel{};
     M.RL = RL; M.n_isize = t->n_isize; M.n_q = nq;
     M.G = (RL + 3) / 4; M.pitch = M.G * 4;
-    std::vector<uint32_t> q_hi(n_qthr), mut_hi(nq + 1);
-    for (size_t i = 0; i < n_qthr; ++i) q_hi[i] = (uint32_t)(t->q_thr[i] >> 26);
-    for (int i = 0; i <= nq; ++i) mut_hi[i] = (uint32_t)(t->mut_thr[i] >> 26);
+    // ---- compressed quality rows for k_main: per (orientation, bin slot, position) the distinct
+    // 16-bit leading digits of the thresholds, packed (t16 << 8 | #thresholds below), + a 64-byte
+    // guide (first entry for each value of the top 6 bits) + a sentinel.
+    int n_slots[2] = {0, 0};
+    for (int o = 0; o < 2; ++o)
+        for (int b = 0; b < 4; ++b) {
+            M.bin_slot[o * 4 + b] = -1;
+            M.slot_bin[o * 4 + b] = 0;
+        }
+    for (int o = 0; o < 2; ++o)
+        for (int b = 0; b < 4; ++b)
+            if (t->bin_nonempty[o * 4 + b]) {
+                M.bin_slot[o * 4 + b] = (int8_t)n_slots[o];
+                M.slot_bin[o * 4 + n_slots[o]] = (int8_t)b;
+                ++n_slots[o];
+            }
+    if (!n_slots[0] || !n_slots[1]) return fail(ctx, ISS_E_INVALID, "model has no quality histograms");
+    M.NB = std::max(n_slots[0], n_slots[1]);
+    for (int o = 0; o < 2; ++o)
+        for (int sl = n_slots[o]; sl < M.NB; ++sl) M.slot_bin[o * 4 + sl] = M.slot_bin[o * 4];
+    auto build_row = [&](int o, int bin, int p, std::vector<uint32_t> &entries) {
+        const uint64_t *row = t->q_thr + ((size_t)(o * 4 + bin) * RL + p) * nq;
+        entries.clear();
+        for (int i = 0; i < nq; ++i) {
+            const uint32_t v = (uint32_t)(row[i] >> 37);
+            if (entries.empty() || (entries.back() >> 8) != v) entries.push_back((v << 8) | (uint32_t)i);
+        }
+        entries.push_back((0x1ffffu << 8) | (uint32_t)nq);  // sentinel: above every 16-bit digit
+    };
+    std::vector<uint32_t> entries;
+    size_t s_max = 0;
+    for (int o = 0; o < 2; ++o)
+        for (int sl = 0; sl < M.NB; ++sl)
+            for (int p = 0; p < RL; ++p) {
+                build_row(o, M.slot_bin[o * 4 + sl], p, entries);
+                s_max = std::max(s_max, entries.size());
+            }
+    M.stride_w = (int32_t)((16 + s_max + 3) / 4 * 4);
+    const size_t lds_budget = 150 * 1024;
+    M.n_tiles = 1;
+    for (;; ++M.n_tiles) {
+        M.TG = (M.G + M.n_tiles - 1) / M.n_tiles;
+        M.TP = M.TG * 4;
+        M.tile_words = 2 * M.NB * M.TP * M.stride_w;
+        if ((size_t)M.tile_words * 4 + (size_t)(nq + 1) * 4 <= lds_budget) break;
+        if (M.TG == 1) return fail(ctx, ISS_E_INVALID, "quality tables do not fit the LDS even for one position group");
+    }
+    M.n_tiles = (M.G + M.TG - 1) / M.TG;
+    std::vector<uint32_t> qrows((size_t)M.n_tiles * M.tile_words, 0);
+    for (int tl = 0; tl < M.n_tiles; ++tl)
+        for (int o = 0; o < 2; ++o)
+            for (int sl = 0; sl < M.NB; ++sl)
+                for (int pp = 0; pp < M.TP; ++pp) {
+                    const int p = std::min(tl * M.TP + pp, RL - 1);
+                    build_row(o, M.slot_bin[o * 4 + sl], p, entries);
+                    uint32_t *dst = qrows.data() + (size_t)tl * M.tile_words +
+                                    ((size_t)(o * M.NB + sl) * M.TP + pp) * M.stride_w;
+                    uint8_t *guide = reinterpret_cast<uint8_t *>(dst);
+                    size_t j = 0;
+                    for (uint32_t b = 0; b < 64; ++b) {
+                        while ((entries[j] >> 8) < (b << 10)) ++j;
+                        guide[b] = (uint8_t)j;
+                    }
+                    std::copy(entries.begin(), entries.end(), dst + 16);
+                    for (size_t k = 16 + entries.size(); k < (size_t)M.stride_w; ++k) dst[k] = entries.back();
+                }
+    std::vector<uint32_t> mut16(nq + 1);
+    for (int i = 0; i <= nq; ++i) mut16[i] = (uint32_t)(t->mut_thr[i] >> 37);
     std::vector<uint64_t> del_max((size_t)2 * RL);
     std::vector<uint8_t> ins_any((size_t)2 * RL), amask(M.G, 0);
     std::vector<int32_t> agroups;
@@ -235,7 +309,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(isize_thr, t->isize_thr, (size_t)t->n_isize, uint64_t);
     UP(bin_thr, t->bin_thr, 8, uint64_t);
     UP(q_thr, t->q_thr, n_qthr, uint64_t);
-    UP(q_thr_hi, q_hi.data(), n_qthr, uint32_t);
+    UP(qrows, qrows.data(), qrows.size(), uint32_t);
+    UP(mut16, mut16.data(), mut16.size(), uint32_t);
     UP(subst_thr, t->subst_thr, (size_t)2 * RL * 12, uint64_t);
     UP(subst_alt, t->subst_alt, (size_t)2 * RL * 12, uint8_t);
     UP(ins_thr, t->ins_thr, (size_t)2 * RL * 4, uint64_t);
@@ -243,7 +318,6 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(del_thr, t->del_thr, (size_t)2 * RL * 4, uint64_t);
     UP(del_thr_max, del_max.data(), del_max.size(), uint64_t);
     UP(mut_thr, t->mut_thr, (size_t)nq + 1, uint64_t);
-    UP(mut_thr_hi, mut_hi.data(), mut_hi.size(), uint32_t);
     UP(ins_any, ins_any.data(), ins_any.size(), uint8_t);
     UP(active_groups, agroups.data(), agroups.size(), int32_t);
     UP(active_mask, amask.data(), amask.size(), uint8_t);
@@ -257,7 +331,8 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     if (!ctx || !ascii || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload: NULL argument");
     if (length < 1 || length >= (int64_t)0x7fffffff) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^31-2]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t n_pk = (size_t)(length + 15) / 16 + 2, n_mk = (size_t)(length + 31) / 32 + 2;
+    // one readable padding word in front (k_main's funnel shifts touch positions >= -3) and two behind
+    const size_t n_pk = (size_t)(length + 15) / 16 + 3, n_mk = (size_t)(length + 31) / 32 + 3;
     std::vector<uint32_t> pk(n_pk, 0), mk(n_mk, 0);
     for (int64_t i = 0; i < length; ++i) {
         const uint8_t c = ascii[i];
@@ -272,16 +347,18 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
                     return fail(ctx, ISS_E_INVALID, buf);
                 }
                 code = 0;
-                mk[i >> 5] |= 1u << (i & 31);
+                mk[1 + (i >> 5)] |= 1u << (i & 31);
         }
-        pk[i >> 4] |= code << ((i & 15) * 2);
+        pk[1 + (i >> 4)] |= code << ((i & 15) * 2);
     }
     Genome G;
     G.L = length;
     int rc;
-    if ((rc = upload<uint32_t>(ctx, pk.data(), n_pk, &G.packed, nullptr))) return rc;
-    if ((rc = upload<uint32_t>(ctx, mk.data(), n_mk, &G.mask, nullptr))) return rc;
+    if ((rc = upload<uint32_t>(ctx, pk.data(), n_pk, &G.packed_alloc, nullptr))) return rc;
+    if ((rc = upload<uint32_t>(ctx, mk.data(), n_mk, &G.mask_alloc, nullptr))) return rc;
     if ((rc = upload<uint8_t>(ctx, ascii, (size_t)length, &G.ascii, nullptr))) return rc;
+    G.packed = G.packed_alloc + 1;
+    G.mask = G.mask_alloc + 1;
     ctx->genomes.push_back(G);
     *genome_id = (int32_t)ctx->genomes.size() - 1;
     return 0;
@@ -290,7 +367,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
 int iss_genome_clear(iss_ctx *ctx) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &G : ctx->genomes) { (void)hipFree(G.packed); (void)hipFree(G.mask); (void)hipFree(G.ascii); }
+    for (auto &G : ctx->genomes) { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); }
     ctx->genomes.clear();
     return 0;
 }
@@ -374,9 +451,13 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         }
         HIP_TRY(ctx, mark(1));
         {
-            const uint64_t items = (uint64_t)n * M.G;
-            const unsigned blocks = (unsigned)((items + 255) / 256);
-            hipLaunchKernelGGL(iss::k_main, dim3(blocks), dim3(256), 0, ctx->stream, M, dg, A, desc);
+            const size_t lds_bytes = (size_t)M.tile_words * 4 + (size_t)(M.n_q + 1) * 4;
+            const uint64_t items = (uint64_t)n * M.TG;
+            unsigned per_tile = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu, (items + 1023) / 1024);
+            per_tile = std::max(1u, per_tile / (unsigned)M.n_tiles * 1u);
+            if (per_tile * (unsigned)M.n_tiles < (unsigned)ctx->n_cu && items > (uint64_t)per_tile * 1024) ++per_tile;
+            hipLaunchKernelGGL(iss::k_main, dim3(per_tile * (unsigned)M.n_tiles), dim3(1024), lds_bytes, ctx->stream, M,
+                               dg, A, desc);
         }
         HIP_TRY(ctx, mark(2));
         if (M.n_active_groups > 0) {
@@ -389,8 +470,8 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         }
         HIP_TRY(ctx, mark(3));
         if (M.n_active_groups > 0) {
-            const unsigned blocks = (unsigned)std::min<int64_t>(4096, (2 * n + 63) / 64);
-            hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64), 0, ctx->stream, M, dg, A, desc, fix_list,
+            const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
+            hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), 0, ctx->stream, M, dg, A, desc, fix_list,
                                ctx->fix_count, ctx->stats);
         }
         HIP_TRY(ctx, mark(4));

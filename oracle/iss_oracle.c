@@ -139,15 +139,22 @@ void iss_oracle_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t
     philox4x32_10(ctr, key, out);
 }
 
-/* Draw kinds of the Philox address map (DESIGN.md "RNG address map"). */
+/* Draw kinds of the Philox address map (DESIGN.md "RNG address map").
+ * A "digit draw" builds its 53-bit numerator as m = (h16 << 37) | l37: the 16-bit leading digit
+ * comes from a PRIMARY block shared by 8 draws (so the device needs one Philox call per 8 draws
+ * and compares 16-bit prefixes), the trailing 37 bits from a SECONDARY block that the device only
+ * evaluates when the prefix ties with a threshold.  u = m / 2^53 exactly. */
 enum {
-    K_PAIR = 0, /* index 0; sub 0 = first words, sub 1 = second words of (isize, bin_fwd, bin_rev, gc) */
-    K_FS = 1,   /* forward-start randbelow words: word t -> index t/4, lane t%4       */
-    K_RS = 2,   /* reverse-end fallback randbelow words, same addressing               */
-    K_QM = 3,   /* index = position p; (qual_fwd, mut_fwd, qual_rev, mut_rev); sub 0/1 */
-    K_SUB = 4,  /* index = p; sub 0 = (fwd.w0, fwd.w1, rev.w0, rev.w1)                 */
-    K_INS = 5,  /* index = n; sub = 2*mate + {0: first words, 1: second words}; 4 letters */
-    K_DEL = 6   /* index = n; sub 0 = (fwd.w0, fwd.w1, rev.w0, rev.w1)                 */
+    K_PAIR = 0,   /* index 0; full draws mk53(sub0.word[s], sub1.word[s]), s = isize, bin_fwd, bin_rev, gc */
+    K_FS = 1,     /* forward-start randbelow words: word t -> index t/4, word t%4        */
+    K_RS = 2,     /* reverse-end fallback randbelow words, same addressing               */
+    K_QM = 3,     /* primary digits; index = p>>1; digit (p&1)*4 + {0 qual_fwd,1 mut_fwd,2 qual_rev,3 mut_rev} */
+    K_SUB = 4,    /* index = p; full draws mk53(w0,w1) fwd, mk53(w2,w3) rev              */
+    K_INS = 5,    /* primary digits; index = n; digit mate*4 + letter slot               */
+    K_DEL = 6,    /* primary digits; index = n>>2; digit (n&3)*2 + mate                   */
+    K_QM_LO = 7,  /* secondary; index = p; sub = mate; (w0,w1) qual, (w2,w3) mut          */
+    K_INS_LO = 8, /* secondary; index = n; sub = mate*2 + (slot>>1); pair slot&1          */
+    K_DEL_LO = 9  /* secondary; index = n; sub 0; (w0,w1) fwd, (w2,w3) rev                */
 };
 
 /* ------------------------------------------------------------- RNG provider */
@@ -217,10 +224,9 @@ static void philox_at(const iss_rng *r, int kind, uint32_t index, uint32_t sub, 
 #define STREAM_PY 0
 #define STREAM_NP 1
 
-/* One uniform double in [0,1): `stream` selects the MT stream in MT mode; the
- * (kind, index, slot) address selects the Philox words in Philox mode.
- * two_block != 0: first word = block sub0 word `slot`, second word = block sub1 word `slot`;
- * two_block == 0: both words from block sub0: words 2*slot, 2*slot+1. */
+/* Full-width draw: MT mode = next double of `stream`; Philox mode = mk53 of two words.
+ * two_block != 0: words `slot` of blocks (kind,index,sub0) and (kind,index,sub0+1);
+ * two_block == 0: words 2*slot, 2*slot+1 of block (kind,index,sub0). */
 static double draw_double(iss_rng *r, int stream, int kind, uint32_t index, uint32_t sub0, int slot, int two_block) {
     if (r->mode == ISS_RNG_MT)
         return stream == STREAM_PY ? iss_oracle_py_random(r) : iss_oracle_np_random(r);
@@ -231,6 +237,21 @@ static double draw_double(iss_rng *r, int stream, int kind, uint32_t index, uint
         return res53(w[slot], w2[slot]);
     }
     return res53(w[2 * slot], w[2 * slot + 1]);
+}
+
+/* Digit draw (see the enum comment): primary block (kind_p, index_p, 0) digit `digit`,
+ * secondary block (kind_l, index_l, sub_l) word pair `pair_l`. */
+static double draw_digit(iss_rng *r, int stream, int kind_p, uint32_t index_p, int digit, int kind_l,
+                         uint32_t index_l, uint32_t sub_l, int pair_l) {
+    if (r->mode == ISS_RNG_MT)
+        return stream == STREAM_PY ? iss_oracle_py_random(r) : iss_oracle_np_random(r);
+    uint32_t wp[4], wl[4];
+    philox_at(r, kind_p, index_p, 0, wp);
+    philox_at(r, kind_l, index_l, sub_l, wl);
+    uint64_t h16 = (wp[digit >> 1] >> (16 * (digit & 1))) & 0xffffu;
+    uint64_t l37 = ((uint64_t)wl[2 * pair_l] << 5) | (wl[2 * pair_l + 1] >> 27);
+    uint64_t m = (h16 << 37) | l37;
+    return (double)m * (1.0 / 9007199254740992.0);
 }
 
 static int bit_length64(uint64_t n) { int k = 0; while (n) { k++; n >>= 1; } return k; }
@@ -384,7 +405,8 @@ static int introduce_indels(const iss_model *m, iss_rng *r, int o, const uint8_t
         const double *insp = m->ins + ((size_t)o * RL + position) * 4;
         const uint8_t *insl = m->ins_letter + ((size_t)o * RL + position) * 4;
         for (int x = 0; x < 4; x++) { /* :193-196, dict order */
-            double u = draw_double(r, STREAM_PY, K_INS, (uint32_t)position, (uint32_t)(2 * o), x, 1);
+            double u = draw_digit(r, STREAM_PY, K_INS, (uint32_t)position, 4 * o + x, K_INS_LO, (uint32_t)position,
+                                  (uint32_t)(2 * o + (x >> 1)), x & 1);
             if (u < insp[x]) {
                 memmove(s + position + 2, s + position + 1, (size_t)(n_s - position - 1));
                 s[position + 1] = insl[x];
@@ -395,7 +417,8 @@ static int introduce_indels(const iss_model *m, iss_rng *r, int o, const uint8_t
         }
         int bi = base_index(cu);
         if (bi < 0) { free(s); return ISS_ERR_KEY; } /* deletions[position][X] KeyError :209 */
-        double u = draw_double(r, STREAM_PY, K_DEL, (uint32_t)position, 0, o, 0);
+        double u = draw_digit(r, STREAM_PY, K_DEL, (uint32_t)position >> 2, (position & 3) * 2 + o, K_DEL_LO,
+                              (uint32_t)position, 0, o);
         if (u < m->del[((size_t)o * RL + position) * 4 + bi]) {
             memmove(s + position, s + position + 1, (size_t)(n_s - position - 1));
             n_s--;
@@ -454,7 +477,8 @@ static void gen_phred_scores(const iss_model *m, iss_rng *r, int o, uint8_t *qua
     if (bin >= 4) bin = 3; /* unreachable (cdf[-1] == 1.0 > u), mirrors kde.py:77-78 */
     const double *rows = m->qcdf + (((size_t)o * 4 + bin) * RL) * m->n_q;
     for (int p = 0; p < RL; p++) { /* kde.py:83-85 */
-        double u = draw_double(r, STREAM_NP, K_QM, (uint32_t)p, 0, 2 * o, 1);
+        double u = draw_digit(r, STREAM_NP, K_QM, (uint32_t)p >> 1, (p & 1) * 4 + 2 * o, K_QM_LO, (uint32_t)p,
+                              (uint32_t)o, 0);
         qual[p] = (uint8_t)searchsorted_left(rows + (size_t)p * m->n_q, m->n_q, u);
     }
 }
@@ -465,7 +489,8 @@ static int mut_sequence(const iss_model *m, iss_rng *r, int o, uint8_t *seq, con
                         const uint8_t *original, mut_sink *sink) {
     const int RL = m->read_length;
     for (int p = 0; p < RL; p++) {
-        double u = draw_double(r, STREAM_PY, K_QM, (uint32_t)p, 0, 2 * o + 1, 1); /* always drawn, :94 */
+        double u = draw_digit(r, STREAM_PY, K_QM, (uint32_t)p >> 1, (p & 1) * 4 + 2 * o + 1, K_QM_LO, (uint32_t)p,
+                              (uint32_t)o, 1); /* always drawn, :94 */
         int cu = upper_c(seq[p]);
         if (u > m->phred_thr[qual[p]] && !is_ambiguous_upper(cu)) {
             int bi = base_index(cu);
