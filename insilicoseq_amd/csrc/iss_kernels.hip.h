@@ -44,8 +44,8 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);  // 3-input xor
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -84,14 +84,18 @@ struct DevModel {
     int32_t RL, n_isize, n_q, G, pitch;  // G = pitch/4 = position groups per read
     // compressed quality rows for k_main (built at upload, see iss_mi355x.hip: build_qrows)
     int32_t NB;          // bin slots per orientation (non-empty bins, compacted)
-    int32_t stride_w;    // u32 words per row: 16 guide words + (S_max + 1) entries, multiple of 4
+    int32_t GB;          // guide bits: a row starts with 1 << GB guide bytes (top GB bits of the digit)
+    int32_t stride_w;    // u32 words per row: guide words + (S_max + 2) entries
+    int32_t GS;          // words per position group = 4 * stride_w + 1 (odd: consecutive lanes hit distinct LDS banks)
     int32_t TG, TP;      // position groups / positions per tile
     int32_t n_tiles;
-    int32_t tile_words;  // 2 * NB * TP * stride_w
+    int32_t tile_words;  // 2 * NB * TG * GS rounded up to a multiple of 4
     int8_t bin_slot[8];  // [o][bin] -> slot (or -1)
     int8_t slot_bin[8];  // [o][slot] -> bin
-    const uint32_t *qrows;      // [n_tiles][2][NB][TP][stride_w]
+    const uint32_t *qrows;      // [n_tiles][2][NB][TG] groups of GS words (4 rows of stride_w + 1 pad)
     const uint32_t *mut16;      // [n_q+1]  mut_thr >> 37
+    const uint32_t *subst16;    // [n_tiles][2][TP][4] x {t0_16 | t1_16 << 16, alt0 | alt1 << 8 | alt2 << 16}
+    int32_t subst_words;        // per tile: 2 * TP * 4 * 2
     const uint64_t *isize_thr;  // [n_isize]
     const uint64_t *bin_thr;    // [2][4]
     const uint64_t *q_thr;      // [2][4][RL][n_q]   (exact tie resolution)
@@ -103,9 +107,8 @@ struct DevModel {
     const uint64_t *del_thr_max;  // [2][RL]  max over bases
     const uint64_t *mut_thr;      // [n_q+1]
     const uint8_t *ins_any;       // [2][RL] any insertion threshold non-zero at (o, n)
-    const int32_t *active_groups;  // groups (4 positions) containing an indel-active (o, n)
-    const uint8_t *active_mask;    // [G] bit (o*4+c): (o, 4*g+c) has a non-zero indel threshold
-    int32_t n_active_groups;
+    const uint32_t *scan_tab;      // [n_scan][SCAN_W]: loop steps n with a non-zero indel probability (k_indel_scan)
+    int32_t n_scan;
 };
 
 struct DevGenome {
@@ -131,6 +134,7 @@ struct RunArgs {
     int32_t gc_bias;
     uint64_t gc_thr;  // ceil(0.90 * 2^53): accept iff m < gc_thr (generator.py:88)
     uint8_t *out[4];  // rows of this launch: R1 base, R1 qual, R2 base, R2 qual
+    uint32_t *slow_ovf;  // k_main: per-workgroup spill area of the deferred-work queue
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -228,15 +232,6 @@ __device__ __forceinline__ int substitute(const DevModel &M, const Addr &a, int 
     return M.subst_alt[row + k];
 }
 
-// quality CDF inversion on a compressed row (LDS or global): 64 guide bytes, then packed entries
-// (t16 << 8 | phred) sorted by t16 with a sentinel; phred = #(thresholds < m) if no tie.
-__device__ __forceinline__ uint32_t qrow_lookup(const uint32_t *row, uint32_t h) {
-    uint32_t j = reinterpret_cast<const uint8_t *>(row)[h >> 10];
-    uint32_t e = row[16 + j];
-    while ((e >> 8) < h) e = row[16 + (++j)];
-    return e;  // (e >> 8) == h  <=>  tie
-}
-
 // ================================================================== k_setup
 __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -300,121 +295,230 @@ __device__ __forceinline__ uint32_t codes_to_ascii4(uint32_t b) {
     return __builtin_amdgcn_perm(0u, 0x47435441u, sel);  // selector values 0..3 pick bytes of "ATCG"
 }
 
-__global__ __launch_bounds__(1024) void k_main(DevModel M, DevGenome g, RunArgs A, const PairDesc *__restrict__ desc) {
+constexpr int MAIN_THREADS = 1024;
+constexpr int SLOW_QCAP = 2048;  // deferred-work queue entries per workgroup (LDS)
+constexpr int SLOW_EVERY = 16;   // drain the queue every SLOW_EVERY loop iterations
+
+// Dynamic LDS of k_main (32-bit words):
+//   [0, mut_words)            error-test table: mut16[q] - 1 (signed), q = 0..n_q
+//   [rows, +tile_words)       compressed quality rows of the position tile: per (mate, bin slot, group)
+//                             GS words = 4 rows of stride_w words + 1 pad word; a row = guide bytes
+//                             (1 << GB of them) then packed entries (t16 << 8 | phred), ascending,
+//                             closed by two sentinels
+//   [subst, +subst_words)     substitution table (leading digits + alternatives)
+//   [q_count], [queue]        deferred-work queue
+struct MainTile {  // per-workgroup constants of k_main (word offsets into the dynamic LDS array)
+    uint32_t rows;
+    uint32_t subst16;
+    int g0;        // first position group of the tile
+    uint32_t tg;   // groups in the tile
+};
+
+// The rare work of one lane-item, done exactly.  `rare` bit (7 - s), s = mate*4 + c: base s hit a rare
+// condition in the hot loop (leading-digit tie, more than two thresholds in its guide bucket, or the
+// substitution test fired / tied).  Everything about such a base is recomputed here from its
+// uniforms; the four dwords the hot path stored are re-read and patched.
+__device__ __forceinline__ void main_slow_item(const DevModel &M, const RunArgs &A, const PairDesc *__restrict__ desc,
+                                               const uint32_t *lds, const MainTile &T, uint32_t it, uint32_t rare) {
+    const uint32_t pair = it / T.tg, grp = it - pair * T.tg;
+    const int p0 = (T.g0 + (int)grp) * 4;
+    const PairDesc d = desc[pair];
+    const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
+    const size_t dw = (size_t)pair * M.G + (size_t)(T.g0 + grp);
+    uint32_t bases[2], quals[2];
+    bases[0] = reinterpret_cast<const uint32_t *>(A.out[0])[dw];
+    quals[0] = reinterpret_cast<const uint32_t *>(A.out[1])[dw];
+    bases[1] = reinterpret_cast<const uint32_t *>(A.out[2])[dw];
+    quals[1] = reinterpret_cast<const uint32_t *>(A.out[3])[dw];
+    const uint32_t gbytes = 1u << M.GB;
+    for (int s = 0; s < 8; ++s) {
+        if (!((rare >> (7 - s)) & 1u)) continue;
+        const int o = s >> 2, c = s & 3, p = p0 + c;
+        if (p >= M.RL) continue;
+        const uint32_t slot = (d.meta >> (2 * o)) & 3u;
+        const u32x4 w = draw_block(a, K_QM, (uint32_t)(p >> 1), 0);
+        const uint32_t wd = word_of(w, (p & 1) * 2 + o);  // low half: quality digit, high half: error-test digit
+        const uint32_t h = wd & 0xffffu, hm = wd >> 16;
+        // quality: full search of the LDS row, exact thresholds on a tie
+        const uint32_t row = T.rows + ((uint32_t)(o * M.NB) + slot) * (uint32_t)M.TG * (uint32_t)M.GS + grp * (uint32_t)M.GS +
+                             (uint32_t)c * (uint32_t)M.stride_w;
+        uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))];
+        uint32_t e = lds[row + gbytes / 4 + j];
+        while ((e >> 8) < h) e = lds[row + gbytes / 4 + (++j)];
+        uint32_t q = e & 0xffu;
+        if ((e >> 8) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
+        quals[o] = (quals[o] & ~(0xffu << (8 * c))) | (q << (8 * c));
+        // substitution test (__init__.py:94)
+        const uint32_t t = (uint32_t)((int32_t)lds[q] + 1);
+        bool err = hm > t;
+        if (hm == t) err = mut_exact(M, a, o, p, hm, (int)q);
+        if (!err) continue;
+        const int base = (int)((bases[o] >> (8 * c)) & 0xffu);
+        const int bi = base_index(base);
+        if (bi < 0) continue;  // nucl.upper() in "RYWSMKHBVDN": left alone
+        const u32x4 sb = draw_block(a, K_SUB, (uint32_t)p, 0);
+        const uint64_t m = o ? mk53(sb.z, sb.w) : mk53(sb.x, sb.y);
+        const uint32_t hs = (uint32_t)(m >> 37);
+        const uint32_t *se = lds + T.subst16 + ((uint32_t)(o * M.TP + (p - T.g0 * 4)) * 4 + bi) * 2;
+        const uint32_t t0 = se[0] & 0xffffu, t1 = se[0] >> 16;
+        int k;
+        if (hs == t0 || hs == t1) {  // tie of a leading digit: exact thresholds
+            const size_t srow = ((size_t)(o * M.RL + p) * 4 + bi) * 3;
+            k = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
+        } else {
+            k = (hs > t0) + (hs > t1);
+        }
+        const uint32_t nb = (se[1] >> (8 * k)) & 0xffu;
+        bases[o] = (bases[o] & ~(0xffu << (8 * c))) | (nb << (8 * c));
+    }
+    reinterpret_cast<uint32_t *>(A.out[0])[dw] = bases[0];
+    reinterpret_cast<uint32_t *>(A.out[1])[dw] = quals[0];
+    reinterpret_cast<uint32_t *>(A.out[2])[dw] = bases[1];
+    reinterpret_cast<uint32_t *>(A.out[3])[dw] = quals[1];
+}
+
+// One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive
+// entries -> select; returns the selected entry (phred in its low byte) and ORs into `x` a word whose
+// SIGN BIT is set when the base needs the exact path (tie, > 2 thresholds in the bucket, error).
+__device__ __forceinline__ uint32_t hot_lookup(const uint32_t *lds, uint32_t row_b, uint32_t ent_b, uint32_t wd,
+                                               int gshift, uint32_t &x) {
+    const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds);
+    const uint32_t h = wd & 0xffffu;
+    const uint32_t j = ldsb[row_b + (h >> gshift)];
+    const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + ent_b + j * 4);
+    const uint32_t e0 = ent[0], e1 = ent[1];
+    const uint32_t h8 = h << 8;
+    const uint32_t sel = e0 >= h8 ? e0 : e1;           // first entry with t16 >= h (if among the two)
+    const int32_t mt1 = *reinterpret_cast<const int32_t *>(ldsb + ((sel & 0xffu) << 2));  // mut16[phred] - 1
+    x = (e1 - h8)               // < 0: a third threshold of the bucket is below h
+        | ((sel ^ h8) - 256u)   // < 0: tie of the leading digit
+        | (uint32_t)(mt1 - (int32_t)(wd >> 16));  // < 0: substitution test fires or ties
+    return sel;
+}
+
+__global__ __launch_bounds__(MAIN_THREADS) void k_main(DevModel M, DevGenome g, RunArgs A,
+                                                       const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tile = blockIdx.x % M.n_tiles;
     const uint32_t wg = blockIdx.x / M.n_tiles, n_wg = gridDim.x / M.n_tiles;
-    {   // stage this tile's quality rows + the substitution-test thresholds in LDS (once per workgroup)
+    const int mut_words = (M.n_q + 1 + 3) & ~3;
+    MainTile T;
+    T.rows = (uint32_t)mut_words;
+    T.subst16 = (uint32_t)(mut_words + M.tile_words);
+    T.g0 = tile * M.TG;
+    T.tg = (uint32_t)min(M.TG, M.G - T.g0);
+    uint32_t *q_count = lds + T.subst16 + M.subst_words;
+    uint32_t *queue = q_count + 4;
+    // global spill area of this workgroup's queue (only touched when > SLOW_QCAP entries are pending)
+    uint32_t *ovf = A.slow_ovf + (size_t)blockIdx.x * (2 * SLOW_EVERY * MAIN_THREADS);
+    {   // stage this tile's tables in LDS (once per workgroup)
+        for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) lds[i] = M.mut16[i] - 1u;
         const uint4 *src = reinterpret_cast<const uint4 *>(M.qrows + (size_t)tile * M.tile_words);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + T.rows);
         for (int i = threadIdx.x; i < M.tile_words / 4; i += blockDim.x) dst[i] = src[i];
-        for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) lds[M.tile_words + i] = M.mut16[i];
+        const uint32_t *ssrc = M.subst16 + (size_t)tile * M.subst_words;
+        for (int i = threadIdx.x; i < M.subst_words; i += blockDim.x) lds[T.subst16 + i] = ssrc[i];
+        if (threadIdx.x == 0) *q_count = 0;
     }
     __syncthreads();
-    const uint32_t *mut16 = lds + M.tile_words;
-    const int g0 = tile * M.TG;
-    const uint32_t tg = (uint32_t)min(M.TG, M.G - g0);  // groups of this tile
+    const uint32_t tg = T.tg;
+    const int g0 = T.g0;
     const uint32_t n_items = (uint32_t)A.n_pairs * tg;
     const uint32_t step = n_wg * blockDim.x;
     const uint32_t step_pair = step / tg, step_grp = step - step_pair * tg;
-    uint32_t it = wg * blockDim.x + threadIdx.x;
+    const uint32_t first = wg * blockDim.x;
+    const uint32_t n_iter = n_items > first ? (n_items - first + step - 1) / step : 0;  // uniform in the workgroup
+    uint32_t it = first + threadIdx.x;
     uint32_t pair = it / tg, grp = it - pair * tg;
     const int RL = M.RL;
-    const size_t mate_rows = (size_t)M.NB * M.TP;  // rows per orientation inside the tile
-    for (; it < n_items; it += step) {
-        const int p0 = (g0 + (int)grp) * 4;
-        const PairDesc d = desc[pair];
-        const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
-        const uint32_t slot_f = d.meta & 3u, slot_r = (d.meta >> 2) & 3u;
-        // ---- template bases: forward g[fs+p0 .. +3]; reverse comp(g[re-1-p0 .. -3])
-        uint32_t fb, fm, rb, rm;
-        {
-            const int32_t pf = d.fs + p0;
-            const uint32_t *pw = g.packed + (pf >> 4);
-            fb = funnel_r(pw[0], pw[1], (uint32_t)(pf & 15) * 2) & 0xffu;
-            const uint32_t *mw = g.mask + (pf >> 5);
-            fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xfu;
-            const int32_t pr = d.re - 4 - p0;  // lowest genome position of the 4 reverse bases
-            const uint32_t *qw = g.packed + (pr >> 4);
-            rb = funnel_r(qw[0], qw[1], (uint32_t)(pr & 15) * 2) & 0xffu;
-            const uint32_t *nw = g.mask + (pr >> 5);
-            rm = funnel_r(nw[0], nw[1], (uint32_t)(pr & 31)) & 0xfu;
-        }
-        uint32_t base_f = codes_to_ascii4(fb);
-        uint32_t base_r = __builtin_amdgcn_perm(0u, codes_to_ascii4(rb ^ 0x55u), 0x00010203u);  // complement, reversed
-        if (fm | rm) {  // IUPAC / lower-case letters: patch from the ASCII copy
-            for (int c = 0; c < 4; ++c) {
-                if ((fm >> c) & 1u) {
-                    const uint32_t ch = g.ascii[(int64_t)d.fs + p0 + c];
-                    base_f = (base_f & ~(0xffu << (8 * c))) | (ch << (8 * c));
-                }
-                if ((rm >> (3 - c)) & 1u) {
-                    const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)d.re - 1 - p0 - c]);
-                    base_r = (base_r & ~(0xffu << (8 * c))) | (ch << (8 * c));
-                }
+    const int gshift = 16 - M.GB;
+    const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
+    const uint32_t slot_b = (uint32_t)M.TG * (uint32_t)M.GS * 4u;  // bytes per (mate, bin slot)
+    for (uint32_t iter = 0; iter < n_iter; ++iter) {
+        if (it < n_items) {
+            const int p0 = (g0 + (int)grp) * 4;
+            const PairDesc d = desc[pair];
+            const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
+            // ---- sixteen 16-bit leading digits: (quality, error test) x (fwd, rev) x 4 positions
+            const u32x4 wq0 = draw_block(a, K_QM, (uint32_t)(p0 >> 1), 0);
+            const u32x4 wq1 = draw_block(a, K_QM, (uint32_t)(p0 >> 1) + 1, 0);
+            // ---- template bases: forward g[fs+p0 .. +3]; reverse comp(g[re-1-p0 .. -3])
+            uint32_t fb, fm, rb, rm;
+            {
+                const int32_t pf = d.fs + p0;
+                const uint32_t *pw = g.packed + (pf >> 4);
+                fb = funnel_r(pw[0], pw[1], (uint32_t)(pf & 15) * 2) & 0xffu;
+                const uint32_t *mw = g.mask + (pf >> 5);
+                fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xfu;
+                const int32_t pr = d.re - 4 - p0;  // lowest genome position of the 4 reverse bases
+                const uint32_t *qw = g.packed + (pr >> 4);
+                rb = funnel_r(qw[0], qw[1], (uint32_t)(pr & 15) * 2) & 0xffu;
+                const uint32_t *nw = g.mask + (pr >> 5);
+                rm = funnel_r(nw[0], nw[1], (uint32_t)(pr & 31)) & 0xfu;
             }
-        }
-        // ---- phred scores and the substitution test, 16-bit leading digits
-        const uint32_t *rows_f = lds + ((size_t)slot_f * M.TP + (p0 - g0 * 4)) * M.stride_w;
-        const uint32_t *rows_r = lds + (mate_rows + (size_t)slot_r * M.TP + (p0 - g0 * 4)) * M.stride_w;
-        uint32_t qual_f = 0, qual_r = 0;
-        uint32_t slow = 0;  // per base c (fwd) / 4+c (rev): bit 0-7 quality tie, 8-15 error, 16-23 error tie
-        const u32x4 wq0 = draw_block(a, K_QM, (uint32_t)(p0 >> 1), 0);
-        const u32x4 wq1 = draw_block(a, K_QM, (uint32_t)(p0 >> 1) + 1, 0);
+            // ---- phred scores + substitution test, loop-free (hot_lookup); 8 independent lookups
+            const uint32_t rowf_b = (T.rows + grp * (uint32_t)M.GS) * 4u + (d.meta & 3u) * slot_b;
+            const uint32_t rowr_b = (T.rows + grp * (uint32_t)M.GS) * 4u + ((uint32_t)M.NB + ((d.meta >> 2) & 3u)) * slot_b;
+            uint32_t sel[8], rare = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int pc = min(p0 + c, RL - 1) - p0;  // clamp the padding lanes of the last group
-            const u32x4 &w = (c >> 1) ? wq1 : wq0;
-            const uint32_t wf = (c & 1) ? w.z : w.x, wr = (c & 1) ? w.w : w.y;
-            {
-                const uint32_t e = qrow_lookup(rows_f + (size_t)pc * M.stride_w, wf & 0xffffu);
-                const uint32_t q = e & 0xffu, hm = wf >> 16, t = mut16[q];
-                qual_f |= q << (8 * c);
-                slow |= ((e >> 8) == (wf & 0xffffu) ? 1u : 0u) << c;
-                slow |= (hm > t ? 1u : 0u) << (8 + c);
-                slow |= (hm == t ? 1u : 0u) << (16 + c);
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t pc_b = (uint32_t)(min(p0 + c, RL - 1) - p0) * stride_b;  // clamp the padding lanes
+                const u32x4 &w = (c >> 1) ? wq1 : wq0;
+                uint32_t x;
+                sel[c] = hot_lookup(lds, rowf_b + pc_b, rowf_b + pc_b + gbytes, (c & 1) ? w.z : w.x, gshift, x);
+                rare = __builtin_amdgcn_alignbit(rare, x, 31);  // rare = rare << 1 | sign(x)
             }
-            {
-                const uint32_t e = qrow_lookup(rows_r + (size_t)pc * M.stride_w, wr & 0xffffu);
-                const uint32_t q = e & 0xffu, hm = wr >> 16, t = mut16[q];
-                qual_r |= q << (8 * c);
-                slow |= ((e >> 8) == (wr & 0xffffu) ? 1u : 0u) << (4 + c);
-                slow |= (hm > t ? 1u : 0u) << (12 + c);
-                slow |= (hm == t ? 1u : 0u) << (20 + c);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t pc_b = (uint32_t)(min(p0 + c, RL - 1) - p0) * stride_b;
+                const u32x4 &w = (c >> 1) ? wq1 : wq0;
+                uint32_t x;
+                sel[4 + c] = hot_lookup(lds, rowr_b + pc_b, rowr_b + pc_b + gbytes, (c & 1) ? w.w : w.y, gshift, x);
+                rare = __builtin_amdgcn_alignbit(rare, x, 31);
             }
-        }
-        if (slow) {  // ties of a leading digit (~2e-4 / draw) and substitution errors (~1e-3 / base)
-            for (int s = 0; s < 8; ++s) {
-                if (!((slow >> s) & 0x010101u)) continue;
-                const int o = s >> 2, c = s & 3, p = p0 + c;
-                if (p >= RL) continue;
-                const uint32_t wd = (c >> 1) ? (o ? ((c & 1) ? wq1.w : wq1.y) : ((c & 1) ? wq1.z : wq1.x))
-                                             : (o ? ((c & 1) ? wq0.w : wq0.y) : ((c & 1) ? wq0.z : wq0.x));
-                uint32_t &qual = o ? qual_r : qual_f;
-                uint32_t &bases = o ? base_r : base_f;
-                uint32_t q = (qual >> (8 * c)) & 0xffu;
-                bool err = (slow >> (8 + s)) & 1u, tie_m = (slow >> (16 + s)) & 1u;
-                if ((slow >> s) & 1u) {  // quality tie: exact phred, then redo the error test
-                    q = (uint32_t)quality_exact(M, a, o, o ? slot_r : slot_f, p, wd & 0xffffu);
-                    qual = (qual & ~(0xffu << (8 * c))) | (q << (8 * c));
-                    const uint32_t t = mut16[q];
-                    err = (wd >> 16) > t;
-                    tie_m = (wd >> 16) == t;
-                }
-                if (tie_m) err = mut_exact(M, a, o, p, wd >> 16, (int)q);
-                if (err) {
-                    const uint32_t nb = (uint32_t)substitute(M, a, o, p, (int)((bases >> (8 * c)) & 0xffu));
-                    bases = (bases & ~(0xffu << (8 * c))) | (nb << (8 * c));
+            // phred bytes: low byte of each selected entry
+            const uint32_t qual_f = __builtin_amdgcn_perm(sel[1], sel[0], 0x0c0c0400u) | __builtin_amdgcn_perm(sel[3], sel[2], 0x04000c0cu);
+            const uint32_t qual_r = __builtin_amdgcn_perm(sel[5], sel[4], 0x0c0c0400u) | __builtin_amdgcn_perm(sel[7], sel[6], 0x04000c0cu);
+            uint32_t base_f = codes_to_ascii4(fb);
+            uint32_t base_r = __builtin_amdgcn_perm(0u, codes_to_ascii4(rb ^ 0x55u), 0x00010203u);  // complement, reversed
+            if (fm | rm) {  // IUPAC / lower-case letters: patch from the ASCII copy
+                for (int c = 0; c < 4; ++c) {
+                    if ((fm >> c) & 1u) {
+                        const uint32_t ch = g.ascii[(int64_t)d.fs + p0 + c];
+                        base_f = (base_f & ~(0xffu << (8 * c))) | (ch << (8 * c));
+                    }
+                    if ((rm >> (3 - c)) & 1u) {
+                        const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)d.re - 1 - p0 - c]);
+                        base_r = (base_r & ~(0xffu << (8 * c))) | (ch << (8 * c));
+                    }
                 }
             }
+            const int nvalid = RL - p0;  // zero the padding bytes of the last group
+            const uint32_t keep = nvalid >= 4 ? 0xffffffffu : ((1u << (8 * nvalid)) - 1u);
+            const size_t dw = (size_t)pair * M.G + (size_t)(g0 + grp);
+            reinterpret_cast<uint32_t *>(A.out[0])[dw] = base_f & keep;
+            reinterpret_cast<uint32_t *>(A.out[1])[dw] = qual_f & keep;
+            reinterpret_cast<uint32_t *>(A.out[2])[dw] = base_r & keep;
+            reinterpret_cast<uint32_t *>(A.out[3])[dw] = qual_r & keep;
+            if (rare & 0xffu) {  // ~1.5 % of lane-items: deferred to a dense pass over an LDS queue
+                const uint32_t slot = atomicAdd(q_count, 1u);
+                uint32_t *dst = slot < (uint32_t)SLOW_QCAP ? queue + 2 * slot : ovf + 2 * (size_t)(slot - SLOW_QCAP);
+                dst[0] = it;
+                dst[1] = rare & 0xffu;
+            }
         }
-        const int nvalid = RL - p0;  // zero the padding bytes of the last group
-        const uint32_t keep = nvalid >= 4 ? 0xffffffffu : ((1u << (8 * nvalid)) - 1u);
-        const size_t dw = (size_t)pair * M.G + (size_t)(g0 + grp);
-        reinterpret_cast<uint32_t *>(A.out[0])[dw] = base_f & keep;
-        reinterpret_cast<uint32_t *>(A.out[1])[dw] = qual_f & keep;
-        reinterpret_cast<uint32_t *>(A.out[2])[dw] = base_r & keep;
-        reinterpret_cast<uint32_t *>(A.out[3])[dw] = qual_r & keep;
+        if ((iter % SLOW_EVERY) == SLOW_EVERY - 1 || iter == n_iter - 1) {
+            __syncthreads();  // also makes this workgroup's global stores visible to all of its lanes
+            const uint32_t nq = *q_count;  // <= SLOW_EVERY * MAIN_THREADS: the overflow area always suffices
+            for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
+                const uint32_t *src = i < (uint32_t)SLOW_QCAP ? queue + 2 * i : ovf + 2 * (size_t)(i - SLOW_QCAP);
+                main_slow_item(M, A, desc, lds, T, src[0], src[1]);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) *q_count = 0;
+            __syncthreads();
+        }
+        it += step;
         pair += step_pair;
         grp += step_grp;
         if (grp >= tg) { grp -= tg; ++pair; }
@@ -425,49 +529,51 @@ __global__ __launch_bounds__(1024) void k_main(DevModel M, DevGenome g, RunArgs 
 // Conservative: flags mate o of a pair when some indel uniform's leading digit is <= the leading
 // digit of a non-zero threshold (max over bases for deletions).  No flag  =>  provably no indel
 // event (the first event in loop order would have been flagged), so k_main's output stands.
-__global__ __launch_bounds__(256) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc,
+// One lane per (pair, loop step n that has a non-zero indel probability); the per-step limits
+// (digit < lim  <=>  candidate; lim = (thr >> 37) + 1, 0 = never) sit in LDS.
+constexpr int SCAN_W = 13;  // words per entry (odd: bank-conflict free): [0] n | any_ins<<16 | any_del<<17,
+                            // [1..8] insertion limits digit o*4+x, [9..10] deletion limits o, [11..12] pad
+
+__global__ __launch_bounds__(512) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc,
                                                     uint32_t *flags, uint32_t *fix_list, uint32_t *fix_count) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_items = (uint32_t)A.n_pairs * (uint32_t)M.n_active_groups;
-    if (t >= n_items) return;
-    const uint32_t pair = t / (uint32_t)M.n_active_groups;
-    const int grp = M.active_groups[t - pair * (uint32_t)M.n_active_groups];
-    const uint32_t amask = M.active_mask[grp];
-    const Addr a = make_addr(A.seed, A.first_ordinal + pair, desc[pair].meta >> 16);
-    uint32_t cand = 0;
-    u32x4 dl = {0, 0, 0, 0};
-    bool have_del = false;
-    for (int c = 0; c < 4; ++c) {
-        const int n = grp * 4 + c;
-        if (n > M.RL - 2) break;  // loop is range(read_length - 1), __init__.py:187
-        if (!((amask >> c) & 0x11u)) continue;
-        u32x4 wi = {0, 0, 0, 0};
-        bool have_ins = false;
-        for (int o = 0; o < 2; ++o) {
-            if (!((amask >> (o * 4 + c)) & 1u)) continue;
-            const size_t e = (size_t)o * M.RL + n;
-            if (M.ins_any[e]) {
-                if (!have_ins) { wi = draw_block(a, K_INS, (uint32_t)n, 0); have_ins = true; }
-                for (int x = 0; x < 4; ++x) {
-                    const uint64_t T = M.ins_thr[e * 4 + x];
-                    if (T && digit16(wi, o * 4 + x) <= (uint32_t)(T >> 37)) cand |= 1u << o;
-                }
-            }
-            const uint64_t Td = M.del_thr_max[e];
-            if (Td) {
-                if (!have_del) { dl = draw_block(a, K_DEL, (uint32_t)grp, 0); have_del = true; }
-                if (digit16(dl, c * 2 + o) <= (uint32_t)(Td >> 37)) cand |= 1u << o;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    for (int i = threadIdx.x; i < M.n_scan * SCAN_W; i += blockDim.x) lds[i] = M.scan_tab[i];
+    __syncthreads();
+    const uint32_t ns = (uint32_t)M.n_scan;
+    const uint32_t n_items = (uint32_t)A.n_pairs * ns;
+    const uint32_t step = gridDim.x * blockDim.x;
+    const uint32_t step_pair = step / ns, step_e = step - step_pair * ns;
+    uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t pair = it / ns, e = it - pair * ns;
+    for (; it < n_items; it += step) {
+        const uint32_t *tab = lds + e * SCAN_W;
+        const uint32_t head = tab[0];
+        const uint32_t n = head & 0xffffu;
+        const Addr a = make_addr(A.seed, A.first_ordinal + pair, desc[pair].meta >> 16);
+        uint32_t cand = 0;
+        if (head & 0x10000u) {
+            const u32x4 w = draw_block(a, K_INS, n, 0);
+#pragma unroll
+            for (int dgt = 0; dgt < 8; ++dgt)
+                if (digit16(w, dgt) < tab[1 + dgt]) cand |= 1u << (dgt >> 2);
+        }
+        if (head & 0x20000u) {
+            const u32x4 w = draw_block(a, K_DEL, n >> 2, 0);
+            if (digit16(w, (int)(n & 3u) * 2) < tab[9]) cand |= 1u;
+            if (digit16(w, (int)(n & 3u) * 2 + 1) < tab[10]) cand |= 2u;
+        }
+        if (cand) {
+            const uint32_t old = atomicOr(&flags[pair], cand);
+            uint32_t fresh = cand & ~old;
+            while (fresh) {
+                const int o = __ffs(fresh) - 1;
+                fresh &= fresh - 1;
+                fix_list[atomicAdd(fix_count, 1u)] = pair * 2u + (uint32_t)o;
             }
         }
-    }
-    if (cand) {
-        const uint32_t old = atomicOr(&flags[pair], cand);
-        uint32_t fresh = cand & ~old;
-        while (fresh) {
-            const int o = __ffs(fresh) - 1;
-            fresh &= fresh - 1;
-            fix_list[atomicAdd(fix_count, 1u)] = pair * 2u + (uint32_t)o;
-        }
+        pair += step_pair;
+        e += step_e;
+        if (e >= ns) { e -= ns; ++pair; }
     }
 }
 

@@ -55,6 +55,8 @@ struct iss_ctx {
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
+    uint32_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][2 * SLOW_EVERY * MAIN_THREADS]
+    unsigned max_main_grid = 0;
     uint64_t *stats = nullptr;
     // timing
     bool timing = false;
@@ -114,6 +116,12 @@ bool valid_letter(uint8_t c) {
     }
 }
 
+// dynamic LDS of k_main: quality rows + error-test thresholds + substitution table + deferred-work queue
+size_t main_lds_bytes(const iss::DevModel &M) {
+    const size_t mut_words = ((size_t)M.n_q + 1 + 3) & ~(size_t)3;
+    return ((size_t)M.tile_words + mut_words + (size_t)M.subst_words + 4 + 2 * (size_t)iss::SLOW_QCAP) * 4;
+}
+
 int settle_timing(iss_ctx *ctx) {
     for (auto &t : ctx->timed) {
         HIP_TRY(ctx, hipEventSynchronize(t.ev[4]));
@@ -161,6 +169,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->fix_count = static_cast<uint32_t *>(p);
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 16);
     HIP_TRY(ctx, hipMemset(p, 0, 64));
+    ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
+    HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * 2 * iss::SLOW_EVERY * iss::MAIN_THREADS * sizeof(uint32_t)));
+    ctx->slow_ovf = static_cast<uint32_t *>(p);
     *out = ctx;
     return 0;
 }
@@ -174,6 +185,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     free_outputs(ctx);
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
+    if (ctx->slow_ovf) (void)hipFree(ctx->slow_ovf);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -248,7 +260,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             const uint32_t v = (uint32_t)(row[i] >> 37);
             if (entries.empty() || (entries.back() >> 8) != v) entries.push_back((v << 8) | (uint32_t)i);
         }
-        entries.push_back((0x1ffffu << 8) | (uint32_t)nq);  // sentinel: above every 16-bit digit
+        entries.push_back((0x1ffffu << 8) | (uint32_t)nq);  // two sentinels above every 16-bit digit: the hot
+        entries.push_back((0x1ffffu << 8) | (uint32_t)nq);  // loop reads entries j and j + 1 unconditionally
     };
     std::vector<uint32_t> entries;
     size_t s_max = 0;
@@ -258,14 +271,18 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                 build_row(o, M.slot_bin[o * 4 + sl], p, entries);
                 s_max = std::max(s_max, entries.size());
             }
-    M.stride_w = (int32_t)((16 + s_max + 3) / 4 * 4);
-    const size_t lds_budget = 150 * 1024;
+    M.GB = 6;
+    const int gwords = (1 << M.GB) / 4;
+    M.stride_w = (int32_t)(gwords + s_max);
+    M.GS = 4 * M.stride_w + 1;
+    const size_t lds_budget = 158 * 1024;
     M.n_tiles = 1;
     for (;; ++M.n_tiles) {
         M.TG = (M.G + M.n_tiles - 1) / M.n_tiles;
         M.TP = M.TG * 4;
-        M.tile_words = 2 * M.NB * M.TP * M.stride_w;
-        if ((size_t)M.tile_words * 4 + (size_t)(nq + 1) * 4 <= lds_budget) break;
+        M.tile_words = (2 * M.NB * M.TG * M.GS + 3) / 4 * 4;
+        M.subst_words = 2 * M.TP * 4 * 2;
+        if (main_lds_bytes(M) <= lds_budget) break;
         if (M.TG == 1) return fail(ctx, ISS_E_INVALID, "quality tables do not fit the LDS even for one position group");
     }
     M.n_tiles = (M.G + M.TG - 1) / M.TG;
@@ -277,21 +294,33 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     const int p = std::min(tl * M.TP + pp, RL - 1);
                     build_row(o, M.slot_bin[o * 4 + sl], p, entries);
                     uint32_t *dst = qrows.data() + (size_t)tl * M.tile_words +
-                                    ((size_t)(o * M.NB + sl) * M.TP + pp) * M.stride_w;
+                                    ((size_t)(o * M.NB + sl) * M.TG + pp / 4) * M.GS + (size_t)(pp & 3) * M.stride_w;
                     uint8_t *guide = reinterpret_cast<uint8_t *>(dst);
                     size_t j = 0;
-                    for (uint32_t b = 0; b < 64; ++b) {
-                        while ((entries[j] >> 8) < (b << 10)) ++j;
+                    for (uint32_t b = 0; b < (1u << M.GB); ++b) {
+                        while ((entries[j] >> 8) < (b << (16 - M.GB))) ++j;
                         guide[b] = (uint8_t)j;
                     }
-                    std::copy(entries.begin(), entries.end(), dst + 16);
-                    for (size_t k = 16 + entries.size(); k < (size_t)M.stride_w; ++k) dst[k] = entries.back();
+                    std::copy(entries.begin(), entries.end(), dst + gwords);
+                    for (size_t k = gwords + entries.size(); k < (size_t)M.stride_w; ++k) dst[k] = entries.back();
+                }
+    std::vector<uint32_t> subst16((size_t)M.n_tiles * M.subst_words, 0);
+    for (int tl = 0; tl < M.n_tiles; ++tl)
+        for (int o = 0; o < 2; ++o)
+            for (int pp = 0; pp < M.TP; ++pp)
+                for (int bi = 0; bi < 4; ++bi) {
+                    const int p = std::min(tl * M.TP + pp, RL - 1);
+                    const size_t row = ((size_t)(o * RL + p) * 4 + bi) * 3;
+                    auto d16 = [](uint64_t T) { return (uint32_t)std::min<uint64_t>(T >> 37, 0xffffu); };
+                    uint32_t *dst = subst16.data() + (size_t)tl * M.subst_words + ((size_t)(o * M.TP + pp) * 4 + bi) * 2;
+                    dst[0] = d16(t->subst_thr[row]) | (d16(t->subst_thr[row + 1]) << 16);
+                    dst[1] = (uint32_t)t->subst_alt[row] | ((uint32_t)t->subst_alt[row + 1] << 8) |
+                             ((uint32_t)t->subst_alt[row + 2] << 16);
                 }
     std::vector<uint32_t> mut16(nq + 1);
     for (int i = 0; i <= nq; ++i) mut16[i] = (uint32_t)(t->mut_thr[i] >> 37);
     std::vector<uint64_t> del_max((size_t)2 * RL);
-    std::vector<uint8_t> ins_any((size_t)2 * RL), amask(M.G, 0);
-    std::vector<int32_t> agroups;
+    std::vector<uint8_t> ins_any((size_t)2 * RL);
     for (int o = 0; o < 2; ++o)
         for (int n = 0; n < RL; ++n) {
             const size_t e = (size_t)o * RL + n;
@@ -299,10 +328,24 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             for (int x = 0; x < 4; ++x) { dm = std::max(dm, t->del_thr[e * 4 + x]); im = std::max(im, t->ins_thr[e * 4 + x]); }
             del_max[e] = dm;
             ins_any[e] = im ? 1 : 0;
-            if ((dm || im) && n <= RL - 2) amask[n / 4] |= (uint8_t)(1u << (o * 4 + (n & 3)));
         }
-    for (int gI = 0; gI < M.G; ++gI) if (amask[gI]) agroups.push_back(gI);
-    M.n_active_groups = (int32_t)agroups.size();
+    // k_indel_scan table: one entry per loop step n <= RL-2 (__init__.py:187) with any non-zero threshold
+    std::vector<uint32_t> scan_tab;
+    auto lim = [](uint64_t T) { return T ? (uint32_t)(T >> 37) + 1u : 0u; };
+    for (int n = 0; n <= RL - 2; ++n) {
+        uint32_t ent[iss::SCAN_W] = {0};
+        bool any_ins = false, any_del = false;
+        for (int o = 0; o < 2; ++o) {
+            const size_t e = (size_t)o * RL + n;
+            for (int x = 0; x < 4; ++x) { ent[1 + o * 4 + x] = lim(t->ins_thr[e * 4 + x]); any_ins |= ent[1 + o * 4 + x] != 0; }
+            ent[9 + o] = lim(del_max[e]);
+            any_del |= ent[9 + o] != 0;
+        }
+        if (!any_ins && !any_del) continue;
+        ent[0] = (uint32_t)n | (any_ins ? 0x10000u : 0u) | (any_del ? 0x20000u : 0u);
+        scan_tab.insert(scan_tab.end(), ent, ent + iss::SCAN_W);
+    }
+    M.n_scan = (int32_t)(scan_tab.size() / iss::SCAN_W);
     int rc = 0;
     auto *tr = &ctx->model_allocs;
 #define UP(field, src, n, T) if ((rc = upload<T>(ctx, src, n, const_cast<T **>(&M.field), tr))) return rc
@@ -311,6 +354,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(q_thr, t->q_thr, n_qthr, uint64_t);
     UP(qrows, qrows.data(), qrows.size(), uint32_t);
     UP(mut16, mut16.data(), mut16.size(), uint32_t);
+    UP(subst16, subst16.data(), subst16.size(), uint32_t);
     UP(subst_thr, t->subst_thr, (size_t)2 * RL * 12, uint64_t);
     UP(subst_alt, t->subst_alt, (size_t)2 * RL * 12, uint8_t);
     UP(ins_thr, t->ins_thr, (size_t)2 * RL * 4, uint64_t);
@@ -319,8 +363,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(del_thr_max, del_max.data(), del_max.size(), uint64_t);
     UP(mut_thr, t->mut_thr, (size_t)nq + 1, uint64_t);
     UP(ins_any, ins_any.data(), ins_any.size(), uint8_t);
-    UP(active_groups, agroups.data(), agroups.size(), int32_t);
-    UP(active_mask, amask.data(), amask.size(), uint8_t);
+    UP(scan_tab, scan_tab.data(), scan_tab.size(), uint32_t);
 #undef UP
     ctx->have_model = true;
     free_outputs(ctx);  // pitch may have changed
@@ -421,7 +464,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
     if (n_pairs == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L};
-    const int64_t max_chunk = std::max<int64_t>(1, (int64_t)0x7fffffff / std::max(M.G, std::max(M.n_active_groups, 1)) / 2);
+    const int64_t max_chunk = std::max<int64_t>(1, (int64_t)0x7fffffff / std::max(M.G, std::max(M.n_scan, 1)) / 2);
     for (int64_t done = 0; done < n_pairs;) {
         const int64_t n = std::min(max_chunk, n_pairs - done);
         const int64_t row0 = out_first_pair + done;
@@ -433,11 +476,12 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         A.gc_bias = gc_bias ? 1 : 0;
         A.gc_thr = 8106479329266893ull;  // ceil(0.90 * 2^53), 0.90 being the f64 nearest to 0.9
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
+        A.slow_ovf = ctx->slow_ovf;
         iss::PairDesc *desc = ctx->desc + row0;
         uint32_t *flags = ctx->flags + row0;
         uint32_t *fix_list = ctx->fix_list + 2 * row0;
         TimedLaunch tl{};
-        tl.has_scan = M.n_active_groups > 0;
+        tl.has_scan = M.n_scan > 0;
         auto mark = [&](int k) -> hipError_t {
             if (!ctx->timing) return hipSuccess;
             hipError_t e = hipEventCreate(&tl.ev[k]);
@@ -451,25 +495,26 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         }
         HIP_TRY(ctx, mark(1));
         {
-            const size_t lds_bytes = (size_t)M.tile_words * 4 + (size_t)(M.n_q + 1) * 4;
+            const size_t lds_bytes = main_lds_bytes(M);
             const uint64_t items = (uint64_t)n * M.TG;
-            unsigned per_tile = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu, (items + 1023) / 1024);
-            per_tile = std::max(1u, per_tile / (unsigned)M.n_tiles * 1u);
-            if (per_tile * (unsigned)M.n_tiles < (unsigned)ctx->n_cu && items > (uint64_t)per_tile * 1024) ++per_tile;
-            hipLaunchKernelGGL(iss::k_main, dim3(per_tile * (unsigned)M.n_tiles), dim3(1024), lds_bytes, ctx->stream, M,
+            // persistent grid: one 1024-lane workgroup per CU, split evenly over the position tiles
+            unsigned per_tile = std::max(1u, (unsigned)ctx->n_cu / (unsigned)M.n_tiles);
+            per_tile = (unsigned)std::min<uint64_t>(per_tile, (items + iss::MAIN_THREADS - 1) / iss::MAIN_THREADS);
+            per_tile = std::max(1u, std::min(per_tile, ctx->max_main_grid / (unsigned)M.n_tiles));
+            hipLaunchKernelGGL(iss::k_main, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes, ctx->stream, M,
                                dg, A, desc);
         }
         HIP_TRY(ctx, mark(2));
-        if (M.n_active_groups > 0) {
+        if (M.n_scan > 0) {
             HIP_TRY(ctx, hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t), ctx->stream));
-            const uint64_t items = (uint64_t)n * M.n_active_groups;
-            const unsigned blocks = (unsigned)((items + 255) / 256);
-            hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(256), 0, ctx->stream, M, A, desc, flags, fix_list,
-                               ctx->fix_count);
+            const uint64_t items = (uint64_t)n * M.n_scan;
+            const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4, (items + 511) / 512);
+            hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(512), (size_t)M.n_scan * iss::SCAN_W * 4, ctx->stream,
+                               M, A, desc, flags, fix_list, ctx->fix_count);
         }
         HIP_TRY(ctx, mark(3));
-        if (M.n_active_groups > 0) {
+        if (M.n_scan > 0) {
             const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
             hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), 0, ctx->stream, M, dg, A, desc, fix_list,
                                ctx->fix_count, ctx->stats);
