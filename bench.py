@@ -79,44 +79,18 @@ def main():
     from insilicoseq_amd.generator import Record, generate_work_divider, lognormal_abundance
     from insilicoseq_amd.model import DenseModel
 
-    # ---- inputs: rank 0 builds them, RCCL broadcast to the other ranks (only when N > 1)
+    # ---- inputs: rank 0 builds them; ONE RCCL broadcast to the other ranks (only when N > 1)
+    from insilicoseq_amd.distributed import broadcast_model_and_genomes
+
     model_path = os.path.join(ROOT, "tests", "golden", "models", args.model + ".dense.npz")
+    dense, genomes = None, None
     if rank == 0:
         dense = DenseModel.load(model_path)
         genomes = synthetic_genomes(N_GENOMES, GENOME_LEN, 123)
-    if dist is not None:
-        t_b = time.time()
-        if rank == 0:
-            fields = [np.ascontiguousarray(getattr(dense, k)) for k in DenseModel.FIELDS]
-            meta = [dense.read_length] + [list(f.shape) for f in fields]
-        else:
-            meta = None
-        box = [meta]
-        dist.broadcast_object_list(box, src=0)
-        meta = box[0]
-        dtypes = {"bin_nonempty": np.uint8, "subst_alt": np.uint8, "ins_letter": np.uint8}
-        recv = []
-        for k, shape in zip(DenseModel.FIELDS, meta[1:]):
-            dt = dtypes.get(k, np.float64)
-            if rank == 0:
-                t = torch.from_numpy(np.ascontiguousarray(getattr(dense, k)).view(np.uint8).reshape(-1)).cuda()
-            else:
-                t = torch.empty(int(np.prod(shape)) * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
-            dist.broadcast(t, src=0)
-            recv.append(t.cpu().numpy().view(dt).reshape(shape))
-        if rank != 0:
-            dense = DenseModel(meta[0], *recv)
-        gt = torch.empty(N_GENOMES * GENOME_LEN, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            gt.copy_(torch.from_numpy(np.concatenate(genomes)))
-        dist.broadcast(gt, src=0)
-        if rank != 0:
-            flat = gt.cpu().numpy()
-            genomes = [flat[i * GENOME_LEN:(i + 1) * GENOME_LEN] for i in range(N_GENOMES)]
-        torch.cuda.synchronize()
-        bcast_s = time.time() - t_b
-    else:
-        bcast_s = 0.0
+    t_b = time.time()
+    dense, genomes = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank))
+    torch.cuda.synchronize()
+    bcast_s = time.time() - t_b if dist is not None else 0.0
 
     records = [Record(g, id="genome_%d" % i) for i, g in enumerate(genomes)]
     abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(123))

@@ -1,0 +1,96 @@
+"""Multi-GPU plumbing: one process per GPU, rank r == the reference's worker ``cpu_number`` r.
+
+The path shards with NO data-path collective (pairs are independent given genome, tables and the
+RNG address): the only collective is one broadcast of the dense model tables and the genomes from
+rank 0 before generation (RCCL over xGMI with backend "nccl"; "gloo" on CPU in the tests), issued
+only when world_size > 1.  Work division and output assembly mirror the reference:
+
+* chunk size ``ceil((n_reads // 2) / world)`` and ``zip(work_chunks, temp_file_list)`` -- a surplus
+  (world+1)-th rounding chunk is dropped exactly like the reference does (iss/app.py:81-83, 99-106);
+* per-rank temp files ``{output}.iss.tmp.{rank}_R1.fastq`` ... concatenated in rank order
+  (iss/app.py:73, 123-127; iss/util.py:213-234) and removed.
+"""
+import os
+import shutil
+
+import numpy as np
+
+from .generator import generate_work_divider
+from .model import DenseModel
+
+_U8_FIELDS = ("bin_nonempty", "subst_alt", "ins_letter")
+
+
+def _bcast_bytes(dist, arr_or_none, nbytes, device, src=0):
+    import torch
+
+    t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if arr_or_none is not None:
+        t.copy_(torch.from_numpy(np.ascontiguousarray(arr_or_none).view(np.uint8).reshape(-1)))
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0):
+    """Rank ``src`` passes (DenseModel, list of uint8 arrays / bytes); other ranks pass (None, None).
+    Returns (DenseModel, [uint8 arrays]) on every rank.  No-op when ``dist`` is None / world == 1."""
+    if dist is None or dist.get_world_size() == 1:
+        return dense, [np.frombuffer(g, dtype=np.uint8) if isinstance(g, (bytes, bytearray)) else np.asarray(
+            g, dtype=np.uint8) for g in genomes]
+    rank = dist.get_rank()
+    if rank == src:
+        fields = [np.ascontiguousarray(getattr(dense, k)) for k in DenseModel.FIELDS]
+        glist = [np.frombuffer(g, dtype=np.uint8) if isinstance(g, (bytes, bytearray)) else np.ascontiguousarray(
+            g, dtype=np.uint8) for g in genomes]
+        meta = {"read_length": dense.read_length, "shapes": [list(f.shape) for f in fields],
+                "genome_lengths": [int(g.size) for g in glist]}
+    else:
+        fields, glist, meta = None, None, None
+    box = [meta]
+    dist.broadcast_object_list(box, src=src)
+    meta = box[0]
+    out_fields = []
+    for i, (k, shape) in enumerate(zip(DenseModel.FIELDS, meta["shapes"])):
+        dt = np.uint8 if k in _U8_FIELDS else np.float64
+        nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+        raw = _bcast_bytes(dist, fields[i] if rank == src else None, nbytes, device, src)
+        out_fields.append(raw.view(dt).reshape(shape))
+    total = int(sum(meta["genome_lengths"]))
+    flat = _bcast_bytes(dist, np.concatenate(glist) if rank == src else None, total, device, src)
+    offs = np.concatenate(([0], np.cumsum(meta["genome_lengths"]))).astype(np.int64)
+    out_genomes = [flat[offs[i]:offs[i + 1]] for i in range(len(meta["genome_lengths"]))]
+    if rank != src:
+        dense = DenseModel(meta["read_length"], *out_fields)
+    return dense, out_genomes
+
+
+def rank_work(records, readcount_dic, abundance_dic, n_reads, coverage, coverage_file, error_model, output, world,
+              rank):
+    """The work list of ``rank``: chunk ``rank`` of the reference's divider with ``cpus = world``.
+    Returns (work, chunk_size, n_chunks)."""
+    n_read_pairs = n_reads // 2
+    chunk_size = -((n_read_pairs) // -world)  # ceildiv, iss/app.py:82
+    chunks = list(generate_work_divider(records, readcount_dic, abundance_dic, n_reads, coverage, coverage_file,
+                                        error_model, output, chunk_size))
+    work = chunks[rank] if rank < len(chunks) else None
+    return work, chunk_size, len(chunks)
+
+
+def temp_prefix(output, rank):
+    return "%s.iss.tmp.%d" % (output, rank)  # iss/app.py:73
+
+
+def concatenate_rank_files(output, world, suffixes=("_R1.fastq", "_R2.fastq"), cleanup=True):
+    """util.concatenate over the per-rank temp files, in rank order (iss/app.py:123-127).  Like the
+    reference, a missing temp file (fewer chunks than workers) is an error (iss/util.py:233)."""
+    for suffix in suffixes:
+        with open(output + suffix, "wb") as out:
+            for r in range(world):
+                with open(temp_prefix(output, r) + suffix, "rb") as fh:
+                    shutil.copyfileobj(fh, out, 1 << 22)
+    if cleanup:
+        for r in range(world):
+            for suffix in tuple(suffixes) + (".vcf",):
+                path = temp_prefix(output, r) + (suffix if suffix != ".vcf" else ".vcf")
+                if os.path.exists(path):
+                    os.remove(path)

@@ -2,6 +2,8 @@
 
 The oracle itself is pinned to the reference in MT mode (tests/test_oracle_golden.py); both
 providers feed the same semantic function, so HIP == oracle(Philox) closes the chain."""
+import os
+
 import numpy as np
 import pytest
 
@@ -111,3 +113,69 @@ def test_invalid_letter_is_rejected(engine):
     with pytest.raises(_native.EngineError) as e:
         engine.add_genome("ACGTXACGT" * 10)
     assert e.value.code == _native.E_INVALID
+
+
+def test_worker_iterator_fastq_matches_oracle(tmp_path):
+    """The drop-in boundary end to end on the GPU: worker_iterator -> FASTQ files == oracle (Philox,
+    worker seed = seed + cpu_number, ordinals running across work items) + the same formatter."""
+    from insilicoseq_amd.engine import fastq_write
+    from insilicoseq_amd.generator import Record, worker_iterator
+    from oracle import oracle as O
+
+    dense = dense_model("hiseq")
+    recs = [Record(random_genome(40 + i, 3000 + 700 * i), id="rec%d" % i) for i in range(3)]
+    recs.insert(1, Record("ACGT" * 20, id="tiny"))  # shorter than read_length: skipped with a warning
+    counts = [700, 50, 1, 1333]
+    work = [(r, n, "default") for r, n in zip(recs, counts)]
+    seed, cpu = 1234, 0
+    prefix = str(tmp_path / "w")
+    worker_iterator(work, dense, cpu, prefix, seed, "metagenomics", True, device=0)
+    rng = O.Rng().seed_philox(seed + cpu)
+    orc = O.Oracle(dense)
+    p1, p2 = tmp_path / "e1", tmp_path / "e2"
+    ordinal = 0
+    with open(p1, "wb") as f1, open(p2, "wb") as f2:
+        for r, n in zip(recs, counts):
+            if len(r.seq) <= dense.read_length:
+                continue
+            res = orc.simulate(rng, r.seq, n, first_ordinal=ordinal, gc_bias=True)
+            assert res["status"] == 0
+            fastq_write(f1.fileno(), f2.fileno(), r.id, 0, cpu, n, dense.read_length, dense.read_length,
+                        res["r1_base"], res["r1_qual"], res["r2_base"], res["r2_qual"], 1)
+            ordinal += n
+    assert open(prefix + "_R1.fastq", "rb").read() == p1.read_bytes()
+    assert open(prefix + "_R2.fastq", "rb").read() == p2.read_bytes()
+    assert os.path.exists(prefix + ".vcf")
+
+
+def test_large_batch_properties(engine):
+    """Size-independent properties at a scale the oracle cannot check (2 M pairs): every phred is a
+    possible one for its (position), bases are in the alphabet, and un-mutated positions equal the
+    template (spot-checked through the pair coordinates); a second run is bit-identical."""
+    dense = dense_model("novaseq")
+    genome = random_genome(77, 1000000)
+    n = 2_000_000
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.generate(gid, n, first_ordinal=0, seed=5)
+    engine.synchronize()
+    a = engine.download(0, n)
+    coords = engine.coords(0, n)
+    assert int(a["r1_qual"].max()) <= 40 and int(a["r2_qual"].max()) <= 40
+    for k in ("r1_base", "r2_base"):
+        assert np.isin(a[k], np.frombuffer(b"ACGT", dtype=np.uint8)).all()
+    g = np.frombuffer(genome.encode(), dtype=np.uint8)
+    RL = dense.read_length
+    idx = np.random.RandomState(0).randint(0, n, size=20000)
+    fs = coords[idx, 0]
+    tmpl = g[fs[:, None] + np.arange(RL)[None, :]]
+    same = (a["r1_base"][idx] == tmpl).mean()
+    assert same > 0.99  # substitutions are rare; indels rarer
+    assert (coords[:, 0] >= 0).all() and (coords[:, 2] <= len(genome)).all()
+    assert (coords[:, 1] == coords[:, 0] + RL + coords[:, 3]).mean() > 0.999  # reverse_start = fwd_end + insert
+    checksum = [int(a[k].astype(np.uint64).sum()) for k in ("r1_base", "r1_qual", "r2_base", "r2_qual")]
+    engine.generate(gid, n, first_ordinal=0, seed=5)
+    engine.synchronize()
+    b = engine.download(0, n)
+    assert checksum == [int(b[k].astype(np.uint64).sum()) for k in ("r1_base", "r1_qual", "r2_base", "r2_qual")]

@@ -1,0 +1,96 @@
+"""world_size > 1 path on CPU (gloo): model/genome broadcast, the reference's chunking with
+cpus = world, per-rank temp files and rank-order concatenation.  The device is replaced by the CPU
+oracle in MT mode (worker seed = seed + rank), so the assembled FASTQ must equal the REFERENCE's own
+`iss generate --cpus N` output byte for byte (golden, tests/golden/generate/)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, tmpdir, golden):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+
+    from insilicoseq_amd import distributed as D
+    from insilicoseq_amd.engine import fastq_write
+    from insilicoseq_amd.generator import Record, lognormal_abundance, parse_fasta
+    from insilicoseq_amd.model import DenseModel
+    from oracle import oracle as O
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        seed, n_reads = 42, 600
+        if rank == 0:
+            dense = DenseModel.load(os.path.join(golden, "models", "hiseq.dense.npz"))
+            recs = list(parse_fasta(os.path.join(golden, "genomes.fasta")))
+            ids = [r.id for r in recs]
+            genomes = [r.seq.encode() for r in recs]
+        else:
+            dense, genomes, ids = None, None, None
+        box = [ids]
+        dist.broadcast_object_list(box, src=0)
+        ids = box[0]
+        dense, genomes = D.broadcast_model_and_genomes(dense, genomes, dist, device="cpu")
+        ref = DenseModel.load(os.path.join(golden, "models", "hiseq.dense.npz"))
+        for k in DenseModel.FIELDS:
+            assert np.array_equal(getattr(dense, k), getattr(ref, k)), k
+        records = [Record(g.tobytes().decode(), id=i) for g, i in zip(genomes, ids)]
+        # parent-process abundance draw: np.random.seed(seed); abundance.lognormal(...)  (generator.py:397-400)
+        abundance = lognormal_abundance(ids, np.random.RandomState(seed))
+        output = os.path.join(tmpdir, "out")
+        work, chunk_size, n_chunks = D.rank_work(records, None, abundance, n_reads, None, None, dense, output, world,
+                                                 rank)
+        orc = O.Oracle(dense)
+        rng = O.Rng().seed_mt(seed + rank)  # worker_iterator: seed + cpu_number
+        prefix = D.temp_prefix(output, rank)
+        with open(prefix + "_R1.fastq", "wb") as f1, open(prefix + "_R2.fastq", "wb") as f2:
+            for rec, n, _ in (work or []):
+                res = orc.simulate(rng, rec.seq, n)
+                if res["status"] == O.SKIP_RECORD:
+                    continue
+                assert res["status"] == 0
+                fastq_write(f1.fileno(), f2.fileno(), rec.id, 0, rank, res["n_done"], dense.read_length,
+                            dense.read_length, res["r1_base"], res["r1_qual"], res["r2_base"], res["r2_qual"], 2)
+        dist.barrier()
+        if rank == 0:
+            D.concatenate_rank_files(output, world)
+            z = np.load(os.path.join(golden, "generate", "genomes_hiseq_n600_seed42_cpus%d.npz" % world))
+            assert open(output + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+            assert open(output + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+            lines = z["abundance"].tobytes().decode().split()
+            for i, rid in enumerate(ids):
+                assert lines[2 * i] == rid and lines[2 * i + 1] == str(abundance[rid])
+            assert not os.path.exists(prefix + "_R1.fastq")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_reproduce_reference_generate(world, tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path), GOLDEN), nprocs=world, join=True)
+
+
+def test_single_rank_is_a_noop_broadcast():
+    from insilicoseq_amd import distributed as D
+    from insilicoseq_amd.model import DenseModel
+
+    dense = DenseModel.load(os.path.join(GOLDEN, "models", "ecoli.dense.npz"))
+    d2, g2 = D.broadcast_model_and_genomes(dense, [b"ACGT" * 10], None)
+    assert d2 is dense and g2[0].tobytes() == b"ACGT" * 10

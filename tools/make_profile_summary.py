@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Condense a tools/gpu_profile.sh output directory into the committed profiles/<tag>_* files."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def counters(root):
+    acc = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(lambda: defaultdict(int))
+    for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            calls[k][r["Counter_Name"]] += 1
+    return acc, calls
+
+
+def main(src, tag):
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    stats = glob.glob(src + "/stats/*kernel_stats.csv")[0]
+    with open(stats) as fh, open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as out:
+        out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+        out.write(fh.read())
+    acc, calls = counters(src)
+    lines = ["# rocprofv3 --pmc <counters> --kernel-trace (separate passes), same bench command; totals over all dispatches",
+             "kernel,counter,total,per_dispatch,dispatches"]
+    for k in sorted(acc):
+        for c in sorted(acc[k]):
+            lines.append("%s,%s,%.6g,%.6g,%d" % (k, c, acc[k][c], acc[k][c] / calls[k][c], calls[k][c]))
+    open(os.path.join(out_dir, tag + "_pmc.csv"), "w").write("\n".join(lines) + "\n")
+    # HBM-side traffic of k_main per launch, corrected per MI355X_MICROARCH.md (FETCH_SIZE x2 for coalesced
+    # reads, calibrated here on k_read_dwordx2; WRITE_SIZE x1, calibrated on k_fill_dword); unit KiB
+    cal = {}
+    if "k_fill_dword" in acc and "k_read_dwordx2" in acc:
+        cal["write_factor"] = (1 << 20) / (acc["k_fill_dword"]["WRITE_SIZE"] / calls["k_fill_dword"]["WRITE_SIZE"])
+        cal["fetch_factor"] = (1 << 20) / (acc["k_read_dwordx2"]["FETCH_SIZE"] / calls["k_read_dwordx2"]["FETCH_SIZE"])
+    m = acc["iss::k_main"]
+    n = calls["iss::k_main"]["FETCH_SIZE"]
+    fetch = m["FETCH_SIZE"] / n * 1024 * cal.get("fetch_factor", 2.0)
+    write = m["WRITE_SIZE"] / calls["iss::k_main"]["WRITE_SIZE"] * 1024 * cal.get("write_factor", 1.0)
+    summary = {"kernel": "iss::k_main", "launches": n, "calibration": cal, "fetch_bytes_per_launch": fetch,
+               "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
+               "command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline (5,000,000 pairs per step in 5 launches)",
+               "pairs_per_launch_avg": 1_000_000}
+    json.dump(summary, open(os.path.join(out_dir, tag + "_traffic.json"), "w"), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -15,7 +15,42 @@ __global__ __launch_bounds__(256) void k_philox(uint32_t *out, int n_calls, uint
     out[t] = acc;
 }
 
+// Calibration kernels for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters in k_main's access patterns:
+// one dword store per lane, contiguous across lanes (k_main's output stores), and one dwordx2 load
+// per lane (its genome window loads).
+__global__ __launch_bounds__(256) void k_fill_dword(uint32_t *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_read_dwordx2(const uint2 *in, uint32_t *out, size_t n) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint2 v = in[i];
+        acc ^= v.x ^ v.y;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
+    {
+        const size_t n = (size_t)1 << 28;  // 1 GiB of dwords written, then read back as 2^27 dwordx2
+        uint32_t *buf, *sink;
+        hipMalloc(&buf, n * 4);
+        hipMalloc(&sink, 64);
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        for (int rep = 0; rep < 2; ++rep) {
+            float ms;
+            hipEventRecord(a);
+            hipLaunchKernelGGL(k_fill_dword, dim3(2048), dim3(256), 0, 0, buf, n);
+            hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+            printf("k_fill_dword: %zu bytes written, %.3f ms, %.1f GB/s\n", n * 4, ms, n * 4 / ms / 1e6);
+            hipEventRecord(a);
+            hipLaunchKernelGGL(k_read_dwordx2, dim3(2048), dim3(256), 0, 0, (const uint2 *)buf, sink, n / 2);
+            hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+            printf("k_read_dwordx2: %zu bytes read, %.3f ms, %.1f GB/s\n", n * 4, ms, n * 4 / ms / 1e6);
+        }
+        hipFree(buf); hipFree(sink);
+    }
     const int blocks = 256 * 8 * 4, threads = 256, calls = 256;
     uint32_t *d;
     hipMalloc(&d, sizeof(uint32_t) * blocks * threads);
