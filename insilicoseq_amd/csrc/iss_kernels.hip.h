@@ -117,12 +117,13 @@ struct DevGenome {
     const uint32_t *mask;    // 1 bit / base: 1 = read the ASCII copy (IUPAC or lower case); same padding
     const uint8_t *ascii;
     int64_t L;
+    int32_t has_exceptions;  // any letter that is not plain A/C/G/T
 };
 
 struct PairDesc {
     int32_t fs;     // forward_start
     int32_t re;     // reverse_end (reverse_start = re - RL)
-    uint32_t meta;  // bits 0-1 bin slot fwd, 2-3 bin slot rev, 16-31 attempt
+    uint32_t meta;  // bits 0-1 bin slot fwd, 2-3 bin slot rev, 4 / 5 fwd / rev window has IUPAC or lower-case letters, 16-31 attempt
     int32_t isz;    // insert size
 };
 
@@ -276,10 +277,21 @@ __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs 
         re = RL + (int64_t)randbelow(a, K_RS, (uint32_t)(L - RL));
         rs = re - RL;
     }
+    // does either template window (incl. the <= 3 padding bases k_main's last group touches) hold a
+    // letter that is not plain A/C/G/T?  k_main reads the exception mask only for such pairs.
+    uint32_t exc = 0;
+    if (g.has_exceptions) {
+        uint32_t any = 0;
+        for (int64_t w = fs >> 5; w <= (fs + RL + 2) >> 5; ++w) any |= g.mask[w];
+        exc |= any ? 16u : 0u;
+        any = 0;
+        for (int64_t w = (rs - 3) >> 5; w <= (re - 1) >> 5; ++w) any |= g.mask[w];
+        exc |= any ? 32u : 0u;
+    }
     PairDesc d;
     d.fs = (int32_t)fs;
     d.re = (int32_t)re;
-    d.meta = (uint32_t)(M.bin_slot[bin_f] & 3) | ((uint32_t)(M.bin_slot[4 + bin_r] & 3) << 2) | (attempt << 16);
+    d.meta = (uint32_t)(M.bin_slot[bin_f] & 3) | ((uint32_t)(M.bin_slot[4 + bin_r] & 3) << 2) | exc | (attempt << 16);
     d.isz = isz;
     desc[i] = d;
 }
@@ -296,14 +308,14 @@ __device__ __forceinline__ uint32_t codes_to_ascii4(uint32_t b) {
 }
 
 constexpr int MAIN_THREADS = 1024;
-constexpr int SLOW_QCAP = 2048;  // deferred-work queue entries per workgroup (LDS)
+constexpr int SLOW_QCAP = 512;   // deferred-work queue entries per workgroup (LDS); overflow spills to global
 constexpr int SLOW_EVERY = 16;   // drain the queue every SLOW_EVERY loop iterations
 
 // Dynamic LDS of k_main (32-bit words):
 //   [0, mut_words)            error-test table: mut16[q] - 1 (signed), q = 0..n_q
 //   [rows, +tile_words)       compressed quality rows of the position tile: per (mate, bin slot, group)
 //                             GS words = 4 rows of stride_w words + 1 pad word; a row = guide bytes
-//                             (1 << GB of them) then packed entries (t16 << 8 | phred), ascending,
+//                             (1 << GB of them) then packed entries (t16 << 15 | phred << 2), ascending,
 //                             closed by two sentinels
 //   [subst, +subst_words)     substitution table (leading digits + alternatives)
 //   [q_count], [queue]        deferred-work queue
@@ -344,9 +356,9 @@ __device__ __forceinline__ void main_slow_item(const DevModel &M, const RunArgs 
                              (uint32_t)c * (uint32_t)M.stride_w;
         uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))];
         uint32_t e = lds[row + gbytes / 4 + j];
-        while ((e >> 8) < h) e = lds[row + gbytes / 4 + (++j)];
-        uint32_t q = e & 0xffu;
-        if ((e >> 8) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
+        while ((e >> 15) < h) e = lds[row + gbytes / 4 + (++j)];
+        uint32_t q = (e >> 2) & 0xffu;
+        if ((e >> 15) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
         quals[o] = (quals[o] & ~(0xffu << (8 * c))) | (q << (8 * c));
         // substitution test (__init__.py:94)
         const uint32_t t = (uint32_t)((int32_t)lds[q] + 1);
@@ -378,25 +390,27 @@ __device__ __forceinline__ void main_slow_item(const DevModel &M, const RunArgs 
 }
 
 // One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive
-// entries -> select; returns the selected entry (phred in its low byte) and ORs into `x` a word whose
-// SIGN BIT is set when the base needs the exact path (tie, > 2 thresholds in the bucket, error).
-__device__ __forceinline__ uint32_t hot_lookup(const uint32_t *lds, uint32_t row_b, uint32_t ent_b, uint32_t wd,
-                                               int gshift, uint32_t &x) {
+// entries -> select.  Entry = (t16 << 15) | (phred << 2): < 2^31, so differences carry their sign; the
+// low byte is the byte offset of the phred's error-test threshold.  Returns the selected entry and
+// ORs into `x` a word whose SIGN BIT is set when the base needs the exact path (tie, > 2 thresholds
+// in the guide bucket, substitution test fires or ties).
+__device__ __forceinline__ uint32_t hot_lookup(const uint32_t *lds, uint32_t row_b, uint32_t wd, int gshift,
+                                               uint32_t gbytes, uint32_t &x) {
     const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds);
     const uint32_t h = wd & 0xffffu;
     const uint32_t j = ldsb[row_b + (h >> gshift)];
-    const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + ent_b + j * 4);
+    const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + row_b + gbytes + j * 4);
     const uint32_t e0 = ent[0], e1 = ent[1];
-    const uint32_t h8 = h << 8;
-    const uint32_t sel = e0 >= h8 ? e0 : e1;           // first entry with t16 >= h (if among the two)
-    const int32_t mt1 = *reinterpret_cast<const int32_t *>(ldsb + ((sel & 0xffu) << 2));  // mut16[phred] - 1
-    x = (e1 - h8)               // < 0: a third threshold of the bucket is below h
-        | ((sel ^ h8) - 256u)   // < 0: tie of the leading digit
+    const uint32_t hs = h << 15;
+    const uint32_t sel = e0 >= hs ? e0 : e1;           // first entry with t16 >= h (if among the two)
+    const int32_t mt1 = *reinterpret_cast<const int32_t *>(ldsb + (sel & 0xffu));  // mut16[phred] - 1
+    x = (e1 - hs)                  // < 0: a third threshold of the bucket is below h
+        | ((sel ^ hs) - 32768u)    // < 0: tie of the leading digit
         | (uint32_t)(mt1 - (int32_t)(wd >> 16));  // < 0: substitution test fires or ties
     return sel;
 }
 
-__global__ __launch_bounds__(MAIN_THREADS) void k_main(DevModel M, DevGenome g, RunArgs A,
+__global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tile = blockIdx.x % M.n_tiles;
@@ -443,42 +457,47 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_main(DevModel M, DevGenome g, 
             const u32x4 wq0 = draw_block(a, K_QM, (uint32_t)(p0 >> 1), 0);
             const u32x4 wq1 = draw_block(a, K_QM, (uint32_t)(p0 >> 1) + 1, 0);
             // ---- template bases: forward g[fs+p0 .. +3]; reverse comp(g[re-1-p0 .. -3])
-            uint32_t fb, fm, rb, rm;
+            uint32_t fb, rb, fm = 0, rm = 0;
             {
                 const int32_t pf = d.fs + p0;
                 const uint32_t *pw = g.packed + (pf >> 4);
                 fb = funnel_r(pw[0], pw[1], (uint32_t)(pf & 15) * 2) & 0xffu;
-                const uint32_t *mw = g.mask + (pf >> 5);
-                fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xfu;
                 const int32_t pr = d.re - 4 - p0;  // lowest genome position of the 4 reverse bases
                 const uint32_t *qw = g.packed + (pr >> 4);
                 rb = funnel_r(qw[0], qw[1], (uint32_t)(pr & 15) * 2) & 0xffu;
-                const uint32_t *nw = g.mask + (pr >> 5);
-                rm = funnel_r(nw[0], nw[1], (uint32_t)(pr & 31)) & 0xfu;
+                if (d.meta & 0x30u) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
+                    const uint32_t *mw = g.mask + (pf >> 5);
+                    fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xfu;
+                    const uint32_t *nw = g.mask + (pr >> 5);
+                    rm = funnel_r(nw[0], nw[1], (uint32_t)(pr & 31)) & 0xfu;
+                }
             }
             // ---- phred scores + substitution test, loop-free (hot_lookup); 8 independent lookups
             const uint32_t rowf_b = (T.rows + grp * (uint32_t)M.GS) * 4u + (d.meta & 3u) * slot_b;
             const uint32_t rowr_b = (T.rows + grp * (uint32_t)M.GS) * 4u + ((uint32_t)M.NB + ((d.meta >> 2) & 3u)) * slot_b;
             uint32_t sel[8], rare = 0;
+            const uint32_t lim_b = (uint32_t)(min(RL - p0, 4) - 1) * stride_b;  // padding lanes of the last group reuse the last row
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const uint32_t pc_b = (uint32_t)(min(p0 + c, RL - 1) - p0) * stride_b;  // clamp the padding lanes
+                const uint32_t pc_b = min((uint32_t)c * stride_b, lim_b);
                 const u32x4 &w = (c >> 1) ? wq1 : wq0;
                 uint32_t x;
-                sel[c] = hot_lookup(lds, rowf_b + pc_b, rowf_b + pc_b + gbytes, (c & 1) ? w.z : w.x, gshift, x);
+                sel[c] = hot_lookup(lds, rowf_b + pc_b, (c & 1) ? w.z : w.x, gshift, gbytes, x);
                 rare = __builtin_amdgcn_alignbit(rare, x, 31);  // rare = rare << 1 | sign(x)
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const uint32_t pc_b = (uint32_t)(min(p0 + c, RL - 1) - p0) * stride_b;
+                const uint32_t pc_b = min((uint32_t)c * stride_b, lim_b);
                 const u32x4 &w = (c >> 1) ? wq1 : wq0;
                 uint32_t x;
-                sel[4 + c] = hot_lookup(lds, rowr_b + pc_b, rowr_b + pc_b + gbytes, (c & 1) ? w.w : w.y, gshift, x);
+                sel[4 + c] = hot_lookup(lds, rowr_b + pc_b, (c & 1) ? w.w : w.y, gshift, gbytes, x);
                 rare = __builtin_amdgcn_alignbit(rare, x, 31);
             }
-            // phred bytes: low byte of each selected entry
-            const uint32_t qual_f = __builtin_amdgcn_perm(sel[1], sel[0], 0x0c0c0400u) | __builtin_amdgcn_perm(sel[3], sel[2], 0x04000c0cu);
-            const uint32_t qual_r = __builtin_amdgcn_perm(sel[5], sel[4], 0x0c0c0400u) | __builtin_amdgcn_perm(sel[7], sel[6], 0x04000c0cu);
+            // phred bytes: (low byte of each selected entry) >> 2
+            const uint32_t qual_f = ((__builtin_amdgcn_perm(sel[1], sel[0], 0x0c0c0400u) |
+                                      __builtin_amdgcn_perm(sel[3], sel[2], 0x04000c0cu)) >> 2) & 0x3f3f3f3fu;
+            const uint32_t qual_r = ((__builtin_amdgcn_perm(sel[5], sel[4], 0x0c0c0400u) |
+                                      __builtin_amdgcn_perm(sel[7], sel[6], 0x04000c0cu)) >> 2) & 0x3f3f3f3fu;
             uint32_t base_f = codes_to_ascii4(fb);
             uint32_t base_r = __builtin_amdgcn_perm(0u, codes_to_ascii4(rb ^ 0x55u), 0x00010203u);  // complement, reversed
             if (fm | rm) {  // IUPAC / lower-case letters: patch from the ASCII copy

@@ -27,6 +27,7 @@ struct Genome {
     uint32_t *mask = nullptr;
     uint8_t *ascii = nullptr;
     int64_t L = 0;
+    bool has_exceptions = false;
 };
 
 struct TimedLaunch {
@@ -201,7 +202,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     if (!ctx || !t) return fail(ctx, ISS_E_INVALID, "iss_model_upload: NULL argument");
     if (t->read_length < 2 || t->read_length > iss::FIX_MAX_RL)
         return fail(ctx, ISS_E_INVALID, "read_length must be in [2, 1024]");
-    if (t->n_isize < 1 || t->n_q < 1 || t->n_q > 255) return fail(ctx, ISS_E_INVALID, "bad table sizes");
+    if (t->n_isize < 1 || t->n_q < 1 || t->n_q > 63)
+        return fail(ctx, ISS_E_INVALID, "bad table sizes (per-position quality CDFs must have 1..63 entries)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_model(ctx);
@@ -257,11 +259,14 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         const uint64_t *row = t->q_thr + ((size_t)(o * 4 + bin) * RL + p) * nq;
         entries.clear();
         for (int i = 0; i < nq; ++i) {
-            const uint32_t v = (uint32_t)(row[i] >> 37);
-            if (entries.empty() || (entries.back() >> 8) != v) entries.push_back((v << 8) | (uint32_t)i);
+            const uint32_t v = (uint32_t)std::min<uint64_t>(row[i] >> 37, 0xffffu);  // 2^53 (cdf == 1.0) clamps: a tie
+            if (entries.empty() || (entries.back() >> 15) != v) entries.push_back((v << 15) | ((uint32_t)i << 2));
         }
-        entries.push_back((0x1ffffu << 8) | (uint32_t)nq);  // two sentinels above every 16-bit digit: the hot
-        entries.push_back((0x1ffffu << 8) | (uint32_t)nq);  // loop reads entries j and j + 1 unconditionally
+        // two closing sentinels (the hot loop reads entries j and j + 1 unconditionally); digit 0xffff
+        // "ties" with them and is resolved exactly
+        if ((entries.back() >> 15) != 0xffffu) entries.push_back((0xffffu << 15) | ((uint32_t)nq << 2));
+        entries.push_back(entries.back());
+        entries.push_back(entries.back());
     };
     std::vector<uint32_t> entries;
     size_t s_max = 0;
@@ -298,7 +303,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     uint8_t *guide = reinterpret_cast<uint8_t *>(dst);
                     size_t j = 0;
                     for (uint32_t b = 0; b < (1u << M.GB); ++b) {
-                        while ((entries[j] >> 8) < (b << (16 - M.GB))) ++j;
+                        while ((entries[j] >> 15) < (b << (16 - M.GB))) ++j;
                         guide[b] = (uint8_t)j;
                     }
                     std::copy(entries.begin(), entries.end(), dst + gwords);
@@ -377,6 +382,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     // one readable padding word in front (k_main's funnel shifts touch positions >= -3) and two behind
     const size_t n_pk = (size_t)(length + 15) / 16 + 3, n_mk = (size_t)(length + 31) / 32 + 3;
     std::vector<uint32_t> pk(n_pk, 0), mk(n_mk, 0);
+    bool any_exception = false;
     for (int64_t i = 0; i < length; ++i) {
         const uint8_t c = ascii[i];
         uint32_t code;
@@ -391,6 +397,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
                 }
                 code = 0;
                 mk[1 + (i >> 5)] |= 1u << (i & 31);
+                any_exception = true;
         }
         pk[1 + (i >> 4)] |= code << ((i & 15) * 2);
     }
@@ -400,6 +407,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     if ((rc = upload<uint32_t>(ctx, pk.data(), n_pk, &G.packed_alloc, nullptr))) return rc;
     if ((rc = upload<uint32_t>(ctx, mk.data(), n_mk, &G.mask_alloc, nullptr))) return rc;
     if ((rc = upload<uint8_t>(ctx, ascii, (size_t)length, &G.ascii, nullptr))) return rc;
+    G.has_exceptions = any_exception;
     G.packed = G.packed_alloc + 1;
     G.mask = G.mask_alloc + 1;
     ctx->genomes.push_back(G);
@@ -463,7 +471,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
     if (!(M.RL < G.L)) return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
     if (n_pairs == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L};
+    const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
     const int64_t max_chunk = std::max<int64_t>(1, (int64_t)0x7fffffff / std::max(M.G, std::max(M.n_scan, 1)) / 2);
     for (int64_t done = 0; done < n_pairs;) {
         const int64_t n = std::min(max_chunk, n_pairs - done);
@@ -497,8 +505,10 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         {
             const size_t lds_bytes = main_lds_bytes(M);
             const uint64_t items = (uint64_t)n * M.TG;
-            // persistent grid: one 1024-lane workgroup per CU, split evenly over the position tiles
-            unsigned per_tile = std::max(1u, (unsigned)ctx->n_cu / (unsigned)M.n_tiles);
+            // persistent grid: 1024-lane workgroups, two per CU when the LDS tables allow it (8 waves / SIMD),
+            // split evenly over the position tiles
+            const unsigned per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;
+            unsigned per_tile = std::max(1u, per_cu * (unsigned)ctx->n_cu / (unsigned)M.n_tiles);
             per_tile = (unsigned)std::min<uint64_t>(per_tile, (items + iss::MAIN_THREADS - 1) / iss::MAIN_THREADS);
             per_tile = std::max(1u, std::min(per_tile, ctx->max_main_grid / (unsigned)M.n_tiles));
             hipLaunchKernelGGL(iss::k_main, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes, ctx->stream, M,
