@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--reads", type=int, default=READS_PER_STEP, help="reads per step per GPU")
     ap.add_argument("--model", default="novaseq")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=1_500_000)
     args = ap.parse_args()
 
     import torch
@@ -151,6 +151,7 @@ def main():
         n_main_launches = len(work) * args.steps
         achieved = (total_pairs_step * args.steps * b_pair) / main_s / 1e9 if main_s > 0 else 0.0
         all_kernels_s = (tm["setup_ms"] + tm["main_ms"] + tm["indel_scan_ms"] + tm["indel_fixup_ms"]) / 1e3
+        traffic, traffic_note = committed_traffic()
         out = {
             "metric": "read_pairs_per_sec", "value": value, "unit": "read-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -164,7 +165,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_main", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_pair * total_pairs_step / max(len(work), 1),
                 "algorithmic_bytes_per_pair": b_pair, "avg_launch_ms": tm["main_ms"] / max(n_main_launches, 1),
                 "launches": n_main_launches,
             },
@@ -181,6 +183,20 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def committed_traffic():
+    """HBM-side bytes per k_main launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
+    runs of this same command, corrected with the calibration kernels as MI355X_MICROARCH.md prescribes).  PMC
+    collection cannot run inside the timed region, so the latest committed measurement is reported."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, "no PMC pass committed"
+    with open(files[-1]) as fh:
+        t = json.load(fh)
+    return t["traffic_bytes_per_launch"], "bytes per launch (avg 1e6 pairs), from %s" % os.path.basename(files[-1])
 
 
 def cpu_baseline(dense, work, sample_pairs):
