@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=READS_PER_STEP, help="reads per step per GPU")
     ap.add_argument("--model", default="novaseq")
+    ap.add_argument("--indel", type=float, nargs=2, default=None, metavar=("P_INS", "P_DEL"),
+                    help="override every insertion / deletion probability (BASELINE configs[4]-like indel-heavy model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_500_000)
     args = ap.parse_args()
@@ -86,6 +88,9 @@ def main():
     dense, genomes = None, None
     if rank == 0:
         dense = DenseModel.load(model_path)
+        if args.indel is not None:
+            dense.ins[:] = args.indel[0]
+            dense.dele[:] = args.indel[1]
         genomes = synthetic_genomes(N_GENOMES, GENOME_LEN, 123)
     t_b = time.time()
     dense, genomes = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank))
@@ -162,6 +167,7 @@ def main():
                                 args.reads, args.model, RL, N_GENOMES, GENOME_LEN, SEED),
                 "pairs_per_step_per_gpu": total_pairs_step, "read_length": RL, "work_items": len(work),
                 "rng": "philox4x32-10", "parallelism": "1 worker/GPU, no data-path collective",
+                "indel_override": args.indel,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_main", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

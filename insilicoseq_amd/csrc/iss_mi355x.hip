@@ -31,9 +31,17 @@ struct Genome {
 };
 
 struct TimedLaunch {
-    hipEvent_t ev[5];  // boundaries: setup | main | scan | fixup
+    // main stream: ev0 setup ev1 main ev2;  indel stream: ev3 scan ev4 ... ev5 fixup ev6
+    hipEvent_t ev[7];
     bool has_scan;
 };
+
+struct PendingIndel {  // indel-stream work still in flight on output rows [row0, row0 + n)
+    int64_t row0, n;
+    hipEvent_t done;
+};
+
+constexpr int FIX_SLOTS = 16;  // ring of fix-list counters (one per chunk in flight on the indel stream)
 
 }  // namespace
 
@@ -41,7 +49,11 @@ struct iss_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // setup + main kernels
+    hipStream_t indel_stream = nullptr;  // indel scan + fix-up of a chunk run beside the next chunk's main kernel
+    bool overlap = false;  // ISS_OVERLAP=1: run the indel passes beside the next chunk (measured: no gain, k_main is VALU-bound)
+    std::vector<PendingIndel> pending;
+    uint64_t chunk_seq = 0;
     std::string last_error;
     // model
     bool have_model = false;
@@ -124,16 +136,28 @@ size_t main_lds_bytes(const iss::DevModel &M) {
 }
 
 int settle_timing(iss_ctx *ctx) {
+    static const int first[4] = {0, 1, 3, 5};
     for (auto &t : ctx->timed) {
-        HIP_TRY(ctx, hipEventSynchronize(t.ev[4]));
+        HIP_TRY(ctx, hipEventSynchronize(t.ev[2]));
+        if (t.has_scan) HIP_TRY(ctx, hipEventSynchronize(t.ev[6]));
         for (int k = 0; k < 4; ++k) {
+            if (k >= 2 && !t.has_scan) continue;
             float ms = 0.f;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, t.ev[k], t.ev[k + 1]));
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, t.ev[first[k]], t.ev[first[k] + 1]));
             ctx->ms_acc[k] += ms;
         }
-        for (auto &e : t.ev) (void)hipEventDestroy(e);
+        for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
     }
     ctx->timed.clear();
+    return 0;
+}
+
+// everything queued on both streams has finished
+int sync_all(iss_ctx *ctx) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->indel_stream));
+    for (auto &pi : ctx->pending) (void)hipEventDestroy(pi.done);
+    ctx->pending.clear();
     return 0;
 }
 
@@ -165,11 +189,13 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->indel_stream, hipStreamNonBlocking));
+    if (const char *e = getenv("ISS_OVERLAP")) ctx->overlap = atoi(e) != 0;
     void *p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, 64));
-    ctx->fix_count = static_cast<uint32_t *>(p);
-    ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 16);
-    HIP_TRY(ctx, hipMemset(p, 0, 64));
+    HIP_TRY(ctx, hipMalloc(&p, 256));
+    ctx->fix_count = static_cast<uint32_t *>(p);  // FIX_SLOTS counters
+    ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
+    HIP_TRY(ctx, hipMemset(p, 0, 256));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
     HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * 2 * iss::SLOW_EVERY * iss::MAIN_THREADS * sizeof(uint32_t)));
     ctx->slow_ovf = static_cast<uint32_t *>(p);
@@ -181,19 +207,22 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto &t : ctx->timed) for (auto &e : t.ev) (void)hipEventDestroy(e);
+    if (ctx->indel_stream) (void)hipStreamSynchronize(ctx->indel_stream);
+    for (auto &pi : ctx->pending) (void)hipEventDestroy(pi.done);
+    for (auto &t : ctx->timed) for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
     free_model(ctx);
     free_outputs(ctx);
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
     if (ctx->slow_ovf) (void)hipFree(ctx->slow_ovf);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->indel_stream) (void)hipStreamDestroy(ctx->indel_stream);
     delete ctx;
 }
 
 int iss_ctx_set_stream(iss_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return 0;
 }
@@ -205,7 +234,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     if (t->n_isize < 1 || t->n_q < 1 || t->n_q > 63)
         return fail(ctx, ISS_E_INVALID, "bad table sizes (per-position quality CDFs must have 1..63 entries)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     free_model(ctx);
     const int RL = t->read_length, nq = t->n_q;
     const uint64_t two53 = 1ull << 53;
@@ -417,7 +446,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
 
 int iss_genome_clear(iss_ctx *ctx) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_all(ctx);
     for (auto &G : ctx->genomes) { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); }
     ctx->genomes.clear();
     return 0;
@@ -428,7 +457,7 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     if (capacity_pairs < 1) return fail(ctx, ISS_E_INVALID, "capacity must be >= 1");
     if (capacity_pairs <= ctx->capacity) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     free_outputs(ctx);
     const size_t row = (size_t)ctx->M.pitch;
     for (auto &p : ctx->out) {
@@ -490,18 +519,36 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         uint32_t *fix_list = ctx->fix_list + 2 * row0;
         TimedLaunch tl{};
         tl.has_scan = M.n_scan > 0;
-        auto mark = [&](int k) -> hipError_t {
+        hipStream_t s_main = ctx->stream;
+        hipStream_t s_indel = ctx->overlap ? ctx->indel_stream : ctx->stream;
+        auto mark = [&](int k, hipStream_t st) -> hipError_t {
             if (!ctx->timing) return hipSuccess;
             hipError_t e = hipEventCreate(&tl.ev[k]);
             if (e != hipSuccess) return e;
-            return hipEventRecord(tl.ev[k], ctx->stream);
+            return hipEventRecord(tl.ev[k], st);
         };
-        HIP_TRY(ctx, mark(0));
+        // rows about to be rewritten may still be in use by an earlier chunk's indel pass
+        for (size_t i = 0; i < ctx->pending.size();) {
+            PendingIndel &pi = ctx->pending[i];
+            if (hipEventQuery(pi.done) == hipSuccess) {
+                (void)hipEventDestroy(pi.done);
+                ctx->pending.erase(ctx->pending.begin() + (long)i);
+                continue;
+            }
+            if (pi.row0 < row0 + n && row0 < pi.row0 + pi.n) HIP_TRY(ctx, hipStreamWaitEvent(s_main, pi.done, 0));
+            ++i;
+        }
+        HIP_TRY(ctx, mark(0, s_main));
         {
             const unsigned blocks = (unsigned)((n + 255) / 256);
-            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), 0, ctx->stream, M, dg, A, desc);
+            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), 0, s_main, M, dg, A, desc);
         }
-        HIP_TRY(ctx, mark(1));
+        hipEvent_t ev_setup = nullptr, ev_main = nullptr;
+        if (M.n_scan > 0 && ctx->overlap) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ev_setup, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(ev_setup, s_main));
+        }
+        HIP_TRY(ctx, mark(1, s_main));
         {
             const size_t lds_bytes = main_lds_bytes(M);
             const uint64_t items = (uint64_t)n * M.TG;
@@ -511,25 +558,44 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
             unsigned per_tile = std::max(1u, per_cu * (unsigned)ctx->n_cu / (unsigned)M.n_tiles);
             per_tile = (unsigned)std::min<uint64_t>(per_tile, (items + iss::MAIN_THREADS - 1) / iss::MAIN_THREADS);
             per_tile = std::max(1u, std::min(per_tile, ctx->max_main_grid / (unsigned)M.n_tiles));
-            hipLaunchKernelGGL(iss::k_main, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes, ctx->stream, M,
+            hipLaunchKernelGGL(iss::k_main, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes, s_main, M,
                                dg, A, desc);
         }
-        HIP_TRY(ctx, mark(2));
+        HIP_TRY(ctx, mark(2, s_main));
         if (M.n_scan > 0) {
-            HIP_TRY(ctx, hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t), ctx->stream));
-            const uint64_t items = (uint64_t)n * M.n_scan;
-            const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4, (items + 511) / 512);
-            hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(512), (size_t)M.n_scan * iss::SCAN_W * 4, ctx->stream,
-                               M, A, desc, flags, fix_list, ctx->fix_count);
+            uint32_t *counter = ctx->fix_count + (ctx->chunk_seq++ % FIX_SLOTS);
+            if (ctx->overlap) {
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+                HIP_TRY(ctx, hipEventRecord(ev_main, s_main));
+                HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_setup, 0));  // the scan needs the pair descriptors only
+            }
+            HIP_TRY(ctx, hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, s_indel));
+            HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_indel));
+            HIP_TRY(ctx, mark(3, s_indel));
+            {
+                const uint64_t items = (uint64_t)n * M.n_scan;
+                const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4, (items + 511) / 512);
+                hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(512), (size_t)M.n_scan * iss::SCAN_W * 4, s_indel,
+                                   M, A, desc, flags, fix_list, counter);
+            }
+            HIP_TRY(ctx, mark(4, s_indel));
+            if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
+            HIP_TRY(ctx, mark(5, s_indel));
+            {
+                const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
+                hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), 0, s_indel, M, dg, A, desc,
+                                   fix_list, counter, ctx->stats);
+            }
+            HIP_TRY(ctx, mark(6, s_indel));
+            if (ctx->overlap) {
+                PendingIndel pi{row0, n, nullptr};
+                HIP_TRY(ctx, hipEventCreateWithFlags(&pi.done, hipEventDisableTiming));
+                HIP_TRY(ctx, hipEventRecord(pi.done, s_indel));
+                ctx->pending.push_back(pi);
+                (void)hipEventDestroy(ev_setup);  // destruction is deferred by the runtime until the waits completed
+                (void)hipEventDestroy(ev_main);
+            }
         }
-        HIP_TRY(ctx, mark(3));
-        if (M.n_scan > 0) {
-            const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
-            hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), 0, ctx->stream, M, dg, A, desc, fix_list,
-                               ctx->fix_count, ctx->stats);
-        }
-        HIP_TRY(ctx, mark(4));
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->timing) ctx->timed.push_back(tl);
         done += n;
@@ -540,8 +606,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
 
 int iss_synchronize(iss_ctx *ctx) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return sync_all(ctx);
 }
 
 int iss_output_download(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, uint8_t *r1_base, uint8_t *r1_qual,
@@ -551,11 +616,12 @@ int iss_output_download(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, uint8
     uint8_t *host[4] = {r1_base, r1_qual, r2_base, r2_qual};
     const size_t pitch = (size_t)ctx->M.pitch;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     for (int k = 0; k < 4; ++k)
         if (host[k] && n_pairs)
             HIP_TRY(ctx, hipMemcpyAsync(host[k], ctx->out[k] + (size_t)first_pair * pitch, pitch * (size_t)n_pairs,
                                         hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     return 0;
 }
 
@@ -567,7 +633,7 @@ int iss_output_download_coords(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs
     if (n_pairs)
         HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->desc + first_pair, sizeof(iss::PairDesc) * (size_t)n_pairs,
                                     hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     for (int64_t i = 0; i < n_pairs; ++i) {
         coords[4 * i + 0] = tmp[i].fs;
         coords[4 * i + 1] = (int64_t)tmp[i].re - ctx->M.RL;
@@ -586,7 +652,7 @@ int iss_timing_enable(iss_ctx *ctx, int enable) {
 
 int iss_timing_read(iss_ctx *ctx, double ms[4], int64_t *n_launches) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     int rc = settle_timing(ctx);
     if (rc) return rc;
     for (int k = 0; k < 4; ++k) { if (ms) ms[k] = ctx->ms_acc[k]; ctx->ms_acc[k] = 0; }
@@ -597,7 +663,7 @@ int iss_timing_read(iss_ctx *ctx, double ms[4], int64_t *n_launches) {
 
 int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     uint64_t v = 0;
     HIP_TRY(ctx, hipMemcpy(&v, ctx->stats, sizeof v, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof v));
