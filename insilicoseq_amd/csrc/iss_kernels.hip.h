@@ -15,7 +15,7 @@
 //              (threshold, phred) entries; bases come from the 2-bit genome with funnel shifts
 //              and one v_perm; four packed dword stores per lane, contiguous across lanes.
 //              Assumes "no indel in this read" (true for all but ~1e-4 of reads of shipped models).
-//   k_indel_scan : 1 lane / (pair, position group with a non-zero indel probability): draws the
+//   k_indel_scan : 1 lane / (pair, group of 4 loop steps with a non-zero indel probability): draws the
 //              indel digits and flags reads in which an indel MAY fire (conservative).
 //   k_indel_fixup: 1 wavefront / flagged read: exact sequential indel semantics (lane 0 walks the
 //              token transducer over an event mask computed by all lanes) + re-mutation by all
@@ -107,7 +107,8 @@ struct DevModel {
     const uint64_t *del_thr_max;  // [2][RL]  max over bases
     const uint64_t *mut_thr;      // [n_q+1]
     const uint8_t *ins_any;       // [2][RL] any insertion threshold non-zero at (o, n)
-    const uint32_t *scan_tab;      // [n_scan][SCAN_W]: loop steps n with a non-zero indel probability (k_indel_scan)
+    const uint32_t *fix_tab;      // [2][RL][8] (thr >> 37) + 1 of the 4 insertion + 4 deletion thresholds, 0 = zero probability
+    const uint32_t *scan_tab;      // [n_scan][SCAN_W]: groups of 4 loop steps with a non-zero indel probability (k_indel_scan)
     int32_t n_scan;
 };
 
@@ -548,48 +549,80 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
 // Conservative: flags mate o of a pair when some indel uniform's leading digit is <= the leading
 // digit of a non-zero threshold (max over bases for deletions).  No flag  =>  provably no indel
 // event (the first event in loop order would have been flagged), so k_main's output stands.
-// One lane per (pair, loop step n that has a non-zero indel probability); the per-step limits
-// (digit < lim  <=>  candidate; lim = (thr >> 37) + 1, 0 = never) sit in LDS.
-constexpr int SCAN_W = 13;  // words per entry (odd: bank-conflict free): [0] n | any_ins<<16 | any_del<<17,
-                            // [1..8] insertion limits digit o*4+x, [9..10] deletion limits o, [11..12] pad
+// One lane per (pair, group of 4 loop steps with a non-zero indel probability): one K_DEL block
+// serves the whole group, one K_INS block each step (both mates).  The per-step limits
+// (digit < lim  <=>  candidate; lim = (thr >> 37) + 1, 0 = never) sit in LDS.  Flagged reads go to a
+// workgroup-local LDS list that is flushed to the global fix list with ONE atomic per flush.
+constexpr int SCAN_W = 41;        // words per group entry (odd: bank-conflict free): [0] group | step flags,
+                                  // then per step c: [1+10c .. +7] insertion limits (digit mate*4+slot),
+                                  // [9+10c], [10+10c] deletion limits fwd / rev
+constexpr int SCAN_THREADS = 512;
+constexpr int SCAN_EVERY = 8;     // flush the LDS list every SCAN_EVERY iterations
+constexpr int SCAN_LIST = 2 * SCAN_EVERY * SCAN_THREADS;  // worst case: both mates of every item
 
-__global__ __launch_bounds__(512) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc,
-                                                    uint32_t *flags, uint32_t *fix_list, uint32_t *fix_count) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc,
+                                                             uint32_t *flags, uint32_t *fix_list, uint32_t *fix_count) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    for (int i = threadIdx.x; i < M.n_scan * SCAN_W; i += blockDim.x) lds[i] = M.scan_tab[i];
+    uint32_t *l_count = lds;      // [0] entries in the list, [1] global base of the current flush
+    uint32_t *l_list = lds + 4;   // SCAN_LIST entries
+    uint32_t *tab0 = l_list + SCAN_LIST;
+    for (int i = threadIdx.x; i < M.n_scan * SCAN_W; i += blockDim.x) tab0[i] = M.scan_tab[i];
+    if (threadIdx.x == 0) l_count[0] = 0;
     __syncthreads();
     const uint32_t ns = (uint32_t)M.n_scan;
     const uint32_t n_items = (uint32_t)A.n_pairs * ns;
     const uint32_t step = gridDim.x * blockDim.x;
     const uint32_t step_pair = step / ns, step_e = step - step_pair * ns;
-    uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t first = blockIdx.x * blockDim.x;
+    const uint32_t n_iter = n_items > first ? (n_items - first + step - 1) / step : 0;  // uniform in the workgroup
+    uint32_t it = first + threadIdx.x;
     uint32_t pair = it / ns, e = it - pair * ns;
-    for (; it < n_items; it += step) {
-        const uint32_t *tab = lds + e * SCAN_W;
-        const uint32_t head = tab[0];
-        const uint32_t n = head & 0xffffu;
-        const Addr a = make_addr(A.seed, A.first_ordinal + pair, desc[pair].meta >> 16);
-        uint32_t cand = 0;
-        if (head & 0x10000u) {
-            const u32x4 w = draw_block(a, K_INS, n, 0);
+    for (uint32_t iter = 0; iter < n_iter; ++iter) {
+        if (it < n_items) {
+            const uint32_t *tab = tab0 + e * SCAN_W;
+            const uint32_t head = tab[0];
+            const uint32_t grp = head & 0xffffu;
+            const Addr a = make_addr(A.seed, A.first_ordinal + pair, desc[pair].meta >> 16);
+            uint32_t cand = 0;
+            if (head & 0x00f00000u) {  // some step of the group has a deletion probability
+                const u32x4 w = draw_block(a, K_DEL, grp, 0);
 #pragma unroll
-            for (int dgt = 0; dgt < 8; ++dgt)
-                if (digit16(w, dgt) < tab[1 + dgt]) cand |= 1u << (dgt >> 2);
-        }
-        if (head & 0x20000u) {
-            const u32x4 w = draw_block(a, K_DEL, n >> 2, 0);
-            if (digit16(w, (int)(n & 3u) * 2) < tab[9]) cand |= 1u;
-            if (digit16(w, (int)(n & 3u) * 2 + 1) < tab[10]) cand |= 2u;
-        }
-        if (cand) {
-            const uint32_t old = atomicOr(&flags[pair], cand);
-            uint32_t fresh = cand & ~old;
-            while (fresh) {
-                const int o = __ffs(fresh) - 1;
-                fresh &= fresh - 1;
-                fix_list[atomicAdd(fix_count, 1u)] = pair * 2u + (uint32_t)o;
+                for (int c = 0; c < 4; ++c) {
+                    if (digit16(w, c * 2) < tab[9 + 10 * c]) cand |= 1u;
+                    if (digit16(w, c * 2 + 1) < tab[10 + 10 * c]) cand |= 2u;
+                }
+            }
+            for (int c = 0; c < 4; ++c) {
+                if (!((head >> (16 + c)) & 1u)) continue;  // no insertion probability at this step
+                const u32x4 w = draw_block(a, K_INS, grp * 4 + (uint32_t)c, 0);
+#pragma unroll
+                for (int dgt = 0; dgt < 8; ++dgt)
+                    if (digit16(w, dgt) < tab[1 + 10 * c + dgt]) cand |= 1u << (dgt >> 2);
+            }
+            if (cand) {
+                const uint32_t old = atomicOr(&flags[pair], cand);
+                uint32_t fresh = cand & ~old;
+                while (fresh) {
+                    const int o = __ffs(fresh) - 1;
+                    fresh &= fresh - 1;
+                    l_list[atomicAdd(&l_count[0], 1u)] = pair * 2u + (uint32_t)o;
+                }
             }
         }
+        if ((iter % SCAN_EVERY) == SCAN_EVERY - 1 || iter == n_iter - 1) {
+            __syncthreads();
+            const uint32_t n = l_count[0];
+            if (n) {
+                if (threadIdx.x == 0) l_count[1] = atomicAdd(fix_count, n);
+                __syncthreads();
+                const uint32_t base = l_count[1];
+                for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) fix_list[base + i] = l_list[i];
+                __syncthreads();
+                if (threadIdx.x == 0) l_count[0] = 0;
+            }
+            __syncthreads();
+        }
+        it += step;
         pair += step_pair;
         e += step_e;
         if (e >= ns) { e -= ns; ++pair; }
@@ -600,105 +633,159 @@ __global__ __launch_bounds__(512) void k_indel_scan(DevModel M, RunArgs A, const
 // One wavefront per flagged read.  Exact introduce_indels + adjust_seq_length as a token transducer:
 // the list prefix [0, n) is final when step n starts; the not-yet-visited suffix is
 // (stack of freshly inserted letters, LIFO) ++ E(k), E(k+1), ...   (DESIGN.md "indel transducer").
-//   phase 1 (all lanes): event mask per loop step n, independent of the token:
-//            bits 0-3 insertion of letter slot x fires, bits 4-7 deletion fires if the token is base b
-//   phase 2 (lane 0):    walk the steps, emit map[j] = source index k (>= 0) or -(inserted letter)
-//   phase 3 (all lanes): token -> mut_sequence -> store base j
+//   phase 1 (all lanes): event mask per loop step n, independent of the token (bits 0-3 insertion of
+//            letter slot x fires, bits 4-7 deletion fires if the token is base b); ballots of the
+//            steps with a non-empty mask; the template E(0 .. RL+63) is staged in LDS.
+//   phase 2 (wave-uniform walk over the ACTIVE steps only): explicit map[] entries for active steps
+//            and for the steps that drain the insertion stack; "from step n0 on, source index =
+//            k0 + (n - n0)" records for everything in between.
+//   phase 3 (all lanes): token -> base -> mut_sequence -> store.
 constexpr int FIX_MAX_RL = 1024;  // read_length limit (checked at model upload)
 constexpr int FIX_WAVES = 4;      // wavefronts (reads) per workgroup
+constexpr int16_t FIX_NONE = 0x7fff;
+
+// dynamic LDS of k_indel_fixup, in bytes: [fix table 2*RL*8 u32][mut16 64 u32][per wave: see below]
+__host__ __device__ inline int fix_rlp(int RL) { return (RL + 63) & ~63; }
+__host__ __device__ inline size_t fix_wave_bytes(int RL) {
+    const size_t rlp = (size_t)fix_rlp(RL);
+    return rlp * 4 /* ev, stk, qual, (pad) */ + (rlp + 64) /* tmpl */ + 3 * 2 * (rlp + 64) /* map, rec_n0, rec_k0 */;
+}
+__host__ __device__ inline size_t fix_lds_bytes(int RL) {
+    return (size_t)2 * RL * 8 * 4 + 64 * 4 + FIX_WAVES * fix_wave_bytes(RL);
+}
 
 __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevGenome g, RunArgs A,
                                                                 const PairDesc *__restrict__ desc,
                                                                 const uint32_t *__restrict__ fix_list,
                                                                 const uint32_t *__restrict__ fix_count,
                                                                 uint64_t *stats) {
-    __shared__ uint8_t s_ev[FIX_WAVES][FIX_MAX_RL];
-    __shared__ int16_t s_map[FIX_WAVES][FIX_MAX_RL];
-    __shared__ uint8_t s_stk[FIX_WAVES][FIX_MAX_RL];
-    const uint32_t n_fix = *fix_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)stats, (unsigned long long)n_fix);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint8_t *ev = s_ev[wv];
-    int16_t *map = s_map[wv];
-    uint8_t *stk = s_stk[wv];
+    extern __shared__ __attribute__((aligned(16))) uint8_t fix_lds[];
     const int RL = M.RL;
+    const int rlp = fix_rlp(RL);
+    uint32_t *tab = reinterpret_cast<uint32_t *>(fix_lds);            // [2][RL][8]: digit limits of ins x4, del x4
+    uint32_t *mut16 = tab + (size_t)2 * RL * 8;                        // [64]
+    const uint32_t n_fix = *fix_count;
+    if (blockIdx.x * FIX_WAVES >= n_fix) return;                       // whole workgroup idle (uniform)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)stats, (unsigned long long)n_fix);
+    for (int i = threadIdx.x; i < 2 * RL * 8; i += blockDim.x) tab[i] = M.fix_tab[i];
+    for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut16[i] = M.mut16[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint8_t *wbase = reinterpret_cast<uint8_t *>(mut16 + 64) + (size_t)wv * fix_wave_bytes(RL);
+    uint8_t *ev = wbase;
+    uint8_t *stk = ev + rlp;
+    uint8_t *qual = stk + rlp;
+    uint8_t *tmpl = qual + 2 * rlp;  // rlp + 64 entries
+    int16_t *map = reinterpret_cast<int16_t *>(tmpl + rlp + 64);
+    int16_t *rec_n0 = map + (rlp + 64);
+    int16_t *rec_k0 = rec_n0 + (rlp + 64);
+    const int n_pre = RL + 64;
+    const int n_chunks = rlp / 64;  // 64-step chunks covering indices 0 .. RL-1
     for (uint32_t i = blockIdx.x * FIX_WAVES + wv; i < n_fix; i += gridDim.x * FIX_WAVES) {
         const uint32_t e = fix_list[i];
         const uint32_t pair = e >> 1;
         const int o = (int)(e & 1u);
         const PairDesc d = desc[pair];
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
-        // ---- phase 1
-        for (int n = lane; n < RL - 1; n += 64) {
-            const size_t en = (size_t)o * RL + n;
+        uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.pitch;
+        const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.pitch;
+        // ---- phase 1: event masks, template, phred row
+        uint64_t act[FIX_MAX_RL / 64];
+#pragma unroll 1
+        for (int c = 0; c < n_chunks; ++c) {
+            const int n = c * 64 + lane;
             uint32_t m8 = 0;
-            if (M.ins_any[en]) {  // :193-196
-                const u32x4 w = draw_block(a, K_INS, (uint32_t)n, 0);
-                for (int x = 0; x < 4; ++x) {
-                    const uint64_t T = M.ins_thr[en * 4 + x];
-                    if (!T) continue;
-                    const uint32_t h = digit16(w, o * 4 + x), th = (uint32_t)(T >> 37);
-                    bool hit = h < th;
-                    if (h == th) {
-                        const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)n, (uint32_t)(o * 2 + (x >> 1)));
-                        hit = mk_digit(h, lo37(l, x & 1)) < T;
+            if (n < RL - 1) {
+                const uint32_t *t8 = tab + ((size_t)o * RL + n) * 8;
+                const size_t en = (size_t)o * RL + n;
+                if (t8[0] | t8[1] | t8[2] | t8[3]) {  // :193-196
+                    const u32x4 w = draw_block(a, K_INS, (uint32_t)n, 0);
+                    for (int x = 0; x < 4; ++x) {
+                        if (!t8[x]) continue;  // zero probability
+                        const uint32_t h = digit16(w, o * 4 + x), th = t8[x] - 1u;
+                        bool hit = h < th;
+                        if (h == th) {  // tie of the leading digit: exact
+                            const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)n, (uint32_t)(o * 2 + (x >> 1)));
+                            hit = mk_digit(h, lo37(l, x & 1)) < M.ins_thr[en * 4 + x];
+                        }
+                        if (hit) m8 |= 1u << x;
                     }
-                    if (hit) m8 |= 1u << x;
+                }
+                if (t8[4] | t8[5] | t8[6] | t8[7]) {  // :209-210
+                    const u32x4 w = draw_block(a, K_DEL, (uint32_t)n >> 2, 0);
+                    const uint32_t h = digit16(w, (n & 3) * 2 + o);
+                    for (int b = 0; b < 4; ++b) {
+                        if (!t8[4 + b]) continue;
+                        const uint32_t th = t8[4 + b] - 1u;
+                        bool hit = h < th;
+                        if (h == th) hit = mk_digit(h, lo37(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < M.del_thr[en * 4 + b];
+                        if (hit) m8 |= 16u << b;
+                    }
                 }
             }
-            if (M.del_thr_max[en]) {  // :209-210
-                const u32x4 w = draw_block(a, K_DEL, (uint32_t)n >> 2, 0);
-                const uint32_t h = digit16(w, (n & 3) * 2 + o);
-                for (int b = 0; b < 4; ++b) {
-                    const uint64_t T = M.del_thr[en * 4 + b];
-                    if (!T) continue;
-                    const uint32_t th = (uint32_t)(T >> 37);
-                    bool hit = h < th;
-                    if (h == th) hit = mk_digit(h, lo37(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < T;
-                    if (hit) m8 |= 16u << b;
-                }
-            }
-            ev[n] = (uint8_t)m8;
+            if (n < RL) { ev[n] = (uint8_t)m8; map[n] = FIX_NONE; qual[n] = out_qual[n]; }
+            act[c] = __ballot(m8 != 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // LDS writes of the wave visible to lane 0
+        for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)read_dir_base(g, o, d, k);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- phase 2
-        if (lane == 0) {
-            int sp = 0, k = 0;  // stack depth (bounded: only the top RL entries can ever surface), source index
-            for (int n = 0; n < RL - 1; ++n) {
+        // ---- phase 2: every lane runs the same walk (wave-uniform values); lane 0 does the LDS writes
+        int sp = 0, k = 0, n_rec = 1, last = -1;  // `last`: last step whose map entry / record is settled
+        if (lane == 0) { rec_n0[0] = 0; rec_k0[0] = 0; }
+#pragma unroll 1
+        for (int c = 0; c < n_chunks; ++c) {
+            uint64_t m = act[c];
+            while (m) {
+                const int b = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const int n = c * 64 + b;
+                k += n - (last + 1);  // the settled record covers steps last+1 .. n-1 from the source
                 const uint32_t m8 = ev[n];
-                int tok;  // >= 0: source index, < 0: -(letter)
-                if (sp > 0) tok = -(int)stk[--sp];
-                else tok = k++;
-                if (m8 == 0 || tok >= RL) { map[n] = (int16_t)tok; continue; }  // no event / n >= len(seq), :223
-                const int ch = tok < 0 ? -tok : read_dir_base(g, o, d, tok);
-                const int bi = base_index(ch);
-                if (bi < 0) { map[n] = (int16_t)tok; continue; }  // ambiguous: skipped, :190-192
-                for (int x = 0; x < 4; ++x)
-                    if ((m8 >> x) & 1u) {
-                        if (sp == FIX_MAX_RL) { for (int z = 1; z < sp; ++z) stk[z - 1] = stk[z]; --sp; }
-                        stk[sp++] = M.ins_letter[((size_t)o * RL + n) * 4 + x];
+                int tok = sp > 0 ? -(int)stk[--sp] : k++;
+                if (tok < RL) {  // tok >= RL: n >= len(seq), IndexError swallowed (:223): emitted unvisited
+                    const int ch = tok < 0 ? -tok : (int)tmpl[tok];
+                    const int bi = base_index(ch);
+                    if (bi >= 0) {  // else ambiguous: skipped (:190-192)
+                        for (int x = 0; x < 4; ++x)
+                            if ((m8 >> x) & 1u) {
+                                if (sp == rlp) {  // only the top RL entries can ever surface: drop the bottom
+                                    if (lane == 0) for (int z = 1; z < sp; ++z) stk[z - 1] = stk[z];
+                                    --sp;
+                                }
+                                if (lane == 0) stk[sp] = M.ins_letter[((size_t)o * RL + n) * 4 + x];
+                                ++sp;
+                            }
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        if ((m8 >> (4 + bi)) & 1u) tok = sp > 0 ? -(int)stk[--sp] : k++;  // deleted: next token slides in
                     }
-                if ((m8 >> (4 + bi)) & 1u) {  // deleted: the next token slides in unvisited
-                    if (sp > 0) tok = -(int)stk[--sp];
-                    else tok = k++;
                 }
-                map[n] = (int16_t)tok;
+                if (lane == 0) map[n] = (int16_t)tok;
+                last = n;
+                // steps after n drain the insertion stack until it is empty or the next active step
+                while (sp > 0 && last + 1 < RL && ev[last + 1] == 0) {
+                    ++last;
+                    --sp;
+                    if (lane == 0) map[last] = (int16_t)(-(int)stk[sp]);
+                }
+                if (lane == 0) { rec_n0[n_rec] = (int16_t)(last + 1); rec_k0[n_rec] = (int16_t)k; }
+                ++n_rec;
             }
-            map[RL - 1] = (int16_t)(sp > 0 ? -(int)stk[sp - 1] : k);  // index RL-1 is never visited
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 3
-        uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.pitch;
-        const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.pitch;
         for (int j = lane; j < RL; j += 64) {
-            const int tok = map[j];
-            int base = tok < 0 ? -tok : read_dir_base(g, o, d, tok);
+            int tok = map[j];
+            if (tok == FIX_NONE) {  // governed by the last record with n0 <= j
+                int r = n_rec - 1;
+                while (rec_n0[r] > j) --r;
+                tok = rec_k0[r] + (j - rec_n0[r]);
+            }
+            int base = tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : read_dir_base(g, o, d, tok));
             const u32x4 w = draw_block(a, K_QM, (uint32_t)j >> 1, 0);
             const uint32_t h = digit16(w, (j & 1) * 4 + 2 * o + 1);
-            const int q = out_qual[j];
-            const uint32_t t = M.mut16[q];
+            const int q = qual[j];
+            const uint32_t t = mut16[q];
             bool err = h > t;
             if (h == t) err = mut_exact(M, a, o, j, h, q);
             if (err) base = substitute(M, a, o, j, base);

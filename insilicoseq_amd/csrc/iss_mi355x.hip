@@ -186,6 +186,10 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_main),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_fixup),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
@@ -363,23 +367,36 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             del_max[e] = dm;
             ins_any[e] = im ? 1 : 0;
         }
-    // k_indel_scan table: one entry per loop step n <= RL-2 (__init__.py:187) with any non-zero threshold
+    // k_indel_scan table: one entry per group of 4 loop steps n <= RL-2 (__init__.py:187) with any non-zero threshold
     std::vector<uint32_t> scan_tab;
     auto lim = [](uint64_t T) { return T ? (uint32_t)(T >> 37) + 1u : 0u; };
-    for (int n = 0; n <= RL - 2; ++n) {
+    for (int gI = 0; gI * 4 <= RL - 2; ++gI) {
         uint32_t ent[iss::SCAN_W] = {0};
-        bool any_ins = false, any_del = false;
-        for (int o = 0; o < 2; ++o) {
-            const size_t e = (size_t)o * RL + n;
-            for (int x = 0; x < 4; ++x) { ent[1 + o * 4 + x] = lim(t->ins_thr[e * 4 + x]); any_ins |= ent[1 + o * 4 + x] != 0; }
-            ent[9 + o] = lim(del_max[e]);
-            any_del |= ent[9 + o] != 0;
+        uint32_t head = (uint32_t)gI;
+        for (int c = 0; c < 4; ++c) {
+            const int n = gI * 4 + c;
+            if (n > RL - 2) break;
+            for (int o = 0; o < 2; ++o) {
+                const size_t e = (size_t)o * RL + n;
+                for (int x = 0; x < 4; ++x) {
+                    ent[1 + 10 * c + o * 4 + x] = lim(t->ins_thr[e * 4 + x]);
+                    if (ent[1 + 10 * c + o * 4 + x]) head |= 1u << (16 + c);
+                }
+                ent[9 + 10 * c + o] = lim(del_max[e]);
+                if (ent[9 + 10 * c + o]) head |= 1u << (20 + c);
+            }
         }
-        if (!any_ins && !any_del) continue;
-        ent[0] = (uint32_t)n | (any_ins ? 0x10000u : 0u) | (any_del ? 0x20000u : 0u);
+        if (!(head & 0x00ff0000u)) continue;
+        ent[0] = head;
         scan_tab.insert(scan_tab.end(), ent, ent + iss::SCAN_W);
     }
     M.n_scan = (int32_t)(scan_tab.size() / iss::SCAN_W);
+    std::vector<uint32_t> fix_tab((size_t)2 * RL * 8);
+    for (size_t e = 0; e < (size_t)2 * RL; ++e)
+        for (int x = 0; x < 4; ++x) {
+            fix_tab[e * 8 + x] = lim(t->ins_thr[e * 4 + x]);
+            fix_tab[e * 8 + 4 + x] = lim(t->del_thr[e * 4 + x]);
+        }
     int rc = 0;
     auto *tr = &ctx->model_allocs;
 #define UP(field, src, n, T) if ((rc = upload<T>(ctx, src, n, const_cast<T **>(&M.field), tr))) return rc
@@ -398,6 +415,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(mut_thr, t->mut_thr, (size_t)nq + 1, uint64_t);
     UP(ins_any, ins_any.data(), ins_any.size(), uint8_t);
     UP(scan_tab, scan_tab.data(), scan_tab.size(), uint32_t);
+    UP(fix_tab, fix_tab.data(), fix_tab.size(), uint32_t);
 #undef UP
     ctx->have_model = true;
     free_outputs(ctx);  // pitch may have changed
@@ -574,16 +592,18 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
             HIP_TRY(ctx, mark(3, s_indel));
             {
                 const uint64_t items = (uint64_t)n * M.n_scan;
-                const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4, (items + 511) / 512);
-                hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(512), (size_t)M.n_scan * iss::SCAN_W * 4, s_indel,
-                                   M, A, desc, flags, fix_list, counter);
+                const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4,
+                                                                     (items + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
+                const size_t lds = (4 + (size_t)iss::SCAN_LIST + (size_t)M.n_scan * iss::SCAN_W) * 4;
+                hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), lds, s_indel, M, A, desc, flags,
+                                   fix_list, counter);
             }
             HIP_TRY(ctx, mark(4, s_indel));
             if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
             HIP_TRY(ctx, mark(5, s_indel));
             {
                 const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
-                hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), 0, s_indel, M, dg, A, desc,
+                hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), iss::fix_lds_bytes(M.RL), s_indel, M, dg, A, desc,
                                    fix_list, counter, ctx->stats);
             }
             HIP_TRY(ctx, mark(6, s_indel));
