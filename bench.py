@@ -84,7 +84,7 @@ def main():
     # ---- inputs: rank 0 builds them; ONE RCCL broadcast to the other ranks (only when N > 1)
     from insilicoseq_amd.distributed import broadcast_model_and_genomes
 
-    model_path = os.path.join(ROOT, "tests", "golden", "models", args.model + ".dense.npz")
+    model_path = os.path.join(ROOT, "insilicoseq_amd", "profiles", args.model + ".dense.npz")
     dense, genomes = None, None
     if rank == 0:
         dense = DenseModel.load(model_path)

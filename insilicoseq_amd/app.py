@@ -1,0 +1,202 @@
+"""`generate`: the reference's ``iss generate`` flow (iss/app.py:23-144) on GPUs.
+
+Same steps, same file names, same flag names for the options this engine supports: load the error
+model, concatenate the genome FASTA files, draw / read abundances (written to ``<out>_abundance.txt``),
+cut the work into ``ceil(n_pairs / workers)``-sized chunks (iss/app.py:81-83), run one worker per GPU
+(``worker_iterator``; a process pool like the reference's, each process owning one device), concatenate
+``<out>.iss.tmp.<k>_R{1,2}.fastq`` in worker order and clean up (iss/app.py:119-143).
+
+Differences a user must know: uniforms come from Philox keyed by ``seed + worker``
+(not the reference's Mersenne Twisters), and the reference's dropped surplus chunk / missing-temp-file
+failure modes are reproduced deliberately so outputs stay comparable.
+"""
+import argparse
+import gzip
+import logging
+import multiprocessing as mp
+import os
+import shutil
+import sys
+
+import numpy as np
+
+from .distributed import concatenate_rank_files, temp_prefix
+from .generator import generate_work_divider, parse_fasta, worker_iterator
+from .model import KDErrorModel
+
+PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+# names of iss/generator.py:377-387 -> dense files converted from the reference's profiles
+PRECOMPUTED = {"hiseq": "hiseq", "novaseq": "novaseq", "miseq": "miseq", "miseq-20": "miseq-20", "miseq-24": "miseq-24",
+               "miseq-28": "miseq-28", "miseq-32": "miseq-32", "miseq-36": "miseq-36", "nextseq": "nextseq"}
+
+
+def convert_n_reads(unit):
+    """iss/util.py:137-161: 'k', 'm', 'g' suffixes."""
+    suffixes = {"k": 3, "m": 6, "g": 9}
+    unit = str(unit)
+    if unit[-1].lower() in suffixes:
+        return int(float(unit[:-1]) * 10 ** suffixes[unit[-1].lower()])
+    return int(unit)
+
+
+def load_error_model(mode, seed, model, fragment_length, fragment_length_sd, store_mutations):
+    """iss/generator.py:359-421 for what the device path covers (kde)."""
+    logger = logging.getLogger(__name__)
+    if mode != "kde":
+        logger.error("--mode %s is not available on the GPU path (kde only)" % mode)
+        sys.exit(1)
+    if fragment_length is not None or fragment_length_sd is not None:
+        logger.error("--fragment-length is not available on the GPU path yet")
+        sys.exit(1)
+    if model is None:
+        logger.error("--model is required in --mode kde")
+        sys.exit(1)
+    if seed:  # generator.py:397-400 (seed 0 leaves the parent unseeded)
+        np.random.seed(seed)
+    if model.lower() in PRECOMPUTED:
+        npz = os.path.join(PROFILES, PRECOMPUTED[model.lower()] + ".dense.npz")
+    else:
+        npz = model
+    return KDErrorModel(npz, None, None, store_mutations)
+
+
+def parse_abundance_file(path):
+    """iss/abundance.py:13-44: tab separated `record<TAB>abundance`."""
+    logger = logging.getLogger(__name__)
+    out = {}
+    try:
+        with open(path) as fh:
+            for line in fh:
+                if not line.strip():
+                    continue
+                rid, val = line.split()[0], float(line.split()[1])
+                out[rid] = val
+    except (IOError, IndexError, ValueError) as e:
+        logger.error("Failed to read abundance file: %s" % e)
+        sys.exit(1)
+    return out
+
+
+def parse_readcount_file(path):
+    return {k: int(v) for k, v in parse_abundance_file(path).items()}
+
+
+def lognormal(record_list):
+    """iss/abundance.py:137-154 (global numpy stream, seeded by load_error_model like the reference)."""
+    dist = np.random.lognormal(size=len(record_list))
+    scaled = dist / sum(dist)
+    return {r: a for r, a in zip(record_list, scaled)}
+
+
+def uniform(record_list):
+    return {r: 1 / len(record_list) for r in record_list}
+
+
+def exponential(record_list):
+    dist = np.random.exponential(size=len(record_list))
+    scaled = dist / sum(dist)
+    return {r: a for r, a in zip(record_list, scaled)}
+
+
+ABUNDANCE = {"lognormal": lognormal, "uniform": uniform, "exponential": exponential}
+
+
+def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias):
+    """One pool process == one GPU.  Records are re-read from the concatenated FASTA (the reference
+    pickles them; same content)."""
+    logging.basicConfig(level=logging.WARNING)
+    records = {r.id: r for r in parse_fasta(genome_file)}
+    model = KDErrorModel(npz)
+    work = [(records[rid], n, "default") for rid, n in work_spec]
+    worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device)
+
+
+def generate_reads(args):
+    logger = logging.getLogger(__name__)
+    error_model = load_error_model(args.mode, args.seed, args.model, args.fragment_length, args.fragment_length_sd,
+                                   args.store_mutations)
+    if not args.genomes:
+        logger.error("One of --genomes/-g is required")
+        sys.exit(1)
+    genome_file = args.output + ".iss.tmp.genomes.fasta"  # generator.py:468-469
+    with open(genome_file, "wb") as out:
+        for g in args.genomes:
+            with open(g, "rb") as fh:
+                shutil.copyfileobj(fh, out)
+    records = list(parse_fasta(genome_file))
+    if not records:
+        logger.error("Genome(s) file seems empty: %s" % genome_file)
+        sys.exit(1)
+    ids = [r.id for r in records]
+    readcount_dic = abundance_dic = None
+    if args.readcount_file:
+        readcount_dic = parse_readcount_file(args.readcount_file)
+        n_reads = sum(readcount_dic.values())
+    else:
+        n_reads = convert_n_reads(args.n_reads)
+        if args.abundance_file:
+            abundance_dic = parse_abundance_file(args.abundance_file)
+        elif args.abundance in ABUNDANCE:
+            abundance_dic = ABUNDANCE[args.abundance](ids)
+            with open(args.output + "_abundance.txt", "w") as fh:  # abundance.to_file, abundance.py:231-251
+                for rid, a in abundance_dic.items():
+                    fh.write("%s\t%s\n" % (rid, a))
+        else:
+            logger.error("Could not get abundance, or coverage or readcount information")
+            sys.exit(1)
+    workers = args.gpus
+    chunk_size = -((n_reads // 2) // -workers)  # ceildiv, app.py:82
+    chunks = list(generate_work_divider(records, readcount_dic, abundance_dic, n_reads, None, None, error_model,
+                                        args.output, chunk_size))
+    jobs = []
+    for rank, chunk in enumerate(chunks[:workers]):  # zip(work_chunks, temp_file_list), app.py:104
+        spec = [(rec.id, n) for rec, n, _ in chunk]
+        jobs.append((rank, rank % max(args.devices, 1), genome_file, spec, error_model.npz_path, args.seed,
+                     temp_prefix(args.output, rank), args.sequence_type, args.gc_bias))
+    if workers == 1:
+        for j in jobs:
+            _worker(*j)
+    else:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            pool.starmap(_worker, jobs)
+    concatenate_rank_files(args.output, workers)  # raises if a worker had no chunk (util.py:233)
+    os.remove(genome_file)
+    if args.compress:
+        for suffix in ("_R1.fastq", "_R2.fastq"):
+            with open(args.output + suffix, "rb") as fi, gzip.open(args.output + suffix + ".gz", "wb") as fo:
+                shutil.copyfileobj(fi, fo)
+            os.remove(args.output + suffix)
+    logger.info("Read generation complete")
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(prog="insilicoseq_amd", description="iss generate on MI355X")
+    sub = p.add_subparsers(dest="cmd")
+    g = sub.add_parser("generate")
+    g.add_argument("--genomes", "-g", nargs="+")
+    g.add_argument("--model", "-m")
+    g.add_argument("--mode", "-e", default="kde", choices=["kde", "basic", "perfect"])
+    g.add_argument("--n_reads", "-n", default="1000000")
+    g.add_argument("--seed", type=int, default=None)
+    g.add_argument("--gpus", "--cpus", "-p", type=int, default=1, dest="gpus", help="workers (one per GPU)")
+    g.add_argument("--devices", type=int, default=0, help="visible GPUs (default: one per worker)")
+    g.add_argument("--abundance", "-a", default="lognormal", choices=sorted(ABUNDANCE))
+    g.add_argument("--abundance_file", "-b")
+    g.add_argument("--readcount_file", "-R")
+    g.add_argument("--gc_bias", "-c", action="store_true")
+    g.add_argument("--sequence_type", "-t", default="metagenomics", choices=["metagenomics", "amplicon"])
+    g.add_argument("--fragment-length", "-l", type=int, default=None, dest="fragment_length")
+    g.add_argument("--fragment-length-sd", "-s", type=int, default=None, dest="fragment_length_sd")
+    g.add_argument("--store_mutations", "-M", action="store_true")
+    g.add_argument("--compress", "-z", action="store_true")
+    g.add_argument("--output", "-o", required=True)
+    g.add_argument("--quiet", "-q", action="store_true")
+    args = p.parse_args(argv)
+    if args.cmd != "generate":
+        p.print_help()
+        return 1
+    if not args.devices:
+        args.devices = args.gpus
+    logging.basicConfig(level=logging.ERROR if args.quiet else logging.INFO)
+    generate_reads(args)
+    return 0

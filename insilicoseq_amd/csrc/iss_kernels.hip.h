@@ -234,6 +234,45 @@ __device__ __forceinline__ int substitute(const DevModel &M, const Addr &a, int 
     return M.subst_alt[row + k];
 }
 
+// ================================================================== k_pack_genome
+// Genome ingest on the device: ASCII (already in HBM) -> 2-bit codes + exception mask; letters outside
+// util.rev_comp's alphabet (iss/util.py:57-88) are reported through `status`.
+// One lane per 32 bases: two packed words and one mask word.  status[0] = number of invalid letters,
+// status[1] = offset of the first one (atomicMin), status[2] = number of exception letters.
+__global__ __launch_bounds__(256) void k_pack_genome(const uint8_t *__restrict__ ascii, int64_t L, uint32_t *packed,
+                                                     uint32_t *mask, unsigned long long *status) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // mask word index
+    const int64_t base = w * 32;
+    if (base >= L) return;
+    uint32_t pk[2] = {0, 0}, mk = 0, bad = 0;
+    int64_t first_bad = L;
+    for (int i = 0; i < 32 && base + i < L; ++i) {
+        const uint32_t c = ascii[base + i];
+        uint32_t code = 0;
+        switch (c) {
+            case 'A': code = 0; break; case 'T': code = 1; break; case 'C': code = 2; break; case 'G': code = 3; break;
+            default: {
+                mk |= 1u << i;
+                const uint32_t u = c & ~0x20u;
+                const bool letter = (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+                const bool ok = letter && (u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'Y' || u == 'R' || u == 'W' ||
+                                           u == 'S' || u == 'K' || u == 'M' || u == 'N' || u == 'B' || u == 'V' ||
+                                           u == 'D' || u == 'H');
+                if (!ok) { if (!bad) first_bad = base + i; ++bad; }
+            }
+        }
+        pk[i >> 4] |= code << ((i & 15) * 2);
+    }
+    packed[2 * w] = pk[0];
+    packed[2 * w + 1] = pk[1];
+    mask[w] = mk;
+    if (mk) atomicAdd(&status[2], (unsigned long long)__popc(mk));
+    if (bad) {
+        atomicAdd(&status[0], (unsigned long long)bad);
+        atomicMin(&status[1], (unsigned long long)first_bad);
+    }
+}
+
 // ================================================================== k_setup
 __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -119,16 +119,6 @@ void free_outputs(iss_ctx *ctx) {
     ctx->capacity = 0;
 }
 
-// letters util.rev_comp accepts (iss/util.py:57-88)
-bool valid_letter(uint8_t c) {
-    switch (c & ~0x20) {
-        case 'A': case 'C': case 'G': case 'T': case 'Y': case 'R': case 'W': case 'S': case 'K': case 'M':
-        case 'N': case 'B': case 'V': case 'D': case 'H':
-            return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
-        default: return false;
-    }
-}
-
 // dynamic LDS of k_main: quality rows + error-test thresholds + substitution table + deferred-work queue
 size_t main_lds_bytes(const iss::DevModel &M) {
     const size_t mut_words = ((size_t)M.n_q + 1 + 3) & ~(size_t)3;
@@ -197,7 +187,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     if (const char *e = getenv("ISS_OVERLAP")) ctx->overlap = atoi(e) != 0;
     void *p = nullptr;
     HIP_TRY(ctx, hipMalloc(&p, 256));
-    ctx->fix_count = static_cast<uint32_t *>(p);  // FIX_SLOTS counters
+    ctx->fix_count = static_cast<uint32_t *>(p);  // FIX_SLOTS counters; +128 B stats; +192 B genome-pack status
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
@@ -426,35 +416,40 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     if (!ctx || !ascii || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload: NULL argument");
     if (length < 1 || length >= (int64_t)0x7fffffff) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^31-2]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // one readable padding word in front (k_main's funnel shifts touch positions >= -3) and two behind
-    const size_t n_pk = (size_t)(length + 15) / 16 + 3, n_mk = (size_t)(length + 31) / 32 + 3;
-    std::vector<uint32_t> pk(n_pk, 0), mk(n_mk, 0);
-    bool any_exception = false;
-    for (int64_t i = 0; i < length; ++i) {
-        const uint8_t c = ascii[i];
-        uint32_t code;
-        switch (c) {
-            case 'A': code = 0; break; case 'T': code = 1; break; case 'C': code = 2; break; case 'G': code = 3; break;
-            default:
-                if (!valid_letter(c)) {
-                    char buf[160];
-                    snprintf(buf, sizeof buf, "genome letter 0x%02x at offset %lld is outside the rev_comp alphabet "
-                             "(the reference raises KeyError, iss/util.py:90)", c, (long long)i);
-                    return fail(ctx, ISS_E_INVALID, buf);
-                }
-                code = 0;
-                mk[1 + (i >> 5)] |= 1u << (i & 31);
-                any_exception = true;
-        }
-        pk[1 + (i >> 4)] |= code << ((i & 15) * 2);
-    }
+    // ASCII -> HBM, then packed on the device (k_pack_genome).  One readable padding word in front
+    // (k_main's funnel shifts touch positions >= -3) and three behind.
+    const size_t n_mk = (size_t)(length + 31) / 32, n_pk = 2 * n_mk;
     Genome G;
     G.L = length;
-    int rc;
-    if ((rc = upload<uint32_t>(ctx, pk.data(), n_pk, &G.packed_alloc, nullptr))) return rc;
-    if ((rc = upload<uint32_t>(ctx, mk.data(), n_mk, &G.mask_alloc, nullptr))) return rc;
-    if ((rc = upload<uint8_t>(ctx, ascii, (size_t)length, &G.ascii, nullptr))) return rc;
-    G.has_exceptions = any_exception;
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, (n_pk + 4) * sizeof(uint32_t)));
+    G.packed_alloc = static_cast<uint32_t *>(p);
+    HIP_TRY(ctx, hipMalloc(&p, (n_mk + 4) * sizeof(uint32_t)));
+    G.mask_alloc = static_cast<uint32_t *>(p);
+    HIP_TRY(ctx, hipMalloc(&p, (size_t)length));
+    G.ascii = static_cast<uint8_t *>(p);
+    auto release = [&]() { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); };
+    unsigned long long *status = reinterpret_cast<unsigned long long *>(ctx->fix_count) + 24;  // 3 words at +192 B
+    const unsigned long long init[3] = {0ull, (unsigned long long)length, 0ull};
+    hipError_t he = hipMemcpyAsync(G.ascii, ascii, (size_t)length, hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + 4) * sizeof(uint32_t), ctx->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(G.mask_alloc, 0, (n_mk + 4) * sizeof(uint32_t), ctx->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(status, init, sizeof init, hipMemcpyHostToDevice, ctx->stream);
+    if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he)); }
+    hipLaunchKernelGGL(iss::k_pack_genome, dim3((unsigned)((n_mk + 255) / 256)), dim3(256), 0, ctx->stream, G.ascii, length,
+                       G.packed_alloc + 1, G.mask_alloc + 1, status);
+    unsigned long long res[3] = {0, 0, 0};
+    he = hipMemcpyAsync(res, status, sizeof res, hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome pack: ") + hipGetErrorString(he)); }
+    if (res[0]) {
+        release();
+        char buf[200];
+        snprintf(buf, sizeof buf, "genome letter 0x%02x at offset %llu is outside the rev_comp alphabet (%llu such letters; "
+                 "the reference raises KeyError, iss/util.py:90)", ascii[res[1]], res[1], res[0]);
+        return fail(ctx, ISS_E_INVALID, buf);
+    }
+    G.has_exceptions = res[2] != 0;
     G.packed = G.packed_alloc + 1;
     G.mask = G.mask_alloc + 1;
     ctx->genomes.push_back(G);

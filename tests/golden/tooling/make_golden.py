@@ -7,7 +7,7 @@ tests/golden/tooling/bio_shim; with it the reference's ow
 golden tests pass, which this script re-checks before capturing anything.
 
 Outputs (all pickle-free ``.npz`` / text, committed under tests/golden/):
-  models/<name>.dense.npz     dense tables of the shipped profiles (insilicoseq_amd.model.DenseModel)
+  ../../insilicoseq_amd/profiles/<name>.dense.npz   dense tables of the shipped profiles (DenseModel)
   pairs/<case>.npz            simulate_read outputs under random.seed(s); np.random.seed(s),
                               plus the next doubles of both MT streams (pins stream consumption)
   units.json                  function-level goldens (reference unit tests re-expressed + extra)
@@ -66,12 +66,14 @@ PROFILES = {
     "miseq-legacy": "iss/profiles/MiSeq", "ecoli": "data/ecoli.npz",
 }
 
-for sub in ("models", "pairs", "worker", "generate"):
+PROFILES_OUT = os.path.join(REPO, "insilicoseq_amd", "profiles")
+os.makedirs(PROFILES_OUT, exist_ok=True)
+for sub in ("pairs", "worker", "generate"):
     os.makedirs(os.path.join(GOLDEN, sub), exist_ok=True)
 
 # 1. dense tables ------------------------------------------------------------------------
 for name, path in PROFILES.items():
-    DenseModel.from_reference_npz(os.path.join(REFCOPY, path)).save(os.path.join(GOLDEN, "models", name + ".dense.npz"))
+    DenseModel.from_reference_npz(os.path.join(REFCOPY, path)).save(os.path.join(PROFILES_OUT, name + ".dense.npz"))
 
 
 # 2. genomes -----------------------------------------------------------------------------

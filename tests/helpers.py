@@ -7,10 +7,11 @@ import numpy as np
 from insilicoseq_amd.model import DenseModel
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PROFILES = os.path.join(os.path.dirname(GOLDEN), "..", "insilicoseq_amd", "profiles")
 
 
 def dense_model(name, indel=None):
-    d = DenseModel.load(os.path.join(GOLDEN, "models", name + ".dense.npz"))
+    d = DenseModel.load(os.path.join(PROFILES, name + ".dense.npz"))
     if indel is not None:
         d.ins[:] = indel[0]
         d.dele[:] = indel[1]

@@ -179,3 +179,71 @@ def test_large_batch_properties(engine):
     engine.synchronize()
     b = engine.download(0, n)
     assert checksum == [int(b[k].astype(np.uint64).sum()) for k in ("r1_base", "r1_qual", "r2_base", "r2_qual")]
+
+
+@pytest.mark.parametrize("workers", [1, 2])
+def test_generate_cli_end_to_end(tmp_path, workers):
+    """`python -m insilicoseq_amd generate` (the reference's `iss generate` flow): abundance file equals the
+    reference's for the same seed; FASTQ equals the oracle (Philox, seed + worker) over the same chunks."""
+    import subprocess
+    import sys
+
+    from helpers import GOLDEN
+    from insilicoseq_amd.distributed import rank_work
+    from insilicoseq_amd.engine import fastq_write
+    from insilicoseq_amd.generator import parse_fasta
+    from oracle import oracle as O
+
+    root = os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0]
+    out = str(tmp_path / "run")
+    fasta = os.path.join(GOLDEN, "genomes.fasta")
+    subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes", fasta, "--model", "hiseq",
+                           "-n", "600", "--seed", "42", "--gpus", str(workers), "--devices", "1", "-o", out,
+                           "--quiet"], cwd=root)
+    z = np.load(os.path.join(GOLDEN, "generate", "genomes_hiseq_n600_seed42_cpus%d.npz" % workers))
+    assert open(out + "_abundance.txt", "rb").read() == z["abundance"].tobytes()  # same numpy stream as the reference
+    dense = dense_model("hiseq")
+    records = list(parse_fasta(fasta))
+    abundance = {}
+    for line in z["abundance"].tobytes().decode().splitlines():
+        k, v = line.split("\t")
+        abundance[k] = float(v)
+    p1, p2 = tmp_path / "e1", tmp_path / "e2"
+    with open(p1, "wb") as f1, open(p2, "wb") as f2:
+        for rank in range(workers):
+            work, _, _ = rank_work(records, None, abundance, 600, None, None, dense, out, workers, rank)
+            rng = O.Rng().seed_philox(42 + rank)
+            ordinal = 0
+            for rec, n, _ in work:
+                if len(rec.seq) <= dense.read_length:
+                    continue
+                res = O.Oracle(dense).simulate(rng, rec.seq, n, first_ordinal=ordinal)
+                assert res["status"] == 0
+                fastq_write(f1.fileno(), f2.fileno(), rec.id, 0, rank, n, dense.read_length, dense.read_length,
+                            res["r1_base"], res["r1_qual"], res["r2_base"], res["r2_qual"], 1)
+                ordinal += n
+    assert open(out + "_R1.fastq", "rb").read() == p1.read_bytes()
+    assert open(out + "_R2.fastq", "rb").read() == p2.read_bytes()
+    assert not os.path.exists(out + ".iss.tmp.genomes.fasta") and not os.path.exists(out + ".iss.tmp.0_R1.fastq")
+
+
+def test_device_genome_packing_roundtrip(engine):
+    """k_pack_genome: every letter class survives (plain, lower case, IUPAC), at word boundaries too."""
+    from helpers import mixed_genome as mg
+
+    dense = dense_model("ecoli")  # read_length 20
+    engine.load_model(dense)
+    for L in (21, 31, 32, 33, 63, 64, 65, 1000, 4099):
+        genome = mg(100 + L, L)
+        engine.clear_genomes()
+        gid = engine.add_genome(genome)
+        n = 64
+        engine.generate(gid, n, seed=3, sequence_type="amplicon")
+        engine.synchronize()
+        got = engine.download(0, n)
+        from oracle import oracle as O
+
+        exp = O.Oracle(dense).simulate(O.Rng().seed_philox(3), genome, n, sequence_type="amplicon")
+        assert exp["status"] == 0
+        for k in ("r1_base", "r2_base", "r1_qual", "r2_qual"):
+            assert np.array_equal(got[k], exp[k]), (L, k)

@@ -35,7 +35,7 @@ def _rank_main(rank, world, port, tmpdir, golden):
     try:
         seed, n_reads = 42, 600
         if rank == 0:
-            dense = DenseModel.load(os.path.join(golden, "models", "hiseq.dense.npz"))
+            dense = DenseModel.load(os.path.join(golden, "..", "..", "insilicoseq_amd", "profiles", "hiseq.dense.npz"))
             recs = list(parse_fasta(os.path.join(golden, "genomes.fasta")))
             ids = [r.id for r in recs]
             genomes = [r.seq.encode() for r in recs]
@@ -45,7 +45,7 @@ def _rank_main(rank, world, port, tmpdir, golden):
         dist.broadcast_object_list(box, src=0)
         ids = box[0]
         dense, genomes = D.broadcast_model_and_genomes(dense, genomes, dist, device="cpu")
-        ref = DenseModel.load(os.path.join(golden, "models", "hiseq.dense.npz"))
+        ref = DenseModel.load(os.path.join(golden, "..", "..", "insilicoseq_amd", "profiles", "hiseq.dense.npz"))
         for k in DenseModel.FIELDS:
             assert np.array_equal(getattr(dense, k), getattr(ref, k)), k
         records = [Record(g.tobytes().decode(), id=i) for g, i in zip(genomes, ids)]
@@ -91,6 +91,6 @@ def test_single_rank_is_a_noop_broadcast():
     from insilicoseq_amd import distributed as D
     from insilicoseq_amd.model import DenseModel
 
-    dense = DenseModel.load(os.path.join(GOLDEN, "models", "ecoli.dense.npz"))
+    dense = DenseModel.load(os.path.join(GOLDEN, "..", "..", "insilicoseq_amd", "profiles", "ecoli.dense.npz"))
     d2, g2 = D.broadcast_model_and_genomes(dense, [b"ACGT" * 10], None)
     assert d2 is dense and g2[0].tobytes() == b"ACGT" * 10
