@@ -129,6 +129,21 @@ int iss_timing_read(iss_ctx *ctx, double ms[4], int64_t *n_launches);
 int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads);
 
 /*
+ * Reference-compatible RNG mode (sequential; for bit-identity with the reference, not throughput).
+ * iss_mt_seed == `random.seed(seed); np.random.seed(seed)` of worker_iterator (iss/generator.py:234-236,
+ * seed = args.seed + cpu_number, must be < 2^32 like numpy's legacy seeding).  iss_generate_mt consumes the
+ * two MT19937 streams exactly as reads_generator/simulate_read do (iss/generator.py:69-192), so rows
+ * [out_first_pair, +*n_done) equal the reference's reads for that worker byte for byte; the stream state
+ * carries over to the next call (the next work item of the worker).  On ISS_E_SHORT_RECORD the one numpy
+ * double the reference draws before its assertion is consumed too.  Not supported here: custom fragment
+ * length, --store_mutations.  iss_mt_peek copies the next n <= 624 words of both streams (not consumed).
+ */
+int iss_mt_seed(iss_ctx *ctx, uint64_t seed);
+int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t sequence_type, int32_t gc_bias,
+                    int64_t out_first_pair, int64_t *n_done);
+int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n);
+
+/*
  * FASTQ emission, replaces SeqIO.write(record, handle, "fastq-sanger") in
  * simulate_reads (iss/generator.py:64-65): records "@{record_id}_{i}_{cpu_number}/{1|2}\n
  * SEQ\n+\nQUAL\n" with QUAL = chr(33+q), ids per iss/generator.py:150, 181; i runs from

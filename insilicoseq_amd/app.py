@@ -12,6 +12,7 @@ failure modes are reproduced deliberately so outputs st
 """
 import argparse
 import gzip
+import random
 import logging
 import multiprocessing as mp
 import os
@@ -52,6 +53,7 @@ def load_error_model(mode, seed, model, fragment_length, fragment_length_sd, sto
         logger.error("--model is required in --mode kde")
         sys.exit(1)
     if seed:  # generator.py:397-400 (seed 0 leaves the parent unseeded)
+        random.seed(seed)
         np.random.seed(seed)
     if model.lower() in PRECOMPUTED:
         npz = os.path.join(PROFILES, PRECOMPUTED[model.lower()] + ".dense.npz")
@@ -101,14 +103,14 @@ def exponential(record_list):
 ABUNDANCE = {"lognormal": lognormal, "uniform": uniform, "exponential": exponential}
 
 
-def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias):
+def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias, rng):
     """One pool process == one GPU.  Records are re-read from the concatenated FASTA (the reference
     pickles them; same content)."""
     logging.basicConfig(level=logging.WARNING)
     records = {r.id: r for r in parse_fasta(genome_file)}
     model = KDErrorModel(npz)
     work = [(records[rid], n, "default") for rid, n in work_spec]
-    worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device)
+    worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device, rng=rng)
 
 
 def generate_reads(args):
@@ -152,7 +154,7 @@ def generate_reads(args):
     for rank, chunk in enumerate(chunks[:workers]):  # zip(work_chunks, temp_file_list), app.py:104
         spec = [(rec.id, n) for rec, n, _ in chunk]
         jobs.append((rank, rank % max(args.devices, 1), genome_file, spec, error_model.npz_path, args.seed,
-                     temp_prefix(args.output, rank), args.sequence_type, args.gc_bias))
+                     temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng))
     if workers == 1:
         for j in jobs:
             _worker(*j)
@@ -189,6 +191,9 @@ def main(argv=None):
     g.add_argument("--fragment-length-sd", "-s", type=int, default=None, dest="fragment_length_sd")
     g.add_argument("--store_mutations", "-M", action="store_true")
     g.add_argument("--compress", "-z", action="store_true")
+    g.add_argument("--rng", default="philox", choices=["philox", "mt"],
+                   help="philox: parallel counter-based streams (default); mt: the reference's Mersenne-Twister "
+                        "streams consumed sequentially on the GPU -- output identical to `iss generate` for the same --seed")
     g.add_argument("--output", "-o", required=True)
     g.add_argument("--quiet", "-q", action="store_true")
     args = p.parse_args(argv)

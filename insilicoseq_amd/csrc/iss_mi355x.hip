@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "iss_kernels.hip.h"
+#include "iss_mt_compat.hip.h"
 
 namespace {
 
@@ -71,6 +72,15 @@ struct iss_ctx {
     uint32_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][2 * SLOW_EVERY * MAIN_THREADS]
     unsigned max_main_grid = 0;
     uint64_t *stats = nullptr;
+    // reference-compatible MT19937 mode (iss_mt_compat.hip.h)
+    struct {
+        bool seeded = false;
+        iss::MtState *d_state = nullptr;      // [2]: CPython random, numpy
+        uint32_t *buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // stream x ping-pong
+        int cur[2] = {0, 0};
+        size_t cap[2] = {0, 0}, fill[2] = {0, 0}, used[2] = {0, 0};
+        iss::MtWalkResult *d_res = nullptr;
+    } mt;
     // timing
     bool timing = false;
     std::vector<TimedLaunch> timed;
@@ -117,6 +127,60 @@ void free_outputs(iss_ctx *ctx) {
     if (ctx->fix_list) (void)hipFree(ctx->fix_list);
     ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
     ctx->capacity = 0;
+}
+
+void free_mt(iss_ctx *ctx) {
+    if (ctx->mt.d_state) (void)hipFree(ctx->mt.d_state);
+    if (ctx->mt.d_res) (void)hipFree(ctx->mt.d_res);
+    for (auto &st : ctx->mt.buf) for (auto &b : st) { if (b) (void)hipFree(b); b = nullptr; }
+    ctx->mt.d_state = nullptr; ctx->mt.d_res = nullptr; ctx->mt.seeded = false;
+    ctx->mt.cap[0] = ctx->mt.cap[1] = 0;
+}
+
+// MT19937 seeding, as CPython's random.seed(int) (init_by_array over the 32-bit digits of |seed|) and
+// numpy's legacy RandomState.seed(int) (init_genrand) do it -- iss/generator.py:234-236.
+void mt_init_genrand(uint32_t *mt, uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+void mt_init_by_array(uint32_t *mt, const uint32_t *key, int len) {
+    mt_init_genrand(mt, 19650218u);
+    int i = 1, j = 0;
+    for (int k = std::max(624, len); k; --k) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+        if (++j >= len) j = 0;
+    }
+    for (int k = 623; k; --k) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+}
+
+// make at least `want[s]` unconsumed words available in stream s (capacity permitting)
+int mt_ensure(iss_ctx *ctx, const size_t want[2]) {
+    uint32_t blocks[2] = {0, 0};
+    uint32_t *dst[2] = {nullptr, nullptr};
+    for (int s = 0; s < 2; ++s) {
+        auto &m = ctx->mt;
+        const size_t left = m.fill[s] - m.used[s];
+        if (left >= want[s]) continue;
+        const int nxt = m.cur[s] ^ 1;
+        if (left)
+            HIP_TRY(ctx, hipMemcpyAsync(m.buf[s][nxt], m.buf[s][m.cur[s]] + m.used[s], left * sizeof(uint32_t),
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+        const size_t room = (m.cap[s] - left) / 624;
+        blocks[s] = (uint32_t)std::min(room, (want[s] - left + 623) / 624);
+        dst[s] = m.buf[s][nxt] + left;
+        m.cur[s] = nxt;
+        m.used[s] = 0;
+        m.fill[s] = left + (size_t)blocks[s] * 624;
+    }
+    if (blocks[0] || blocks[1])
+        hipLaunchKernelGGL(iss::k_mt_fill, dim3(2), dim3(256), 0, ctx->stream, ctx->mt.d_state, dst[0], dst[1], blocks[0],
+                           blocks[1]);
+    return 0;
 }
 
 // dynamic LDS of k_main: quality rows + error-test thresholds + substitution table + deferred-work queue
@@ -176,6 +240,8 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_main),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_mt_walk),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_fixup),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
@@ -209,6 +275,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
     if (ctx->slow_ovf) (void)hipFree(ctx->slow_ovf);
+    free_mt(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->indel_stream) (void)hipStreamDestroy(ctx->indel_stream);
     delete ctx;
@@ -683,6 +750,131 @@ int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads) {
     HIP_TRY(ctx, hipMemcpy(&v, ctx->stats, sizeof v, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof v));
     if (n_fixup_reads) *n_fixup_reads = (int64_t)v;
+    return 0;
+}
+
+// ------------------------------------------------------------------ reference-compatible MT mode
+int iss_mt_seed(iss_ctx *ctx, uint64_t seed) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    if (seed > 0xffffffffull) return fail(ctx, ISS_E_INVALID, "seed must be < 2^32 (numpy's legacy seeding raises)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    auto &m = ctx->mt;
+    if (!m.d_state) {
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, 2 * sizeof(iss::MtState)));
+        m.d_state = static_cast<iss::MtState *>(p);
+        HIP_TRY(ctx, hipMalloc(&p, sizeof(iss::MtWalkResult)));
+        m.d_res = static_cast<iss::MtWalkResult *>(p);
+    }
+    iss::MtState st[2];
+    const uint32_t key[1] = {(uint32_t)seed};
+    mt_init_by_array(st[0].mt, key, 1);       // random.seed(seed)
+    mt_init_genrand(st[1].mt, (uint32_t)seed);  // np.random.seed(seed)
+    HIP_TRY(ctx, hipMemcpy(m.d_state, st, sizeof st, hipMemcpyHostToDevice));
+    m.fill[0] = m.fill[1] = m.used[0] = m.used[1] = 0;
+    m.seeded = true;
+    return 0;
+}
+
+static int mt_reserve(iss_ctx *ctx, size_t cap_py, size_t cap_np) {
+    auto &m = ctx->mt;
+    const size_t want[2] = {cap_py, cap_np};
+    for (int s = 0; s < 2; ++s) {
+        if (m.cap[s] >= want[s]) continue;
+        if (m.fill[s] != m.used[s]) {  // keep the unconsumed words
+            std::vector<uint32_t> keep(m.fill[s] - m.used[s]);
+            HIP_TRY(ctx, hipMemcpy(keep.data(), m.buf[s][m.cur[s]] + m.used[s], keep.size() * 4, hipMemcpyDeviceToHost));
+            for (auto &b : m.buf[s]) { if (b) (void)hipFree(b); b = nullptr; }
+            for (auto &b : m.buf[s]) { void *p = nullptr; HIP_TRY(ctx, hipMalloc(&p, want[s] * 4)); b = static_cast<uint32_t *>(p); }
+            HIP_TRY(ctx, hipMemcpy(m.buf[s][0], keep.data(), keep.size() * 4, hipMemcpyHostToDevice));
+            m.fill[s] = keep.size();
+        } else {
+            for (auto &b : m.buf[s]) { if (b) (void)hipFree(b); b = nullptr; }
+            for (auto &b : m.buf[s]) { void *p = nullptr; HIP_TRY(ctx, hipMalloc(&p, want[s] * 4)); b = static_cast<uint32_t *>(p); }
+            m.fill[s] = 0;
+        }
+        m.cur[s] = 0;
+        m.used[s] = 0;
+        m.cap[s] = want[s];
+    }
+    return 0;
+}
+
+int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t sequence_type, int32_t gc_bias,
+                    int64_t out_first_pair, int64_t *n_done) {
+    if (n_done) *n_done = 0;
+    if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_generate_mt: upload a model first");
+    if (!ctx->mt.seeded) return fail(ctx, ISS_E_INVALID, "iss_generate_mt: call iss_mt_seed first");
+    if (genome_id < 0 || genome_id >= (int32_t)ctx->genomes.size()) return fail(ctx, ISS_E_INVALID, "unknown genome id");
+    if (sequence_type != ISS_SEQ_METAGENOMICS && sequence_type != ISS_SEQ_AMPLICON)
+        return fail(ctx, ISS_E_INVALID, "sequence type is not supported");
+    if (n_pairs < 0 || out_first_pair < 0 || out_first_pair + n_pairs > ctx->capacity)
+        return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
+    const Genome &G = ctx->genomes[genome_id];
+    const iss::DevModel &M = ctx->M;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    const int64_t CH = 8192;
+    const size_t py_need = iss::mt_py_need(M.RL), np_need = iss::mt_np_need(M.RL);
+    { int rc_ = mt_reserve(ctx, (size_t)(CH + 1) * py_need + 1248, (size_t)(CH + 1) * np_need + 1248); if (rc_) return rc_; }
+    auto &m = ctx->mt;
+    if (!(M.RL < G.L)) {
+        // the reference draws the insert size BEFORE its assertion fails (generator.py:125, 130): one numpy double
+        const size_t want[2] = {0, 2};
+        { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
+        m.used[1] += 2;
+        return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
+    }
+    if (n_pairs == 0) return 0;
+    const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
+    const size_t fixed_lds = iss::mt_walk_fixed_lds_bytes(M.RL);
+    const bool use_rows = M.n_tiles == 1 && (size_t)M.tile_words * 4 + fixed_lds <= 150 * 1024;
+    const size_t lds_bytes = fixed_lds + (use_rows ? (size_t)M.tile_words * 4 : 0);
+    int64_t done = 0;
+    while (done < n_pairs) {
+        const int64_t n = std::min(CH, n_pairs - done);
+        const size_t want[2] = {std::min(m.cap[0] / 624 * 624 - 624, (size_t)(n + 1) * py_need),
+                                std::min(m.cap[1] / 624 * 624 - 624, (size_t)(n + 1) * np_need)};
+        { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
+        iss::MtWalkArgs A{};
+        A.py = m.buf[0][m.cur[0]] + m.used[0];
+        A.np = m.buf[1][m.cur[1]] + m.used[1];
+        A.py_avail = (uint32_t)(m.fill[0] - m.used[0]);
+        A.np_avail = (uint32_t)(m.fill[1] - m.used[1]);
+        A.n_pairs = n;
+        A.sequence_type = sequence_type;
+        A.gc_bias = gc_bias ? 1 : 0;
+        A.gc_thr = 8106479329266893ull;
+        const int64_t row0 = out_first_pair + done;
+        for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
+        A.res = m.d_res;
+        A.use_rows = use_rows ? 1 : 0;
+        hipLaunchKernelGGL(iss::k_mt_walk, dim3(1), dim3(64), lds_bytes, ctx->stream, M, dg, A, ctx->desc + row0);
+        iss::MtWalkResult res{};
+        HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipGetLastError());
+        m.used[0] += res.py_used;
+        m.used[1] += res.np_used;
+        done += res.n_done;
+        if (res.n_done == 0 && res.starved && A.py_avail >= want[0] && A.np_avail >= want[1])
+            return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+    }
+    if (n_done) *n_done = done;
+    return 0;
+}
+
+int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n) {
+    if (!ctx || !ctx->mt.seeded || n < 0 || n > 624) return fail(ctx, ISS_E_INVALID, "iss_mt_peek: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = mt_reserve(ctx, 4 * 624, 4 * 624); if (rc_) return rc_; }
+    const size_t want[2] = {(size_t)n, (size_t)n};
+    { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
+    auto &m = ctx->mt;
+    if (py_words) HIP_TRY(ctx, hipMemcpyAsync(py_words, m.buf[0][m.cur[0]] + m.used[0], (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (np_words) HIP_TRY(ctx, hipMemcpyAsync(np_words, m.buf[1][m.cur[1]] + m.used[1], (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

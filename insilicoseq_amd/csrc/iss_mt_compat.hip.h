@@ -1,0 +1,300 @@
+// iss_mt_compat.hip.h -- reference-compatible RNG mode: the two sequential MT19937 streams of the
+// reference (CPython `random` and numpy's legacy global RandomState) generated and consumed ON THE
+// DEVICE in the reference's exact order, so that the GPU output equals the reference's output for a
+// given (seed, cpu_number) byte for byte.
+//
+//   k_mt_fill : one workgroup per stream; MT19937 block recurrence in four parallel phases
+//               (k < 227 | 227 <= k < 454 | 454 <= k < 623 | k = 623), tempering, coalesced stores.
+//   k_mt_walk : ONE wavefront per worker walks the pairs sequentially (a pair's stream offsets
+//               depend on everything before it: rejection sampling in randrange, one extra numpy
+//               double per substitution event); inside a pair the 64 lanes work across positions.
+//               Stream consumption order is the reference's:
+//                 np: insert size | py: randrange | [per mate] py: 5 doubles per visited indel step,
+//                 np: bin + RL phred doubles, py: RL substitution-test doubles, np: 1 per event |
+//                 py: reverse-end fallback randrange between the mates | np: gc_bias double.
+//
+// This mode is sequential by construction (~1e5 pairs/s): it exists for bit-identity with the
+// reference, not for throughput; the Philox path (iss_kernels.hip.h) is the performance path.
+#pragma once
+#include "iss_kernels.hip.h"
+
+namespace iss {
+
+struct MtState {
+    uint32_t mt[624];  // state at a block boundary (the next output needs a twist)
+};
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b) {
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// grid = 2 (stream 0: CPython random, stream 1: numpy), block = 256
+__global__ __launch_bounds__(256) void k_mt_fill(MtState *states, uint32_t *out0, uint32_t *out1, uint32_t blocks0,
+                                                 uint32_t blocks1) {
+    __shared__ uint32_t buf[2][624];
+    const int s = blockIdx.x;
+    uint32_t *out = s ? out1 : out0;
+    const uint32_t n_blocks = s ? blocks1 : blocks0;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 624; k += 256) buf[0][k] = states[s].mt[k];
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t *o = buf[cur];
+        uint32_t *n = buf[cur ^ 1];
+        if (tid < 227) n[tid] = o[tid + 397] ^ mt_twist(o[tid], o[tid + 1]);
+        __syncthreads();
+        if (tid < 227) n[227 + tid] = n[tid] ^ mt_twist(o[227 + tid], o[228 + tid]);
+        __syncthreads();
+        if (tid < 169) n[454 + tid] = n[227 + tid] ^ mt_twist(o[454 + tid], o[455 + tid]);
+        __syncthreads();
+        if (tid == 0) n[623] = n[396] ^ mt_twist(o[623], n[0]);
+        __syncthreads();
+        for (int k = tid; k < 624; k += 256) out[(size_t)b * 624 + k] = mt_temper(n[k]);
+        cur ^= 1;
+        __syncthreads();
+    }
+    for (int k = tid; k < 624; k += 256) states[s].mt[k] = buf[cur][k];
+}
+
+struct MtWalkResult {
+    uint32_t py_used, np_used;  // words consumed from each stream buffer
+    int64_t n_done;             // pairs emitted
+    int32_t starved;            // stopped because a stream buffer could run dry
+    int32_t pad;
+};
+
+struct MtWalkArgs {
+    const uint32_t *py, *np;  // stream words, starting at the current consumption point
+    uint32_t py_avail, np_avail;
+    int64_t n_pairs;
+    int32_t sequence_type, gc_bias;
+    uint64_t gc_thr;
+    uint8_t *out[4];
+    MtWalkResult *res;
+    int32_t use_rows;  // the compressed quality rows (single tile) are staged in LDS
+    int32_t win_words; // LDS words for the slow indel path's stream window (10 * (RL - 1))
+};
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// worst-case stream words one attempt at a pair can consume (randrange bounded at 64 words each)
+__host__ __device__ inline uint32_t mt_py_need(int RL) { return 128u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
+__host__ __device__ inline uint32_t mt_np_need(int RL) { return 2u + 2u * (2u + 4u * (uint32_t)RL) + 2u; }
+__host__ __device__ inline size_t mt_walk_fixed_lds_bytes(int RL) {
+    const size_t rlp = (size_t)((RL + 63) & ~63);
+    return 64 * 8 /* mut_thr */ + (rlp + 64) /* tmpl */ + 3 * rlp /* read, qual, stack */ + (size_t)10 * RL * 4 /* window */;
+}
+
+// CPython _randbelow_with_getrandbits on the stream: 64 candidate words per round, first one < n wins
+__device__ __forceinline__ uint32_t mt_randbelow(const uint32_t *py, uint32_t &opy, uint32_t n, int lane) {
+    const int k = 32 - __clz(n);
+    for (;;) {
+        const uint32_t r = py[opy + lane] >> (32 - k);
+        const unsigned long long ok = __ballot(r < n);
+        if (ok) {
+            const int t = __ffsll(ok) - 1;
+            opy += (uint32_t)t + 1u;
+            return (uint32_t)__shfl((int)r, t);
+        }
+        opy += 64u;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkArgs A, PairDesc *desc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x;
+    const int RL = M.RL;
+    const int rlp = (RL + 63) & ~63;
+    // LDS carve: [rows (optional)] [mut_thr u64 x 64] [tmpl rlp+64] [read rlp] [qual rlp] [stk rlp] [win]
+    uint32_t *rows = lds;
+    uint64_t *mut_thr = reinterpret_cast<uint64_t *>(lds + (A.use_rows ? M.tile_words : 0));
+    uint8_t *tmpl = reinterpret_cast<uint8_t *>(mut_thr + 64);
+    uint8_t *rd = tmpl + rlp + 64;
+    uint8_t *ql = rd + rlp;
+    uint8_t *stk = ql + rlp;
+    uint32_t *win = reinterpret_cast<uint32_t *>(stk + rlp);
+    if (A.use_rows)
+        for (int i = lane; i < M.tile_words; i += 64) rows[i] = M.qrows[i];
+    for (int i = lane; i <= M.n_q; i += 64) mut_thr[i] = M.mut_thr[i];
+    __syncthreads();
+    const uint32_t py_need = mt_py_need(RL), np_need = mt_np_need(RL);
+    const uint32_t *py = A.py, *np = A.np;
+    uint32_t opy = 0, onp = 0;
+    const int64_t L = g.L;
+    const uint32_t gbytes = 1u << M.GB;
+    int64_t i = 0;
+    int starved = 0;
+    while (i < A.n_pairs) {
+        if (opy + py_need > A.py_avail || onp + np_need > A.np_avail) { starved = 1; break; }
+        // ---- insert size: np.searchsorted(cdf, np.random.rand())  (kde.py:97)
+        int isz;
+        {
+            const uint64_t m = mk53(np[onp], np[onp + 1]);
+            onp += 2;
+            int cnt = 0;
+            for (int j = lane; j < M.n_isize; j += 64) cnt += M.isize_thr[j] < m ? 1 : 0;
+            isz = wave_sum(cnt);
+        }
+        PairDesc d;
+        d.isz = isz;
+        d.meta = 0;
+        int64_t fs, rs = 0, re = 0;
+        if (A.sequence_type == 0) {  // generator.py:134-135, 142-144
+            const int64_t width = L - ((int64_t)isz + 2 * RL);
+            fs = mt_randbelow(py, opy, (uint32_t)(width > 0 ? width : L - RL), lane);
+        } else {
+            fs = 0;
+        }
+        d.fs = (int32_t)fs;
+        for (int o = 0; o < 2; ++o) {
+            if (o == 1) {  // generator.py:164-177
+                if (A.sequence_type == 0) { rs = fs + RL + isz; re = rs + RL; }
+                else { rs = L - RL; re = L; }
+                if (re > L) { re = RL + (int64_t)mt_randbelow(py, opy, (uint32_t)(L - RL), lane); rs = re - RL; }
+            }
+            d.re = (int32_t)(o == 1 ? re : 0);
+            // ---- template E(0 .. RL+63) (read direction; beyond RL: adjust_seq_length padding)
+            for (int k = lane; k < RL + 64; k += 64) tmpl[k] = (uint8_t)read_dir_base(g, o, d, k);
+            __syncthreads();
+            // ---- introduce_indels: fast check (no event, no ambiguous letter => 5 doubles per step, read unchanged)
+            bool any = false;
+            for (int n = lane; n < RL - 1; n += 64) {
+                const int bi = base_index(tmpl[n]);
+                const uint32_t *w = py + opy + 10u * (uint32_t)n;
+                const size_t en = ((size_t)o * RL + n) * 4;
+                bool hit = bi < 0;
+                for (int x = 0; x < 4; ++x) hit |= mk53(w[2 * x], w[2 * x + 1]) < M.ins_thr[en + x];
+                if (bi >= 0) hit |= mk53(w[8], w[9]) < M.del_thr[en + bi];
+                any |= hit;
+            }
+            if (!__ballot(any)) {
+                for (int p = lane; p < RL; p += 64) rd[p] = tmpl[p];
+                opy += 10u * (uint32_t)(RL - 1);
+            } else {
+                // exact sequential list semantics (all lanes run the same walk on wave-uniform values)
+                for (int k = lane; k < 10 * (RL - 1); k += 64) win[k] = py[opy + k];
+                __syncthreads();
+                int sp = 0, k = 0, j = 0;
+                uint32_t pos = 0;
+                auto src = [&](int kk) { return kk < RL + 64 ? (int)tmpl[kk] : read_dir_base(g, o, d, kk); };
+                for (int n = 0; n < RL - 1; ++n) {
+                    int tok;
+                    if (sp > 0) tok = stk[--sp];
+                    else if (k < RL) tok = src(k++);
+                    else { if (lane == 0) rd[j] = (uint8_t)src(k); ++k; ++j; continue; }  // n >= len(seq)
+                    const int bi = base_index(tok);
+                    if (bi < 0) { if (lane == 0) rd[j] = (uint8_t)tok; ++j; continue; }  // ambiguous: no draws
+                    const size_t en = ((size_t)o * RL + n) * 4;
+                    for (int x = 0; x < 4; ++x) {
+                        const uint64_t m = mk53(win[pos], win[pos + 1]);
+                        pos += 2;
+                        if (m < M.ins_thr[en + x]) {
+                            if (sp == rlp) { if (lane == 0) for (int z = 1; z < sp; ++z) stk[z - 1] = stk[z]; --sp; }
+                            if (lane == 0) stk[sp] = M.ins_letter[en + x];
+                            ++sp;
+                            __syncthreads();
+                        }
+                    }
+                    const uint64_t m = mk53(win[pos], win[pos + 1]);
+                    pos += 2;
+                    if (m < M.del_thr[en + bi]) tok = sp > 0 ? (int)stk[--sp] : src(k++);  // next token slides in
+                    if (lane == 0) rd[j] = (uint8_t)tok;
+                    ++j;
+                }
+                if (lane == 0) rd[j] = (uint8_t)(sp > 0 ? (int)stk[sp - 1] : src(k));
+                opy += pos;
+            }
+            __syncthreads();
+            // ---- gen_phred_scores: bin choice + one CDF inversion per position (kde.py:72-85)
+            int bin;
+            {
+                const uint64_t m = mk53(np[onp], np[onp + 1]);
+                onp += 2;
+                bin = count_le(M.bin_thr + 4 * o, 4, m);
+                bin = bin > 3 ? 3 : bin;
+            }
+            const int slot = M.bin_slot[o * 4 + bin] & 3;
+            d.meta |= (uint32_t)slot << (2 * o);
+            for (int p = lane; p < RL; p += 64) {
+                const uint64_t m = mk53(np[onp + 2u * (uint32_t)p], np[onp + 2u * (uint32_t)p + 1]);
+                int q;
+                const uint64_t *full = M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * M.n_q;
+                if (A.use_rows) {
+                    const uint32_t h = (uint32_t)(m >> 37);
+                    const uint32_t row = ((uint32_t)(o * M.NB + slot) * (uint32_t)M.TG + (uint32_t)(p >> 2)) * (uint32_t)M.GS +
+                                         (uint32_t)(p & 3) * (uint32_t)M.stride_w;
+                    uint32_t j = reinterpret_cast<const uint8_t *>(rows)[row * 4 + (h >> (16 - M.GB))];
+                    uint32_t e = rows[row + gbytes / 4 + j];
+                    while ((e >> 15) < h) e = rows[row + gbytes / 4 + (++j)];
+                    q = (int)((e >> 2) & 0xffu);
+                    if ((e >> 15) == h) q = count_lt(full, M.n_q, m);
+                } else {
+                    q = count_lt(full, M.n_q, m);
+                }
+                ql[p] = (uint8_t)q;
+            }
+            onp += 2u * (uint32_t)RL;
+            __syncthreads();
+            // ---- mut_sequence: one py double per position, one np double per substitution event, in order
+            uint8_t *ob = A.out[2 * o] + (size_t)i * M.pitch;
+            uint8_t *oq = A.out[2 * o + 1] + (size_t)i * M.pitch;
+            uint32_t nev = 0;
+            for (int p0 = 0; p0 < RL; p0 += 64) {
+                const int p = p0 + lane;
+                bool err = false;
+                int ch = 0, q = 0, bi = -1;
+                if (p < RL) {
+                    ch = rd[p];
+                    q = ql[p];
+                    bi = base_index(ch);
+                    const uint64_t m = mk53(py[opy + 2u * (uint32_t)p], py[opy + 2u * (uint32_t)p + 1]);
+                    err = m > mut_thr[q] && bi >= 0;
+                }
+                const unsigned long long evm = __ballot(err);
+                if (err) {
+                    const uint32_t rank = nev + (uint32_t)__popcll(evm & ((1ull << lane) - 1ull));
+                    const uint64_t ms = mk53(np[onp + 2u * rank], np[onp + 2u * rank + 1]);
+                    const size_t row = ((size_t)(o * RL + p) * 4 + bi) * 3;
+                    const int k = (ms >= M.subst_thr[row]) + (ms >= M.subst_thr[row + 1]);
+                    ch = M.subst_alt[row + k];
+                }
+                nev += (uint32_t)__popcll(evm);
+                if (p < RL) { ob[p] = (uint8_t)ch; oq[p] = (uint8_t)q; }
+            }
+            opy += 2u * (uint32_t)RL;
+            onp += 2u * nev;
+            __syncthreads();
+        }
+        d.re = (int32_t)re;
+        bool keep = true;
+        if (A.gc_bias) {  // generator.py:82-92
+            keep = mk53(np[onp], np[onp + 1]) < A.gc_thr;
+            onp += 2;
+        }
+        if (keep) {
+            if (lane == 0) desc[i] = d;
+            ++i;
+        }
+    }
+    if (lane == 0) {
+        A.res->py_used = opy;
+        A.res->np_used = onp;
+        A.res->n_done = i;
+        A.res->starved = starved;
+    }
+}
+
+}  // namespace iss

@@ -109,6 +109,28 @@ class ReadEngine(object):
                                            int(seed) & (2**64 - 1), SEQ_TYPES[sequence_type], int(bool(gc_bias)),
                                            int(out_first_pair)))
 
+    # ------------------------------------------------------------------ reference-compatible MT mode
+    def seed_mt(self, seed):
+        """random.seed(seed); np.random.seed(seed) -- on the device (iss/generator.py:234-236)."""
+        self._check(self._lib.iss_mt_seed(self._ctx, int(seed)))
+
+    def generate_mt(self, genome_id, n_pairs, sequence_type="metagenomics", gc_bias=False, out_first_pair=0):
+        """Sequential, reference-identical generation; returns the number of pairs emitted."""
+        if sequence_type not in SEQ_TYPES:
+            raise ValueError("Sequence type %s not known" % sequence_type)
+        self.reserve(out_first_pair + n_pairs)
+        done = C.c_int64(0)
+        self._check(self._lib.iss_generate_mt(self._ctx, int(genome_id), int(n_pairs), SEQ_TYPES[sequence_type],
+                                              int(bool(gc_bias)), int(out_first_pair), C.byref(done)))
+        return done.value
+
+    def mt_peek(self, n=8):
+        """The next n 32-bit words of (CPython random, numpy) -- not consumed."""
+        a = np.zeros(n, dtype=np.uint32)
+        b = np.zeros(n, dtype=np.uint32)
+        self._check(self._lib.iss_mt_peek(self._ctx, a.ctypes.data, b.ctypes.data, int(n)))
+        return a, b
+
     def synchronize(self):
         self._check(self._lib.iss_synchronize(self._ctx))
 

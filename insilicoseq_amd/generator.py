@@ -148,12 +148,19 @@ class Worker(object):
 
     BATCH_PAIRS = 1 << 20  # rows generated / downloaded / formatted per step of the streaming loop
 
-    def __init__(self, error_model, cpu_number, seed, device=None):
+    def __init__(self, error_model, cpu_number, seed, device=None, rng="philox"):
+        if rng not in ("philox", "mt"):
+            raise ValueError("rng must be 'philox' (parallel, default) or 'mt' (reference-identical, sequential)")
+        self.rng = rng
         self.cpu_number = int(cpu_number)
         self.seed = worker_seed(seed, cpu_number)
         self.engine = ReadEngine(self.cpu_number if device is None else device)
         self.dense = _dense_of(error_model)
         self.engine.load_model(self.dense)
+        if rng == "mt":
+            # random.seed(seed + cpu_number); np.random.seed(seed + cpu_number)  (generator.py:234-236);
+            # unseeded workers draw an OS-entropy seed (the reference is then not reproducible either)
+            self.engine.seed_mt(self.seed & 0xFFFFFFFF if seed is None else self.seed)
         self.ordinal = 0
         self._gids = {}
 
@@ -177,6 +184,13 @@ class Worker(object):
             # AssertionError in simulate_read -> warning + record skipped (generator.py:77-80)
             logger.warning("%s shorter than read length for this ErrorModel" % record.id)
             logger.warning("Skipping %s. You will have less reads than specified" % record.id)
+            if self.rng == "mt" and n_pairs > 0:
+                # the reference has already drawn the insert size when its assertion fails: keep the streams aligned
+                try:
+                    eng.generate_mt(self.genome_id(record), 1)
+                except _native.EngineError as e:
+                    if e.code != _native.E_SHORT_RECORD:
+                        raise
             return 0
         gid = self.genome_id(record)
         for fh in (forward_handle, reverse_handle):
@@ -184,8 +198,11 @@ class Worker(object):
         done = 0
         while done < n_pairs:
             n = min(self.BATCH_PAIRS, n_pairs - done)
-            eng.generate(gid, n, first_ordinal=self.ordinal, seed=self.seed, sequence_type=sequence_type,
-                         gc_bias=gc_bias, out_first_pair=0)
+            if self.rng == "mt":
+                assert eng.generate_mt(gid, n, sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0) == n
+            else:
+                eng.generate(gid, n, first_ordinal=self.ordinal, seed=self.seed, sequence_type=sequence_type,
+                             gc_bias=gc_bias, out_first_pair=0)
             eng.synchronize()
             rows = eng.download(0, n)["_pitched"]
             fastq_write(forward_handle.fileno(), reverse_handle.fileno(), record.id, done, self.cpu_number, n,
@@ -206,8 +223,11 @@ def simulate_reads(record, error_model, n_pairs, cpu_number, forward_handle, rev
         w.close()
 
 
-def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence_type, gc_bias, device=None):
-    """iss/generator.py:223-251 on GPU ``device`` (default: ``cpu_number``)."""
+def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence_type, gc_bias, device=None,
+                    rng="philox"):
+    """iss/generator.py:223-251 on GPU ``device`` (default: ``cpu_number``).  ``rng="mt"`` consumes the
+    reference's two Mersenne-Twister streams on the device: the files then equal the reference's byte for
+    byte (sequential, ~1e5 pairs/s); ``rng="philox"`` is the parallel path."""
     logger = logging.getLogger(__name__)
     if getattr(error_model, "store_mutations", False):
         raise NotImplementedError("--store_mutations (VCF rows) is not on the device path yet (SURVEY.md 8 f3)")
@@ -220,7 +240,7 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
     except PermissionError as e:
         logger.error("Failed to write temporary output file(s): %s" % e)
         sys.exit(1)
-    w = Worker(error_model, cpu_number, seed, device=device)
+    w = Worker(error_model, cpu_number, seed, device=device, rng=rng)
     try:
         with forward_handle, reverse_handle, mutation_handle:
             for record, n_pairs, _mode in work:

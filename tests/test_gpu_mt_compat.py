@@ -1,0 +1,113 @@
+"""Reference-compatible MT mode on the GPU: the device consumes the reference's two MT19937 streams in
+the reference's order, so its output must equal the REFERENCE's golden vectors directly (no oracle in
+between): pair sets, stream positions afterwards, worker FASTQ files, and whole `iss generate` runs."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, dense_model, load_pairs_case, pairs_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from insilicoseq_amd.engine import ReadEngine
+
+    eng = ReadEngine(0)
+    yield eng
+    eng.close()
+
+
+def _res53(words):
+    w = words.astype(np.uint64)
+    return ((w[0::2] >> np.uint64(5)) * np.uint64(67108864) + (w[1::2] >> np.uint64(6))).astype(np.float64) / 9007199254740992.0
+
+
+def test_mt_streams_on_device(engine):
+    z = np.load(os.path.join(GOLDEN, "mt_taps.npz"))
+    engine.load_model(dense_model("ecoli"))
+    for s in (0, 1, 42, 43, 2**31, 2**32 - 1):
+        engine.seed_mt(s)
+        py, npw = engine.mt_peek(624)
+        assert (py == z["py_%d" % s][:624]).all()
+        assert (_res53(npw) == z["npd_%d" % s][:312]).all()
+
+
+MT_CASES = [c for c in pairs_cases() if "frag" not in c and c != "miseq_legacy_amplicon"]  # no custom fragment length
+
+
+@pytest.mark.parametrize("case", MT_CASES)
+def test_pairs_equal_reference(engine, case):
+    z, meta = load_pairs_case(case)
+    dense = dense_model(meta["model"], meta["indel"])
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(z["genome"].tobytes())
+    engine.seed_mt(meta["seed"])
+    n = meta["n_pairs"]
+    if meta["n_done"] == 0:
+        pytest.skip("record skipped by the reference")
+    assert engine.generate_mt(gid, n, sequence_type=meta["sequence_type"], gc_bias=meta["gc_bias"]) == n
+    got = engine.download(0, n)
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        bad = np.argwhere(got[k] != z[k])
+        assert bad.size == 0, "%s differs from the reference at %s (%d cells)" % (k, bad[:5].tolist(), len(bad))
+    py, npw = engine.mt_peek(8)  # both streams stand where the reference's stand
+    assert list(_res53(py)) == list(z["tail_py"]) and list(_res53(npw)) == list(z["tail_np"])
+
+
+@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc"])
+def test_worker_files_equal_reference(case, tmp_path):
+    from insilicoseq_amd.generator import Record, worker_iterator
+
+    z = np.load(os.path.join(GOLDEN, "worker", case + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    recs = [Record(z["genome_%d" % i].tobytes().decode(), id=rid) for i, rid in enumerate(meta["ids"])]
+    work = [(r, n, "default") for r, n in zip(recs, meta["counts"])]
+    prefix = str(tmp_path / "w")
+    worker_iterator(work, dense_model(meta["model"]), meta["cpu_number"], prefix, meta["seed"], meta["sequence_type"],
+                    meta["gc_bias"], device=0, rng="mt")
+    assert open(prefix + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(prefix + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+
+
+@pytest.mark.parametrize("cpus", [1, 2, 3])
+def test_generate_cli_equals_reference(cpus, tmp_path):
+    """python -m insilicoseq_amd generate --rng mt == the reference's `iss generate --cpus N` output files."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "run")
+    subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes",
+                           os.path.join(GOLDEN, "genomes.fasta"), "--model", "hiseq", "-n", "600", "--seed", "42",
+                           "--cpus", str(cpus), "--devices", "1", "--rng", "mt", "-o", out, "--quiet"], cwd=root)
+    z = np.load(os.path.join(GOLDEN, "generate", "genomes_hiseq_n600_seed42_cpus%d.npz" % cpus))
+    assert open(out + "_abundance.txt", "rb").read() == z["abundance"].tobytes()
+    assert open(out + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(out + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+
+
+def test_mt_mode_large_equals_oracle(engine):
+    """20k pairs (several stream refills) against the CPU oracle in MT mode, plus the stream positions."""
+    from helpers import random_genome
+    from oracle import oracle as O
+
+    dense = dense_model("novaseq")
+    genome = random_genome(91, 300000)
+    n = 20000
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.seed_mt(4242)
+    assert engine.generate_mt(gid, n) == n
+    got = engine.download(0, n)
+    rng = O.Rng().seed_mt(4242)
+    exp = O.Oracle(dense).simulate(rng, genome, n)
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        assert np.array_equal(got[k], exp[k]), k
+    py, npw = engine.mt_peek(8)
+    assert list(_res53(py)) == [rng.py_random() for _ in range(4)]
+    assert list(_res53(npw)) == [rng.np_random() for _ in range(4)]
