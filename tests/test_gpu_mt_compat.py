@@ -111,3 +111,36 @@ def test_mt_mode_large_equals_oracle(engine):
     py, npw = engine.mt_peek(8)
     assert list(_res53(py)) == [rng.py_random() for _ in range(4)]
     assert list(_res53(npw)) == [rng.np_random() for _ in range(4)]
+
+
+def test_config1_scale_short_genomes_miseq(engine):
+    """BASELINE configs[1] flavour: data/genomes.fasta (records shorter than the MiSeq fragment: fallback
+    branches everywhere), --model miseq, seed-fixed, GPU (MT mode) vs CPU (oracle with the reference's MT
+    streams) bit-exact -- 60 k pairs spread over the records like a worker's work list."""
+    from insilicoseq_amd.generator import parse_fasta
+    from oracle import oracle as O
+
+    dense = dense_model("miseq")
+    records = list(parse_fasta(os.path.join(GOLDEN, "genomes.fasta")))
+    counts = [24000, 9000, 12000, 15000, 100]
+    engine.load_model(dense)
+    engine.clear_genomes()
+    engine.seed_mt(42)
+    rng = O.Rng().seed_mt(42)
+    orc = O.Oracle(dense)
+    from insilicoseq_amd import _native
+
+    for rec, n in zip(records, counts):
+        exp = orc.simulate(rng, rec.seq, n)
+        if exp["status"] == O.SKIP_RECORD:
+            with pytest.raises(_native.EngineError):
+                engine.generate_mt(engine.add_genome(rec.seq), n)
+            continue
+        gid = engine.add_genome(rec.seq)
+        assert engine.generate_mt(gid, n) == n
+        got = engine.download(0, n)
+        for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+            assert np.array_equal(got[k], exp[k]), (rec.id, k)
+    py, npw = engine.mt_peek(8)
+    assert list(_res53(py)) == [rng.py_random() for _ in range(4)]
+    assert list(_res53(npw)) == [rng.np_random() for _ in range(4)]
