@@ -1,0 +1,86 @@
+"""Host-side model plumbing: the reference's pickled .npz schema -> dense tables, KDErrorModel mirror
+(attributes, in-place edits, error behaviour of load_npz), integer threshold identities."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, dense_model
+from insilicoseq_amd.model import DenseModel, KDErrorModel, ModelError
+
+
+def test_reference_npz_flattens_to_the_shipped_dense_file():
+    a = DenseModel.from_reference_npz(os.path.join(GOLDEN, "ecoli.npz"))  # data/ecoli.npz of the reference
+    b = dense_model("ecoli")
+    assert a.read_length == b.read_length == 20
+    for k in DenseModel.FIELDS:
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+
+
+def test_kderrormodel_mirror_attributes_and_edits():
+    em = KDErrorModel(os.path.join(GOLDEN, "ecoli.npz"))
+    assert int(em.read_length) == 20 and em.fragment_length is None and em.store_mutations is False
+    for attr in ("i_size_cdf", "mean_forward", "mean_reverse", "quality_forward", "quality_reverse",
+                 "subst_choices_for", "subst_choices_rev", "ins_for", "ins_rev", "del_for", "del_rev"):
+        assert hasattr(em, attr)
+    em.del_for[0]["A"] = 1.0  # what iss/test/test_error_model.py:79 does
+    d = em.dense()
+    assert d.dele[0, 0, 0] == 1.0 and d.dele[0, 0, 1] == 0.0
+
+
+def test_bad_err_mod_exits_like_the_reference(tmp_path):
+    # iss/test/test_error_model.py:108-110: KDErrorModel("data/empty_file") -> SystemExit
+    empty = tmp_path / "empty_file"
+    empty.write_bytes(b"")
+    with pytest.raises(SystemExit):
+        KDErrorModel(str(empty))
+    with pytest.raises(SystemExit):
+        KDErrorModel(str(tmp_path / "does_not_exist.npz"))
+
+
+def test_dense_roundtrip_and_kderrormodel_from_dense(tmp_path):
+    d = dense_model("hiseq")
+    p = str(tmp_path / "m.npz")
+    d.save(p)
+    e = DenseModel.load(p)
+    for k in DenseModel.FIELDS:
+        assert np.array_equal(getattr(d, k), getattr(e, k))
+    em = KDErrorModel(p)
+    f = em.dense()
+    for k in DenseModel.FIELDS:
+        assert np.array_equal(getattr(d, k), getattr(f, k)), k
+
+
+def test_integer_thresholds_are_the_f64_predicates():
+    """floor/ceil(c * 2^53) restate `c < u`, `c <= u`, `u < c` exactly for u = m / 2^53."""
+    d = dense_model("novaseq")
+    t = d.device_tables()
+    rng = np.random.RandomState(0)
+    m = rng.randint(0, 2**53, size=4000, dtype=np.int64).astype(np.uint64)
+    u = m.astype(np.float64) / 2.0**53
+    c = d.qcdf[0, 3, 17]
+    thr = t["q_thr"][0, 3, 17]
+    for mi, ui in zip(m[:500], u[:500]):
+        assert int(np.searchsorted(c, ui, side="left")) == int((thr < mi).sum())
+    cb = d.bin_cdf[1]
+    for mi, ui in zip(m[:500], u[:500]):
+        assert int(np.searchsorted(cb, ui, side="right")) == int((t["bin_thr"][1] <= mi).sum())
+    p = np.array([0.0, 1e-300, 2.1e-6, 0.5, 1.0, np.nan])
+    ce = np.ceil(np.clip(np.nan_to_num(p, nan=0.0), 0, 1) * 2.0**53).astype(np.uint64)
+    for mi, ui in zip(m[:200], u[:200]):
+        assert list(ui < p) == list(mi < ce)
+    # boundary values of m around every threshold of one row
+    for T in np.unique(thr):
+        for mi in (int(T) - 1, int(T), int(T) + 1):
+            if 0 <= mi < 2**53:
+                ui = mi / 2.0**53
+                assert int(np.searchsorted(c, ui, side="left")) == int((thr < np.uint64(mi)).sum())
+
+
+def test_model_validation_rejects_what_the_engine_cannot_reproduce():
+    d = dense_model("ecoli")
+    bad = d.qcdf.copy()
+    bad[1, 3, 0, 40] = 0.0  # non-monotone CDF: np.searchsorted would binary-search garbage
+    with pytest.raises(ModelError):
+        DenseModel(d.read_length, d.isize_cdf, d.bin_cdf, d.bin_nonempty, bad, d.subst_cdf, d.subst_alt, d.ins,
+                   d.ins_letter, d.dele, d.phred_thr)
