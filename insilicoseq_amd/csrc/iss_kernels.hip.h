@@ -348,7 +348,8 @@ __device__ __forceinline__ uint32_t codes_to_ascii4(uint32_t b) {
 }
 
 constexpr int MAIN_THREADS = 1024;
-constexpr int SLOW_QCAP = 512;   // deferred-work queue entries per workgroup (LDS); overflow spills to global
+constexpr int SLOW_QCAP = 1024;  // deferred-work queue entries (one u32 per flagged base) per workgroup in LDS;
+                                 // overflow spills to global
 constexpr int SLOW_EVERY = 16;   // drain the queue every SLOW_EVERY loop iterations
 
 // Dynamic LDS of k_main (32-bit words):
@@ -366,67 +367,55 @@ struct MainTile {  // per-workgroup constants of k_main (word offsets into the d
     uint32_t tg;   // groups in the tile
 };
 
-// The rare work of one lane-item, done exactly.  `rare` bit (7 - s), s = mate*4 + c: base s hit a rare
-// condition in the hot loop (leading-digit tie, more than two thresholds in its guide bucket, or the
-// substitution test fired / tied).  Everything about such a base is recomputed here from its
-// uniforms; the four dwords the hot path stored are re-read and patched.
-__device__ __forceinline__ void main_slow_item(const DevModel &M, const RunArgs &A, const PairDesc *__restrict__ desc,
-                                               const uint32_t *lds, const MainTile &T, uint32_t it, uint32_t rare) {
+// The rare work of ONE base, done exactly (one lane per flagged base, so the pass is dense): base s =
+// mate*4 + c of lane-item `it` hit a rare condition in the hot loop (leading-digit tie, more than two
+// thresholds in its guide bucket, or the substitution test fired / tied).  Everything about the base is
+// recomputed from its uniforms; its phred / base BYTES are patched in place (two lanes may patch
+// different bytes of one dword, hence byte stores).
+__device__ __forceinline__ void main_slow_base(const DevModel &M, const RunArgs &A, const PairDesc *__restrict__ desc,
+                                               const uint32_t *lds, const MainTile &T, uint32_t it, int s) {
     const uint32_t pair = it / T.tg, grp = it - pair * T.tg;
-    const int p0 = (T.g0 + (int)grp) * 4;
+    const int o = s >> 2, c = s & 3;
+    const int p = (T.g0 + (int)grp) * 4 + c;
+    if (p >= M.RL) return;
     const PairDesc d = desc[pair];
     const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
-    const size_t dw = (size_t)pair * M.G + (size_t)(T.g0 + grp);
-    uint32_t bases[2], quals[2];
-    bases[0] = reinterpret_cast<const uint32_t *>(A.out[0])[dw];
-    quals[0] = reinterpret_cast<const uint32_t *>(A.out[1])[dw];
-    bases[1] = reinterpret_cast<const uint32_t *>(A.out[2])[dw];
-    quals[1] = reinterpret_cast<const uint32_t *>(A.out[3])[dw];
-    const uint32_t gbytes = 1u << M.GB;
-    for (int s = 0; s < 8; ++s) {
-        if (!((rare >> (7 - s)) & 1u)) continue;
-        const int o = s >> 2, c = s & 3, p = p0 + c;
-        if (p >= M.RL) continue;
-        const uint32_t slot = (d.meta >> (2 * o)) & 3u;
-        const u32x4 w = draw_block(a, K_QM, (uint32_t)(p >> 1), 0);
-        const uint32_t wd = word_of(w, (p & 1) * 2 + o);  // low half: quality digit, high half: error-test digit
-        const uint32_t h = wd & 0xffffu, hm = wd >> 16;
-        // quality: full search of the LDS row, exact thresholds on a tie
-        const uint32_t row = T.rows + ((uint32_t)(o * M.NB) + slot) * (uint32_t)M.TG * (uint32_t)M.GS + grp * (uint32_t)M.GS +
-                             (uint32_t)c * (uint32_t)M.stride_w;
-        uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))];
-        uint32_t e = lds[row + gbytes / 4 + j];
-        while ((e >> 15) < h) e = lds[row + gbytes / 4 + (++j)];
-        uint32_t q = (e >> 2) & 0xffu;
-        if ((e >> 15) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
-        quals[o] = (quals[o] & ~(0xffu << (8 * c))) | (q << (8 * c));
-        // substitution test (__init__.py:94)
-        const uint32_t t = (uint32_t)((int32_t)lds[q] + 1);
-        bool err = hm > t;
-        if (hm == t) err = mut_exact(M, a, o, p, hm, (int)q);
-        if (!err) continue;
-        const int base = (int)((bases[o] >> (8 * c)) & 0xffu);
-        const int bi = base_index(base);
-        if (bi < 0) continue;  // nucl.upper() in "RYWSMKHBVDN": left alone
-        const u32x4 sb = draw_block(a, K_SUB, (uint32_t)p, 0);
-        const uint64_t m = o ? mk53(sb.z, sb.w) : mk53(sb.x, sb.y);
-        const uint32_t hs = (uint32_t)(m >> 37);
-        const uint32_t *se = lds + T.subst16 + ((uint32_t)(o * M.TP + (p - T.g0 * 4)) * 4 + bi) * 2;
-        const uint32_t t0 = se[0] & 0xffffu, t1 = se[0] >> 16;
-        int k;
-        if (hs == t0 || hs == t1) {  // tie of a leading digit: exact thresholds
-            const size_t srow = ((size_t)(o * M.RL + p) * 4 + bi) * 3;
-            k = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
-        } else {
-            k = (hs > t0) + (hs > t1);
-        }
-        const uint32_t nb = (se[1] >> (8 * k)) & 0xffu;
-        bases[o] = (bases[o] & ~(0xffu << (8 * c))) | (nb << (8 * c));
+    const size_t byte_off = (size_t)pair * M.pitch + (size_t)p;
+    const uint32_t slot = (d.meta >> (2 * o)) & 3u;
+    const u32x4 w = draw_block(a, K_QM, (uint32_t)(p >> 1), 0);
+    const uint32_t wd = word_of(w, (p & 1) * 2 + o);  // low half: quality digit, high half: error-test digit
+    const uint32_t h = wd & 0xffffu, hm = wd >> 16;
+    // quality: full search of the LDS row, exact thresholds on a tie
+    const uint32_t gwords = (1u << M.GB) / 4;
+    const uint32_t row = T.rows + (((uint32_t)(o * M.NB) + slot) * (uint32_t)M.TG + grp) * (uint32_t)M.GS +
+                         (uint32_t)c * (uint32_t)M.stride_w;
+    uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))];
+    uint32_t e = lds[row + gwords + j];
+    while ((e >> 15) < h) e = lds[row + gwords + (++j)];
+    uint32_t q = (e >> 2) & 0xffu;
+    if ((e >> 15) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
+    A.out[2 * o + 1][byte_off] = (uint8_t)q;
+    // substitution test (__init__.py:94)
+    const uint32_t t = (uint32_t)((int32_t)lds[q] + 1);
+    bool err = hm > t;
+    if (hm == t) err = mut_exact(M, a, o, p, hm, (int)q);
+    if (!err) return;
+    const int base = A.out[2 * o][byte_off];
+    const int bi = base_index(base);
+    if (bi < 0) return;  // nucl.upper() in "RYWSMKHBVDN": left alone
+    const u32x4 sb = draw_block(a, K_SUB, (uint32_t)p, 0);
+    const uint64_t m = o ? mk53(sb.z, sb.w) : mk53(sb.x, sb.y);
+    const uint32_t hs = (uint32_t)(m >> 37);
+    const uint32_t *se = lds + T.subst16 + ((uint32_t)(o * M.TP + (p - T.g0 * 4)) * 4 + bi) * 2;
+    const uint32_t t0 = se[0] & 0xffffu, t1 = se[0] >> 16;
+    int k;
+    if (hs == t0 || hs == t1) {  // tie of a leading digit: exact thresholds
+        const size_t srow = ((size_t)(o * M.RL + p) * 4 + bi) * 3;
+        k = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
+    } else {
+        k = (hs > t0) + (hs > t1);
     }
-    reinterpret_cast<uint32_t *>(A.out[0])[dw] = bases[0];
-    reinterpret_cast<uint32_t *>(A.out[1])[dw] = quals[0];
-    reinterpret_cast<uint32_t *>(A.out[2])[dw] = bases[1];
-    reinterpret_cast<uint32_t *>(A.out[3])[dw] = quals[1];
+    A.out[2 * o][byte_off] = (uint8_t)((se[1] >> (8 * k)) & 0xffu);
 }
 
 // One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive
@@ -464,7 +453,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     uint32_t *q_count = lds + T.subst16 + M.subst_words;
     uint32_t *queue = q_count + 4;
     // global spill area of this workgroup's queue (only touched when > SLOW_QCAP entries are pending)
-    uint32_t *ovf = A.slow_ovf + (size_t)blockIdx.x * (2 * SLOW_EVERY * MAIN_THREADS);
+    uint32_t *ovf = A.slow_ovf + (size_t)blockIdx.x * (8 * SLOW_EVERY * MAIN_THREADS);
     {   // stage this tile's tables in LDS (once per workgroup)
         for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) lds[i] = M.mut16[i] - 1u;
         const uint4 *src = reinterpret_cast<const uint4 *>(M.qrows + (size_t)tile * M.tile_words);
@@ -559,19 +548,21 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             reinterpret_cast<uint32_t *>(A.out[1])[dw] = qual_f & keep;
             reinterpret_cast<uint32_t *>(A.out[2])[dw] = base_r & keep;
             reinterpret_cast<uint32_t *>(A.out[3])[dw] = qual_r & keep;
-            if (rare & 0xffu) {  // ~1.5 % of lane-items: deferred to a dense pass over an LDS queue
+            rare &= 0xffu;  // bit (7 - s) <=> base s needs the exact path (~0.3 % of bases)
+            while (rare) {  // one queue entry per flagged base: the deferred pass has no divergence over s
+                const int bit = 31 - __clz(rare);
+                rare &= ~(1u << bit);
                 const uint32_t slot = atomicAdd(q_count, 1u);
-                uint32_t *dst = slot < (uint32_t)SLOW_QCAP ? queue + 2 * slot : ovf + 2 * (size_t)(slot - SLOW_QCAP);
-                dst[0] = it;
-                dst[1] = rare & 0xffu;
+                uint32_t *dst = slot < (uint32_t)SLOW_QCAP ? queue + slot : ovf + (size_t)(slot - SLOW_QCAP);
+                *dst = (it << 3) | (uint32_t)(7 - bit);
             }
         }
         if ((iter % SLOW_EVERY) == SLOW_EVERY - 1 || iter == n_iter - 1) {
             __syncthreads();  // also makes this workgroup's global stores visible to all of its lanes
-            const uint32_t nq = *q_count;  // <= SLOW_EVERY * MAIN_THREADS: the overflow area always suffices
+            const uint32_t nq = *q_count;  // <= 8 * SLOW_EVERY * MAIN_THREADS: the overflow area always suffices
             for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
-                const uint32_t *src = i < (uint32_t)SLOW_QCAP ? queue + 2 * i : ovf + 2 * (size_t)(i - SLOW_QCAP);
-                main_slow_item(M, A, desc, lds, T, src[0], src[1]);
+                const uint32_t ent = i < (uint32_t)SLOW_QCAP ? queue[i] : ovf[i - SLOW_QCAP];
+                main_slow_base(M, A, desc, lds, T, ent >> 3, (int)(ent & 7u));
             }
             __syncthreads();
             if (threadIdx.x == 0) *q_count = 0;

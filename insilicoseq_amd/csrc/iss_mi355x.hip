@@ -186,7 +186,7 @@ int mt_ensure(iss_ctx *ctx, const size_t want[2]) {
 // dynamic LDS of k_main: quality rows + error-test thresholds + substitution table + deferred-work queue
 size_t main_lds_bytes(const iss::DevModel &M) {
     const size_t mut_words = ((size_t)M.n_q + 1 + 3) & ~(size_t)3;
-    return ((size_t)M.tile_words + mut_words + (size_t)M.subst_words + 4 + 2 * (size_t)iss::SLOW_QCAP) * 4;
+    return ((size_t)M.tile_words + mut_words + (size_t)M.subst_words + 4 + (size_t)iss::SLOW_QCAP) * 4;
 }
 
 int settle_timing(iss_ctx *ctx) {
@@ -257,7 +257,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
-    HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * 2 * iss::SLOW_EVERY * iss::MAIN_THREADS * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * 8 * iss::SLOW_EVERY * iss::MAIN_THREADS * sizeof(uint32_t)));
     ctx->slow_ovf = static_cast<uint32_t *>(p);
     *out = ctx;
     return 0;
@@ -366,20 +366,58 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                 build_row(o, M.slot_bin[o * 4 + sl], p, entries);
                 s_max = std::max(s_max, entries.size());
             }
+    // Guide resolution: the hot loop resolves a draw with two probes unless > 2 thresholds of its guide
+    // bucket lie below the digit ("more", sent to the exact path).  Pick the smallest number of guide bits
+    // (6..8) that keeps the expected "more" rate under 0.4 % per draw.
+    auto more_rate = [&](int gb) {
+        double acc = 0;
+        size_t rows = 0;
+        for (int o = 0; o < 2; ++o)
+            for (int sl = 0; sl < n_slots[o]; ++sl)
+                for (int p = 0; p < RL; p += 3) {
+                    build_row(o, M.slot_bin[o * 4 + sl], p, entries);
+                    const uint32_t width = 1u << (16 - gb);
+                    size_t j = 0;
+                    for (uint32_t b = 0; b < (1u << gb); ++b) {
+                        const uint32_t lo = b * width, hi = lo + width;
+                        while (j < entries.size() && (entries[j] >> 15) < lo) ++j;
+                        size_t k = j;
+                        int inside = 0;
+                        uint32_t second = 0;
+                        while (k < entries.size() && (entries[k] >> 15) < hi) { if (++inside == 2) second = entries[k] >> 15; ++k; }
+                        if (inside >= 2 && hi - 1 > second) acc += (double)(hi - 1 - second);
+                    }
+                    ++rows;
+                }
+        return acc / 65536.0 / (double)std::max<size_t>(rows, 1);
+    };
     M.GB = 6;
+    if (const char *e = getenv("ISS_GUIDE_BITS")) M.GB = std::min(8, std::max(6, atoi(e)));
+    else while (M.GB < 8 && more_rate(M.GB) > 0.004) ++M.GB;
     const int gwords = (1 << M.GB) / 4;
     M.stride_w = (int32_t)(gwords + s_max);
     M.GS = 4 * M.stride_w + 1;
-    const size_t lds_budget = 158 * 1024;
-    M.n_tiles = 1;
-    for (;; ++M.n_tiles) {
-        M.TG = (M.G + M.n_tiles - 1) / M.n_tiles;
+    // Position tiling: prefer tiles small enough for TWO resident workgroups per CU (8 waves / SIMD) as long
+    // as a tile keeps >= 12 groups (48-byte output segments); otherwise the largest tile one workgroup can hold.
+    auto fits = [&](int n_tiles, size_t budget) {
+        M.TG = (M.G + n_tiles - 1) / n_tiles;
         M.TP = M.TG * 4;
         M.tile_words = (2 * M.NB * M.TG * M.GS + 3) / 4 * 4;
         M.subst_words = 2 * M.TP * 4 * 2;
-        if (main_lds_bytes(M) <= lds_budget) break;
-        if (M.TG == 1) return fail(ctx, ISS_E_INVALID, "quality tables do not fit the LDS even for one position group");
+        return main_lds_bytes(M) <= budget;
+    };
+    const size_t two_per_cu = 79 * 1024, one_per_cu = 158 * 1024;
+    const int env_tiles = getenv("ISS_TILES") ? atoi(getenv("ISS_TILES")) : 0;  // tuning aid
+    M.n_tiles = 0;
+    if (env_tiles > 0 && fits(env_tiles, one_per_cu)) M.n_tiles = env_tiles;
+    for (int nt = 1; !M.n_tiles && nt <= M.G; ++nt) {
+        if ((M.G + nt - 1) / nt < std::min(12, M.G)) break;
+        if (fits(nt, two_per_cu)) M.n_tiles = nt;
     }
+    for (int nt = 1; !M.n_tiles && nt <= M.G; ++nt)
+        if (fits(nt, one_per_cu)) M.n_tiles = nt;
+    if (!M.n_tiles) return fail(ctx, ISS_E_INVALID, "quality tables do not fit the LDS even for one position group");
+    (void)fits(M.n_tiles, one_per_cu);
     M.n_tiles = (M.G + M.TG - 1) / M.TG;
     std::vector<uint32_t> qrows((size_t)M.n_tiles * M.tile_words, 0);
     for (int tl = 0; tl < M.n_tiles; ++tl)
@@ -581,7 +619,8 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
     if (n_pairs == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
-    const int64_t max_chunk = std::max<int64_t>(1, (int64_t)0x7fffffff / std::max(M.G, std::max(M.n_scan, 1)) / 2);
+    // lane-item indices are packed with 3 more bits in the deferred queue: keep them below 2^28
+    const int64_t max_chunk = std::max<int64_t>(1, ((int64_t)1 << 28) / std::max(M.G, std::max(M.n_scan, 1)));
     for (int64_t done = 0; done < n_pairs;) {
         const int64_t n = std::min(max_chunk, n_pairs - done);
         const int64_t row0 = out_first_pair + done;
