@@ -137,6 +137,7 @@ struct RunArgs {
     uint64_t gc_thr;  // ceil(0.90 * 2^53): accept iff m < gc_thr (generator.py:88)
     uint8_t *out[4];  // rows of this launch: R1 base, R1 qual, R2 base, R2 qual
     uint32_t *slow_ovf;  // k_main: per-workgroup spill area of the deferred-work queue
+    int32_t slow_every;  // k_main: drain period (iterations), chosen from the model's expected rare-base rate
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -350,7 +351,8 @@ __device__ __forceinline__ uint32_t codes_to_ascii4(uint32_t b) {
 constexpr int MAIN_THREADS = 1024;
 constexpr int SLOW_QCAP = 1024;  // deferred-work queue entries (one u32 per flagged base) per workgroup in LDS;
                                  // overflow spills to global
-constexpr int SLOW_EVERY = 16;   // drain the queue every SLOW_EVERY loop iterations
+constexpr int SLOW_EVERY_MAX = 32;  // drain the queue every RunArgs::slow_every (<= this) loop iterations
+constexpr int SLOW_SPILL = 8 * SLOW_EVERY_MAX * MAIN_THREADS;  // global spill entries per workgroup: the worst case of a period
 
 // Dynamic LDS of k_main (32-bit words):
 //   [0, mut_words)            error-test table: mut16[q] - 1 (signed), q = 0..n_q
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     uint32_t *q_count = lds + T.subst16 + M.subst_words;
     uint32_t *queue = q_count + 4;
     // global spill area of this workgroup's queue (only touched when > SLOW_QCAP entries are pending)
-    uint32_t *ovf = A.slow_ovf + (size_t)blockIdx.x * (8 * SLOW_EVERY * MAIN_THREADS);
+    uint32_t *ovf = A.slow_ovf + (size_t)blockIdx.x * SLOW_SPILL;
     {   // stage this tile's tables in LDS (once per workgroup)
         for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) lds[i] = M.mut16[i] - 1u;
         const uint4 *src = reinterpret_cast<const uint4 *>(M.qrows + (size_t)tile * M.tile_words);
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     const int gshift = 16 - M.GB;
     const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
     const uint32_t slot_b = (uint32_t)M.TG * (uint32_t)M.GS * 4u;  // bytes per (mate, bin slot)
+    uint32_t since_drain = 0;
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
         if (it < n_items) {
             const int p0 = (g0 + (int)grp) * 4;
@@ -553,13 +556,14 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
                 const int bit = 31 - __clz(rare);
                 rare &= ~(1u << bit);
                 const uint32_t slot = atomicAdd(q_count, 1u);
-                uint32_t *dst = slot < (uint32_t)SLOW_QCAP ? queue + slot : ovf + (size_t)(slot - SLOW_QCAP);
+                uint32_t *dst = slot < (uint32_t)SLOW_QCAP ? queue + slot : ovf + (slot - SLOW_QCAP);  // the spill always suffices
                 *dst = (it << 3) | (uint32_t)(7 - bit);
             }
         }
-        if ((iter % SLOW_EVERY) == SLOW_EVERY - 1 || iter == n_iter - 1) {
+        if (++since_drain == (uint32_t)A.slow_every || iter == n_iter - 1) {
+            since_drain = 0;
             __syncthreads();  // also makes this workgroup's global stores visible to all of its lanes
-            const uint32_t nq = *q_count;  // <= 8 * SLOW_EVERY * MAIN_THREADS: the overflow area always suffices
+            const uint32_t nq = *q_count;
             for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
                 const uint32_t ent = i < (uint32_t)SLOW_QCAP ? queue[i] : ovf[i - SLOW_QCAP];
                 main_slow_base(M, A, desc, lds, T, ent >> 3, (int)(ent & 7u));

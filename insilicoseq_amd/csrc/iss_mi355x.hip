@@ -69,7 +69,8 @@ struct iss_ctx {
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
-    uint32_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][2 * SLOW_EVERY * MAIN_THREADS]
+    uint32_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][SLOW_SPILL]
+    int slow_every = iss::SLOW_EVERY_MAX;
     unsigned max_main_grid = 0;
     uint64_t *stats = nullptr;
     // reference-compatible MT19937 mode (iss_mt_compat.hip.h)
@@ -257,7 +258,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
-    HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * 8 * iss::SLOW_EVERY * iss::MAIN_THREADS * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * iss::SLOW_SPILL * sizeof(uint32_t)));
     ctx->slow_ovf = static_cast<uint32_t *>(p);
     *out = ctx;
     return 0;
@@ -394,6 +395,24 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     M.GB = 6;
     if (const char *e = getenv("ISS_GUIDE_BITS")) M.GB = std::min(8, std::max(6, atoi(e)));
     else while (M.GB < 8 && more_rate(M.GB) > 0.004) ++M.GB;
+    {   // drain period of k_main's deferred queue: aim at <= 64 k entries per period and workgroup
+        double err = 0;
+        size_t rows = 0;
+        for (int o = 0; o < 2; ++o)
+            for (int sl = 0; sl < n_slots[o]; ++sl)
+                for (int p = 0; p < RL; p += 3, ++rows) {
+                    const uint64_t *row = t->q_thr + ((size_t)(o * 4 + M.slot_bin[o * 4 + sl]) * RL + p) * nq;
+                    double prev = 0;
+                    for (int q = 0; q <= nq; ++q) {  // P(phred == q) = cdf[q] - cdf[q-1]; phred nq has the rest
+                        const double c = q < nq ? (double)row[q] / 9007199254740992.0 : 1.0;
+                        err += (c - prev) * (1.0 - (double)t->mut_thr[q] / 9007199254740992.0);
+                        prev = c;
+                    }
+                }
+        const double rare = more_rate(M.GB) + err / (double)std::max<size_t>(rows, 1) + 2e-4;
+        const double per_iter = rare * 8.0 * iss::MAIN_THREADS;
+        ctx->slow_every = (int)std::max(2.0, std::min((double)iss::SLOW_EVERY_MAX, 65536.0 / std::max(per_iter, 1.0)));
+    }
     const int gwords = (1 << M.GB) / 4;
     M.stride_w = (int32_t)(gwords + s_max);
     M.GS = 4 * M.stride_w + 1;
@@ -633,6 +652,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         A.gc_thr = 8106479329266893ull;  // ceil(0.90 * 2^53), 0.90 being the f64 nearest to 0.9
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
         A.slow_ovf = ctx->slow_ovf;
+        A.slow_every = ctx->slow_every;
         iss::PairDesc *desc = ctx->desc + row0;
         uint32_t *flags = ctx->flags + row0;
         uint32_t *fix_list = ctx->fix_list + 2 * row0;
