@@ -142,3 +142,27 @@ def test_parse_fasta_and_work_divider_match_reference_generate():
         for key, n in seen.items():
             assert key in expect and expect[key] >= n, (key, n, expect.get(key))
         assert set(seen) == set(expect)
+
+
+def test_oracle_vcf_rows_match_reference():
+    """--store_mutations: the oracle's mutation records, formatted like write_mutations
+    (iss/generator.py:598-620), reproduce the reference worker's .vcf byte for byte."""
+    from oracle import oracle as O
+
+    z, meta, genomes = _worker_case("syn_novaseq_vcf")
+    assert meta["store_mutations"]
+    d = dense_model(meta["model"])
+    orc = O.Oracle(d)
+    rng = O.Rng().seed_mt(meta["seed"] + meta["cpu_number"])
+    lines = []
+    for rid, n, g in zip(meta["ids"], meta["counts"], genomes):
+        res = orc.simulate(rng, g, n, store_mutations=True)
+        assert res["status"] == 0
+        for m in res["mutations"]:
+            read_id = "%s_%d_%d/%d" % (rid, m["pair"], meta["cpu_number"], 1 + int(m["mate"]))
+            ref, alt = chr(m["ref"]), chr(m["alt"])
+            if m["type"] == 1:  # insertion: alt = ref + inserted letter (__init__.py:203)
+                alt = ref + alt
+            qual = str(int(m["quality"])) if m["type"] == 0 else "."
+            lines.append("\t".join([read_id, str(int(m["position"]) + 1), ".", ref, alt, qual, "", ""]) + "\n")
+    assert "".join(lines).encode() == z["vcf"].tobytes()
