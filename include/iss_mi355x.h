@@ -143,6 +143,21 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
                     int64_t out_first_pair, int64_t *n_done);
 int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n);
 
+/* --store_mutations in MT mode: the VCF rows of the reference (iss/error_models/__init__.py:98-108, 197-221,
+ * written by write_mutations, iss/generator.py:598-620), in the reference's order.  After
+ * iss_mt_mutations_reserve(capacity > 0) every iss_generate_mt call records its rows from index 0;
+ * iss_mt_mutations_download copies min(rows, capacity) of them and reports the total row count. */
+typedef struct {
+    int32_t pair;     /* pair index i within the call (read id {record.id}_{i}_{cpu}/{mate+1}) */
+    int8_t mate;      /* 0 forward, 1 reverse */
+    int8_t type;      /* 0 substitution, 1 insertion (VCF alt = ref + alt), 2 deletion (alt '.') */
+    int16_t position; /* 0-based (VCF POS = position + 1) */
+    uint8_t ref, alt; /* ASCII */
+    int16_t quality;  /* phred for substitutions, -1 ('.') otherwise */
+} iss_mutation;
+int iss_mt_mutations_reserve(iss_ctx *ctx, int64_t capacity);
+int iss_mt_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, int64_t *n_total);
+
 /*
  * FASTQ emission, replaces SeqIO.write(record, handle, "fastq-sanger") in
  * simulate_reads (iss/generator.py:64-65): records "@{record_id}_{i}_{cpu_number}/{1|2}\n

@@ -21,7 +21,7 @@ import sys
 
 import numpy as np
 
-from .distributed import concatenate_rank_files, temp_prefix
+from .distributed import VCF_HEADER, concatenate_rank_files, temp_prefix
 from .generator import generate_work_divider, parse_fasta, worker_iterator
 from .model import KDErrorModel
 
@@ -103,12 +103,12 @@ def exponential(record_list):
 ABUNDANCE = {"lognormal": lognormal, "uniform": uniform, "exponential": exponential}
 
 
-def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias, rng):
+def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias, rng, store_mutations):
     """One pool process == one GPU.  Records are re-read from the concatenated FASTA (the reference
     pickles them; same content)."""
     logging.basicConfig(level=logging.WARNING)
     records = {r.id: r for r in parse_fasta(genome_file)}
-    model = KDErrorModel(npz)
+    model = KDErrorModel(npz, None, None, store_mutations)
     work = [(records[rid], n, "default") for rid, n in work_spec]
     worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device, rng=rng)
 
@@ -146,6 +146,9 @@ def generate_reads(args):
         else:
             logger.error("Could not get abundance, or coverage or readcount information")
             sys.exit(1)
+    if args.store_mutations and args.rng != "mt":
+        logger.error("--store_mutations needs --rng mt on the GPU path")
+        sys.exit(1)
     workers = args.gpus
     chunk_size = -((n_reads // 2) // -workers)  # ceildiv, app.py:82
     chunks = list(generate_work_divider(records, readcount_dic, abundance_dic, n_reads, None, None, error_model,
@@ -154,17 +157,21 @@ def generate_reads(args):
     for rank, chunk in enumerate(chunks[:workers]):  # zip(work_chunks, temp_file_list), app.py:104
         spec = [(rec.id, n) for rec, n, _ in chunk]
         jobs.append((rank, rank % max(args.devices, 1), genome_file, spec, error_model.npz_path, args.seed,
-                     temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng))
+                     temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng, args.store_mutations))
     if workers == 1:
         for j in jobs:
             _worker(*j)
     else:
         with mp.get_context("spawn").Pool(workers) as pool:
             pool.starmap(_worker, jobs)
-    concatenate_rank_files(args.output, workers)  # raises if a worker had no chunk (util.py:233)
+    if args.store_mutations:  # app.py:128-133
+        concatenate_rank_files(args.output, workers, suffixes=("_R1.fastq", "_R2.fastq", ".vcf"),
+                               headers={".vcf": VCF_HEADER})
+    else:
+        concatenate_rank_files(args.output, workers)  # raises if a worker had no chunk (util.py:233)
     os.remove(genome_file)
     if args.compress:
-        for suffix in ("_R1.fastq", "_R2.fastq"):
+        for suffix in ("_R1.fastq", "_R2.fastq") + ((".vcf",) if args.store_mutations else ()):
             with open(args.output + suffix, "rb") as fi, gzip.open(args.output + suffix + ".gz", "wb") as fo:
                 shutil.copyfileobj(fi, fo)
             os.remove(args.output + suffix)

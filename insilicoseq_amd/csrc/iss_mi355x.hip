@@ -81,6 +81,8 @@ struct iss_ctx {
         int cur[2] = {0, 0};
         size_t cap[2] = {0, 0}, fill[2] = {0, 0}, used[2] = {0, 0};
         iss::MtWalkResult *d_res = nullptr;
+        iss::MutRecord *d_mut = nullptr;  // --store_mutations rows of the last iss_generate_mt call
+        int64_t mut_cap = 0, mut_n = 0;
     } mt;
     // timing
     bool timing = false;
@@ -133,6 +135,8 @@ void free_outputs(iss_ctx *ctx) {
 void free_mt(iss_ctx *ctx) {
     if (ctx->mt.d_state) (void)hipFree(ctx->mt.d_state);
     if (ctx->mt.d_res) (void)hipFree(ctx->mt.d_res);
+    if (ctx->mt.d_mut) (void)hipFree(ctx->mt.d_mut);
+    ctx->mt.d_mut = nullptr; ctx->mt.mut_cap = 0;
     for (auto &st : ctx->mt.buf) for (auto &b : st) { if (b) (void)hipFree(b); b = nullptr; }
     ctx->mt.d_state = nullptr; ctx->mt.d_res = nullptr; ctx->mt.seeded = false;
     ctx->mt.cap[0] = ctx->mt.cap[1] = 0;
@@ -891,6 +895,7 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     const bool use_rows = M.n_tiles == 1 && (size_t)M.tile_words * 4 + fixed_lds <= 150 * 1024;
     const size_t lds_bytes = fixed_lds + (use_rows ? (size_t)M.tile_words * 4 : 0);
     int64_t done = 0;
+    m.mut_n = 0;
     while (done < n_pairs) {
         const int64_t n = std::min(CH, n_pairs - done);
         const size_t want[2] = {std::min(m.cap[0] / 624 * 624 - 624, (size_t)(n + 1) * py_need),
@@ -909,6 +914,10 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
         A.res = m.d_res;
         A.use_rows = use_rows ? 1 : 0;
+        A.mut = m.d_mut;
+        A.mut_cap = m.mut_cap;
+        A.mut_base = m.mut_n;
+        A.pair_base = done;
         hipLaunchKernelGGL(iss::k_mt_walk, dim3(1), dim3(64), lds_bytes, ctx->stream, M, dg, A, ctx->desc + row0);
         iss::MtWalkResult res{};
         HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
@@ -917,10 +926,38 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         m.used[0] += res.py_used;
         m.used[1] += res.np_used;
         done += res.n_done;
+        m.mut_n += res.n_mut;
         if (res.n_done == 0 && res.starved && A.py_avail >= want[0] && A.np_avail >= want[1])
             return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
     }
     if (n_done) *n_done = done;
+    return 0;
+}
+
+int iss_mt_mutations_reserve(iss_ctx *ctx, int64_t capacity) {
+    if (!ctx || capacity < 0) return fail(ctx, ISS_E_INVALID, "iss_mt_mutations_reserve: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    auto &m = ctx->mt;
+    if (m.d_mut) (void)hipFree(m.d_mut);
+    m.d_mut = nullptr;
+    m.mut_cap = m.mut_n = 0;
+    if (capacity) {
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, (size_t)capacity * sizeof(iss::MutRecord)));
+        m.d_mut = static_cast<iss::MutRecord *>(p);
+        m.mut_cap = capacity;
+    }
+    return 0;
+}
+
+int iss_mt_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, int64_t *n_total) {
+    if (!ctx || capacity < 0) return fail(ctx, ISS_E_INVALID, "iss_mt_mutations_download: bad argument");
+    static_assert(sizeof(iss_mutation) == sizeof(iss::MutRecord), "ABI and device mutation records differ");
+    auto &m = ctx->mt;
+    if (n_total) *n_total = m.mut_n;
+    const int64_t n = std::min(std::min(m.mut_n, m.mut_cap), capacity);
+    if (n > 0 && out) HIP_TRY(ctx, hipMemcpy(out, m.d_mut, (size_t)n * sizeof(iss::MutRecord), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -70,6 +70,18 @@ struct MtWalkResult {
     int64_t n_done;             // pairs emitted
     int32_t starved;            // stopped because a stream buffer could run dry
     int32_t pad;
+    int64_t n_mut;              // mutation records written (may exceed the capacity: the surplus is dropped)
+};
+
+// one VCF row of --store_mutations (iss/error_models/__init__.py:98-108, 197-221; generator.py:598-620)
+struct MutRecord {
+    int32_t pair;      // pair index within the call (the read id's i)
+    int8_t mate;       // 0 forward, 1 reverse
+    int8_t type;       // 0 substitution, 1 insertion, 2 deletion
+    int16_t position;  // 0-based
+    uint8_t ref;       // ASCII
+    uint8_t alt;       // ASCII: new base / inserted letter / '.'
+    int16_t quality;   // phred for substitutions, -1 ('.') otherwise
 };
 
 struct MtWalkArgs {
@@ -82,6 +94,9 @@ struct MtWalkArgs {
     MtWalkResult *res;
     int32_t use_rows;  // the compressed quality rows (single tile) are staged in LDS
     int32_t win_words; // LDS words for the slow indel path's stream window (10 * (RL - 1))
+    MutRecord *mut;    // --store_mutations rows (NULL: off)
+    int64_t mut_cap, mut_base;  // capacity; rows already written by earlier launches of this call
+    int64_t pair_base;          // pair index of this launch's first pair within the call
 };
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -137,7 +152,17 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
     const uint32_t gbytes = 1u << M.GB;
     int64_t i = 0;
     int starved = 0;
+    int64_t n_mut = 0;  // wave-uniform
+    auto put_mut = [&](int mate, int type, int pos, int ref, int alt, int qual, int64_t at) {
+        if (A.mut && A.mut_base + at < A.mut_cap) {
+            MutRecord r;
+            r.pair = (int32_t)(A.pair_base + i); r.mate = (int8_t)mate; r.type = (int8_t)type; r.position = (int16_t)pos;
+            r.ref = (uint8_t)ref; r.alt = (uint8_t)alt; r.quality = (int16_t)qual;
+            A.mut[A.mut_base + at] = r;
+        }
+    };
     while (i < A.n_pairs) {
+        const int64_t mut_mark = n_mut;
         if (opy + py_need > A.py_avail || onp + np_need > A.np_avail) { starved = 1; break; }
         // ---- insert size: np.searchsorted(cdf, np.random.rand())  (kde.py:97)
         int isz;
@@ -206,11 +231,17 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
                             if (lane == 0) stk[sp] = M.ins_letter[en + x];
                             ++sp;
                             __syncthreads();
+                            if (lane == 0) put_mut(o, 1, n, tok, M.ins_letter[en + x], -1, n_mut);  // ref = seq[position]
+                            ++n_mut;
                         }
                     }
                     const uint64_t m = mk53(win[pos], win[pos + 1]);
                     pos += 2;
-                    if (m < M.del_thr[en + bi]) tok = sp > 0 ? (int)stk[--sp] : src(k++);  // next token slides in
+                    if (m < M.del_thr[en + bi]) {  // next token slides in
+                        const bool exists = sp > 0 || k < RL;  // else mutable_seq[position] raises IndexError: no row
+                        tok = sp > 0 ? (int)stk[--sp] : src(k++);
+                        if (exists) { if (lane == 0) put_mut(o, 2, n, tok, '.', -1, n_mut); ++n_mut; }
+                    }
                     if (lane == 0) rd[j] = (uint8_t)tok;
                     ++j;
                 }
@@ -254,8 +285,8 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
             uint32_t nev = 0;
             for (int p0 = 0; p0 < RL; p0 += 64) {
                 const int p = p0 + lane;
-                bool err = false;
-                int ch = 0, q = 0, bi = -1;
+                bool err = false, rec = false;
+                int ch = 0, q = 0, bi = -1, ref_ch = 0;
                 if (p < RL) {
                     ch = rd[p];
                     q = ql[p];
@@ -269,8 +300,14 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
                     const uint64_t ms = mk53(np[onp + 2u * rank], np[onp + 2u * rank + 1]);
                     const size_t row = ((size_t)(o * RL + p) * 4 + bi) * 3;
                     const int k = (ms >= M.subst_thr[row]) + (ms >= M.subst_thr[row + 1]);
-                    ch = M.subst_alt[row + k];
+                    const int alt = M.subst_alt[row + k];
+                    rec = alt != (int)tmpl[p];  // only if it differs from the ORIGINAL read (:98)
+                    ref_ch = ch;
+                    ch = alt;
                 }
+                const unsigned long long recm = __ballot(rec);
+                if (rec) put_mut(o, 0, p, ref_ch, ch, q, n_mut + (int64_t)__popcll(recm & ((1ull << lane) - 1ull)));
+                n_mut += (int64_t)__popcll(recm);
                 nev += (uint32_t)__popcll(evm);
                 if (p < RL) { ob[p] = (uint8_t)ch; oq[p] = (uint8_t)q; }
             }
@@ -287,6 +324,8 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
         if (keep) {
             if (lane == 0) desc[i] = d;
             ++i;
+        } else {
+            n_mut = mut_mark;  // the rejected pair's mutations are not yielded (generator.py:88-92)
         }
     }
     if (lane == 0) {
@@ -294,6 +333,7 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
         A.res->np_used = onp;
         A.res->n_done = i;
         A.res->starved = starved;
+        A.res->n_mut = n_mut;
     }
 }
 

@@ -80,11 +80,17 @@ def temp_prefix(output, rank):
     return "%s.iss.tmp.%d" % (output, rank)  # iss/app.py:73
 
 
-def concatenate_rank_files(output, world, suffixes=("_R1.fastq", "_R2.fastq"), cleanup=True):
-    """util.concatenate over the per-rank temp files, in rank order (iss/app.py:123-127).  Like the
-    reference, a missing temp file (fewer chunks than workers) is an error (iss/util.py:233)."""
+VCF_HEADER = "##fileformat=VCFv4.1\n" + "\t".join(["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO"])
+
+
+def concatenate_rank_files(output, world, suffixes=("_R1.fastq", "_R2.fastq"), cleanup=True, headers=None):
+    """util.concatenate over the per-rank temp files, in rank order (iss/app.py:123-133).  Like the
+    reference, a missing temp file (fewer chunks than workers) is an error (iss/util.py:233).
+    ``headers``: optional {suffix: header text} written first, followed by a newline (util.py:229-230)."""
     for suffix in suffixes:
         with open(output + suffix, "wb") as out:
+            if headers and suffix in headers:
+                out.write((headers[suffix] + "\n").encode())
             for r in range(world):
                 with open(temp_prefix(output, r) + suffix, "rb") as fh:
                     shutil.copyfileobj(fh, out, 1 << 22)

@@ -13,6 +13,10 @@ from . import _native
 from ._native import EngineError, SEQ_TYPES, check
 
 
+MUT_DTYPE = np.dtype([("pair", "<i4"), ("mate", "i1"), ("type", "i1"), ("position", "<i2"), ("ref", "u1"),
+                      ("alt", "u1"), ("quality", "<i2")], align=True)
+
+
 def _u64(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
 
@@ -123,6 +127,21 @@ class ReadEngine(object):
         self._check(self._lib.iss_generate_mt(self._ctx, int(genome_id), int(n_pairs), SEQ_TYPES[sequence_type],
                                               int(bool(gc_bias)), int(out_first_pair), C.byref(done)))
         return done.value
+
+    def mt_mutations_reserve(self, capacity):
+        """Enable (capacity > 0) / disable --store_mutations row capture of generate_mt."""
+        self._check(self._lib.iss_mt_mutations_reserve(self._ctx, int(capacity)))
+        self._mut_cap = int(capacity)
+
+    def mt_mutations(self):
+        """Rows of the last generate_mt call as a structured array (see iss_mutation in the C header)."""
+        cap = getattr(self, "_mut_cap", 0)
+        out = np.zeros(cap, dtype=MUT_DTYPE)
+        n = C.c_int64(0)
+        self._check(self._lib.iss_mt_mutations_download(self._ctx, out.ctypes.data, cap, C.byref(n)))
+        if n.value > cap:
+            raise EngineError(_native.E_INVALID, "mutation buffer too small: %d rows, capacity %d" % (n.value, cap))
+        return out[: n.value]
 
     def mt_peek(self, n=8):
         """The next n 32-bit words of (CPython random, numpy) -- not consumed."""

@@ -157,6 +157,7 @@ class Worker(object):
         self.engine = ReadEngine(self.cpu_number if device is None else device)
         self.dense = _dense_of(error_model)
         self.engine.load_model(self.dense)
+        self.store_mutations = False
         if rng == "mt":
             # random.seed(seed + cpu_number); np.random.seed(seed + cpu_number)  (generator.py:234-236);
             # unseeded workers draw an OS-entropy seed (the reference is then not reproducible either)
@@ -200,6 +201,8 @@ class Worker(object):
             n = min(self.BATCH_PAIRS, n_pairs - done)
             if self.rng == "mt":
                 assert eng.generate_mt(gid, n, sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0) == n
+                if self.store_mutations:
+                    write_mutations(eng.mt_mutations(), mutations_handle, record.id, done, self.cpu_number)
             else:
                 eng.generate(gid, n, first_ordinal=self.ordinal, seed=self.seed, sequence_type=sequence_type,
                              gc_bias=gc_bias, out_first_pair=0)
@@ -210,6 +213,17 @@ class Worker(object):
             self.ordinal += n
             done += n
         return done
+
+
+def write_mutations(rows, mutations_handle, record_id, first_i, cpu_number):
+    """iss/generator.py:598-620 for the device's mutation records."""
+    for m in rows:
+        ref, alt = chr(m["ref"]), chr(m["alt"])
+        if m["type"] == 1:  # insertion: alt = ref + inserted letter (__init__.py:203)
+            alt = ref + alt
+        qual = str(int(m["quality"])) if m["type"] == 0 else "."
+        read_id = "%s_%d_%d/%d" % (record_id, first_i + int(m["pair"]), cpu_number, 1 + int(m["mate"]))
+        mutations_handle.write("\t".join([read_id, str(int(m["position"]) + 1), ".", ref, alt, qual, "", ""]) + "\n")
 
 
 def simulate_reads(record, error_model, n_pairs, cpu_number, forward_handle, reverse_handle, mutations_handle,
@@ -229,8 +243,10 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
     reference's two Mersenne-Twister streams on the device: the files then equal the reference's byte for
     byte (sequential, ~1e5 pairs/s); ``rng="philox"`` is the parallel path."""
     logger = logging.getLogger(__name__)
-    if getattr(error_model, "store_mutations", False):
-        raise NotImplementedError("--store_mutations (VCF rows) is not on the device path yet (SURVEY.md 8 f3)")
+    store_mutations = bool(getattr(error_model, "store_mutations", False))
+    if store_mutations and rng != "mt":
+        raise NotImplementedError("--store_mutations (VCF rows) needs rng='mt' (the parallel Philox path does not "
+                                  "record mutations yet, SURVEY.md 8 f3)")
     if sequence_type not in _native.SEQ_TYPES:
         raise RuntimeError("sequence type '%s' is not supported" % sequence_type)  # generator.py:139
     try:
@@ -241,6 +257,9 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
         logger.error("Failed to write temporary output file(s): %s" % e)
         sys.exit(1)
     w = Worker(error_model, cpu_number, seed, device=device, rng=rng)
+    if store_mutations:
+        w.store_mutations = True
+        w.engine.mt_mutations_reserve(Worker.BATCH_PAIRS * 8)
     try:
         with forward_handle, reverse_handle, mutation_handle:
             for record, n_pairs, _mode in work:

@@ -144,3 +144,46 @@ def test_config1_scale_short_genomes_miseq(engine):
     py, npw = engine.mt_peek(8)
     assert list(_res53(py)) == [rng.py_random() for _ in range(4)]
     assert list(_res53(npw)) == [rng.np_random() for _ in range(4)]
+
+
+def test_store_mutations_vcf_equals_reference(tmp_path):
+    """--store_mutations in MT mode: the worker's .vcf (and FASTQ) equal the reference's files."""
+    from insilicoseq_amd.generator import Record, worker_iterator
+    from insilicoseq_amd.model import KDErrorModel
+
+    z = np.load(os.path.join(GOLDEN, "worker", "syn_novaseq_vcf.npz"))
+    meta = json.loads(str(z["meta"]))
+    recs = [Record(z["genome_%d" % i].tobytes().decode(), id=rid) for i, rid in enumerate(meta["ids"])]
+    work = [(r, n, "default") for r, n in zip(recs, meta["counts"])]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    em = KDErrorModel(os.path.join(root, "insilicoseq_amd", "profiles", "novaseq.dense.npz"), None, None, True)
+    prefix = str(tmp_path / "w")
+    worker_iterator(work, em, meta["cpu_number"], prefix, meta["seed"], meta["sequence_type"], meta["gc_bias"],
+                    device=0, rng="mt")
+    assert open(prefix + ".vcf", "rb").read() == z["vcf"].tobytes()
+    assert open(prefix + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(prefix + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+
+
+@pytest.mark.parametrize("gc_bias", [False, True])
+def test_mutation_records_with_indels_equal_oracle(engine, gc_bias):
+    """Insertion / deletion / substitution rows of an indel-heavy model on a mixed-case + IUPAC genome."""
+    from helpers import mixed_genome
+    from oracle import oracle as O
+
+    dense = dense_model("novaseq", (0.01, 0.03))
+    genome = mixed_genome(5, 20000)
+    n = 1500
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.mt_mutations_reserve(200000)
+    engine.seed_mt(77)
+    assert engine.generate_mt(gid, n, gc_bias=gc_bias) == n
+    got = engine.mt_mutations()
+    engine.mt_mutations_reserve(0)
+    exp = O.Oracle(dense).simulate(O.Rng().seed_mt(77), genome, n, gc_bias=gc_bias, store_mutations=True)["mutations"]
+    assert len(got) == len(exp) and len(got) > 1000
+    for f in ("pair", "mate", "type", "position", "ref", "alt", "quality"):
+        assert np.array_equal(got[f], exp[f]), f
+    assert set(np.unique(got["type"])) == {0, 1, 2}
