@@ -142,6 +142,11 @@ int iss_mt_seed(iss_ctx *ctx, uint64_t seed);
 int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t sequence_type, int32_t gc_bias,
                     int64_t out_first_pair, int64_t *n_done);
 int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n);
+/* Custom fragment length in MT mode (--fragment-length / --fragment-length-sd, iss/generator.py:121-123):
+ * fragment = int(np.random.normal(mu, sd)) with numpy's legacy polar Box-Muller incl. its cached second value
+ * (reset by iss_mt_seed like np.random.seed does).  The device evaluates it; draws that land within 1e-6 of an
+ * integer are re-evaluated on the host with libm so the truncation provably equals numpy's. */
+int iss_mt_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, double fragment_sd);
 
 /* --store_mutations in MT mode: the VCF rows of the reference (iss/error_models/__init__.py:98-108, 197-221,
  * written by write_mutations, iss/generator.py:598-620), in the reference's order.  After

@@ -40,14 +40,20 @@ def convert_n_reads(unit):
     return int(unit)
 
 
-def load_error_model(mode, seed, model, fragment_length, fragment_length_sd, store_mutations):
+def load_error_model(mode, seed, model, fragment_length, fragment_length_sd, store_mutations, rng="philox"):
     """iss/generator.py:359-421 for what the device path covers (kde)."""
     logger = logging.getLogger(__name__)
     if mode != "kde":
         logger.error("--mode %s is not available on the GPU path (kde only)" % mode)
         sys.exit(1)
-    if fragment_length is not None or fragment_length_sd is not None:
-        logger.error("--fragment-length is not available on the GPU path yet")
+    if fragment_length is not None and fragment_length_sd is not None:
+        if rng != "mt":
+            logger.error("--fragment-length needs --rng mt on the GPU path")
+            sys.exit(1)
+        logger.info("Using custom fragment length %s and default fragment length sd %s" % (fragment_length,
+                                                                                           fragment_length_sd))
+    elif bool(fragment_length) ^ bool(fragment_length_sd):  # generator.py:393-395
+        logger.error("fragment_length and fragment_length_sd must be specified together")
         sys.exit(1)
     if model is None:
         logger.error("--model is required in --mode kde")
@@ -59,7 +65,7 @@ def load_error_model(mode, seed, model, fragment_length, fragment_length_sd, sto
         npz = os.path.join(PROFILES, PRECOMPUTED[model.lower()] + ".dense.npz")
     else:
         npz = model
-    return KDErrorModel(npz, None, None, store_mutations)
+    return KDErrorModel(npz, fragment_length, fragment_length_sd, store_mutations)
 
 
 def parse_abundance_file(path):
@@ -103,12 +109,13 @@ def exponential(record_list):
 ABUNDANCE = {"lognormal": lognormal, "uniform": uniform, "exponential": exponential}
 
 
-def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias, rng, store_mutations):
+def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias, rng, store_mutations,
+            fragment):
     """One pool process == one GPU.  Records are re-read from the concatenated FASTA (the reference
     pickles them; same content)."""
     logging.basicConfig(level=logging.WARNING)
     records = {r.id: r for r in parse_fasta(genome_file)}
-    model = KDErrorModel(npz, None, None, store_mutations)
+    model = KDErrorModel(npz, fragment[0], fragment[1], store_mutations)
     work = [(records[rid], n, "default") for rid, n in work_spec]
     worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device, rng=rng)
 
@@ -116,7 +123,7 @@ def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_ty
 def generate_reads(args):
     logger = logging.getLogger(__name__)
     error_model = load_error_model(args.mode, args.seed, args.model, args.fragment_length, args.fragment_length_sd,
-                                   args.store_mutations)
+                                   args.store_mutations, args.rng)
     if not args.genomes:
         logger.error("One of --genomes/-g is required")
         sys.exit(1)
@@ -157,7 +164,8 @@ def generate_reads(args):
     for rank, chunk in enumerate(chunks[:workers]):  # zip(work_chunks, temp_file_list), app.py:104
         spec = [(rec.id, n) for rec, n, _ in chunk]
         jobs.append((rank, rank % max(args.devices, 1), genome_file, spec, error_model.npz_path, args.seed,
-                     temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng, args.store_mutations))
+                     temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng, args.store_mutations,
+                     (args.fragment_length, args.fragment_length_sd)))
     if workers == 1:
         for j in jobs:
             _worker(*j)

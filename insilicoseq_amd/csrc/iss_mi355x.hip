@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <thread>
 #include <vector>
@@ -81,6 +82,9 @@ struct iss_ctx {
         int cur[2] = {0, 0};
         size_t cap[2] = {0, 0}, fill[2] = {0, 0}, used[2] = {0, 0};
         iss::MtWalkResult *d_res = nullptr;
+        iss::MtGauss *d_gauss = nullptr;
+        bool has_frag = false;
+        double frag_mu = 0, frag_sd = 0;
         iss::MutRecord *d_mut = nullptr;  // --store_mutations rows of the last iss_generate_mt call
         int64_t mut_cap = 0, mut_n = 0;
     } mt;
@@ -136,6 +140,8 @@ void free_mt(iss_ctx *ctx) {
     if (ctx->mt.d_state) (void)hipFree(ctx->mt.d_state);
     if (ctx->mt.d_res) (void)hipFree(ctx->mt.d_res);
     if (ctx->mt.d_mut) (void)hipFree(ctx->mt.d_mut);
+    if (ctx->mt.d_gauss) (void)hipFree(ctx->mt.d_gauss);
+    ctx->mt.d_gauss = nullptr;
     ctx->mt.d_mut = nullptr; ctx->mt.mut_cap = 0;
     for (auto &st : ctx->mt.buf) for (auto &b : st) { if (b) (void)hipFree(b); b = nullptr; }
     ctx->mt.d_state = nullptr; ctx->mt.d_res = nullptr; ctx->mt.seeded = false;
@@ -829,7 +835,10 @@ int iss_mt_seed(iss_ctx *ctx, uint64_t seed) {
         m.d_state = static_cast<iss::MtState *>(p);
         HIP_TRY(ctx, hipMalloc(&p, sizeof(iss::MtWalkResult)));
         m.d_res = static_cast<iss::MtWalkResult *>(p);
+        HIP_TRY(ctx, hipMalloc(&p, sizeof(iss::MtGauss)));
+        m.d_gauss = static_cast<iss::MtGauss *>(p);
     }
+    HIP_TRY(ctx, hipMemset(m.d_gauss, 0, sizeof(iss::MtGauss)));  // np.random.seed() drops the cached gaussian
     iss::MtState st[2];
     const uint32_t key[1] = {(uint32_t)seed};
     mt_init_by_array(st[0].mt, key, 1);       // random.seed(seed)
@@ -883,7 +892,9 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     { int rc_ = mt_reserve(ctx, (size_t)(CH + 1) * py_need + 1248, (size_t)(CH + 1) * np_need + 1248); if (rc_) return rc_; }
     auto &m = ctx->mt;
     if (!(M.RL < G.L)) {
-        // the reference draws the insert size BEFORE its assertion fails (generator.py:125, 130): one numpy double
+        // the reference draws the insert size BEFORE its assertion fails (generator.py:121-126, 130)
+        if (m.has_frag)
+            return fail(ctx, ISS_E_INVALID, "short record with a custom fragment length: stream alignment not supported");
         const size_t want[2] = {0, 2};
         { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
         m.used[1] += 2;
@@ -896,6 +907,8 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     const size_t lds_bytes = fixed_lds + (use_rows ? (size_t)M.tile_words * 4 : 0);
     int64_t done = 0;
     m.mut_n = 0;
+    bool ov_valid = false;
+    int64_t ov_frag = 0;
     while (done < n_pairs) {
         const int64_t n = std::min(CH, n_pairs - done);
         const size_t want[2] = {std::min(m.cap[0] / 624 * 624 - 624, (size_t)(n + 1) * py_need),
@@ -918,6 +931,13 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         A.mut_cap = m.mut_cap;
         A.mut_base = m.mut_n;
         A.pair_base = done;
+        A.has_frag = m.has_frag ? 1 : 0;
+        A.frag_mu = m.frag_mu;
+        A.frag_sd = m.frag_sd;
+        A.ov_valid = ov_valid ? 1 : 0;
+        A.ov_frag = ov_frag;
+        A.guard = getenv("ISS_MT_GUARD") ? atof(getenv("ISS_MT_GUARD")) : 1e-6;
+        A.gauss = m.d_gauss;
         hipLaunchKernelGGL(iss::k_mt_walk, dim3(1), dim3(64), lds_bytes, ctx->stream, M, dg, A, ctx->desc + row0);
         iss::MtWalkResult res{};
         HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
@@ -927,10 +947,36 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         m.used[1] += res.np_used;
         done += res.n_done;
         m.mut_n += res.n_mut;
+        ov_valid = false;
+        if (res.need_host) {
+            // int(np.random.normal(mu, sd)) of the next pair with the host's libm, exactly as numpy's legacy_gauss:
+            // f = sqrt(-2*log(r2)/r2); fresh value f*x2, cached value f*x1; loc + scale*g; int() truncates
+            volatile double x1 = res.host_x1, x2 = res.host_x2;
+            volatile double r2 = x1 * x1;
+            volatile double t2 = x2 * x2;
+            r2 = r2 + t2;
+            volatile double f = -2.0 * log(r2);
+            f = f / r2;
+            f = sqrt(f);
+            volatile double gval = res.host_cached ? f * x1 : f * x2;
+            volatile double sc = m.frag_sd * gval;
+            const double x = m.frag_mu + sc;
+            ov_frag = (int64_t)x;
+            ov_valid = true;
+            continue;
+        }
         if (res.n_done == 0 && res.starved && A.py_avail >= want[0] && A.np_avail >= want[1])
             return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
     }
     if (n_done) *n_done = done;
+    return 0;
+}
+
+int iss_mt_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, double fragment_sd) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    ctx->mt.has_frag = enabled != 0;
+    ctx->mt.frag_mu = fragment_length;
+    ctx->mt.frag_sd = fragment_sd;
     return 0;
 }
 

@@ -71,6 +71,16 @@ struct MtWalkResult {
     int32_t starved;            // stopped because a stream buffer could run dry
     int32_t pad;
     int64_t n_mut;              // mutation records written (may exceed the capacity: the surplus is dropped)
+    int32_t need_host;          // custom fragment length: the next pair's int(normal(...)) is too close to an
+                                // integer boundary to trust the device's log(): the host evaluates it (libm)
+    int32_t host_cached;        // ... from the cached second gaussian (f * x1) instead of the fresh one (f * x2)
+    double host_x1, host_x2;    // the polar pair that produced it
+};
+
+// numpy's legacy gaussian state (polar Box-Muller caches its second value) + what produced the cached value
+struct MtGauss {
+    int32_t has_gauss, pad;
+    double gauss, x1, x2;
 };
 
 // one VCF row of --store_mutations (iss/error_models/__init__.py:98-108, 197-221; generator.py:598-620)
@@ -97,6 +107,12 @@ struct MtWalkArgs {
     MutRecord *mut;    // --store_mutations rows (NULL: off)
     int64_t mut_cap, mut_base;  // capacity; rows already written by earlier launches of this call
     int64_t pair_base;          // pair index of this launch's first pair within the call
+    int32_t has_frag;           // error_model.fragment_length / fragment_sd given (generator.py:121-123)
+    int32_t ov_valid;           // the first pair's fragment length was evaluated on the host
+    double frag_mu, frag_sd;
+    double guard;               // |x - round(x)| below this goes to the host (1e-6; tests widen it)
+    int64_t ov_frag;
+    MtGauss *gauss;             // persistent across launches
 };
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -107,7 +123,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // worst-case stream words one attempt at a pair can consume (randrange bounded at 64 words each)
 __host__ __device__ inline uint32_t mt_py_need(int RL) { return 128u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
-__host__ __device__ inline uint32_t mt_np_need(int RL) { return 2u + 2u * (2u + 4u * (uint32_t)RL) + 2u; }
+__host__ __device__ inline uint32_t mt_np_need(int RL) { return 64u /* polar loop */ + 2u + 2u * (2u + 4u * (uint32_t)RL) + 2u; }
 __host__ __device__ inline size_t mt_walk_fixed_lds_bytes(int RL) {
     const size_t rlp = (size_t)((RL + 63) & ~63);
     return 64 * 8 /* mut_thr */ + (rlp + 64) /* tmpl */ + 3 * rlp /* read, qual, stack */ + (size_t)10 * RL * 4 /* window */;
@@ -151,7 +167,9 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
     const int64_t L = g.L;
     const uint32_t gbytes = 1u << M.GB;
     int64_t i = 0;
-    int starved = 0;
+    int starved = 0, need_host = 0, host_cached = 0, ov_valid = A.ov_valid;
+    double host_x1 = 0, host_x2 = 0;
+    MtGauss gs = *A.gauss;  // wave-uniform copy; written back at the end
     int64_t n_mut = 0;  // wave-uniform
     auto put_mut = [&](int mate, int type, int pos, int ref, int alt, int qual, int64_t at) {
         if (A.mut && A.mut_base + at < A.mut_cap) {
@@ -164,39 +182,99 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
     while (i < A.n_pairs) {
         const int64_t mut_mark = n_mut;
         if (opy + py_need > A.py_avail || onp + np_need > A.np_avail) { starved = 1; break; }
-        // ---- insert size: np.searchsorted(cdf, np.random.rand())  (kde.py:97)
-        int isz;
-        {
+        const uint32_t opy0 = opy, onp0 = onp;
+        const MtGauss gs0 = gs;
+        int64_t isz, frag;
+        if (A.has_frag) {
+            // int(np.random.normal(mu, sd)): legacy polar Box-Muller with a cached second value (generator.py:122)
+            double gval;
+            int cached = 0;
+            if (gs.has_gauss) {
+                gval = gs.gauss;
+                gs.has_gauss = 0;
+                cached = 1;
+            } else {
+                double x1, x2, r2;
+                do {
+                    x1 = __dadd_rn(__dmul_rn(2.0, (double)mk53(np[onp], np[onp + 1]) * (1.0 / 9007199254740992.0)), -1.0);
+                    x2 = __dadd_rn(__dmul_rn(2.0, (double)mk53(np[onp + 2], np[onp + 3]) * (1.0 / 9007199254740992.0)), -1.0);
+                    onp += 4;
+                    r2 = __dadd_rn(__dmul_rn(x1, x1), __dmul_rn(x2, x2));
+                } while (r2 >= 1.0 || r2 == 0.0);
+                const double f = sqrt(__ddiv_rn(__dmul_rn(-2.0, log(r2)), r2));
+                gs.gauss = __dmul_rn(f, x1);
+                gs.has_gauss = 1;
+                gs.x1 = x1;
+                gs.x2 = x2;
+                gval = __dmul_rn(f, x2);
+            }
+            const double x = __dadd_rn(A.frag_mu, __dmul_rn(A.frag_sd, gval));
+            if (ov_valid) {
+                frag = A.ov_frag;
+                ov_valid = 0;
+            } else if (!(fabs(x) < 1e15) || fabs(x - rint(x)) < A.guard) {
+                // device log() is within an ulp or two of libm's, not identical: let the host decide this one
+                need_host = 1;
+                host_cached = cached;
+                host_x1 = cached ? gs0.x1 : gs.x1;
+                host_x2 = cached ? gs0.x2 : gs.x2;
+                opy = opy0; onp = onp0; gs = gs0;
+                break;
+            } else {
+                frag = (int64_t)x;  // int(): truncation toward zero
+            }
+            isz = frag - 2 * (int64_t)RL;
+        } else {
+            // insert size: np.searchsorted(cdf, np.random.rand())  (kde.py:97)
             const uint64_t m = mk53(np[onp], np[onp + 1]);
             onp += 2;
             int cnt = 0;
             for (int j = lane; j < M.n_isize; j += 64) cnt += M.isize_thr[j] < m ? 1 : 0;
             isz = wave_sum(cnt);
+            frag = isz + 2 * (int64_t)RL;
         }
         PairDesc d;
-        d.isz = isz;
+        d.isz = (int32_t)isz;
         d.meta = 0;
         int64_t fs, rs = 0, re = 0;
         if (A.sequence_type == 0) {  // generator.py:134-135, 142-144
-            const int64_t width = L - ((int64_t)isz + 2 * RL);
+            const int64_t width = L - frag;
             fs = mt_randbelow(py, opy, (uint32_t)(width > 0 ? width : L - RL), lane);
         } else {
             fs = 0;
         }
+        const int64_t fe = fs + RL;
         d.fs = (int32_t)fs;
         for (int o = 0; o < 2; ++o) {
-            if (o == 1) {  // generator.py:164-177
-                if (A.sequence_type == 0) { rs = fs + RL + isz; re = rs + RL; }
+            // ---- template = Python slice of the genome (may be shorter than RL with odd fragment lengths),
+            //      then the adjust_seq_length padding rule (__init__.py:141-155)
+            int64_t lo, hi;  // normalised slice bounds
+            if (o == 0) {
+                lo = fs < L ? fs : L;
+                hi = fe < L ? fe : L;
+            } else {  // generator.py:164-177
+                if (A.sequence_type == 0) { rs = fe + isz; re = rs + RL; }
                 else { rs = L - RL; re = L; }
                 if (re > L) { re = RL + (int64_t)mt_randbelow(py, opy, (uint32_t)(L - RL), lane); rs = re - RL; }
+                lo = rs; hi = re;
+                if (lo < 0) { lo += L; if (lo < 0) lo = 0; } else if (lo > L) lo = L;
+                if (hi < 0) { hi += L; if (hi < 0) hi = 0; } else if (hi > L) hi = L;
             }
-            d.re = (int32_t)(o == 1 ? re : 0);
-            // ---- template E(0 .. RL+63) (read direction; beyond RL: adjust_seq_length padding)
-            for (int k = lane; k < RL + 64; k += 64) tmpl[k] = (uint8_t)read_dir_base(g, o, d, k);
+            if (hi < lo) hi = lo;
+            const int t_len = (int)(hi - lo);  // <= RL
+            auto E = [&](int k) -> int {  // token k of the read direction: template, then padding
+                if (k < t_len) return o == 0 ? fetch_ascii(g, lo + k) : complement_ascii(fetch_ascii(g, hi - 1 - k));
+                const int64_t i2 = k - t_len;
+                if (o == 0) { const int64_t idx = fe + i2; return idx >= L ? 'A' : fetch_ascii(g, idx); }
+                const int64_t idx = rs - 1 - i2;
+                return idx < 0 ? 'A' : complement_ascii(fetch_ascii(g, idx < L ? idx : L - 1));
+            };
+            for (int k = lane; k < RL + 64; k += 64) tmpl[k] = (uint8_t)E(k);
             __syncthreads();
+            const int n_visit = t_len < RL - 1 ? t_len : RL - 1;  // loop steps that find a template token
             // ---- introduce_indels: fast check (no event, no ambiguous letter => 5 doubles per step, read unchanged)
             bool any = false;
-            for (int n = lane; n < RL - 1; n += 64) {
+            for (int n = lane; n < n_visit; n += 64) {
                 const int bi = base_index(tmpl[n]);
                 const uint32_t *w = py + opy + 10u * (uint32_t)n;
                 const size_t en = ((size_t)o * RL + n) * 4;
@@ -207,18 +285,18 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
             }
             if (!__ballot(any)) {
                 for (int p = lane; p < RL; p += 64) rd[p] = tmpl[p];
-                opy += 10u * (uint32_t)(RL - 1);
+                opy += 10u * (uint32_t)n_visit;
             } else {
                 // exact sequential list semantics (all lanes run the same walk on wave-uniform values)
                 for (int k = lane; k < 10 * (RL - 1); k += 64) win[k] = py[opy + k];
                 __syncthreads();
                 int sp = 0, k = 0, j = 0;
                 uint32_t pos = 0;
-                auto src = [&](int kk) { return kk < RL + 64 ? (int)tmpl[kk] : read_dir_base(g, o, d, kk); };
+                auto src = [&](int kk) { return kk < RL + 64 ? (int)tmpl[kk] : E(kk); };
                 for (int n = 0; n < RL - 1; ++n) {
                     int tok;
                     if (sp > 0) tok = stk[--sp];
-                    else if (k < RL) tok = src(k++);
+                    else if (k < t_len) tok = src(k++);
                     else { if (lane == 0) rd[j] = (uint8_t)src(k); ++k; ++j; continue; }  // n >= len(seq)
                     const int bi = base_index(tok);
                     if (bi < 0) { if (lane == 0) rd[j] = (uint8_t)tok; ++j; continue; }  // ambiguous: no draws
@@ -238,7 +316,7 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
                     const uint64_t m = mk53(win[pos], win[pos + 1]);
                     pos += 2;
                     if (m < M.del_thr[en + bi]) {  // next token slides in
-                        const bool exists = sp > 0 || k < RL;  // else mutable_seq[position] raises IndexError: no row
+                        const bool exists = sp > 0 || k < t_len;  // else mutable_seq[position] raises IndexError: no row
                         tok = sp > 0 ? (int)stk[--sp] : src(k++);
                         if (exists) { if (lane == 0) put_mut(o, 2, n, tok, '.', -1, n_mut); ++n_mut; }
                     }
@@ -334,6 +412,11 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
         A.res->n_done = i;
         A.res->starved = starved;
         A.res->n_mut = n_mut;
+        A.res->need_host = need_host;
+        A.res->host_cached = host_cached;
+        A.res->host_x1 = host_x1;
+        A.res->host_x2 = host_x2;
+        *A.gauss = gs;
     }
 }
 

@@ -128,6 +128,12 @@ class ReadEngine(object):
                                               int(bool(gc_bias)), int(out_first_pair), C.byref(done)))
         return done.value
 
+    def mt_set_fragment(self, fragment_length=None, fragment_sd=None):
+        """Custom fragment length for generate_mt (None, None switches back to the model's insert sizes)."""
+        on = fragment_length is not None and fragment_sd is not None
+        self._check(self._lib.iss_mt_set_fragment(self._ctx, int(on), float(fragment_length or 0.0),
+                                                  float(fragment_sd or 0.0)))
+
     def mt_mutations_reserve(self, capacity):
         """Enable (capacity > 0) / disable --store_mutations row capture of generate_mt."""
         self._check(self._lib.iss_mt_mutations_reserve(self._ctx, int(capacity)))

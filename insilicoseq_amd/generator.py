@@ -162,6 +162,10 @@ class Worker(object):
             # random.seed(seed + cpu_number); np.random.seed(seed + cpu_number)  (generator.py:234-236);
             # unseeded workers draw an OS-entropy seed (the reference is then not reproducible either)
             self.engine.seed_mt(self.seed & 0xFFFFFFFF if seed is None else self.seed)
+            self.engine.mt_set_fragment(getattr(error_model, "fragment_length", None),
+                                        getattr(error_model, "fragment_sd", None))
+        elif getattr(error_model, "fragment_length", None) is not None:
+            raise NotImplementedError("custom fragment length needs rng='mt' (not on the Philox path yet)")
         self.ordinal = 0
         self._gids = {}
 

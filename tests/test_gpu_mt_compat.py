@@ -38,7 +38,7 @@ def test_mt_streams_on_device(engine):
         assert (_res53(npw) == z["npd_%d" % s][:312]).all()
 
 
-MT_CASES = [c for c in pairs_cases() if "frag" not in c and c != "miseq_legacy_amplicon"]  # no custom fragment length
+MT_CASES = pairs_cases()  # every golden pair set, custom fragment lengths (negative inserts) included
 
 
 @pytest.mark.parametrize("case", MT_CASES)
@@ -49,10 +49,14 @@ def test_pairs_equal_reference(engine, case):
     engine.clear_genomes()
     gid = engine.add_genome(z["genome"].tobytes())
     engine.seed_mt(meta["seed"])
+    engine.mt_set_fragment(meta["fragment_length"], meta["fragment_sd"])
     n = meta["n_pairs"]
     if meta["n_done"] == 0:
         pytest.skip("record skipped by the reference")
-    assert engine.generate_mt(gid, n, sequence_type=meta["sequence_type"], gc_bias=meta["gc_bias"]) == n
+    try:
+        assert engine.generate_mt(gid, n, sequence_type=meta["sequence_type"], gc_bias=meta["gc_bias"]) == n
+    finally:
+        engine.mt_set_fragment(None, None)
     got = engine.download(0, n)
     for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
         bad = np.argwhere(got[k] != z[k])
@@ -187,3 +191,25 @@ def test_mutation_records_with_indels_equal_oracle(engine, gc_bias):
     for f in ("pair", "mate", "type", "position", "ref", "alt", "quality"):
         assert np.array_equal(got[f], exp[f]), f
     assert set(np.unique(got["type"])) == {0, 1, 2}
+
+
+def test_fragment_length_host_guard_path(monkeypatch):
+    """Widen the 'too close to an integer' guard so EVERY normal draw is re-evaluated on the host: the
+    stop / override / resume protocol must still reproduce the reference (incl. the cached gaussian)."""
+    from insilicoseq_amd.engine import ReadEngine
+
+    monkeypatch.setenv("ISS_MT_GUARD", "0.6")
+    for case in ("novaseq_frag160", "ecoli_gcbias_frag"):
+        z, meta = load_pairs_case(case)
+        with ReadEngine(0) as eng:
+            eng.load_model(dense_model(meta["model"], meta["indel"]))
+            gid = eng.add_genome(z["genome"].tobytes())
+            eng.seed_mt(meta["seed"])
+            eng.mt_set_fragment(meta["fragment_length"], meta["fragment_sd"])
+            n = meta["n_pairs"]
+            assert eng.generate_mt(gid, n, sequence_type=meta["sequence_type"], gc_bias=meta["gc_bias"]) == n
+            got = eng.download(0, n)
+            for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+                assert np.array_equal(got[k], z[k]), (case, k)
+            py, npw = eng.mt_peek(8)
+            assert list(_res53(py)) == list(z["tail_py"]) and list(_res53(npw)) == list(z["tail_np"])
