@@ -247,3 +247,36 @@ def test_device_genome_packing_roundtrip(engine):
         assert exp["status"] == 0
         for k in ("r1_base", "r2_base", "r1_qual", "r2_qual"):
             assert np.array_equal(got[k], exp[k]), (L, k)
+
+
+def test_chunked_launches_compose(engine):
+    """One call larger than the library's per-launch chunk (2^28 lane-items) == two smaller calls with
+    consecutive ordinals; spot-checked around the chunk boundary and at both ends."""
+    dense = dense_model("hiseq")  # G = 32 groups -> chunk = 2^28 / 32 = 8,388,608 pairs
+    chunk = (1 << 28) // 32
+    n = chunk + 300_000
+    genome = random_genome(123, 2_000_000)
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.generate(gid, n, first_ordinal=7, seed=31)
+    engine.synchronize()
+    windows = [(0, 2000), (chunk - 1500, 3000), (n - 2000, 2000)]
+    whole = [{k: v.copy() for k, v in engine.download(a, m).items() if not k.startswith("_")} for a, m in windows]
+    coords_whole = [engine.coords(a, m).copy() for a, m in windows]
+    half = n // 2 + 17
+    engine.generate(gid, half, first_ordinal=7, seed=31, out_first_pair=0)
+    engine.generate(gid, n - half, first_ordinal=7 + half, seed=31, out_first_pair=half)
+    engine.synchronize()
+    for (a, m), w, cw in zip(windows, whole, coords_whole):
+        got = engine.download(a, m)
+        for k in w:
+            assert np.array_equal(got[k], w[k]), (a, k)
+        assert np.array_equal(engine.coords(a, m), cw)
+    # and the boundary rows agree with the oracle
+    from oracle import oracle as O
+
+    a, m = windows[1]
+    exp = O.Oracle(dense).simulate(O.Rng().seed_philox(31), genome, m, first_ordinal=7 + a)
+    for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+        assert np.array_equal(whole[1][k], exp[k]), k
