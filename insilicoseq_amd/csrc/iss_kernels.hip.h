@@ -138,6 +138,7 @@ struct RunArgs {
     uint8_t *out[4];  // rows of this launch: R1 base, R1 qual, R2 base, R2 qual
     uint32_t *slow_ovf;  // k_main: per-workgroup spill area of the deferred-work queue
     int32_t slow_every;  // k_main: drain period (iterations), chosen from the model's expected rare-base rate
+    int32_t scan_every;  // k_indel_scan: flush period (iterations), chosen from the model's indel probabilities
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -276,6 +277,9 @@ __global__ __launch_bounds__(256) void k_pack_genome(const uint8_t *__restrict__
 
 // ================================================================== k_setup
 __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_isize[];  // insert-size thresholds (binary-searched per pair)
+    for (int k = threadIdx.x; k < M.n_isize; k += blockDim.x) s_isize[k] = M.isize_thr[k];
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_pairs) return;
     const uint64_t ordinal = A.first_ordinal + (uint64_t)i;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs 
     const u32x4 w1 = draw_block(a, K_PAIR, 0, 1);
     const int RL = M.RL;
     const int64_t L = g.L;
-    const int isz = count_lt(M.isize_thr, M.n_isize, mk53(w0.x, w1.x));  // kde.py:97
+    const int isz = count_lt(s_isize, M.n_isize, mk53(w0.x, w1.x));  // kde.py:97
     int bin_f = count_le(M.bin_thr, 4, mk53(w0.y, w1.y));                  // kde.py:74
     int bin_r = count_le(M.bin_thr + 4, 4, mk53(w0.z, w1.z));
     bin_f = bin_f > 3 ? 3 : bin_f;  // kde.py:77-78
@@ -591,8 +595,9 @@ constexpr int SCAN_W = 41;        // words per group entry (odd: bank-conflict f
                                   // then per step c: [1+10c .. +7] insertion limits (digit mate*4+slot),
                                   // [9+10c], [10+10c] deletion limits fwd / rev
 constexpr int SCAN_THREADS = 512;
-constexpr int SCAN_EVERY = 8;     // flush the LDS list every SCAN_EVERY iterations
-constexpr int SCAN_LIST = 2 * SCAN_EVERY * SCAN_THREADS;  // worst case: both mates of every item
+constexpr int SCAN_LIST = 8192;   // LDS list entries; flushed every RunArgs::scan_every iterations, chosen on the
+                                  // host so that a period cannot overflow it (2 * scan_every * SCAN_THREADS <= SCAN_LIST
+                                  // in the worst case, longer periods when the model's indel probabilities are small)
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc,
                                                              uint32_t *flags, uint32_t *fix_list, uint32_t *fix_count) {
@@ -611,12 +616,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     const uint32_t n_iter = n_items > first ? (n_items - first + step - 1) / step : 0;  // uniform in the workgroup
     uint32_t it = first + threadIdx.x;
     uint32_t pair = it / ns, e = it - pair * ns;
+    uint32_t since_flush = 0;
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
         if (it < n_items) {
             const uint32_t *tab = tab0 + e * SCAN_W;
             const uint32_t head = tab[0];
             const uint32_t grp = head & 0xffffu;
-            const Addr a = make_addr(A.seed, A.first_ordinal + pair, desc[pair].meta >> 16);
+            // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
+            const Addr a = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
             uint32_t cand = 0;
             if (head & 0x00f00000u) {  // some step of the group has a deletion probability
                 const u32x4 w = draw_block(a, K_DEL, grp, 0);
@@ -639,13 +646,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
                 while (fresh) {
                     const int o = __ffs(fresh) - 1;
                     fresh &= fresh - 1;
-                    l_list[atomicAdd(&l_count[0], 1u)] = pair * 2u + (uint32_t)o;
+                    const uint32_t at = atomicAdd(&l_count[0], 1u);
+                    if (at < (uint32_t)SCAN_LIST) l_list[at] = pair * 2u + (uint32_t)o;
+                    else fix_list[atomicAdd(fix_count, 1u)] = pair * 2u + (uint32_t)o;  // list full (rates above the estimate)
                 }
             }
         }
-        if ((iter % SCAN_EVERY) == SCAN_EVERY - 1 || iter == n_iter - 1) {
+        if (++since_flush == (uint32_t)A.scan_every || iter == n_iter - 1) {
+            since_flush = 0;
             __syncthreads();
-            const uint32_t n = l_count[0];
+            const uint32_t n = min(l_count[0], (uint32_t)SCAN_LIST);
             if (n) {
                 if (threadIdx.x == 0) l_count[1] = atomicAdd(fix_count, n);
                 __syncthreads();

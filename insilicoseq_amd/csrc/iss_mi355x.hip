@@ -72,6 +72,7 @@ struct iss_ctx {
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
     uint32_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][SLOW_SPILL]
     int slow_every = iss::SLOW_EVERY_MAX;
+    int scan_every = 8;
     unsigned max_main_grid = 0;
     uint64_t *stats = nullptr;
     // reference-compatible MT19937 mode (iss_mt_compat.hip.h)
@@ -303,6 +304,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     if (!ctx || !t) return fail(ctx, ISS_E_INVALID, "iss_model_upload: NULL argument");
     if (t->read_length < 2 || t->read_length > iss::FIX_MAX_RL)
         return fail(ctx, ISS_E_INVALID, "read_length must be in [2, 1024]");
+    if (t->n_isize > 8000) return fail(ctx, ISS_E_INVALID, "insert-size CDF longer than 8000 entries");
     if (t->n_isize < 1 || t->n_q < 1 || t->n_q > 63)
         return fail(ctx, ISS_E_INVALID, "bad table sizes (per-position quality CDFs must have 1..63 entries)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -515,6 +517,15 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         scan_tab.insert(scan_tab.end(), ent, ent + iss::SCAN_W);
     }
     M.n_scan = (int32_t)(scan_tab.size() / iss::SCAN_W);
+    {   // expected flagged mates per scan item -> flush period of the LDS list (half-full on average)
+        double rate = 0;
+        for (size_t e = 0; e + iss::SCAN_W <= scan_tab.size(); e += iss::SCAN_W)
+            for (int c = 0; c < 4; ++c)
+                for (int k = 1; k <= 10; ++k) rate += (double)scan_tab[e + 10 * c + k] / 65536.0;
+        rate = M.n_scan ? rate / M.n_scan : 0.0;
+        const double per_iter = std::max(rate, 1e-6) * iss::SCAN_THREADS;
+        ctx->scan_every = (int)std::max(8.0, std::min(512.0, 0.5 * iss::SCAN_LIST / per_iter));
+    }
     std::vector<uint32_t> fix_tab((size_t)2 * RL * 8);
     for (size_t e = 0; e < (size_t)2 * RL; ++e)
         for (int x = 0; x < 4; ++x) {
@@ -663,6 +674,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
         A.slow_ovf = ctx->slow_ovf;
         A.slow_every = ctx->slow_every;
+        A.scan_every = ctx->scan_every;
         iss::PairDesc *desc = ctx->desc + row0;
         uint32_t *flags = ctx->flags + row0;
         uint32_t *fix_list = ctx->fix_list + 2 * row0;
@@ -690,7 +702,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         HIP_TRY(ctx, mark(0, s_main));
         {
             const unsigned blocks = (unsigned)((n + 255) / 256);
-            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), 0, s_main, M, dg, A, desc);
+            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), (size_t)M.n_isize * 8, s_main, M, dg, A, desc);
         }
         hipEvent_t ev_setup = nullptr, ev_main = nullptr;
         if (M.n_scan > 0 && ctx->overlap) {
