@@ -280,3 +280,45 @@ def test_chunked_launches_compose(engine):
     exp = O.Oracle(dense).simulate(O.Rng().seed_philox(31), genome, m, first_ordinal=7 + a)
     for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
         assert np.array_equal(whole[1][k], exp[k]), k
+
+
+def test_api_misuse_is_reported_not_crashed():
+    """Error conventions of the C ABI: negative code + message, never exit()/crash."""
+    import ctypes as C
+
+    from insilicoseq_amd import _native
+    from insilicoseq_amd.engine import ReadEngine
+    from insilicoseq_amd.model import DenseModel
+
+    with ReadEngine(0) as eng:
+        with pytest.raises(_native.EngineError) as e:  # no model yet
+            eng._check(eng._lib.iss_output_reserve(eng._ctx, 10))
+        assert e.value.code == _native.E_INVALID
+        with pytest.raises(_native.EngineError):
+            eng._check(eng._lib.iss_generate(eng._ctx, 0, 10, 0, 0, 0, 0, 0))
+        d = dense_model("ecoli")
+        eng.load_model(d)
+        with pytest.raises(_native.EngineError):  # unknown genome id
+            eng.generate(3, 10)
+        gid = eng.add_genome("ACGT" * 100)
+        eng.reserve(100)
+        with pytest.raises(_native.EngineError):  # rows beyond the reservation
+            eng._check(eng._lib.iss_generate(eng._ctx, gid, 200, 0, 0, 0, 0, 0))
+        with pytest.raises(_native.EngineError):  # MT mode needs a seed first
+            eng.generate_mt(gid, 10)
+        with pytest.raises(ValueError):
+            eng.generate(gid, 10, sequence_type="shotgun")
+        with pytest.raises(_native.EngineError):  # numpy's legacy seeding range
+            eng.seed_mt(2**32)
+        # a model the engine cannot hold: more than 63 entries per quality CDF
+        big = DenseModel(d.read_length, d.isize_cdf, d.bin_cdf, d.bin_nonempty,
+                         np.concatenate([d.qcdf, np.ones(d.qcdf.shape[:3] + (30,))], axis=3), d.subst_cdf, d.subst_alt,
+                         d.ins, d.ins_letter, d.dele, np.concatenate([d.phred_thr, np.ones(30)]))
+        with pytest.raises(_native.EngineError):
+            eng.load_model(big)
+        # the context is still usable afterwards
+        eng.load_model(d)
+        gid = eng.add_genome("ACGT" * 100)
+        eng.generate(gid, 50, seed=1)
+        eng.synchronize()
+        assert eng.download(0, 50)["r1_base"].shape == (50, 20)
