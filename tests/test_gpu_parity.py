@@ -322,3 +322,47 @@ def test_api_misuse_is_reported_not_crashed():
         eng.generate(gid, 50, seed=1)
         eng.synchronize()
         assert eng.download(0, 50)["r1_base"].shape == (50, 20)
+
+
+def test_philox_mode_statistics_match_the_model(engine):
+    """Size-independent property at scale (2 M pairs): the empirical distributions produced by the Philox
+    address map match the model -- phred PMF per position (mixture over the mean-quality bins), insert sizes,
+    uniform forward starts, substitution rate = E[10^(-Q/10)] -- within 6 sigma."""
+    dense = dense_model("hiseq")
+    L = 400_000
+    genome = random_genome(99, L)
+    n = 2_000_000
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.generate(gid, n, first_ordinal=0, seed=2024)
+    engine.synchronize()
+    got = engine.download(0, n)
+    coords = engine.coords(0, n)
+    RL, nq = dense.read_length, dense.n_q
+    # phred PMF at a few positions, forward and reverse
+    for o, key in ((0, "r1_qual"), (1, "r2_qual")):
+        w = np.diff(np.concatenate(([0.0], dense.bin_cdf[o])))
+        for p in (0, 37, RL - 1):
+            pmf = np.zeros(nq + 1)
+            for b in range(4):
+                if dense.bin_nonempty[o, b]:
+                    c = dense.qcdf[o, b, p]
+                    pmf[:nq] += w[b] * np.diff(np.concatenate(([0.0], c)))
+            emp = np.bincount(got[key][:, p], minlength=nq + 1)[: nq + 1] / n
+            sigma = np.sqrt(np.maximum(pmf * (1 - pmf), 1e-12) / n)
+            assert (np.abs(emp - pmf) < 6 * sigma + 1e-9).all(), (key, p)
+    # insert sizes
+    pmf = np.diff(np.concatenate(([0.0], dense.isize_cdf)))
+    emp = np.bincount(coords[:, 3], minlength=len(pmf))[: len(pmf)] / n
+    assert (np.abs(emp - pmf) < 6 * np.sqrt(np.maximum(pmf * (1 - pmf), 1e-12) / n) + 1e-9).all()
+    # forward start uniform on [0, L - fragment): compare the mean of fs / width with 1/2
+    width = L - (coords[:, 3] + 2 * RL)
+    u = coords[:, 0] / width
+    assert abs(u.mean() - 0.5) < 6 * np.sqrt(1 / 12 / n) and (coords[:, 0] < width).all()
+    # substitution rate of the forward mate at one position: P(base != template) vs E[P(err)] * P(alt != base) = E[P(err)]
+    g = np.frombuffer(genome.encode(), dtype=np.uint8)
+    for p in (5, 100):
+        exp_err = (10.0 ** (-got["r1_qual"][:, p].astype(np.float64) / 10)).mean()
+        emp_err = (got["r1_base"][:, p] != g[coords[:, 0] + p]).mean()
+        assert abs(emp_err - exp_err) < 6 * np.sqrt(exp_err / n) + 2e-5, (p, emp_err, exp_err)  # indels: ~1e-5
