@@ -108,6 +108,12 @@ int iss_output_device_ptrs(const iss_ctx *ctx, void **r1_base, void **r1_qual, v
 int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                  int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair);
 
+/* Custom fragment length on the Philox path (--fragment-length / --fragment-length-sd, iss/generator.py:121-123):
+ * fragment = int(mu + sd * gaussian), each pair running its own polar Box-Muller loop on its K_FRAG uniforms
+ * (nothing is cached across pairs).  Negative inserts, templates cut by the genome end and Python's slice rules
+ * are honoured.  Values within 1e-6 of an integer are re-evaluated by the host with libm. */
+int iss_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, double fragment_sd);
+
 int iss_synchronize(iss_ctx *ctx);
 
 /* Copy rows [first_pair, first_pair + n_pairs) to host arrays of pitch iss_output_pitch(). */

@@ -47,9 +47,6 @@ def load_error_model(mode, seed, model, fragment_length, fragment_length_sd, sto
         logger.error("--mode %s is not available on the GPU path (kde only)" % mode)
         sys.exit(1)
     if fragment_length is not None and fragment_length_sd is not None:
-        if rng != "mt":
-            logger.error("--fragment-length needs --rng mt on the GPU path")
-            sys.exit(1)
         logger.info("Using custom fragment length %s and default fragment length sd %s" % (fragment_length,
                                                                                            fragment_length_sd))
     elif bool(fragment_length) ^ bool(fragment_length_sd):  # generator.py:393-395

@@ -31,7 +31,7 @@ namespace iss {
 // ---------------------------------------------------------------- RNG address map
 enum : uint32_t {
     K_PAIR = 0, K_FS = 1, K_RS = 2, K_QM = 3, K_SUB = 4, K_INS = 5, K_DEL = 6, K_QM_LO = 7, K_INS_LO = 8,
-    K_DEL_LO = 9
+    K_DEL_LO = 9, K_FRAG = 10
 };
 
 struct u32x4 {
@@ -124,8 +124,14 @@ struct DevGenome {
 struct PairDesc {
     int32_t fs;     // forward_start
     int32_t re;     // reverse_end (reverse_start = re - RL)
-    uint32_t meta;  // bits 0-1 bin slot fwd, 2-3 bin slot rev, 4 / 5 fwd / rev window has IUPAC or lower-case letters, 16-31 attempt
+    uint32_t meta;  // bits 0-1 bin slot fwd, 2-3 bin slot rev, 4 / 5 fwd / rev window has IUPAC or lower-case letters,
+                    // 6 irregular geometry (custom fragment lengths only), 16-31 attempt
     int32_t isz;    // insert size
+};
+
+struct FragAmb {
+    uint32_t pair, pad;
+    double x1, x2;  // the accepted polar candidate
 };
 
 struct RunArgs {
@@ -139,6 +145,15 @@ struct RunArgs {
     uint32_t *slow_ovf;  // k_main: per-workgroup spill area of the deferred-work queue
     int32_t slow_every;  // k_main: drain period (iterations), chosen from the model's expected rare-base rate
     int32_t scan_every;  // k_indel_scan: flush period (iterations), chosen from the model's indel probabilities
+    // custom fragment length (generator.py:121-123): fragment = int(mu + sd * gaussian), per-pair polar Box-Muller
+    int32_t has_frag;
+    double frag_mu, frag_sd, frag_guard;
+    struct FragAmb *amb_list;     // pairs whose value is too close to an integer for the device's log(): host decides
+    uint32_t *amb_count;
+    const uint32_t *ov_pairs;     // k_setup override pass: these pairs ...
+    const int64_t *ov_frags;      // ... with these host-evaluated fragment lengths
+    uint32_t n_ov;
+    uint32_t *flags, *fix_list, *fix_count;  // irregular pairs (template shorter than the read, ...) go straight to the fix-up
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -181,6 +196,38 @@ __device__ __forceinline__ int read_dir_base(const DevGenome &g, int o, const Pa
     }
     const int64_t pos = (int64_t)d.re - 1 - k;
     return pos >= 0 ? complement_ascii(fetch_ascii(g, pos)) : 'A';
+}
+
+// General geometry of one mate (Python slice semantics + adjust_seq_length padding), needed once custom
+// fragment lengths allow negative inserts / templates cut by the genome end (generator.py:146-180,
+// __init__.py:141-155).  For the model's own insert sizes t_len == RL and this equals read_dir_base.
+struct MateGeom {
+    int64_t lo, hi;   // normalised slice [lo, hi) of the genome
+    int64_t fe, rs;   // un-normalised forward end / reverse start (the padding rule uses them)
+    int t_len;        // template length (<= RL)
+};
+__device__ __forceinline__ MateGeom mate_geom(int o, const PairDesc &d, int RL, int64_t L) {
+    MateGeom m;
+    m.fe = (int64_t)d.fs + RL;
+    m.rs = (int64_t)d.re - RL;
+    if (o == 0) {
+        m.lo = d.fs < L ? d.fs : L;
+        m.hi = m.fe < L ? m.fe : L;
+    } else {
+        m.lo = m.rs; m.hi = d.re;
+        if (m.lo < 0) { m.lo += L; if (m.lo < 0) m.lo = 0; } else if (m.lo > L) m.lo = L;
+        if (m.hi < 0) { m.hi += L; if (m.hi < 0) m.hi = 0; } else if (m.hi > L) m.hi = L;
+    }
+    if (m.hi < m.lo) m.hi = m.lo;
+    m.t_len = (int)(m.hi - m.lo);
+    return m;
+}
+__device__ __forceinline__ int geom_base(const DevGenome &g, int o, const MateGeom &m, int k) {
+    if (k < m.t_len) return o == 0 ? fetch_ascii(g, m.lo + k) : complement_ascii(fetch_ascii(g, m.hi - 1 - k));
+    const int64_t i = k - m.t_len;
+    if (o == 0) { const int64_t idx = m.fe + i; return idx >= g.L ? 'A' : fetch_ascii(g, idx); }
+    const int64_t idx = m.rs - 1 - i;
+    return idx < 0 ? 'A' : complement_ascii(fetch_ascii(g, idx < g.L ? idx : g.L - 1));
 }
 
 // #(thr[i] < m), thr sorted ascending (np.searchsorted side='left')
@@ -276,12 +323,9 @@ __global__ __launch_bounds__(256) void k_pack_genome(const uint8_t *__restrict__
 }
 
 // ================================================================== k_setup
-__global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
-    extern __shared__ __attribute__((aligned(16))) uint64_t s_isize[];  // insert-size thresholds (binary-searched per pair)
-    for (int k = threadIdx.x; k < M.n_isize; k += blockDim.x) s_isize[k] = M.isize_thr[k];
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n_pairs) return;
+// `ov_frag` != NULL: second pass for the few pairs whose fragment length the host evaluated.
+__device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g, const RunArgs &A, PairDesc *desc,
+                                           const uint64_t *s_isize, int64_t i, const int64_t *ov_frag) {
     const uint64_t ordinal = A.first_ordinal + (uint64_t)i;
     uint32_t attempt = 0;
     if (A.gc_bias) {  // generator.py:82-92 -- the 40<gc<60 window is dead, every candidate pair
@@ -301,14 +345,41 @@ __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs 
     const u32x4 w1 = draw_block(a, K_PAIR, 0, 1);
     const int RL = M.RL;
     const int64_t L = g.L;
-    const int isz = count_lt(s_isize, M.n_isize, mk53(w0.x, w1.x));  // kde.py:97
-    int bin_f = count_le(M.bin_thr, 4, mk53(w0.y, w1.y));                  // kde.py:74
+    int64_t isz, frag;
+    if (A.has_frag) {  // generator.py:121-123
+        if (ov_frag) {
+            frag = *ov_frag;
+        } else {
+            double x1, x2, r2;
+            uint32_t t = 0;
+            do {
+                const u32x4 w = draw_block(a, K_FRAG, t++, 0);
+                x1 = __dadd_rn(__dmul_rn(2.0, (double)mk53(w.x, w.y) * (1.0 / 9007199254740992.0)), -1.0);
+                x2 = __dadd_rn(__dmul_rn(2.0, (double)mk53(w.z, w.w) * (1.0 / 9007199254740992.0)), -1.0);
+                r2 = __dadd_rn(__dmul_rn(x1, x1), __dmul_rn(x2, x2));
+            } while (r2 >= 1.0 || r2 == 0.0);
+            const double f = sqrt(__ddiv_rn(__dmul_rn(-2.0, log(r2)), r2));
+            const double x = __dadd_rn(A.frag_mu, __dmul_rn(A.frag_sd, __dmul_rn(f, x2)));
+            if (!(fabs(x) < 1e15) || fabs(x - rint(x)) < A.frag_guard) {
+                // the device's log() is not libm's: the host evaluates this one and k_setup_override redoes the pair
+                FragAmb rec;
+                rec.pair = (uint32_t)i; rec.pad = 0; rec.x1 = x1; rec.x2 = x2;
+                A.amb_list[atomicAdd(A.amb_count, 1u)] = rec;
+            }
+            frag = fabs(x) < 1e15 ? (int64_t)x : 0;  // int(): truncation toward zero
+        }
+        isz = frag - 2 * (int64_t)RL;
+    } else {
+        isz = count_lt(s_isize, M.n_isize, mk53(w0.x, w1.x));  // kde.py:97
+        frag = isz + 2 * (int64_t)RL;
+    }
+    int bin_f = count_le(M.bin_thr, 4, mk53(w0.y, w1.y));      // kde.py:74
     int bin_r = count_le(M.bin_thr + 4, 4, mk53(w0.z, w1.z));
     bin_f = bin_f > 3 ? 3 : bin_f;  // kde.py:77-78
     bin_r = bin_r > 3 ? 3 : bin_r;
     int64_t fs, rs, re;
     if (A.sequence_type == 0) {
-        const int64_t width = L - ((int64_t)isz + 2 * RL);  // generator.py:135
+        const int64_t width = L - frag;                     // generator.py:135
         if (width > 0) fs = randbelow(a, K_FS, (uint32_t)width);
         else fs = randbelow(a, K_FS, (uint32_t)(L - RL));   // generator.py:144
         rs = fs + RL + isz;                                 // generator.py:165
@@ -322,10 +393,13 @@ __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs 
         re = RL + (int64_t)randbelow(a, K_RS, (uint32_t)(L - RL));
         rs = re - RL;
     }
+    // a template cut by the genome end / a reverse start before the genome start: only with custom fragment
+    // lengths; k_main skips such pairs' genome loads and the fix-up kernel builds both mates exactly
+    const bool irregular = fs + RL > L || rs < 0;
     // does either template window (incl. the <= 3 padding bases k_main's last group touches) hold a
     // letter that is not plain A/C/G/T?  k_main reads the exception mask only for such pairs.
     uint32_t exc = 0;
-    if (g.has_exceptions) {
+    if (g.has_exceptions && !irregular) {
         uint32_t any = 0;
         for (int64_t w = fs >> 5; w <= (fs + RL + 2) >> 5; ++w) any |= g.mask[w];
         exc |= any ? 16u : 0u;
@@ -333,12 +407,34 @@ __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs 
         for (int64_t w = (rs - 3) >> 5; w <= (re - 1) >> 5; ++w) any |= g.mask[w];
         exc |= any ? 32u : 0u;
     }
+    if (irregular && !(A.flags[i] & 3u)) {
+        A.flags[i] = 3u;
+        const uint32_t at = atomicAdd(A.fix_count, 2u);
+        A.fix_list[at] = (uint32_t)i * 2u;
+        A.fix_list[at + 1] = (uint32_t)i * 2u + 1u;
+    }
     PairDesc d;
     d.fs = (int32_t)fs;
     d.re = (int32_t)re;
-    d.meta = (uint32_t)(M.bin_slot[bin_f] & 3) | ((uint32_t)(M.bin_slot[4 + bin_r] & 3) << 2) | exc | (attempt << 16);
-    d.isz = isz;
+    d.meta = (uint32_t)(M.bin_slot[bin_f] & 3) | ((uint32_t)(M.bin_slot[4 + bin_r] & 3) << 2) | exc | (irregular ? 64u : 0u) |
+             (attempt << 16);
+    d.isz = (int32_t)isz;
     desc[i] = d;
+}
+
+__global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_isize[];  // insert-size thresholds (binary-searched per pair)
+    for (int k = threadIdx.x; k < M.n_isize; k += blockDim.x) s_isize[k] = M.isize_thr[k];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n_pairs) return;
+    setup_pair(M, g, A, desc, s_isize, i, nullptr);
+}
+
+__global__ __launch_bounds__(64) void k_setup_override(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= A.n_ov) return;
+    setup_pair(M, g, A, desc, nullptr, (int64_t)A.ov_pairs[j], A.ov_frags + j);
 }
 
 // ================================================================== k_main
@@ -493,8 +589,8 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             const u32x4 wq0 = draw_block(a, K_QM, (uint32_t)(p0 >> 1), 0);
             const u32x4 wq1 = draw_block(a, K_QM, (uint32_t)(p0 >> 1) + 1, 0);
             // ---- template bases: forward g[fs+p0 .. +3]; reverse comp(g[re-1-p0 .. -3])
-            uint32_t fb, rb, fm = 0, rm = 0;
-            {
+            uint32_t fb = 0, rb = 0, fm = 0, rm = 0;
+            if (!(A.has_frag && (d.meta & 64u))) {  // irregular pairs are built by the fix-up kernel
                 const int32_t pf = d.fs + p0;
                 const uint32_t *pw = g.packed + (pf >> 4);
                 fb = funnel_r(pw[0], pw[1], (uint32_t)(pf & 15) * 2) & 0xffu;
@@ -731,6 +827,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
         const int o = (int)(e & 1u);
         const PairDesc d = desc[pair];
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
+        const MateGeom geo = mate_geom(o, d, RL, g.L);
         uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.pitch;
         const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.pitch;
         // ---- phase 1: event masks, template, phred row
@@ -770,7 +867,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
             if (n < RL) { ev[n] = (uint8_t)m8; map[n] = FIX_NONE; qual[n] = out_qual[n]; }
             act[c] = __ballot(m8 != 0);
         }
-        for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)read_dir_base(g, o, d, k);
+        for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)geom_base(g, o, geo, k);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 2: every lane runs the same walk (wave-uniform values); lane 0 does the LDS writes
@@ -786,7 +883,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
                 k += n - (last + 1);  // the settled record covers steps last+1 .. n-1 from the source
                 const uint32_t m8 = ev[n];
                 int tok = sp > 0 ? -(int)stk[--sp] : k++;
-                if (tok < RL) {  // tok >= RL: n >= len(seq), IndexError swallowed (:223): emitted unvisited
+                if (tok < geo.t_len) {  // tok >= len(template): n >= len(seq), IndexError swallowed (:223): emitted unvisited
                     const int ch = tok < 0 ? -tok : (int)tmpl[tok];
                     const int bi = base_index(ch);
                     if (bi >= 0) {  // else ambiguous: skipped (:190-192)
@@ -825,7 +922,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
                 while (rec_n0[r] > j) --r;
                 tok = rec_k0[r] + (j - rec_n0[r]);
             }
-            int base = tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : read_dir_base(g, o, d, tok));
+            int base = tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : geom_base(g, o, geo, tok));
             const u32x4 w = draw_block(a, K_QM, (uint32_t)j >> 1, 0);
             const uint32_t h = digit16(w, (j & 1) * 4 + 2 * o + 1);
             const int q = qual[j];

@@ -73,6 +73,14 @@ struct iss_ctx {
     uint32_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][SLOW_SPILL]
     int slow_every = iss::SLOW_EVERY_MAX;
     int scan_every = 8;
+    // custom fragment length on the Philox path
+    bool has_frag = false;
+    double frag_mu = 0, frag_sd = 0;
+    iss::FragAmb *d_amb = nullptr;
+    uint32_t *d_amb_count = nullptr;
+    uint32_t *d_ov_pairs = nullptr;
+    int64_t *d_ov_frags = nullptr;
+    int64_t amb_cap = 0;
     unsigned max_main_grid = 0;
     uint64_t *stats = nullptr;
     // reference-compatible MT19937 mode (iss_mt_compat.hip.h)
@@ -168,6 +176,22 @@ void mt_init_by_array(uint32_t *mt, const uint32_t *key, int len) {
         if (++i >= 624) { mt[0] = mt[623]; i = 1; }
     }
     mt[0] = 0x80000000u;
+}
+
+// int(loc + scale * gaussian) exactly as numpy's legacy_gauss / normal evaluate it (libm, no contraction):
+// f = sqrt(-2*log(r2)/r2); fresh value f*x2, cached value f*x1.
+int64_t host_int_normal(double x1v, double x2v, bool cached, double loc, double scale) {
+    volatile double x1 = x1v, x2 = x2v;
+    volatile double r2 = x1 * x1;
+    volatile double t2 = x2 * x2;
+    r2 = r2 + t2;
+    volatile double f = -2.0 * log(r2);
+    f = f / r2;
+    f = sqrt(f);
+    volatile double gval = cached ? f * x1 : f * x2;
+    volatile double sc = scale * gval;
+    const double x = loc + sc;
+    return (int64_t)x;
 }
 
 // make at least `want[s]` unconsumed words available in stream s (capacity permitting)
@@ -287,6 +311,9 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
     if (ctx->slow_ovf) (void)hipFree(ctx->slow_ovf);
+    if (ctx->d_amb) (void)hipFree(ctx->d_amb);
+    if (ctx->d_ov_pairs) (void)hipFree(ctx->d_ov_pairs);
+    if (ctx->d_ov_frags) (void)hipFree(ctx->d_ov_frags);
     free_mt(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->indel_stream) (void)hipStreamDestroy(ctx->indel_stream);
@@ -679,7 +706,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         uint32_t *flags = ctx->flags + row0;
         uint32_t *fix_list = ctx->fix_list + 2 * row0;
         TimedLaunch tl{};
-        tl.has_scan = M.n_scan > 0;
+        tl.has_scan = M.n_scan > 0 || ctx->has_frag;
         hipStream_t s_main = ctx->stream;
         hipStream_t s_indel = ctx->overlap ? ctx->indel_stream : ctx->stream;
         auto mark = [&](int k, hipStream_t st) -> hipError_t {
@@ -699,13 +726,64 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
             if (pi.row0 < row0 + n && row0 < pi.row0 + pi.n) HIP_TRY(ctx, hipStreamWaitEvent(s_main, pi.done, 0));
             ++i;
         }
+        uint32_t *counter = ctx->fix_count + (ctx->chunk_seq++ % FIX_SLOTS);
+        HIP_TRY(ctx, hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, s_main));
+        HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
+        A.flags = flags;
+        A.fix_list = fix_list;
+        A.fix_count = counter;
+        A.has_frag = ctx->has_frag ? 1 : 0;
+        A.frag_mu = ctx->frag_mu;
+        A.frag_sd = ctx->frag_sd;
+        A.frag_guard = getenv("ISS_MT_GUARD") ? atof(getenv("ISS_MT_GUARD")) : 1e-6;
+        if (ctx->has_frag) {
+            if (ctx->amb_cap < n) {
+                if (ctx->d_amb) (void)hipFree(ctx->d_amb);
+                if (ctx->d_ov_pairs) (void)hipFree(ctx->d_ov_pairs);
+                if (ctx->d_ov_frags) (void)hipFree(ctx->d_ov_frags);
+                void *p = nullptr;
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)n * sizeof(iss::FragAmb)));
+                ctx->d_amb = static_cast<iss::FragAmb *>(p);
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)n * sizeof(uint32_t)));
+                ctx->d_ov_pairs = static_cast<uint32_t *>(p);
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)n * sizeof(int64_t)));
+                ctx->d_ov_frags = static_cast<int64_t *>(p);
+                ctx->amb_cap = n;
+            }
+            ctx->d_amb_count = reinterpret_cast<uint32_t *>(ctx->fix_count) + 56;  // +224 B of the 256-byte scratch block
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_amb_count, 0, sizeof(uint32_t), s_main));
+            A.amb_list = ctx->d_amb;
+            A.amb_count = ctx->d_amb_count;
+        }
         HIP_TRY(ctx, mark(0, s_main));
         {
             const unsigned blocks = (unsigned)((n + 255) / 256);
             hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), (size_t)M.n_isize * 8, s_main, M, dg, A, desc);
         }
+        if (ctx->has_frag) {
+            // fragment lengths the device could not decide (|x - round(x)| < guard): libm on the host, then redo those pairs
+            uint32_t n_amb = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&n_amb, ctx->d_amb_count, sizeof n_amb, hipMemcpyDeviceToHost, s_main));
+            HIP_TRY(ctx, hipStreamSynchronize(s_main));
+            if (n_amb) {
+                std::vector<iss::FragAmb> amb(n_amb);
+                HIP_TRY(ctx, hipMemcpy(amb.data(), ctx->d_amb, n_amb * sizeof(iss::FragAmb), hipMemcpyDeviceToHost));
+                std::vector<uint32_t> pairs(n_amb);
+                std::vector<int64_t> frags(n_amb);
+                for (uint32_t k = 0; k < n_amb; ++k) {
+                    pairs[k] = amb[k].pair;
+                    frags[k] = host_int_normal(amb[k].x1, amb[k].x2, false, ctx->frag_mu, ctx->frag_sd);
+                }
+                HIP_TRY(ctx, hipMemcpy(ctx->d_ov_pairs, pairs.data(), n_amb * sizeof(uint32_t), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(ctx->d_ov_frags, frags.data(), n_amb * sizeof(int64_t), hipMemcpyHostToDevice));
+                A.ov_pairs = ctx->d_ov_pairs;
+                A.ov_frags = ctx->d_ov_frags;
+                A.n_ov = n_amb;
+                hipLaunchKernelGGL(iss::k_setup_override, dim3((n_amb + 63) / 64), dim3(64), 0, s_main, M, dg, A, desc);
+            }
+        }
         hipEvent_t ev_setup = nullptr, ev_main = nullptr;
-        if (M.n_scan > 0 && ctx->overlap) {
+        if ((M.n_scan > 0 || ctx->has_frag) && ctx->overlap) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&ev_setup, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventRecord(ev_setup, s_main));
         }
@@ -723,17 +801,15 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
                                dg, A, desc);
         }
         HIP_TRY(ctx, mark(2, s_main));
-        if (M.n_scan > 0) {
-            uint32_t *counter = ctx->fix_count + (ctx->chunk_seq++ % FIX_SLOTS);
+        const bool indel_pass = M.n_scan > 0 || ctx->has_frag;
+        if (indel_pass) {
             if (ctx->overlap) {
                 HIP_TRY(ctx, hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
                 HIP_TRY(ctx, hipEventRecord(ev_main, s_main));
                 HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_setup, 0));  // the scan needs the pair descriptors only
             }
-            HIP_TRY(ctx, hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, s_indel));
-            HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_indel));
             HIP_TRY(ctx, mark(3, s_indel));
-            {
+            if (M.n_scan > 0) {
                 const uint64_t items = (uint64_t)n * M.n_scan;
                 const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4,
                                                                      (items + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
@@ -963,17 +1039,7 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         if (res.need_host) {
             // int(np.random.normal(mu, sd)) of the next pair with the host's libm, exactly as numpy's legacy_gauss:
             // f = sqrt(-2*log(r2)/r2); fresh value f*x2, cached value f*x1; loc + scale*g; int() truncates
-            volatile double x1 = res.host_x1, x2 = res.host_x2;
-            volatile double r2 = x1 * x1;
-            volatile double t2 = x2 * x2;
-            r2 = r2 + t2;
-            volatile double f = -2.0 * log(r2);
-            f = f / r2;
-            f = sqrt(f);
-            volatile double gval = res.host_cached ? f * x1 : f * x2;
-            volatile double sc = m.frag_sd * gval;
-            const double x = m.frag_mu + sc;
-            ov_frag = (int64_t)x;
+            ov_frag = host_int_normal(res.host_x1, res.host_x2, res.host_cached != 0, m.frag_mu, m.frag_sd);
             ov_valid = true;
             continue;
         }
@@ -981,6 +1047,14 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
             return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
     }
     if (n_done) *n_done = done;
+    return 0;
+}
+
+int iss_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, double fragment_sd) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    ctx->has_frag = enabled != 0;
+    ctx->frag_mu = fragment_length;
+    ctx->frag_sd = fragment_sd;
     return 0;
 }
 

@@ -113,6 +113,11 @@ class ReadEngine(object):
                                            int(seed) & (2**64 - 1), SEQ_TYPES[sequence_type], int(bool(gc_bias)),
                                            int(out_first_pair)))
 
+    def set_fragment(self, fragment_length=None, fragment_sd=None):
+        """Custom fragment length for generate() (None, None: the model's insert sizes)."""
+        on = fragment_length is not None and fragment_sd is not None
+        self._check(self._lib.iss_set_fragment(self._ctx, int(on), float(fragment_length or 0.0), float(fragment_sd or 0.0)))
+
     # ------------------------------------------------------------------ reference-compatible MT mode
     def seed_mt(self, seed):
         """random.seed(seed); np.random.seed(seed) -- on the device (iss/generator.py:234-236)."""

@@ -164,8 +164,9 @@ class Worker(object):
             self.engine.seed_mt(self.seed & 0xFFFFFFFF if seed is None else self.seed)
             self.engine.mt_set_fragment(getattr(error_model, "fragment_length", None),
                                         getattr(error_model, "fragment_sd", None))
-        elif getattr(error_model, "fragment_length", None) is not None:
-            raise NotImplementedError("custom fragment length needs rng='mt' (not on the Philox path yet)")
+        else:
+            self.engine.set_fragment(getattr(error_model, "fragment_length", None),
+                                     getattr(error_model, "fragment_sd", None))
         self.ordinal = 0
         self._gids = {}
 

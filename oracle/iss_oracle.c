@@ -154,7 +154,8 @@ enum {
     K_DEL = 6,    /* primary digits; index = n>>2; digit (n&3)*2 + mate                   */
     K_QM_LO = 7,  /* secondary; index = p; sub = mate; (w0,w1) qual, (w2,w3) mut          */
     K_INS_LO = 8, /* secondary; index = n; sub = mate*2 + (slot>>1); pair slot&1          */
-    K_DEL_LO = 9  /* secondary; index = n; sub 0; (w0,w1) fwd, (w2,w3) rev                */
+    K_DEL_LO = 9, /* secondary; index = n; sub 0; (w0,w1) fwd, (w2,w3) rev                */
+    K_FRAG = 10   /* custom fragment length: polar candidate t -> index t; x1 from mk53(w0,w1), x2 from mk53(w2,w3) */
 };
 
 /* ------------------------------------------------------------- RNG provider */
@@ -531,8 +532,24 @@ static int simulate_read(const iss_model *m, iss_rng *r, const iss_run_params *r
     const int RL = m->read_length;
     int64_t insert_size, fragment_length;
     if (rp->has_fragment) { /* :121-123 */
-        if (r->mode != ISS_RNG_MT) return ISS_ERR_UNSUPPORTED;
-        double x = iss_oracle_np_normal(r, rp->fragment_length, rp->fragment_sd);
+        double x;
+        if (r->mode == ISS_RNG_MT) {
+            x = iss_oracle_np_normal(r, rp->fragment_length, rp->fragment_sd);
+        } else {
+            /* Philox mode: every pair runs its own polar Box-Muller loop on the K_FRAG candidates and takes the
+             * value numpy returns for a fresh draw (f * x2); nothing is cached across pairs (they are parallel). */
+            double x1, x2, r2;
+            uint32_t t = 0;
+            do {
+                uint32_t w[4];
+                philox_at(r, K_FRAG, t++, 0, w);
+                x1 = 2.0 * res53(w[0], w[1]) - 1.0;
+                x2 = 2.0 * res53(w[2], w[3]) - 1.0;
+                r2 = x1 * x1 + x2 * x2;
+            } while (r2 >= 1.0 || r2 == 0.0);
+            double f = sqrt(-2.0 * log(r2) / r2);
+            x = rp->fragment_length + rp->fragment_sd * (f * x2);
+        }
         fragment_length = (int64_t)x; /* int(): truncation toward zero */
         insert_size = fragment_length - 2 * (int64_t)RL;
     } else if (m->quality_mode == 1) { /* basic.py:56-63 */

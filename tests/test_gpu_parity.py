@@ -366,3 +366,44 @@ def test_philox_mode_statistics_match_the_model(engine):
         exp_err = (10.0 ** (-got["r1_qual"][:, p].astype(np.float64) / 10)).mean()
         emp_err = (got["r1_base"][:, p] != g[coords[:, 0] + p]).mean()
         assert abs(emp_err - exp_err) < 6 * np.sqrt(exp_err / n) + 2e-5, (p, emp_err, exp_err)  # indels: ~1e-5
+
+
+FRAG_CASES = [
+    # (model, indel, genome, n_pairs, seed, seq_type, gc_bias, fragment_length, fragment_sd)
+    ("novaseq", None, lambda: random_genome(41, 3000), 3000, 5, "metagenomics", False, 160, 40),     # negative inserts,
+    ("novaseq", None, lambda: random_genome(42, 400), 1500, 6, "metagenomics", False, 160, 40),      # cut templates
+    ("novaseq", None, lambda: random_genome(43, 50000), 3000, 7, "metagenomics", False, 450, 30),
+    ("ecoli", None, lambda: mixed_genome(44, 3000), 3000, 8, "metagenomics", True, 300, 25),
+    ("miseq-legacy", None, lambda: random_genome(45, 700), 600, 9, "amplicon", False, 1000, 10),
+    ("novaseq", (0.01, 0.03), lambda: mixed_genome(46, 2000), 1500, 10, "metagenomics", False, 200, 60),
+    ("hiseq", None, lambda: random_genome(47, 100000), 2000, 11, "metagenomics", False, 0, 0),        # degenerate sd
+]
+
+
+@pytest.mark.parametrize("case", range(len(FRAG_CASES)))
+@pytest.mark.parametrize("guard", ["1e-6", "0.6"])
+def test_custom_fragment_length_matches_oracle(case, guard, monkeypatch):
+    """--fragment-length on the Philox path vs the oracle (Philox): per-pair polar Box-Muller, Python slice
+    semantics for the odd geometries; guard 0.6 forces every pair through the host-evaluated override pass."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    model, indel, mk, n, seed, seq_type, gc_bias, mu, sd = FRAG_CASES[case]
+    monkeypatch.setenv("ISS_MT_GUARD", guard)
+    dense = dense_model(model, indel)
+    genome = mk()
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        eng.set_fragment(mu, sd)
+        eng.generate(gid, n, first_ordinal=3, seed=seed, sequence_type=seq_type, gc_bias=gc_bias)
+        eng.synchronize()
+        got = eng.download(0, n)
+        coords = eng.coords(0, n)
+    exp = O.Oracle(dense).simulate(O.Rng().seed_philox(seed), genome, n, first_ordinal=3, sequence_type=seq_type,
+                                   gc_bias=gc_bias, fragment_length=mu, fragment_sd=sd, want_coords=True)
+    assert exp["status"] == 0 and exp["n_done"] == n
+    assert np.array_equal(coords[:, [0, 2, 3]], exp["coords"][:, [0, 2, 3]])  # forward start, reverse end, insert size
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        bad = np.argwhere(got[k] != exp[k])
+        assert bad.size == 0, "%s differs at %s (%d cells)" % (k, bad[:5].tolist(), len(bad))
