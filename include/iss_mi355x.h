@@ -116,6 +116,24 @@ int iss_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, doub
 
 int iss_synchronize(iss_ctx *ctx);
 
+/* --store_mutations: one VCF row of the reference (iss/error_models/__init__.py:98-108, 197-221, written by
+ * write_mutations, iss/generator.py:598-620). */
+typedef struct {
+    int32_t pair;     /* pair index i within the call (read id {record.id}_{i}_{cpu}/{mate+1}) */
+    int8_t mate;      /* 0 forward, 1 reverse */
+    int8_t type;      /* 0 substitution, 1 insertion (VCF alt = ref + alt), 2 deletion (alt '.') */
+    int16_t position; /* 0-based (VCF POS = position + 1) */
+    uint8_t ref, alt; /* ASCII */
+    int16_t quality;  /* phred for substitutions, -1 ('.') otherwise */
+} iss_mutation;
+/* Philox path: after iss_mutations_reserve(capacity > 0) iss_generate records the rows of each call (capacity
+ * counts 256-row reservation chunks per wavefront, so reserve generously: ~2 rows per expected mutation + 64 k);
+ * iss_mutations_download waits for the call, drops the rows of reads the indel fix-up rebuilt, sorts into the
+ * reference's order (pair, mate, indel rows in loop order, substitution rows by position) and returns them.
+ * ISS_E_NOMEM when the buffer was too small for the call. */
+int iss_mutations_reserve(iss_ctx *ctx, int64_t capacity);
+int iss_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, int64_t *n_rows);
+
 /* Copy rows [first_pair, first_pair + n_pairs) to host arrays of pitch iss_output_pitch(). */
 int iss_output_download(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, uint8_t *r1_base, uint8_t *r1_qual,
                         uint8_t *r2_base, uint8_t *r2_qual);
@@ -154,18 +172,9 @@ int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n)
  * integer are re-evaluated on the host with libm so the truncation provably equals numpy's. */
 int iss_mt_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, double fragment_sd);
 
-/* --store_mutations in MT mode: the VCF rows of the reference (iss/error_models/__init__.py:98-108, 197-221,
- * written by write_mutations, iss/generator.py:598-620), in the reference's order.  After
- * iss_mt_mutations_reserve(capacity > 0) every iss_generate_mt call records its rows from index 0;
- * iss_mt_mutations_download copies min(rows, capacity) of them and reports the total row count. */
-typedef struct {
-    int32_t pair;     /* pair index i within the call (read id {record.id}_{i}_{cpu}/{mate+1}) */
-    int8_t mate;      /* 0 forward, 1 reverse */
-    int8_t type;      /* 0 substitution, 1 insertion (VCF alt = ref + alt), 2 deletion (alt '.') */
-    int16_t position; /* 0-based (VCF POS = position + 1) */
-    uint8_t ref, alt; /* ASCII */
-    int16_t quality;  /* phred for substitutions, -1 ('.') otherwise */
-} iss_mutation;
+/* --store_mutations in MT mode: after iss_mt_mutations_reserve(capacity > 0) every iss_generate_mt call records
+ * its rows (iss_mutation, in the reference's order) from index 0; iss_mt_mutations_download copies
+ * min(rows, capacity) of them and reports the total row count. */
 int iss_mt_mutations_reserve(iss_ctx *ctx, int64_t capacity);
 int iss_mt_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, int64_t *n_total);
 

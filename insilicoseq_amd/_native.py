@@ -19,7 +19,7 @@ EXPORTS = (
     "iss_output_device_ptrs", "iss_generate", "iss_synchronize", "iss_output_download",
     "iss_output_download_coords", "iss_timing_enable", "iss_timing_read", "iss_stats_read", "iss_fastq_write",
     "iss_mt_seed", "iss_generate_mt", "iss_mt_peek", "iss_mt_mutations_reserve", "iss_mt_mutations_download",
-    "iss_mt_set_fragment", "iss_set_fragment",
+    "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
 )
 
 
@@ -85,6 +85,8 @@ def lib():
     L.iss_mt_mutations_reserve.argtypes = [vp, i64]
     L.iss_mt_set_fragment.argtypes = [vp, i32, C.c_double, C.c_double]
     L.iss_set_fragment.argtypes = [vp, i32, C.c_double, C.c_double]
+    L.iss_mutations_reserve.argtypes = [vp, i64]
+    L.iss_mutations_download.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.iss_mt_mutations_download.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.iss_fastq_write.argtypes = [C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i32, i32, vp, vp, vp, vp, i32]
     for name in EXPORTS:

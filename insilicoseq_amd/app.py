@@ -150,9 +150,6 @@ def generate_reads(args):
         else:
             logger.error("Could not get abundance, or coverage or readcount information")
             sys.exit(1)
-    if args.store_mutations and args.rng != "mt":
-        logger.error("--store_mutations needs --rng mt on the GPU path")
-        sys.exit(1)
     workers = args.gpus
     chunk_size = -((n_reads // 2) // -workers)  # ceildiv, app.py:82
     chunks = list(generate_work_divider(records, readcount_dic, abundance_dic, n_reads, None, None, error_model,

@@ -129,6 +129,25 @@ struct PairDesc {
     int32_t isz;    // insert size
 };
 
+// one VCF row of --store_mutations (iss/error_models/__init__.py:98-108, 197-221; generator.py:598-620)
+struct MutRecord {
+    int32_t pair;      // pair index within the call (the read id's i); -1: unused slot
+    int8_t mate;       // 0 forward, 1 reverse
+    int8_t type;       // bits 0-1: 0 substitution, 1 insertion, 2 deletion.  Philox path only, stripped by the host:
+                       // bits 2-4 order inside the loop step (insertion slot 0-3, deletion 4), bit 5 written by the fix-up
+    int16_t position;  // 0-based
+    uint8_t ref;       // ASCII
+    uint8_t alt;       // ASCII: new base / inserted letter / '.'
+    int16_t quality;   // phred for substitutions, -1 ('.') otherwise
+};
+
+// Philox path: the kernels append rows unordered; every wavefront reserves MUT_CHUNK slots at a time with one
+// atomic and fills them (unused slots keep pair == -1); the host drops stale rows and sorts (iss_mutations_download).
+constexpr uint32_t MUT_CHUNK = 256;
+struct MutChunk {
+    uint32_t base, used;  // wave-uniform
+};
+
 struct FragAmb {
     uint32_t pair, pad;
     double x1, x2;  // the accepted polar candidate
@@ -154,7 +173,33 @@ struct RunArgs {
     const int64_t *ov_frags;      // ... with these host-evaluated fragment lengths
     uint32_t n_ov;
     uint32_t *flags, *fix_list, *fix_count;  // irregular pairs (template shorter than the read, ...) go straight to the fix-up
+    MutRecord *mut;               // --store_mutations rows (NULL: off)
+    uint32_t *mut_count;          // slots reserved so far
+    uint32_t mut_cap;
+    int64_t pair_base;            // index of this launch's first pair within the iss_generate call
 };
+
+// reserve n <= 64 record slots for the active lanes of this wavefront; returns the first slot (wave-uniform) or
+// 0xffffffff when the buffer is full (the host then reports the overflow)
+__device__ __forceinline__ uint32_t mut_alloc(const RunArgs &A, MutChunk &c, uint32_t n) {
+    if (c.used + n > MUT_CHUNK) {
+        const int leader = __ffsll((unsigned long long)__ballot(1)) - 1;
+        uint32_t b = 0;
+        if ((int)(threadIdx.x & 63) == leader) b = atomicAdd(A.mut_count, MUT_CHUNK);
+        c.base = (uint32_t)__shfl((int)b, leader);
+        c.used = 0;
+    }
+    const uint32_t r = c.base + c.used;
+    c.used += n;
+    return r + n <= A.mut_cap ? r : 0xffffffffu;
+}
+// all active lanes call this; lanes with `have` write their row
+__device__ __forceinline__ void mut_emit(const RunArgs &A, MutChunk &c, bool have, const MutRecord &r) {
+    const unsigned long long m = __ballot(have);
+    if (!m) return;
+    const uint32_t at = mut_alloc(A, c, (uint32_t)__popcll(m));
+    if (have && at != 0xffffffffu) A.mut[at + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = r;
+}
 
 // ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ uint8_t code_to_ascii(uint32_t code) { return (uint8_t)((0x47435441u >> (8 * code)) & 0xffu); }
@@ -474,12 +519,13 @@ struct MainTile {  // per-workgroup constants of k_main (word offsets into the d
 // thresholds in its guide bucket, or the substitution test fired / tied).  Everything about the base is
 // recomputed from its uniforms; its phred / base BYTES are patched in place (two lanes may patch
 // different bytes of one dword, hence byte stores).
-__device__ __forceinline__ void main_slow_base(const DevModel &M, const RunArgs &A, const PairDesc *__restrict__ desc,
-                                               const uint32_t *lds, const MainTile &T, uint32_t it, int s) {
+// Returns true and fills `rec` when the base was substituted by a different letter (a --store_mutations row).
+__device__ __forceinline__ bool main_slow_base(const DevModel &M, const RunArgs &A, const PairDesc *__restrict__ desc,
+                                               const uint32_t *lds, const MainTile &T, uint32_t it, int s, MutRecord &rec) {
     const uint32_t pair = it / T.tg, grp = it - pair * T.tg;
     const int o = s >> 2, c = s & 3;
     const int p = (T.g0 + (int)grp) * 4 + c;
-    if (p >= M.RL) return;
+    if (p >= M.RL) return false;
     const PairDesc d = desc[pair];
     const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
     const size_t byte_off = (size_t)pair * M.pitch + (size_t)p;
@@ -501,10 +547,10 @@ __device__ __forceinline__ void main_slow_base(const DevModel &M, const RunArgs 
     const uint32_t t = (uint32_t)((int32_t)lds[q] + 1);
     bool err = hm > t;
     if (hm == t) err = mut_exact(M, a, o, p, hm, (int)q);
-    if (!err) return;
+    if (!err) return false;
     const int base = A.out[2 * o][byte_off];
     const int bi = base_index(base);
-    if (bi < 0) return;  // nucl.upper() in "RYWSMKHBVDN": left alone
+    if (bi < 0) return false;  // nucl.upper() in "RYWSMKHBVDN": left alone
     const u32x4 sb = draw_block(a, K_SUB, (uint32_t)p, 0);
     const uint64_t m = o ? mk53(sb.z, sb.w) : mk53(sb.x, sb.y);
     const uint32_t hs = (uint32_t)(m >> 37);
@@ -517,7 +563,12 @@ __device__ __forceinline__ void main_slow_base(const DevModel &M, const RunArgs 
     } else {
         k = (hs > t0) + (hs > t1);
     }
-    A.out[2 * o][byte_off] = (uint8_t)((se[1] >> (8 * k)) & 0xffu);
+    const uint32_t nb = (se[1] >> (8 * k)) & 0xffu;
+    A.out[2 * o][byte_off] = (uint8_t)nb;
+    // without indels the original read equals the template, i.e. the base just replaced (__init__.py:98)
+    rec.pair = (int32_t)(A.pair_base + pair); rec.mate = (int8_t)o; rec.type = 0; rec.position = (int16_t)p;
+    rec.ref = (uint8_t)base; rec.alt = (uint8_t)nb; rec.quality = (int16_t)q;
+    return (int)nb != base;
 }
 
 // One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive
@@ -541,6 +592,8 @@ __device__ __forceinline__ uint32_t hot_lookup(const uint32_t *lds, uint32_t row
     return sel;
 }
 
+// STORE_MUT: --store_mutations variant (keeps the row bookkeeping out of the common kernel's register budget)
+template <bool STORE_MUT>
 __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -580,6 +633,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
     const uint32_t slot_b = (uint32_t)M.TG * (uint32_t)M.GS * 4u;  // bytes per (mate, bin slot)
     uint32_t since_drain = 0;
+    MutChunk mchunk = {0u, MUT_CHUNK};  // --store_mutations: forces a reservation at first use
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
         if (it < n_items) {
             const int p0 = (g0 + (int)grp) * 4;
@@ -666,7 +720,9 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             const uint32_t nq = *q_count;
             for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
                 const uint32_t ent = i < (uint32_t)SLOW_QCAP ? queue[i] : ovf[i - SLOW_QCAP];
-                main_slow_base(M, A, desc, lds, T, ent >> 3, (int)(ent & 7u));
+                MutRecord rec;
+                const bool have = main_slow_base(M, A, desc, lds, T, ent >> 3, (int)(ent & 7u), rec);
+                if (STORE_MUT) mut_emit(A, mchunk, have, rec);
             }
             __syncthreads();
             if (threadIdx.x == 0) *q_count = 0;
@@ -821,6 +877,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
     int16_t *rec_k0 = rec_n0 + (rlp + 64);
     const int n_pre = RL + 64;
     const int n_chunks = rlp / 64;  // 64-step chunks covering indices 0 .. RL-1
+    MutChunk mchunk = {0u, MUT_CHUNK};
     for (uint32_t i = blockIdx.x * FIX_WAVES + wv; i < n_fix; i += gridDim.x * FIX_WAVES) {
         const uint32_t e = fix_list[i];
         const uint32_t pair = e >> 1;
@@ -871,6 +928,8 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 2: every lane runs the same walk (wave-uniform values); lane 0 does the LDS writes
+        MutRecord row;  // --store_mutations row being built (wave-uniform)
+        row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
         int sp = 0, k = 0, n_rec = 1, last = -1;  // `last`: last step whose map entry / record is settled
         if (lane == 0) { rec_n0[0] = 0; rec_k0[0] = 0; }
 #pragma unroll 1
@@ -893,11 +952,26 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
                                     if (lane == 0) for (int z = 1; z < sp; ++z) stk[z - 1] = stk[z];
                                     --sp;
                                 }
-                                if (lane == 0) stk[sp] = M.ins_letter[((size_t)o * RL + n) * 4 + x];
+                                const int letter = M.ins_letter[((size_t)o * RL + n) * 4 + x];
+                                if (lane == 0) stk[sp] = (uint8_t)letter;
                                 ++sp;
+                                if (A.mut) {  // ref = mutable_seq[position], alt = ref + letter (__init__.py:197-207)
+                                    row.type = (int8_t)(1 | (x << 2) | 32); row.position = (int16_t)n;
+                                    row.ref = (uint8_t)ch; row.alt = (uint8_t)letter;
+                                    mut_emit(A, mchunk, lane == 0, row);
+                                }
                             }
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                        if ((m8 >> (4 + bi)) & 1u) tok = sp > 0 ? -(int)stk[--sp] : k++;  // deleted: next token slides in
+                        if ((m8 >> (4 + bi)) & 1u) {  // deleted: next token slides in
+                            const bool exists = sp > 0 || k < geo.t_len;  // else mutable_seq[position] raises IndexError: no row
+                            tok = sp > 0 ? -(int)stk[--sp] : k++;
+                            if (A.mut && exists) {  // ref = mutable_seq[position] after the pop (__init__.py:211-221)
+                                row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
+                                row.ref = (uint8_t)(tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : geom_base(g, o, geo, tok)));
+                                row.alt = '.';
+                                mut_emit(A, mchunk, lane == 0, row);
+                            }
+                        }
                     }
                 }
                 if (lane == 0) map[n] = (int16_t)tok;
@@ -929,8 +1003,15 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
             const uint32_t t = mut16[q];
             bool err = h > t;
             if (h == t) err = mut_exact(M, a, o, j, h, q);
+            const int before = base;
             if (err) base = substitute(M, a, o, j, base);
             out_base[j] = (uint8_t)base;
+            if (A.mut) {  // only if the new letter differs from the ORIGINAL read at this index (__init__.py:98)
+                MutRecord sub;
+                sub.pair = (int32_t)(A.pair_base + pair); sub.mate = (int8_t)o; sub.type = (int8_t)32; sub.position = (int16_t)j;
+                sub.ref = (uint8_t)before; sub.alt = (uint8_t)base; sub.quality = (int16_t)q;
+                mut_emit(A, mchunk, err && base_index(before) >= 0 && base != (int)tmpl[j], sub);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -81,6 +81,11 @@ struct iss_ctx {
     uint32_t *d_ov_pairs = nullptr;
     int64_t *d_ov_frags = nullptr;
     int64_t amb_cap = 0;
+    // --store_mutations on the Philox path
+    iss::MutRecord *d_pmut = nullptr;
+    uint32_t *d_pmut_count = nullptr;
+    int64_t pmut_cap = 0;
+    int64_t last_row0 = 0, last_n = 0;  // rows of the last iss_generate call (their flags tell which rows are stale)
     unsigned max_main_grid = 0;
     uint64_t *stats = nullptr;
     // reference-compatible MT19937 mode (iss_mt_compat.hip.h)
@@ -274,7 +279,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, device_ordinal));
         ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_main),
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_main<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_main<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_mt_walk),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -312,6 +319,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
     if (ctx->slow_ovf) (void)hipFree(ctx->slow_ovf);
     if (ctx->d_amb) (void)hipFree(ctx->d_amb);
+    if (ctx->d_pmut) (void)hipFree(ctx->d_pmut);
     if (ctx->d_ov_pairs) (void)hipFree(ctx->d_ov_pairs);
     if (ctx->d_ov_frags) (void)hipFree(ctx->d_ov_frags);
     free_mt(ctx);
@@ -688,6 +696,13 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
     const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
     // lane-item indices are packed with 3 more bits in the deferred queue: keep them below 2^28
     const int64_t max_chunk = std::max<int64_t>(1, ((int64_t)1 << 28) / std::max(M.G, std::max(M.n_scan, 1)));
+    if (ctx->d_pmut) {  // rows of THIS call only
+        ctx->d_pmut_count = reinterpret_cast<uint32_t *>(ctx->fix_count) + 60;  // +240 B of the scratch block
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_pmut, 0xff, (size_t)ctx->pmut_cap * sizeof(iss::MutRecord), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_pmut_count, 0, sizeof(uint32_t), ctx->stream));
+    }
+    ctx->last_row0 = out_first_pair;
+    ctx->last_n = n_pairs;
     for (int64_t done = 0; done < n_pairs;) {
         const int64_t n = std::min(max_chunk, n_pairs - done);
         const int64_t row0 = out_first_pair + done;
@@ -729,6 +744,10 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         uint32_t *counter = ctx->fix_count + (ctx->chunk_seq++ % FIX_SLOTS);
         HIP_TRY(ctx, hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, s_main));
         HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
+        A.mut = ctx->d_pmut;
+        A.mut_count = ctx->d_pmut_count;
+        A.mut_cap = (uint32_t)ctx->pmut_cap;
+        A.pair_base = done;
         A.flags = flags;
         A.fix_list = fix_list;
         A.fix_count = counter;
@@ -797,8 +816,12 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
             unsigned per_tile = std::max(1u, per_cu * (unsigned)ctx->n_cu / (unsigned)M.n_tiles);
             per_tile = (unsigned)std::min<uint64_t>(per_tile, (items + iss::MAIN_THREADS - 1) / iss::MAIN_THREADS);
             per_tile = std::max(1u, std::min(per_tile, ctx->max_main_grid / (unsigned)M.n_tiles));
-            hipLaunchKernelGGL(iss::k_main, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes, s_main, M,
-                               dg, A, desc);
+            if (A.mut)
+                hipLaunchKernelGGL(iss::k_main<true>, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes,
+                                   s_main, M, dg, A, desc);
+            else
+                hipLaunchKernelGGL(iss::k_main<false>, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes,
+                                   s_main, M, dg, A, desc);
         }
         HIP_TRY(ctx, mark(2, s_main));
         const bool indel_pass = M.n_scan > 0 || ctx->has_frag;
@@ -1055,6 +1078,64 @@ int iss_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, doub
     ctx->has_frag = enabled != 0;
     ctx->frag_mu = fragment_length;
     ctx->frag_sd = fragment_sd;
+    return 0;
+}
+
+int iss_mutations_reserve(iss_ctx *ctx, int64_t capacity) {
+    if (!ctx || capacity < 0 || capacity > 0x7fffffff) return fail(ctx, ISS_E_INVALID, "iss_mutations_reserve: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    if (ctx->d_pmut) (void)hipFree(ctx->d_pmut);
+    ctx->d_pmut = nullptr;
+    ctx->pmut_cap = 0;
+    if (capacity) {
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, (size_t)capacity * sizeof(iss::MutRecord)));
+        ctx->d_pmut = static_cast<iss::MutRecord *>(p);
+        ctx->pmut_cap = capacity;
+    }
+    return 0;
+}
+
+int iss_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, int64_t *n_rows) {
+    if (n_rows) *n_rows = 0;
+    if (!ctx || capacity < 0) return fail(ctx, ISS_E_INVALID, "iss_mutations_download: bad argument");
+    if (!ctx->d_pmut) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    uint32_t reserved = 0;
+    HIP_TRY(ctx, hipMemcpy(&reserved, ctx->d_pmut_count, sizeof reserved, hipMemcpyDeviceToHost));
+    if ((int64_t)reserved > ctx->pmut_cap)
+        return fail(ctx, ISS_E_NOMEM, "mutation buffer too small for this call (reserve more with iss_mutations_reserve)");
+    std::vector<iss::MutRecord> rows(reserved);
+    std::vector<uint32_t> flags((size_t)ctx->last_n);
+    if (reserved) HIP_TRY(ctx, hipMemcpy(rows.data(), ctx->d_pmut, (size_t)reserved * sizeof(iss::MutRecord), hipMemcpyDeviceToHost));
+    if (ctx->last_n)
+        HIP_TRY(ctx, hipMemcpy(flags.data(), ctx->flags + ctx->last_row0, (size_t)ctx->last_n * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost));
+    // keep: used slots; k_main's rows only for mates the fix-up did not rebuild.  Order: pair, mate, indel rows in
+    // loop order (step, insertion slot / deletion) before the substitution rows in position order.
+    std::vector<std::pair<uint64_t, uint32_t>> keyed;
+    keyed.reserve(rows.size());
+    for (uint32_t i = 0; i < rows.size(); ++i) {
+        const iss::MutRecord &r = rows[i];
+        if (r.pair < 0) continue;
+        const int t = (uint8_t)r.type;
+        const bool from_fixup = (t & 32) != 0;
+        if (!from_fixup && (flags[(size_t)r.pair] >> r.mate) & 1u) continue;
+        const uint64_t phase = (t & 3) == 0 ? 1 : 0;
+        const uint64_t key = ((uint64_t)(uint32_t)r.pair << 32) | ((uint64_t)(r.mate & 1) << 31) | (phase << 30) |
+                             ((uint64_t)(uint16_t)r.position << 8) | (uint64_t)((t >> 2) & 7);
+        keyed.emplace_back(key, i);
+    }
+    std::sort(keyed.begin(), keyed.end());
+    if (n_rows) *n_rows = (int64_t)keyed.size();
+    const int64_t n = std::min<int64_t>((int64_t)keyed.size(), capacity);
+    for (int64_t i = 0; i < n && out; ++i) {
+        const iss::MutRecord &r = rows[keyed[(size_t)i].second];
+        out[i].pair = r.pair; out[i].mate = r.mate; out[i].type = (int8_t)(r.type & 3); out[i].position = r.position;
+        out[i].ref = r.ref; out[i].alt = r.alt; out[i].quality = r.quality;
+    }
     return 0;
 }
 

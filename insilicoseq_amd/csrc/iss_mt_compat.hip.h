@@ -83,17 +83,6 @@ struct MtGauss {
     double gauss, x1, x2;
 };
 
-// one VCF row of --store_mutations (iss/error_models/__init__.py:98-108, 197-221; generator.py:598-620)
-struct MutRecord {
-    int32_t pair;      // pair index within the call (the read id's i)
-    int8_t mate;       // 0 forward, 1 reverse
-    int8_t type;       // 0 substitution, 1 insertion, 2 deletion
-    int16_t position;  // 0-based
-    uint8_t ref;       // ASCII
-    uint8_t alt;       // ASCII: new base / inserted letter / '.'
-    int16_t quality;   // phred for substitutions, -1 ('.') otherwise
-};
-
 struct MtWalkArgs {
     const uint32_t *py, *np;  // stream words, starting at the current consumption point
     uint32_t py_avail, np_avail;

@@ -118,6 +118,19 @@ class ReadEngine(object):
         on = fragment_length is not None and fragment_sd is not None
         self._check(self._lib.iss_set_fragment(self._ctx, int(on), float(fragment_length or 0.0), float(fragment_sd or 0.0)))
 
+    def mutations_reserve(self, capacity):
+        """Enable (capacity > 0) / disable --store_mutations row capture of generate() (Philox path)."""
+        self._check(self._lib.iss_mutations_reserve(self._ctx, int(capacity)))
+        self._pmut_cap = int(capacity)
+
+    def mutations(self):
+        """Rows of the last generate() call, in the reference's order (structured array, see iss_mutation)."""
+        cap = getattr(self, "_pmut_cap", 0)
+        out = np.zeros(cap, dtype=MUT_DTYPE)
+        n = C.c_int64(0)
+        self._check(self._lib.iss_mutations_download(self._ctx, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value]
+
     # ------------------------------------------------------------------ reference-compatible MT mode
     def seed_mt(self, seed):
         """random.seed(seed); np.random.seed(seed) -- on the device (iss/generator.py:234-236)."""

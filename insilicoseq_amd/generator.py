@@ -211,6 +211,8 @@ class Worker(object):
             else:
                 eng.generate(gid, n, first_ordinal=self.ordinal, seed=self.seed, sequence_type=sequence_type,
                              gc_bias=gc_bias, out_first_pair=0)
+                if self.store_mutations:
+                    write_mutations(eng.mutations(), mutations_handle, record.id, done, self.cpu_number)
             eng.synchronize()
             rows = eng.download(0, n)["_pitched"]
             fastq_write(forward_handle.fileno(), reverse_handle.fileno(), record.id, done, self.cpu_number, n,
@@ -249,9 +251,6 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
     byte (sequential, ~1e5 pairs/s); ``rng="philox"`` is the parallel path."""
     logger = logging.getLogger(__name__)
     store_mutations = bool(getattr(error_model, "store_mutations", False))
-    if store_mutations and rng != "mt":
-        raise NotImplementedError("--store_mutations (VCF rows) needs rng='mt' (the parallel Philox path does not "
-                                  "record mutations yet, SURVEY.md 8 f3)")
     if sequence_type not in _native.SEQ_TYPES:
         raise RuntimeError("sequence type '%s' is not supported" % sequence_type)  # generator.py:139
     try:
@@ -264,7 +263,10 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
     w = Worker(error_model, cpu_number, seed, device=device, rng=rng)
     if store_mutations:
         w.store_mutations = True
-        w.engine.mt_mutations_reserve(Worker.BATCH_PAIRS * 8)
+        if rng == "mt":
+            w.engine.mt_mutations_reserve(Worker.BATCH_PAIRS * 8)
+        else:
+            w.engine.mutations_reserve(Worker.BATCH_PAIRS * 16)
     try:
         with forward_handle, reverse_handle, mutation_handle:
             for record, n_pairs, _mode in work:

@@ -407,3 +407,75 @@ def test_custom_fragment_length_matches_oracle(case, guard, monkeypatch):
     for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
         bad = np.argwhere(got[k] != exp[k])
         assert bad.size == 0, "%s differs at %s (%d cells)" % (k, bad[:5].tolist(), len(bad))
+
+
+MUT_CASES = [
+    # (model, indel, genome, n_pairs, seed, seq_type, gc_bias, fragment)
+    ("novaseq", None, lambda: random_genome(51, 100000), 20000, 3, "metagenomics", False, None),
+    ("hiseq", None, lambda: mixed_genome(52, 30000), 8000, 4, "metagenomics", True, None),
+    ("novaseq", (0.01, 0.03), lambda: mixed_genome(53, 20000), 3000, 5, "metagenomics", False, None),
+    ("novaseq", (0.2, 0.35), lambda: random_genome(54, 5000), 500, 6, "metagenomics", False, None),
+    ("novaseq", (0.001, 0.003), lambda: random_genome(55, 2000), 3000, 7, "metagenomics", False, (200, 60)),
+    ("ecoli", None, lambda: random_genome(56, 3000), 5000, 8, "amplicon", False, None),
+]
+
+
+@pytest.mark.parametrize("case", range(len(MUT_CASES)))
+def test_store_mutations_rows_match_oracle(engine, case):
+    """--store_mutations on the Philox path: rows (after the host's stale-row filter and sort) equal the oracle's,
+    and the reads themselves are unchanged by the bookkeeping kernel variant."""
+    from oracle import oracle as O
+
+    model, indel, mk, n, seed, seq_type, gc_bias, frag = MUT_CASES[case]
+    dense = dense_model(model, indel)
+    genome = mk()
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.mutations_reserve(4_000_000)
+    engine.set_fragment(*(frag or (None, None)))
+    try:
+        engine.generate(gid, n, first_ordinal=11, seed=seed, sequence_type=seq_type, gc_bias=gc_bias)
+        engine.synchronize()
+        got_rows = engine.mutations()
+        got = engine.download(0, n)
+    finally:
+        engine.mutations_reserve(0)
+        engine.set_fragment(None, None)
+    exp = O.Oracle(dense).simulate(O.Rng().seed_philox(seed), genome, n, first_ordinal=11, sequence_type=seq_type,
+                                   gc_bias=gc_bias, store_mutations=True,
+                                   fragment_length=frag[0] if frag else None, fragment_sd=frag[1] if frag else None)
+    assert exp["status"] == 0
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        assert np.array_equal(got[k], exp[k]), k
+    rows = exp["mutations"]
+    assert len(got_rows) == len(rows) and len(rows) > 0
+    for f in ("pair", "mate", "type", "position", "ref", "alt", "quality"):
+        bad = np.flatnonzero(got_rows[f] != rows[f])
+        assert bad.size == 0, (f, bad[:5], got_rows[bad[:3]], rows[bad[:3]])
+
+
+def test_worker_vcf_philox(tmp_path):
+    """worker_iterator with store_mutations on the Philox path writes the rows in VCF form."""
+    from insilicoseq_amd.generator import Record, worker_iterator
+    from insilicoseq_amd.model import KDErrorModel
+    from oracle import oracle as O
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    em = KDErrorModel(os.path.join(root, "insilicoseq_amd", "profiles", "hiseq.dense.npz"), None, None, True)
+    recs = [Record(random_genome(60 + i, 5000), id="g%d" % i) for i in range(2)]
+    prefix = str(tmp_path / "w")
+    worker_iterator([(recs[0], 900, "default"), (recs[1], 400, "default")], em, 2, prefix, 5, "metagenomics", False, device=0)
+    dense = dense_model("hiseq")
+    rng = O.Rng().seed_philox(5 + 2)
+    lines, ordinal = [], 0
+    for r, n in zip(recs, (900, 400)):
+        res = O.Oracle(dense).simulate(rng, r.seq, n, first_ordinal=ordinal, store_mutations=True)
+        ordinal += n
+        for m in res["mutations"]:
+            ref, alt = chr(m["ref"]), chr(m["alt"])
+            alt = ref + alt if m["type"] == 1 else alt
+            qual = str(int(m["quality"])) if m["type"] == 0 else "."
+            lines.append("\t".join(["%s_%d_2/%d" % (r.id, m["pair"], 1 + int(m["mate"])), str(int(m["position"]) + 1), ".",
+                                    ref, alt, qual, "", ""]) + "\n")
+    assert open(prefix + ".vcf").read() == "".join(lines) and len(lines) > 50
