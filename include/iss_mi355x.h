@@ -159,13 +159,16 @@ int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads);
  * two MT19937 streams exactly as reads_generator/simulate_read do (iss/generator.py:69-192), so rows
  * [out_first_pair, +*n_done) equal the reference's reads for that worker byte for byte; the stream state
  * carries over to the next call (the next work item of the worker).  On ISS_E_SHORT_RECORD the one numpy
- * double the reference draws before its assertion is consumed too.  Not supported here: custom fragment
- * length, --store_mutations.  iss_mt_peek copies the next n <= 624 words of both streams (not consumed).
+ * double the reference draws before its assertion is consumed too.  iss_mt_peek copies the next n <= 624 words of both streams (not consumed).
  */
 int iss_mt_seed(iss_ctx *ctx, uint64_t seed);
 int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t sequence_type, int32_t gc_bias,
                     int64_t out_first_pair, int64_t *n_done);
 int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n);
+/* Pairs produced so far by each device path of iss_generate_mt: the offset resolver + parallel emitter
+ * (plain pairs) and the sequential walker (pairs with an indel candidate or letters outside ACGT, custom
+ * fragment lengths, --store_mutations; everything when ISS_MT_PATH=walk is set in the environment). */
+int iss_mt_path_counts(iss_ctx *ctx, int64_t *n_resolved, int64_t *n_walked);
 /* Custom fragment length in MT mode (--fragment-length / --fragment-length-sd, iss/generator.py:121-123):
  * fragment = int(np.random.normal(mu, sd)) with numpy's legacy polar Box-Muller incl. its cached second value
  * (reset by iss_mt_seed like np.random.seed does).  The device evaluates it; draws that land within 1e-6 of an

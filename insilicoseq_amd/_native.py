@@ -20,6 +20,7 @@ EXPORTS = (
     "iss_output_download_coords", "iss_timing_enable", "iss_timing_read", "iss_stats_read", "iss_fastq_write",
     "iss_mt_seed", "iss_generate_mt", "iss_mt_peek", "iss_mt_mutations_reserve", "iss_mt_mutations_download",
     "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
+    "iss_mt_path_counts",
 )
 
 
@@ -82,6 +83,7 @@ def lib():
     L.iss_mt_seed.argtypes = [vp, u64]
     L.iss_generate_mt.argtypes = [vp, i32, i64, i32, i32, i64, C.POINTER(i64)]
     L.iss_mt_peek.argtypes = [vp, vp, vp, i32]
+    L.iss_mt_path_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.iss_mt_mutations_reserve.argtypes = [vp, i64]
     L.iss_mt_set_fragment.argtypes = [vp, i32, C.c_double, C.c_double]
     L.iss_set_fragment.argtypes = [vp, i32, C.c_double, C.c_double]

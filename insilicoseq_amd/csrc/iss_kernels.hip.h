@@ -110,6 +110,10 @@ struct DevModel {
     const uint32_t *fix_tab;      // [2][RL][8] (thr >> 37) + 1 of the 4 insertion + 4 deletion thresholds, 0 = zero probability
     const uint32_t *scan_tab;      // [n_scan][SCAN_W]: groups of 4 loop steps with a non-zero indel probability (k_indel_scan)
     int32_t n_scan;
+    // reference-compatible MT mode, k_mt_resolve (iss_mt_compat.hip.h)
+    int32_t mt_row_w;             // 32-bit words per row of mt_rows (odd)
+    const uint16_t *mt_rows;      // [2][NB][RL] rows of n_q leading digits min(q_thr >> 37, 0xffff) (no merging: index == phred)
+    const uint32_t *mt_lim;       // [2][RL][5] thr >> 26 of the 4 insertion thresholds and the largest deletion threshold
 };
 
 struct DevGenome {

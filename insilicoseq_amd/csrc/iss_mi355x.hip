@@ -73,6 +73,7 @@ struct iss_ctx {
     uint32_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][SLOW_SPILL]
     int slow_every = iss::SLOW_EVERY_MAX;
     int scan_every = 8;
+    double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
     // custom fragment length on the Philox path
     bool has_frag = false;
     double frag_mu = 0, frag_sd = 0;
@@ -101,6 +102,9 @@ struct iss_ctx {
         double frag_mu = 0, frag_sd = 0;
         iss::MutRecord *d_mut = nullptr;  // --store_mutations rows of the last iss_generate_mt call
         int64_t mut_cap = 0, mut_n = 0;
+        hipEvent_t ev_main = nullptr, ev_fill = nullptr;  // ordering between ctx->stream and the fill stream
+        iss::MtPairRec *d_rec = nullptr;  // k_mt_resolve -> k_mt_emit: stream offsets of one launch's pairs
+        int64_t n_resolved = 0, n_walked = 0;  // pairs by path (statistics, iss_mt_path_counts)
     } mt;
     // timing
     bool timing = false;
@@ -155,6 +159,11 @@ void free_mt(iss_ctx *ctx) {
     if (ctx->mt.d_res) (void)hipFree(ctx->mt.d_res);
     if (ctx->mt.d_mut) (void)hipFree(ctx->mt.d_mut);
     if (ctx->mt.d_gauss) (void)hipFree(ctx->mt.d_gauss);
+    if (ctx->mt.d_rec) (void)hipFree(ctx->mt.d_rec);
+    ctx->mt.d_rec = nullptr;
+    if (ctx->mt.ev_main) (void)hipEventDestroy(ctx->mt.ev_main);
+    if (ctx->mt.ev_fill) (void)hipEventDestroy(ctx->mt.ev_fill);
+    ctx->mt.ev_main = ctx->mt.ev_fill = nullptr;
     ctx->mt.d_gauss = nullptr;
     ctx->mt.d_mut = nullptr; ctx->mt.mut_cap = 0;
     for (auto &st : ctx->mt.buf) for (auto &b : st) { if (b) (void)hipFree(b); b = nullptr; }
@@ -199,10 +208,34 @@ int64_t host_int_normal(double x1v, double x2v, bool cached, double loc, double 
     return (int64_t)x;
 }
 
+// MT19937 blocks are generated on the auxiliary stream (ctx->indel_stream) so that the NEXT chunk's words can be
+// produced while the current chunk is consumed on ctx->stream.  The fill first waits for everything queued on
+// ctx->stream so far (an earlier k_mt_emit may still read the target buffer); ctx->stream waits for ev_fill
+// before it touches the new words (mt_fill_join).
+int mt_fill_async(iss_ctx *ctx, uint32_t *const dst[2], const uint32_t blocks[2]) {
+    auto &m = ctx->mt;
+    if (!blocks[0] && !blocks[1]) return 0;
+    if (!m.ev_main) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&m.ev_main, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&m.ev_fill, hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, hipEventRecord(m.ev_main, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, m.ev_main, 0));
+    hipLaunchKernelGGL(iss::k_mt_fill, dim3(2), dim3(iss::FILL_THREADS), 0, ctx->indel_stream, m.d_state, dst[0], dst[1], blocks[0],
+                       blocks[1]);
+    HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->indel_stream));
+    return 0;
+}
+int mt_fill_join(iss_ctx *ctx) {
+    if (ctx->mt.ev_fill) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->mt.ev_fill, 0));
+    return 0;
+}
+
 // make at least `want[s]` unconsumed words available in stream s (capacity permitting)
 int mt_ensure(iss_ctx *ctx, const size_t want[2]) {
     uint32_t blocks[2] = {0, 0};
     uint32_t *dst[2] = {nullptr, nullptr};
+    { int rc_ = mt_fill_join(ctx); if (rc_) return rc_; }
     for (int s = 0; s < 2; ++s) {
         auto &m = ctx->mt;
         const size_t left = m.fill[s] - m.used[s];
@@ -218,9 +251,47 @@ int mt_ensure(iss_ctx *ctx, const size_t want[2]) {
         m.used[s] = 0;
         m.fill[s] = left + (size_t)blocks[s] * 624;
     }
-    if (blocks[0] || blocks[1])
-        hipLaunchKernelGGL(iss::k_mt_fill, dim3(2), dim3(256), 0, ctx->stream, ctx->mt.d_state, dst[0], dst[1], blocks[0],
-                           blocks[1]);
+    { int rc_ = mt_fill_async(ctx, dst, blocks); if (rc_) return rc_; }
+    return mt_fill_join(ctx);
+}
+
+// Prefetch for the chunk AFTER the one about to be launched: stream s gets `want_next[s]` fresh words in its
+// other buffer, placed behind room for everything that is unconsumed now (the running chunk will consume some
+// of it).  mt_prefetch_commit, called once the running chunk has finished, moves the actual leftover in front
+// of the prefetched words and switches buffers.
+struct MtPrefetch {
+    bool on[2] = {false, false};
+    size_t at[2] = {0, 0};
+    uint32_t blocks[2] = {0, 0};
+};
+int mt_prefetch_begin(iss_ctx *ctx, const size_t want_cur[2], const size_t want_next[2], MtPrefetch *pf) {
+    auto &m = ctx->mt;
+    uint32_t *dst[2] = {nullptr, nullptr};
+    for (int s = 0; s < 2; ++s) {
+        const size_t avail = m.fill[s] - m.used[s];
+        if (avail >= want_cur[s] + want_next[s]) continue;  // enough for both chunks already
+        const size_t blocks = (want_next[s] + 623) / 624;
+        if (avail + blocks * 624 > m.cap[s]) continue;       // no room: the next mt_ensure fills synchronously
+        pf->on[s] = true;
+        pf->at[s] = avail;
+        pf->blocks[s] = (uint32_t)blocks;
+        dst[s] = m.buf[s][m.cur[s] ^ 1] + avail;
+    }
+    return mt_fill_async(ctx, dst, pf->blocks);
+}
+int mt_prefetch_commit(iss_ctx *ctx, const MtPrefetch &pf) {
+    auto &m = ctx->mt;
+    for (int s = 0; s < 2; ++s) {
+        if (!pf.on[s]) continue;
+        const size_t left = m.fill[s] - m.used[s];  // <= pf.at[s]
+        const int nxt = m.cur[s] ^ 1;
+        if (left)
+            HIP_TRY(ctx, hipMemcpyAsync(m.buf[s][nxt] + (pf.at[s] - left), m.buf[s][m.cur[s]] + m.used[s],
+                                        left * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        m.cur[s] = nxt;
+        m.used[s] = pf.at[s] - left;
+        m.fill[s] = pf.at[s] + (size_t)pf.blocks[s] * 624;
+    }
     return 0;
 }
 
@@ -567,6 +638,29 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             fix_tab[e * 8 + x] = lim(t->ins_thr[e * 4 + x]);
             fix_tab[e * 8 + 4 + x] = lim(t->del_thr[e * 4 + x]);
         }
+    // k_mt_resolve tables: un-merged 16-bit leading digits per (orientation, bin slot, position) -- a row of n_q
+    // digits padded to an odd number of words -- and 27-bit leading parts of the indel thresholds
+    M.mt_row_w = (nq + 2) / 2;  // >= one 0xffff padding digit after the n_q digits
+    if (!(M.mt_row_w & 1)) ++M.mt_row_w;
+    std::vector<uint16_t> mt_rows((size_t)2 * M.NB * RL * M.mt_row_w * 2, 0xffffu);
+    for (int o = 0; o < 2; ++o)
+        for (int sl = 0; sl < M.NB; ++sl)
+            for (int p = 0; p < RL; ++p) {
+                const uint64_t *row = t->q_thr + ((size_t)(o * 4 + M.slot_bin[o * 4 + sl]) * RL + p) * nq;
+                uint16_t *dst = mt_rows.data() + ((size_t)(o * M.NB + sl) * RL + p) * M.mt_row_w * 2;
+                for (int i = 0; i < nq; ++i) dst[i] = (uint16_t)std::min<uint64_t>(row[i] >> 37, 0xffffu);
+            }
+    std::vector<uint32_t> mt_lim((size_t)2 * RL * 5);
+    for (size_t e = 0; e < (size_t)2 * RL; ++e) {
+        for (int x = 0; x < 4; ++x) mt_lim[e * 5 + x] = (uint32_t)(t->ins_thr[e * 4 + x] >> 26);
+        mt_lim[e * 5 + 4] = (uint32_t)(del_max[e] >> 26);
+    }
+    {   // expected share of pairs the resolver hands to the sequential walker (an indel candidate in either mate)
+        double rate = 0;
+        for (size_t e = 0; e < (size_t)2 * RL; ++e)
+            for (int x = 0; x < 5; ++x) rate += ((double)mt_lim[e * 5 + x] + 1.0) / 134217728.0;
+        ctx->mt_bounce_rate = rate;
+    }
     int rc = 0;
     auto *tr = &ctx->model_allocs;
 #define UP(field, src, n, T) if ((rc = upload<T>(ctx, src, n, const_cast<T **>(&M.field), tr))) return rc
@@ -586,6 +680,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(ins_any, ins_any.data(), ins_any.size(), uint8_t);
     UP(scan_tab, scan_tab.data(), scan_tab.size(), uint32_t);
     UP(fix_tab, fix_tab.data(), fix_tab.size(), uint32_t);
+    UP(mt_rows, mt_rows.data(), mt_rows.size(), uint16_t);
+    UP(mt_lim, mt_lim.data(), mt_lim.size(), uint32_t);
 #undef UP
     ctx->have_model = true;
     free_outputs(ctx);  // pitch may have changed
@@ -1000,7 +1096,7 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     const int64_t CH = 8192;
     const size_t py_need = iss::mt_py_need(M.RL), np_need = iss::mt_np_need(M.RL);
-    { int rc_ = mt_reserve(ctx, (size_t)(CH + 1) * py_need + 1248, (size_t)(CH + 1) * np_need + 1248); if (rc_) return rc_; }
+    { int rc_ = mt_reserve(ctx, 3 * ((size_t)(CH + 1) * py_need + 1248), 3 * ((size_t)(CH + 1) * np_need + 1248)); if (rc_) return rc_; }
     auto &m = ctx->mt;
     if (!(M.RL < G.L)) {
         // the reference draws the insert size BEFORE its assertion fails (generator.py:121-126, 130)
@@ -1016,15 +1112,91 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     const size_t fixed_lds = iss::mt_walk_fixed_lds_bytes(M.RL);
     const bool use_rows = M.n_tiles == 1 && (size_t)M.tile_words * 4 + fixed_lds <= 150 * 1024;
     const size_t lds_bytes = fixed_lds + (use_rows ? (size_t)M.tile_words * 4 : 0);
+    // Resolver path (k_mt_resolve + k_mt_emit) for plain runs; the sequential walker for custom fragment
+    // lengths, --store_mutations, indel-heavy models, and for the single pairs the resolver hands back.
+    typedef void (*resolve_fn)(iss::DevModel, iss::DevGenome, iss::MtResolveArgs, iss::PairDesc *);
+    resolve_fn resolve = nullptr;
+    size_t resolve_lds = 0;
+    {
+        const char *force = getenv("ISS_MT_PATH");  // "walk": sequential walker only (testing aid)
+        const bool allowed = !(force && !strcmp(force, "walk")) && !m.has_frag && !m.d_mut && ctx->mt_bounce_rate < 0.05 &&
+                             iss::mt_res_need_np(M.RL) <= 2048u && M.n_isize <= 4096;
+        const size_t budget = 160 * 1024 - 256;
+        const uint32_t need = iss::mt_res_need_py(M.RL);
+        struct Cand { int pyv; bool rows; resolve_fn fn; };
+        const Cand cands[4] = {{8, true, iss::k_mt_resolve<8, 2, true>}, {4, true, iss::k_mt_resolve<4, 2, true>},
+                               {8, false, iss::k_mt_resolve<8, 2, false>}, {4, false, iss::k_mt_resolve<4, 2, false>}};
+        for (const Cand &c : cands) {
+            if (!allowed || resolve) break;
+            if (need > (uint32_t)c.pyv * 1024u) continue;
+            const size_t b = iss::mt_res_lds_bytes(M, c.pyv, 2, c.rows);
+            if (b > budget) continue;
+            resolve = c.fn;
+            resolve_lds = b;
+        }
+        if (resolve) {
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)budget));
+            if (!m.d_rec) {
+                void *p = nullptr;
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)CH * sizeof(iss::MtPairRec)));
+                m.d_rec = static_cast<iss::MtPairRec *>(p);
+            }
+        }
+    }
     int64_t done = 0;
     m.mut_n = 0;
-    bool ov_valid = false;
+    bool ov_valid = false, walk_one = false;
     int64_t ov_frag = 0;
     while (done < n_pairs) {
-        const int64_t n = std::min(CH, n_pairs - done);
+        const int64_t n = walk_one ? 1 : std::min(CH, n_pairs - done);
         const size_t want[2] = {std::min(m.cap[0] / 624 * 624 - 624, (size_t)(n + 1) * py_need),
                                 std::min(m.cap[1] / 624 * 624 - 624, (size_t)(n + 1) * np_need)};
         { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
+        MtPrefetch pf;
+        if (!walk_one && done + n < n_pairs) {  // produce the next chunk's words while this chunk runs
+            const int64_t n_next = std::min(CH, n_pairs - done - n);
+            const size_t want_next[2] = {(size_t)(n_next + 1) * py_need, (size_t)(n_next + 1) * np_need};
+            { int rc_ = mt_prefetch_begin(ctx, want, want_next, &pf); if (rc_) return rc_; }
+        }
+        const int64_t row0 = out_first_pair + done;
+        iss::MtWalkResult res{};
+        if (resolve && !walk_one) {
+            iss::MtResolveArgs R{};
+            R.py_base = m.buf[0][m.cur[0]];
+            R.np_base = m.buf[1][m.cur[1]];
+            R.py_off = (uint32_t)m.used[0];
+            R.np_off = (uint32_t)m.used[1];
+            R.py_fill = (uint32_t)m.fill[0];
+            R.np_fill = (uint32_t)m.fill[1];
+            R.py_cap = (uint32_t)m.cap[0];
+            R.np_cap = (uint32_t)m.cap[1];
+            R.n_pairs = n;
+            R.sequence_type = sequence_type;
+            R.gc_bias = gc_bias ? 1 : 0;
+            R.gc_thr = 8106479329266893ull;
+            R.res = m.d_res;
+            R.rec = m.d_rec;
+            hipLaunchKernelGGL(resolve, dim3(1), dim3(iss::RES_THREADS), resolve_lds, ctx->stream, M, dg, R, ctx->desc + row0);
+            HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipGetLastError());
+            if (res.n_done > 0)
+                hipLaunchKernelGGL(iss::k_mt_emit, dim3((unsigned)((2 * res.n_done + 3) / 4)), dim3(256), 0, ctx->stream, M, dg,
+                                   R.py_base, R.np_base, res.n_done, ctx->desc + row0, m.d_rec,
+                                   ctx->out[0] + (size_t)row0 * M.pitch, ctx->out[1] + (size_t)row0 * M.pitch,
+                                   ctx->out[2] + (size_t)row0 * M.pitch, ctx->out[3] + (size_t)row0 * M.pitch);
+            m.used[0] += res.py_used;
+            m.used[1] += res.np_used;
+            { int rc_ = mt_prefetch_commit(ctx, pf); if (rc_) return rc_; }
+            done += res.n_done;
+            m.n_resolved += res.n_done;
+            if (res.pad) { walk_one = true; continue; }  // the next pair is not plain: one turn of the walker
+            if (res.n_done == 0 && res.starved && (size_t)(R.py_fill - R.py_off) >= want[0] &&
+                (size_t)(R.np_fill - R.np_off) >= want[1])
+                return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+            continue;
+        }
         iss::MtWalkArgs A{};
         A.py = m.buf[0][m.cur[0]] + m.used[0];
         A.np = m.buf[1][m.cur[1]] + m.used[1];
@@ -1034,7 +1206,6 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         A.sequence_type = sequence_type;
         A.gc_bias = gc_bias ? 1 : 0;
         A.gc_thr = 8106479329266893ull;
-        const int64_t row0 = out_first_pair + done;
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
         A.res = m.d_res;
         A.use_rows = use_rows ? 1 : 0;
@@ -1050,13 +1221,14 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         A.guard = getenv("ISS_MT_GUARD") ? atof(getenv("ISS_MT_GUARD")) : 1e-6;
         A.gauss = m.d_gauss;
         hipLaunchKernelGGL(iss::k_mt_walk, dim3(1), dim3(64), lds_bytes, ctx->stream, M, dg, A, ctx->desc + row0);
-        iss::MtWalkResult res{};
         HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipGetLastError());
         m.used[0] += res.py_used;
         m.used[1] += res.np_used;
+        { int rc_ = mt_prefetch_commit(ctx, pf); if (rc_) return rc_; }
         done += res.n_done;
+        m.n_walked += res.n_done;
         m.mut_n += res.n_mut;
         ov_valid = false;
         if (res.need_host) {
@@ -1068,6 +1240,7 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         }
         if (res.n_done == 0 && res.starved && A.py_avail >= want[0] && A.np_avail >= want[1])
             return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+        if (res.n_done > 0) walk_one = false;
     }
     if (n_done) *n_done = done;
     return 0;
@@ -1171,6 +1344,13 @@ int iss_mt_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity,
     if (n_total) *n_total = m.mut_n;
     const int64_t n = std::min(std::min(m.mut_n, m.mut_cap), capacity);
     if (n > 0 && out) HIP_TRY(ctx, hipMemcpy(out, m.d_mut, (size_t)n * sizeof(iss::MutRecord), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int iss_mt_path_counts(iss_ctx *ctx, int64_t *n_resolved, int64_t *n_walked) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    if (n_resolved) *n_resolved = ctx->mt.n_resolved;
+    if (n_walked) *n_walked = ctx->mt.n_walked;
     return 0;
 }
 

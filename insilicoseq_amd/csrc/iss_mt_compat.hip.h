@@ -3,8 +3,8 @@
 // DEVICE in the reference's exact order, so that the GPU output equals the reference's output for a
 // given (seed, cpu_number) byte for byte.
 //
-//   k_mt_fill : one workgroup per stream; MT19937 block recurrence in four parallel phases
-//               (k < 227 | 227 <= k < 454 | 454 <= k < 623 | k = 623), tempering, coalesced stores.
+//   k_mt_fill : one workgroup per stream; every word of a 624-word block written in terms of the previous
+//               block (one barrier per block), tempered and stored by its producer.
 //   k_mt_walk : ONE wavefront per worker walks the pairs sequentially (a pair's stream offsets
 //               depend on everything before it: rejection sampling in randrange, one extra numpy
 //               double per substitution event); inside a pair the 64 lanes work across positions.
@@ -13,8 +13,11 @@
 //                 np: bin + RL phred doubles, py: RL substitution-test doubles, np: 1 per event |
 //                 py: reverse-end fallback randrange between the mates | np: gc_bias double.
 //
-// This mode is sequential by construction (~1e5 pairs/s): it exists for bit-identity with the
-// reference, not for throughput; the Philox path (iss_kernels.hip.h) is the performance path.
+//   k_mt_resolve / k_mt_emit : the fast path for plain pairs (see below): only the stream offsets are
+//               chained, by one workgroup working from LDS; the reads are then built in parallel.
+//
+// This mode is chained by construction (~3e5 pairs/s per worker): it exists for bit-identity with the
+// reference; the Philox path (iss_kernels.hip.h) is the performance path.
 #pragma once
 #include "iss_kernels.hip.h"
 
@@ -23,6 +26,10 @@ namespace iss {
 struct MtState {
     uint32_t mt[624];  // state at a block boundary (the next output needs a twist)
 };
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter, i.e. it
+// would wait for the global stores / prefetch loads these kernels deliberately leave in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b) {
     const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
@@ -36,33 +43,50 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// grid = 2 (stream 0: CPython random, stream 1: numpy), block = 256
-__global__ __launch_bounds__(256) void k_mt_fill(MtState *states, uint32_t *out0, uint32_t *out1, uint32_t blocks0,
-                                                 uint32_t blocks1) {
+// grid = 2 (stream 0: CPython random, stream 1: numpy), block = 256.
+// Every word of the next block is written in terms of the OLD block only, so a block costs one barrier:
+// with F(k) = twist(o[k], o[k+1]),
+//   n[k]       = o[k+397] ^ F(k)                               k < 227
+//   n[227 + j] = n[j] ^ F(227 + j) = o[j+397] ^ F(j) ^ F(227 + j)        j < 227
+//   n[454 + j] = n[227 + j] ^ F(454 + j)                                  j < 169
+//   n[623]     = n[396] ^ twist(o[623], n[0])    (lane 169 holds n[396]; n[0] costs it one more twist)
+constexpr int FILL_THREADS = 256;
+__global__ __launch_bounds__(FILL_THREADS) void k_mt_fill(MtState *states, uint32_t *out0, uint32_t *out1, uint32_t blocks0,
+                                                          uint32_t blocks1) {
     __shared__ uint32_t buf[2][624];
     const int s = blockIdx.x;
     uint32_t *out = s ? out1 : out0;
     const uint32_t n_blocks = s ? blocks1 : blocks0;
     const int tid = threadIdx.x;
-    for (int k = tid; k < 624; k += 256) buf[0][k] = states[s].mt[k];
+    for (int k = tid; k < 624; k += FILL_THREADS) buf[0][k] = states[s].mt[k];
     __syncthreads();
     int cur = 0;
     for (uint32_t b = 0; b < n_blocks; ++b) {
         const uint32_t *o = buf[cur];
         uint32_t *n = buf[cur ^ 1];
-        if (tid < 227) n[tid] = o[tid + 397] ^ mt_twist(o[tid], o[tid + 1]);
-        __syncthreads();
-        if (tid < 227) n[227 + tid] = n[tid] ^ mt_twist(o[227 + tid], o[228 + tid]);
-        __syncthreads();
-        if (tid < 169) n[454 + tid] = n[227 + tid] ^ mt_twist(o[454 + tid], o[455 + tid]);
-        __syncthreads();
-        if (tid == 0) n[623] = n[396] ^ mt_twist(o[623], n[0]);
-        __syncthreads();
-        for (int k = tid; k < 624; k += 256) out[(size_t)b * 624 + k] = mt_temper(n[k]);
+        uint32_t *ob = out + (size_t)b * 624;
+        if (tid < 227) {
+            const uint32_t a = o[tid + 397] ^ mt_twist(o[tid], o[tid + 1]);          // n[tid]
+            const uint32_t c = a ^ mt_twist(o[227 + tid], o[228 + tid]);             // n[227 + tid]
+            n[tid] = a;
+            n[227 + tid] = c;
+            ob[tid] = mt_temper(a);
+            ob[227 + tid] = mt_temper(c);
+            if (tid < 169) {
+                const uint32_t e = c ^ mt_twist(o[454 + tid], o[455 + tid]);         // n[454 + tid]
+                n[454 + tid] = e;
+                ob[454 + tid] = mt_temper(e);
+            } else if (tid == 169) {
+                const uint32_t n0 = o[397] ^ mt_twist(o[0], o[1]);
+                const uint32_t e = c ^ mt_twist(o[623], n0);                          // n[623]
+                n[623] = e;
+                ob[623] = mt_temper(e);
+            }
+        }
         cur ^= 1;
-        __syncthreads();
+        lds_barrier();
     }
-    for (int k = tid; k < 624; k += 256) states[s].mt[k] = buf[cur][k];
+    for (int k = tid; k < 624; k += FILL_THREADS) states[s].mt[k] = buf[cur][k];
 }
 
 struct MtWalkResult {
@@ -407,6 +431,359 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
         A.res->host_x2 = host_x2;
         *A.gauss = gs;
     }
+}
+
+// ====================================================================== resolver + emitter
+// The stream offsets are the only thing that chains the pairs of a worker: once a pair's offsets are known
+// the pair itself is ordinary parallel work.  k_mt_resolve walks the pairs computing ONLY the offsets: per
+// mate, one lane per position inverts the quality CDF, runs the substitution test and looks for indel
+// candidates, all from LDS (stream words in two-half rings refilled through registers one half ahead,
+// digit rows, thresholds); one workgroup barrier per mate sums the substitution events, which is all the
+// next mate's offsets need.  It stops (need_generic) at the first pair that is not plain -- an indel
+// candidate, a letter outside ACGT in a template, a randrange that needs a second round of words -- and
+// the host runs k_mt_walk for exactly that pair.  k_mt_emit then builds the reads of the resolved pairs,
+// one wavefront per mate, from the recorded offsets.
+struct MtPairRec {
+    uint32_t opy_err[2];  // py words: first substitution-test double of mate o
+    uint32_t onp_bin[2];  // np words: bin draw of mate o (then RL phred doubles, then the substitution picks)
+};
+
+struct MtResolveArgs {
+    const uint32_t *py_base, *np_base;  // stream buffers (16-byte aligned)
+    uint32_t py_off, np_off;            // consumption point (words from the base)
+    uint32_t py_fill, np_fill;          // valid words
+    uint32_t py_cap, np_cap;            // allocated words
+    int64_t n_pairs;
+    int32_t sequence_type, gc_bias;
+    uint64_t gc_thr;
+    MtWalkResult *res;
+    MtPairRec *rec;
+};
+
+constexpr int RES_THREADS = 256;
+__host__ __device__ inline uint32_t mt_res_need_py(int RL) { return 64u + 10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL; }  // per mate
+__host__ __device__ inline uint32_t mt_res_need_np(int RL) { return 8u + 4u * (uint32_t)RL; }
+__host__ __device__ inline size_t mt_res_lds_bytes(const DevModel &M, int pyv, int npv, bool rows_lds) {
+    size_t b = (size_t)(2 * pyv + 2 * npv) * 1024 * 4 + 2 * 16 * 4;  // rings + their 16-word mirrors
+    b += (size_t)(64 + 8 + M.n_isize) * 8;                           // mut_thr, bin_thr, isize_thr
+    b += (size_t)2 * M.RL * 5 * 4 + 16 * 4;                          // indel limits, scratch
+    if (rows_lds) b += (size_t)2 * M.NB * M.RL * M.mt_row_w * 4;     // digit rows
+    return b;
+}
+
+template <int PYV, int NPV, bool ROWS_LDS>
+__global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenome g, MtResolveArgs A, PairDesc *desc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr uint32_t HPY = PYV * 1024u, WPY = 2u * HPY, HNP = NPV * 1024u, WNP = 2u * HNP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int RL = M.RL, nq = M.n_q;
+    // ring[W .. W + 16) mirrors ring[0 .. 16): a run of <= 16 words starting anywhere needs no wrap-around
+    uint32_t *ring_py = lds;
+    uint32_t *ring_np = ring_py + WPY + 16;
+    uint64_t *mut_thr = reinterpret_cast<uint64_t *>(ring_np + WNP + 16);
+    uint64_t *bin_thr = mut_thr + 64;
+    uint64_t *isz_thr = bin_thr + 8;
+    uint32_t *lim = reinterpret_cast<uint32_t *>(isz_thr + M.n_isize);
+    uint32_t *scratch = lim + 2 * RL * 5;
+    uint16_t *rows_l = reinterpret_cast<uint16_t *>(scratch + 16);
+    const uint32_t row_h = (uint32_t)M.mt_row_w * 2u;  // u16 entries per row
+    for (int i = tid; i <= nq; i += RES_THREADS) mut_thr[i] = M.mut_thr[i];
+    for (int i = tid; i < 8; i += RES_THREADS) bin_thr[i] = M.bin_thr[i];
+    for (int i = tid; i < M.n_isize; i += RES_THREADS) isz_thr[i] = M.isize_thr[i];
+    for (int i = tid; i < 2 * RL * 5; i += RES_THREADS) lim[i] = M.mt_lim[i];
+    if (ROWS_LDS) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(M.mt_rows);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(rows_l);
+        for (int i = tid; i < 2 * M.NB * RL * M.mt_row_w; i += RES_THREADS) dst[i] = src[i];
+    }
+    // ---- stream rings: halves kpy, kpy + 1 are in the ring, half kpy + 2 is on its way in registers
+    uint4 pv[PYV], nv[NPV];
+    auto fetch_py = [&](uint32_t half) {
+#pragma unroll
+        for (int v = 0; v < PYV; ++v) {
+            const uint32_t idx = half * HPY + (uint32_t)v * 1024u + (uint32_t)tid * 4u;
+            pv[v] = idx + 4u <= A.py_cap ? *reinterpret_cast<const uint4 *>(A.py_base + idx) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto fetch_np = [&](uint32_t half) {
+#pragma unroll
+        for (int v = 0; v < NPV; ++v) {
+            const uint32_t idx = half * HNP + (uint32_t)v * 1024u + (uint32_t)tid * 4u;
+            nv[v] = idx + 4u <= A.np_cap ? *reinterpret_cast<const uint4 *>(A.np_base + idx) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_py = [&](uint32_t half) {
+#pragma unroll
+        for (int v = 0; v < PYV; ++v)
+            *reinterpret_cast<uint4 *>(ring_py + (half & 1u) * HPY + (uint32_t)v * 1024u + (uint32_t)tid * 4u) = pv[v];
+        if (!(half & 1u) && tid < 4) *reinterpret_cast<uint4 *>(ring_py + WPY + (uint32_t)tid * 4u) = pv[0];
+    };
+    auto store_np = [&](uint32_t half) {
+#pragma unroll
+        for (int v = 0; v < NPV; ++v)
+            *reinterpret_cast<uint4 *>(ring_np + (half & 1u) * HNP + (uint32_t)v * 1024u + (uint32_t)tid * 4u) = nv[v];
+        if (!(half & 1u) && tid < 4) *reinterpret_cast<uint4 *>(ring_np + WNP + (uint32_t)tid * 4u) = nv[0];
+    };
+    uint32_t opy = A.py_off, onp = A.np_off;
+    uint32_t kpy = opy / HPY, knp = onp / HNP;
+    fetch_py(kpy); store_py(kpy);
+    fetch_py(kpy + 1); store_py(kpy + 1);
+    fetch_np(knp); store_np(knp);
+    fetch_np(knp + 1); store_np(knp + 1);
+    fetch_py(kpy + 2);
+    fetch_np(knp + 2);
+    __syncthreads();
+    auto pyr = [&](uint32_t x) { return ring_py[x & (WPY - 1u)]; };
+    auto npr = [&](uint32_t x) { return ring_np[x & (WNP - 1u)]; };
+    const uint32_t py_need = mt_py_need(RL), np_need = mt_np_need(RL);
+    const int64_t L = g.L;
+    uint32_t sl = 0;  // scratch slot (alternates per barrier)
+    int64_t i = 0;
+    int starved = 0, need_generic = 0;
+
+    uint32_t slots = 0;  // bin -> slot, 2 bits each, [o][bin]
+    for (int k = 0; k < 8; ++k) slots |= ((uint32_t)M.bin_slot[k] & 3u) << (2 * k);
+    const bool spare_wave = RL <= RES_THREADS - 64;  // the last wavefront has no position: it checks the indel draws
+
+    // one mate on the fast path: returns substitution events, sets hit when the mate is not plain
+    auto mate_fast = [&](int o, uint32_t opy_m, uint32_t onp_m, int &slot_out, bool &hit_out) -> uint32_t {
+        const uint64_t mb = mk53(npr(onp_m), npr(onp_m + 1));
+        const uint64_t *bt = bin_thr + 4 * o;  // np.random.choice: #(cdf <= u), kde.py:74
+        int bin = (bt[0] <= mb ? 1 : 0) + (bt[1] <= mb ? 1 : 0) + (bt[2] <= mb ? 1 : 0) + (bt[3] <= mb ? 1 : 0);
+        bin = bin > 3 ? 3 : bin;
+        const int slot = (int)((slots >> (2 * (o * 4 + bin))) & 3u);
+        slot_out = slot;
+        const uint32_t opy_err = opy_m + 10u * (uint32_t)(RL - 1);
+        uint32_t nev = 0;
+        bool cand = false;
+        auto indel_step = [&](int p) {
+            const uint32_t *lm = lim + ((size_t)o * RL + p) * 5;
+            const uint32_t *w = ring_py + ((opy_m + 10u * (uint32_t)p) & (WPY - 1u));
+#pragma unroll
+            for (int x = 0; x < 5; ++x) cand |= (w[2 * x] >> 5) <= lm[x];
+        };
+        if (spare_wave && wave == RES_THREADS / 64 - 1)
+            for (int p = lane; p < RL - 1; p += 64) indel_step(p);
+        for (int p = tid; p < RL; p += RES_THREADS) {
+            const uint32_t *wq = ring_np + ((onp_m + 2u + 2u * (uint32_t)p) & (WNP - 1u));
+            const uint32_t *we = ring_py + ((opy_err + 2u * (uint32_t)p) & (WPY - 1u));
+            const uint64_t mq = mk53(wq[0], wq[1]);
+            const uint64_t me = mk53(we[0], we[1]);
+            const uint32_t h = (uint32_t)(mq >> 37);
+            const size_t roff = ((size_t)(o * M.NB + slot) * RL + p) * row_h;
+            const uint16_t *row = ROWS_LDS ? rows_l + roff : M.mt_rows + roff;
+            int q;
+            bool tie = false;
+            if (nq == 41) {  // every shipped model: keys at fixed offsets, no clamping
+                const uint32_t d0 = row[6], d1 = row[13], d2 = row[20], d3 = row[27], d4 = row[34];
+                const int c1 = (d0 < h) + (d1 < h) + (d2 < h) + (d3 < h) + (d4 < h);
+                tie = d0 == h || d1 == h || d2 == h || d3 == h || d4 == h;
+                const uint16_t *seg = row + 7 * c1;
+                q = 7 * c1;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const uint32_t dgt = seg[j];
+                    q += dgt < h ? 1 : 0;
+                    tie |= dgt == h;
+                }
+            } else {
+                int c1 = 0;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {  // keys 6, 13, ... (n_q <= 63); indices past n_q read the 0xffff padding
+                    const int k = min(6 + 7 * j, nq);
+                    const uint32_t dgt = row[k];
+                    c1 += dgt < h ? 1 : 0;
+                    tie |= dgt == h;
+                }
+                q = 7 * c1;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int k = min(7 * c1 + j, nq);
+                    const uint32_t dgt = row[k];
+                    q += dgt < h ? 1 : 0;
+                    tie |= dgt == h;
+                }
+            }
+            if (tie) {  // thresholds sharing the leading digit: compare in full, from the first of them on
+                const uint64_t *full = M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * nq;
+                while (q < nq && full[q] < mq) ++q;
+            }
+            const bool err = me > mut_thr[q];
+            nev += (uint32_t)__popcll(__ballot(err));
+            if (!spare_wave && p < RL - 1) indel_step(p);
+        }
+        const bool hit = __ballot(cand) != 0ull;
+        if (lane == 0) scratch[sl * 8 + wave] = nev | (hit ? 0x80000000u : 0u);
+        lds_barrier();
+        uint32_t tot = 0, any_hit = 0;
+#pragma unroll
+        for (int w = 0; w < RES_THREADS / 64; ++w) {
+            const uint32_t v = scratch[sl * 8 + w];
+            tot += v & 0xffffu;
+            any_hit |= v >> 31;
+        }
+        sl ^= 1u;  // the next barrier uses the other slot (a fast wave may write before a slow one has read)
+        hit_out = any_hit != 0u;
+        return tot;
+    };
+    while (i < A.n_pairs) {
+        if (opy + py_need > A.py_fill || onp + np_need > A.np_fill) { starved = 1; break; }
+        const uint32_t opy0 = opy, onp0 = onp;
+        if (opy >= (kpy + 1) * HPY) { store_py(kpy + 2); ++kpy; lds_barrier(); fetch_py(kpy + 2); }
+        if (onp >= (knp + 1) * HNP) { store_np(knp + 2); ++knp; lds_barrier(); fetch_np(knp + 2); }
+        // ---- insert size: np.searchsorted(cdf, np.random.rand())  (kde.py:97), two-level count in LDS
+        int64_t isz;
+        {
+            const uint64_t m = mk53(npr(onp), npr(onp + 1));
+            onp += 2;
+            const int n = M.n_isize, S = (n + 63) / 64;
+            const int js = min((lane + 1) * S - 1, n - 1);
+            const int b = __popcll(__ballot(isz_thr[js] < m));
+            int cnt = n;
+            if (b < 64) {
+                int c2 = 0;
+                for (int r = 0; r < S; r += 64) {
+                    const int idx = b * S + r + lane;
+                    c2 += __popcll(__ballot(r + lane < S && idx < n && isz_thr[idx] < m));
+                }
+                cnt = b * S + c2;
+            }
+            isz = cnt;
+        }
+        const int64_t frag = isz + 2 * (int64_t)RL;
+        int64_t fs = 0;
+        bool odd = false;  // this pair goes to the sequential walker
+        auto randbelow1 = [&](uint32_t n) -> uint32_t {  // one round of 64 candidate words
+            const int k = 32 - __clz(n);
+            const uint32_t r = pyr(opy + (uint32_t)lane) >> (32 - k);
+            const unsigned long long ok = __ballot(r < n);
+            if (!ok) { odd = true; return 0u; }
+            const int t = __ffsll(ok) - 1;
+            opy += (uint32_t)t + 1u;
+            return (uint32_t)__shfl((int)r, t);
+        };
+        if (A.sequence_type == 0) {  // generator.py:134-135, 142-144
+            const int64_t width = L - frag;
+            fs = randbelow1((uint32_t)(width > 0 ? width : L - RL));
+        }
+        const int64_t fe = fs + RL;
+        auto exceptions_in = [&](int64_t lo, int64_t hi) -> bool {  // any letter outside ACGT in [lo, hi)
+            if (!g.has_exceptions) return false;
+            const int64_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+            bool any = false;
+            for (int64_t w = w0 + lane; w <= w1; w += 64) {
+                uint32_t bits = g.mask[w];
+                if (w == w0) bits &= 0xffffffffu << (lo & 31);
+                if (w == w1) bits &= 0xffffffffu >> (31 - ((hi - 1) & 31));
+                any |= bits != 0u;
+            }
+            return __ballot(any) != 0ull;
+        };
+        PairDesc d;
+        d.fs = (int32_t)fs;
+        d.isz = (int32_t)isz;
+        d.meta = 0;
+        MtPairRec rc;
+        int64_t re = 0;
+        if (!odd) odd = exceptions_in(fs, fe);
+        if (!odd) {
+            int slot;
+            bool hit;
+            const uint32_t nev = mate_fast(0, opy, onp, slot, hit);
+            odd = hit;
+            d.meta |= (uint32_t)slot;
+            rc.opy_err[0] = opy + 10u * (uint32_t)(RL - 1);
+            rc.onp_bin[0] = onp;
+            opy += 10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL;
+            onp += 2u + 2u * (uint32_t)RL + 2u * nev;
+        }
+        if (!odd) {
+            if (opy >= (kpy + 1) * HPY) { store_py(kpy + 2); ++kpy; lds_barrier(); fetch_py(kpy + 2); }
+            if (onp >= (knp + 1) * HNP) { store_np(knp + 2); ++knp; lds_barrier(); fetch_np(knp + 2); }
+            int64_t rs;
+            if (A.sequence_type == 0) { rs = fe + isz; re = rs + RL; }  // generator.py:164-177
+            else { rs = L - RL; re = L; }
+            if (re > L) { re = RL + (int64_t)randbelow1((uint32_t)(L - RL)); rs = re - RL; }
+            if (!odd) odd = exceptions_in(rs, re);
+        }
+        if (!odd) {
+            int slot;
+            bool hit;
+            const uint32_t nev = mate_fast(1, opy, onp, slot, hit);
+            odd = hit;
+            d.meta |= (uint32_t)slot << 2;
+            rc.opy_err[1] = opy + 10u * (uint32_t)(RL - 1);
+            rc.onp_bin[1] = onp;
+            opy += 10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL;
+            onp += 2u + 2u * (uint32_t)RL + 2u * nev;
+        }
+        if (odd) { opy = opy0; onp = onp0; need_generic = 1; break; }
+        d.re = (int32_t)re;
+        bool keep = true;
+        if (A.gc_bias) {  // generator.py:82-92
+            keep = mk53(npr(onp), npr(onp + 1)) < A.gc_thr;
+            onp += 2;
+        }
+        if (keep) {
+            if (tid == 0) { desc[i] = d; A.rec[i] = rc; }
+            ++i;
+        }
+    }
+    if (tid == 0) {
+        A.res->py_used = opy - A.py_off;
+        A.res->np_used = onp - A.np_off;
+        A.res->n_done = i;
+        A.res->starved = starved;
+        A.res->pad = need_generic;
+        A.res->n_mut = 0;
+        A.res->need_host = 0;
+        A.res->host_cached = 0;
+    }
+}
+
+// reads of the pairs k_mt_resolve resolved: one wavefront per (pair, mate); the read is the template
+// (no indel, only ACGT), phred scores and substitutions come from the recorded stream offsets
+__global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const uint32_t *py, const uint32_t *np,
+                                                 int64_t n_pairs, const PairDesc *desc, const MtPairRec *rec, uint8_t *out0,
+                                                 uint8_t *out1, uint8_t *out2, uint8_t *out3) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= 2 * n_pairs) return;
+    const int64_t i = item >> 1;
+    const int o = (int)(item & 1);
+    const int RL = M.RL;
+    const PairDesc d = desc[i];
+    const MtPairRec r = rec[i];
+    const uint32_t onp_q = r.onp_bin[o] + 2u, onp_s = onp_q + 2u * (uint32_t)RL, opy_e = r.opy_err[o];
+    int bin = count_le(M.bin_thr + 4 * o, 4, mk53(np[r.onp_bin[o]], np[r.onp_bin[o] + 1]));
+    bin = bin > 3 ? 3 : bin;
+    uint8_t *ob = (o ? out2 : out0) + (size_t)i * M.pitch;
+    uint8_t *oq = (o ? out3 : out1) + (size_t)i * M.pitch;
+    uint32_t nev = 0;
+    for (int p0 = 0; p0 < RL; p0 += 64) {
+        const int p = p0 + lane;
+        bool err = false;
+        int ch = 0, q = 0, bi = -1;
+        if (p < RL) {
+            ch = o == 0 ? fetch_ascii(g, (int64_t)d.fs + p) : complement_ascii(fetch_ascii(g, (int64_t)d.re - 1 - p));
+            const uint64_t mq = mk53(np[onp_q + 2u * (uint32_t)p], np[onp_q + 2u * (uint32_t)p + 1u]);
+            q = count_lt(M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * M.n_q, M.n_q, mq);
+            bi = base_index(ch);
+            const uint64_t m = mk53(py[opy_e + 2u * (uint32_t)p], py[opy_e + 2u * (uint32_t)p + 1u]);
+            err = m > M.mut_thr[q] && bi >= 0;
+        }
+        const unsigned long long evm = __ballot(err);
+        if (err) {
+            const uint32_t rank = nev + (uint32_t)__popcll(evm & ((1ull << lane) - 1ull));
+            const uint64_t ms = mk53(np[onp_s + 2u * rank], np[onp_s + 2u * rank + 1u]);
+            const size_t row = ((size_t)(o * RL + p) * 4 + bi) * 3;
+            const int k = (ms >= M.subst_thr[row]) + (ms >= M.subst_thr[row + 1]);
+            ch = M.subst_alt[row + k];
+        }
+        nev += (uint32_t)__popcll(evm);
+        if (p < RL) { ob[p] = (uint8_t)ch; oq[p] = (uint8_t)q; }
+    }
+    for (int p = RL + lane; p < M.pitch; p += 64) { ob[p] = 0; oq[p] = 0; }
 }
 
 }  // namespace iss

@@ -174,6 +174,12 @@ class ReadEngine(object):
         self._check(self._lib.iss_mt_peek(self._ctx, a.ctypes.data, b.ctypes.data, int(n)))
         return a, b
 
+    def mt_path_counts(self):
+        """(pairs resolved in parallel, pairs walked sequentially) by generate_mt so far."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.iss_mt_path_counts(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def synchronize(self):
         self._check(self._lib.iss_synchronize(self._ctx))
 

@@ -117,6 +117,78 @@ def test_mt_mode_large_equals_oracle(engine):
     assert list(_res53(npw)) == [rng.np_random() for _ in range(4)]
 
 
+def _sparse_exception_genome(seed, n):
+    """Mostly plain ACGT with a few N runs and lower-case stretches: most pairs resolve, some are walked."""
+    from helpers import random_genome
+
+    g = bytearray(random_genome(seed, n).encode())
+    rng = np.random.RandomState(seed + 1)
+    for start in rng.randint(0, n - 200, size=12):
+        g[start:start + 40] = b"N" * 40
+    for start in rng.randint(0, n - 200, size=12):
+        g[start:start + 60] = bytes(g[start:start + 60]).lower()
+    return g.decode()
+
+
+RESOLVER_CASES = {
+    "novaseq": dict(model="novaseq", L=300000, n=30000),
+    "hiseq": dict(model="hiseq", L=250000, n=12000),
+    "miseq": dict(model="miseq", L=250000, n=9000),          # digit rows too large for the LDS: read from memory
+    "miseq-36": dict(model="miseq-36", L=250000, n=9000),    # 2000-entry insert-size CDF, a single quality bin
+    "novaseq_gc": dict(model="novaseq", L=300000, n=12000, gc_bias=True),
+    "novaseq_amplicon": dict(model="novaseq", L=5000, n=6000, sequence_type="amplicon"),
+    "novaseq_short": dict(model="novaseq", L=400, n=6000),   # width <= 0 and reverse-end fallback randrange
+    "novaseq_exceptions": dict(model="novaseq", L=200000, n=20000, exceptions=True),
+    "miseq_legacy_indels": dict(model="miseq-legacy", L=200000, n=3000),  # indel candidates everywhere: walker only
+}
+
+
+@pytest.mark.parametrize("case", sorted(RESOLVER_CASES))
+def test_resolver_equals_walker(engine, monkeypatch, case):
+    """iss_generate_mt has two device paths (offset resolver + parallel emitter; sequential walker).  The walker
+    is pinned to the reference by the goldens above; here both paths must agree byte for byte, stream
+    positions included, and the resolver must really have been the one running."""
+    from helpers import random_genome
+
+    c = RESOLVER_CASES[case]
+    dense = dense_model(c["model"])
+    genome = _sparse_exception_genome(7, c["L"]) if c.get("exceptions") else random_genome(7, c["L"])
+    kw = dict(sequence_type=c.get("sequence_type", "metagenomics"), gc_bias=c.get("gc_bias", False))
+    n = c["n"]
+    outs = {}
+    for path in ("walk", "resolve"):
+        if path == "walk":
+            monkeypatch.setenv("ISS_MT_PATH", "walk")
+        else:
+            monkeypatch.delenv("ISS_MT_PATH", raising=False)
+        engine.load_model(dense)
+        engine.clear_genomes()
+        gid = engine.add_genome(genome)
+        engine.seed_mt(77)
+        engine.reserve(n + 500)
+        r0, w0 = engine.mt_path_counts()
+        assert engine.generate_mt(gid, n, **kw) == n
+        # a second work item on the same streams (offsets that do not start at a buffer boundary)
+        assert engine.generate_mt(gid, 500, out_first_pair=n, **kw) == 500
+        r1, w1 = engine.mt_path_counts()
+        got = engine.download(0, n + 500)
+        coords = engine.coords(0, n + 500)
+        outs[path] = (got, coords, engine.mt_peek(16), (r1 - r0, w1 - w0))
+    (ga, ca, pa, cnt_walk), (gb, cb, pb, cnt_res) = outs["walk"], outs["resolve"]
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        bad = np.argwhere(ga[k] != gb[k])
+        assert bad.size == 0, "%s differs at %s (%d cells)" % (k, bad[:5].tolist(), len(bad))
+    assert np.array_equal(np.asarray(ca), np.asarray(cb))
+    assert (pa[0] == pb[0]).all() and (pa[1] == pb[1]).all()
+    assert cnt_walk == (0, n + 500)
+    if case == "miseq_legacy_indels":
+        assert cnt_res == (0, n + 500)
+    elif case == "novaseq_exceptions":
+        assert cnt_res[0] > 0.5 * n and cnt_res[1] > 50 and sum(cnt_res) == n + 500
+    else:
+        assert cnt_res[0] > 0.95 * n and sum(cnt_res) == n + 500
+
+
 def test_config1_scale_short_genomes_miseq(engine):
     """BASELINE configs[1] flavour: data/genomes.fasta (records shorter than the MiSeq fragment: fallback
     branches everywhere), --model miseq, seed-fixed, GPU (MT mode) vs CPU (oracle with the reference's MT
