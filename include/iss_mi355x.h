@@ -182,6 +182,20 @@ int iss_mt_mutations_reserve(iss_ctx *ctx, int64_t capacity);
 int iss_mt_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, int64_t *n_total);
 
 /*
+ * FASTQ text built ON THE DEVICE (the host formatter below tops out near 3 GB/s of text, four hundred times
+ * under the kernel's rate): rows [first_pair, +n_pairs) of the output buffers become the records of
+ * simulate_reads' SeqIO.write calls (iss/generator.py:64-65, ids per :150, 181, i from first_i) -- one wavefront
+ * per record, byte offsets in closed form -- and are appended to fd_r1 / fd_r2 at their current positions.
+ * Asynchronous: the format kernel runs on the context's stream behind the generation it reads, the copy to
+ * pinned host memory on a copy stream, the file writes (pwrite, n_threads pieces per file) on a writer thread,
+ * so the next batch can be generated meanwhile (two text slots).  iss_fastq_flush waits until every queued
+ * byte is in the files and leaves the descriptors positioned at the end; call it before using the files.
+ */
+int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, int64_t first_i, int32_t cpu_number,
+                   int64_t first_pair, int64_t n_pairs, int32_t n_threads);
+int iss_fastq_flush(iss_ctx *ctx);
+
+/*
  * FASTQ emission, replaces SeqIO.write(record, handle, "fastq-sanger") in
  * simulate_reads (iss/generator.py:64-65): records "@{record_id}_{i}_{cpu_number}/{1|2}\n
  * SEQ\n+\nQUAL\n" with QUAL = chr(33+q), ids per iss/generator.py:150, 181; i runs from

@@ -12,10 +12,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include "iss_fastq.hip.h"
 #include "iss_kernels.hip.h"
 #include "iss_mt_compat.hip.h"
 
@@ -44,6 +49,37 @@ struct PendingIndel {  // indel-stream work still in flight on output rows [row0
 };
 
 constexpr int FIX_SLOTS = 16;  // ring of fix-list counters (one per chunk in flight on the indel stream)
+
+// Device-formatted FASTQ on its way to the files: two slots of (device text, pinned host text) per mate; the
+// format kernel runs on the context's stream, the copy back on a copy stream, the file writes on a writer thread.
+struct FastqJob {
+    int slot;
+    size_t bytes;
+    int fd[2];
+    int64_t off[2];
+    int threads;
+};
+struct FastqPipe {
+    bool ready = false;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_fmt[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
+    uint8_t *d_text[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [slot][mate]
+    uint8_t *h_text[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    char *d_id = nullptr;  // [2][ID_MAX]
+    std::string id_keep[2];
+    size_t cap = 0;
+    int next = 0;
+    int fd[2] = {-1, -1};
+    int64_t off[2] = {0, 0};
+    std::thread writer;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<FastqJob> jobs;
+    bool busy[2] = {false, false};
+    bool stop = false;
+    std::string error;
+};
+constexpr size_t FASTQ_ID_MAX = 4096;
 
 }  // namespace
 
@@ -106,6 +142,7 @@ struct iss_ctx {
         iss::MtPairRec *d_rec = nullptr;  // k_mt_resolve -> k_mt_emit: stream offsets of one launch's pairs
         int64_t n_resolved = 0, n_walked = 0;  // pairs by path (statistics, iss_mt_path_counts)
     } mt;
+    FastqPipe fq;
     // timing
     bool timing = false;
     std::vector<TimedLaunch> timed;
@@ -327,6 +364,110 @@ int sync_all(iss_ctx *ctx) {
     return 0;
 }
 
+int pwrite_all(int fd, const uint8_t *p, size_t n, int64_t off) {
+    while (n) {
+        const ssize_t k = pwrite(fd, p, n, (off_t)off);
+        if (k < 0) { if (errno == EINTR) continue; return -1; }
+        p += k; n -= (size_t)k; off += k;
+    }
+    return 0;
+}
+
+void fastq_writer_loop(iss_ctx *ctx) {
+    FastqPipe &q = ctx->fq;
+    (void)hipSetDevice(ctx->device);
+    for (;;) {
+        FastqJob job;
+        {
+            std::unique_lock<std::mutex> lk(q.mu);
+            q.cv.wait(lk, [&] { return q.stop || !q.jobs.empty(); });
+            if (q.jobs.empty()) return;
+            job = q.jobs.front();
+        }
+        std::string err;
+        const bool dbg = getenv("ISS_FASTQ_DEBUG") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (hipEventSynchronize(q.ev_copy[job.slot]) != hipSuccess) err = "device copy of the FASTQ text failed";
+        const auto t1 = std::chrono::steady_clock::now();
+        if (err.empty()) {
+            // both files in parallel, each cut into pieces written with pwrite at their final offsets
+            const size_t piece = std::max<size_t>((job.bytes + (size_t)job.threads - 1) / (size_t)job.threads, 1 << 20);
+            std::vector<std::thread> th;
+            std::vector<int> rc;
+            for (int mate = 0; mate < 2; ++mate)
+                for (size_t at = 0; at < job.bytes; at += piece) rc.push_back(0);
+            size_t k = 0;
+            for (int mate = 0; mate < 2; ++mate)
+                for (size_t at = 0; at < job.bytes; at += piece, ++k) {
+                    const size_t n = std::min(piece, job.bytes - at);
+                    const uint8_t *src = q.h_text[job.slot][mate] + at;
+                    int *r = &rc[k];
+                    const int fd = job.fd[mate];
+                    const int64_t off = job.off[mate] + (int64_t)at;
+                    th.emplace_back([=] { *r = pwrite_all(fd, src, n, off) ? errno : 0; });
+                }
+            for (auto &t : th) t.join();
+            for (int r : rc) if (r) err = std::string("write failed: ") + strerror(r);
+        }
+        if (dbg) {
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[fastq] slot %d: %.1f MB per file, waited %.1f ms for the copy, wrote in %.1f ms (%d pieces per file)\n",
+                    job.slot, job.bytes / 1e6, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t1).count(), job.threads);
+        }
+        {
+            std::lock_guard<std::mutex> lk(q.mu);
+            q.jobs.pop_front();
+            q.busy[job.slot] = false;
+            if (!err.empty() && q.error.empty()) q.error = err;
+        }
+        q.cv.notify_all();
+    }
+}
+
+// all queued text is in the files; the descriptors stand at the end of what was written
+int fastq_flush(iss_ctx *ctx) {
+    FastqPipe &q = ctx->fq;
+    if (!q.ready) return 0;
+    std::string err;
+    {
+        std::unique_lock<std::mutex> lk(q.mu);
+        q.cv.wait(lk, [&] { return q.jobs.empty(); });
+        err = q.error;
+        q.error.clear();
+    }
+    for (int m = 0; m < 2; ++m)
+        if (q.fd[m] >= 0) (void)lseek(q.fd[m], (off_t)q.off[m], SEEK_SET);
+    q.fd[0] = q.fd[1] = -1;
+    if (!err.empty()) return fail(ctx, ISS_E_IO, err);
+    return 0;
+}
+
+void fastq_free_buffers(iss_ctx *ctx) {
+    FastqPipe &q = ctx->fq;
+    for (auto &sl : q.d_text) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto &sl : q.h_text) for (auto &p : sl) { if (p) (void)hipHostFree(p); p = nullptr; }
+    q.cap = 0;
+}
+
+void fastq_shutdown(iss_ctx *ctx) {
+    FastqPipe &q = ctx->fq;
+    if (!q.ready) return;
+    (void)fastq_flush(ctx);
+    {
+        std::lock_guard<std::mutex> lk(q.mu);
+        q.stop = true;
+    }
+    q.cv.notify_all();
+    if (q.writer.joinable()) q.writer.join();
+    fastq_free_buffers(ctx);
+    if (q.d_id) (void)hipFree(q.d_id);
+    for (auto &e : q.ev_fmt) if (e) (void)hipEventDestroy(e);
+    for (auto &e : q.ev_copy) if (e) (void)hipEventDestroy(e);
+    if (q.copy_stream) (void)hipStreamDestroy(q.copy_stream);
+    q.ready = false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -380,6 +521,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
 void iss_ctx_destroy(iss_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    fastq_shutdown(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->indel_stream) (void)hipStreamSynchronize(ctx->indel_stream);
     for (auto &pi : ctx->pending) (void)hipEventDestroy(pi.done);
@@ -746,6 +888,7 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     if (capacity_pairs < 1) return fail(ctx, ISS_E_INVALID, "capacity must be >= 1");
     if (capacity_pairs <= ctx->capacity) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     free_outputs(ctx);
     const size_t row = (size_t)ctx->M.pitch;
@@ -1368,6 +1511,99 @@ int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n)
 }
 
 // ------------------------------------------------------------------ FASTQ formatting (host)
+int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, int64_t first_i, int32_t cpu_number,
+                   int64_t first_pair, int64_t n_pairs, int32_t n_threads) {
+    if (!ctx || !ctx->have_model || !record_id || first_i < 0 || cpu_number < 0 || first_pair < 0 || n_pairs < 0 ||
+        first_pair + n_pairs > ctx->capacity || fd_r1 < 0 || fd_r2 < 0)
+        return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: bad argument");
+    const size_t idlen = strlen(record_id);
+    if (idlen > FASTQ_ID_MAX) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: record id longer than 4096 bytes");
+    if (n_pairs == 0) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FastqPipe &q = ctx->fq;
+    const iss::DevModel &M = ctx->M;
+    if (!q.ready) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&q.copy_stream, hipStreamNonBlocking));
+        for (auto &e : q.ev_fmt) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : q.ev_copy) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, 2 * FASTQ_ID_MAX));
+        q.d_id = static_cast<char *>(p);
+        q.stop = false;
+        q.writer = std::thread(fastq_writer_loop, ctx);
+        q.ready = true;
+    }
+    if (ctx->overlap) { int rc_ = sync_all(ctx); if (rc_) return rc_; }  // fix-ups may still run on the indel stream
+    iss::FastqArgs A{};
+    A.cpu_len = (int32_t)snprintf(A.cpu, sizeof A.cpu, "%d", cpu_number);
+    A.id_len = (int32_t)idlen;
+    A.pitch = M.pitch;
+    A.RL = M.RL;
+    A.n_pairs = n_pairs;
+    A.first_i = (uint64_t)first_i;
+    A.before_first = iss::digits_before(A.first_i);
+    const size_t C = idlen + (size_t)A.cpu_len + 2 * (size_t)M.RL + 10;
+    const size_t bytes = (size_t)n_pairs * C + (size_t)(iss::digits_before(A.first_i + (uint64_t)n_pairs) - A.before_first);
+    if (q.fd[0] != fd_r1 || q.fd[1] != fd_r2) {
+        { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
+        q.fd[0] = fd_r1; q.fd[1] = fd_r2;
+        for (int m = 0; m < 2; ++m) {
+            const off_t at = lseek(q.fd[m], 0, SEEK_CUR);
+            if (at < 0) return fail(ctx, ISS_E_IO, std::string("lseek failed: ") + strerror(errno));
+            q.off[m] = at;
+        }
+    }
+    if (bytes > q.cap) {
+        const int fd_keep[2] = {q.fd[0], q.fd[1]};
+        const int64_t off_keep[2] = {q.off[0], q.off[1]};
+        { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
+        q.fd[0] = fd_keep[0]; q.fd[1] = fd_keep[1]; q.off[0] = off_keep[0]; q.off[1] = off_keep[1];
+        fastq_free_buffers(ctx);
+        for (auto &sl : q.d_text) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipMalloc(&v, bytes)); p = static_cast<uint8_t *>(v); }
+        for (auto &sl : q.h_text) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipHostMalloc(&v, bytes, hipHostMallocDefault)); p = static_cast<uint8_t *>(v); }
+        q.cap = bytes;
+    }
+    const int slot = q.next;
+    {
+        std::unique_lock<std::mutex> lk(q.mu);
+        q.cv.wait(lk, [&] { return !q.busy[slot]; });
+        if (!q.error.empty()) { const std::string e = q.error; q.error.clear(); return fail(ctx, ISS_E_IO, e); }
+    }
+    q.id_keep[slot].assign(record_id, idlen);
+    char *d_id = q.d_id + (size_t)slot * FASTQ_ID_MAX;
+    if (idlen) HIP_TRY(ctx, hipMemcpyAsync(d_id, q.id_keep[slot].data(), idlen, hipMemcpyHostToDevice, ctx->stream));
+    A.id = d_id;
+    for (int m = 0; m < 2; ++m) {
+        A.base[m] = ctx->out[2 * m] + (size_t)first_pair * M.pitch;
+        A.qual[m] = ctx->out[2 * m + 1] + (size_t)first_pair * M.pitch;
+        A.text[m] = q.d_text[slot][m];
+    }
+    hipLaunchKernelGGL(iss::k_fastq_format, dim3((unsigned)((n_pairs + iss::FASTQ_WAVES - 1) / iss::FASTQ_WAVES), 2),
+                       dim3(64 * iss::FASTQ_WAVES), 0, ctx->stream, A);
+    HIP_TRY(ctx, hipEventRecord(q.ev_fmt[slot], ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(q.copy_stream, q.ev_fmt[slot], 0));
+    for (int m = 0; m < 2; ++m)
+        HIP_TRY(ctx, hipMemcpyAsync(q.h_text[slot][m], q.d_text[slot][m], bytes, hipMemcpyDeviceToHost, q.copy_stream));
+    HIP_TRY(ctx, hipEventRecord(q.ev_copy[slot], q.copy_stream));
+    {
+        std::lock_guard<std::mutex> lk(q.mu);
+        if (const char *e = getenv("ISS_FASTQ_PIECES")) n_threads = atoi(e);  // tuning aid
+        FastqJob job{slot, bytes, {q.fd[0], q.fd[1]}, {q.off[0], q.off[1]}, std::max(1, std::min<int>(n_threads, 128))};
+        q.jobs.push_back(job);
+        q.busy[slot] = true;
+    }
+    q.cv.notify_all();
+    q.off[0] += (int64_t)bytes;
+    q.off[1] += (int64_t)bytes;
+    q.next ^= 1;
+    return 0;
+}
+
+int iss_fastq_flush(iss_ctx *ctx) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    return fastq_flush(ctx);
+}
+
 static int write_all(int fd, const char *p, size_t n) {
     while (n) {
         ssize_t w = write(fd, p, n);

@@ -174,6 +174,15 @@ class ReadEngine(object):
         self._check(self._lib.iss_mt_peek(self._ctx, a.ctypes.data, b.ctypes.data, int(n)))
         return a, b
 
+    def fastq_emit(self, fd_r1, fd_r2, record_id, first_i, cpu_number, first_pair, n_pairs, n_threads=1):
+        """Format rows [first_pair, +n_pairs) as FASTQ on the device and append them to the two file
+        descriptors (asynchronous; ``fastq_flush`` before the files are used)."""
+        self._check(self._lib.iss_fastq_emit(self._ctx, int(fd_r1), int(fd_r2), str(record_id).encode(), int(first_i),
+                                             int(cpu_number), int(first_pair), int(n_pairs), int(n_threads)))
+
+    def fastq_flush(self):
+        self._check(self._lib.iss_fastq_flush(self._ctx))
+
     def mt_path_counts(self):
         """(pairs resolved in parallel, pairs walked sequentially) by generate_mt so far."""
         a, b = C.c_int64(0), C.c_int64(0)

@@ -158,6 +158,7 @@ class Worker(object):
         self.dense = _dense_of(error_model)
         self.engine.load_model(self.dense)
         self.store_mutations = False
+        self.device_fastq = os.environ.get("ISS_HOST_FASTQ", "") != "1"  # ISS_HOST_FASTQ=1: host formatter (iss_fastq_write)
         if rng == "mt":
             # random.seed(seed + cpu_number); np.random.seed(seed + cpu_number)  (generator.py:234-236);
             # unseeded workers draw an OS-entropy seed (the reference is then not reproducible either)
@@ -180,7 +181,7 @@ class Worker(object):
         return self._gids[key]
 
     def simulate_reads(self, record, n_pairs, forward_handle, reverse_handle, mutations_handle, sequence_type,
-                       gc_bias=False, writer_threads=4):
+                       gc_bias=False, writer_threads=4, flush=True):
         """iss/generator.py:21-66 for one work item, streamed in batches: generate on the GPU, copy
         back, format FASTQ on host threads."""
         logger = logging.getLogger(__name__)
@@ -213,12 +214,20 @@ class Worker(object):
                              gc_bias=gc_bias, out_first_pair=0)
                 if self.store_mutations:
                     write_mutations(eng.mutations(), mutations_handle, record.id, done, self.cpu_number)
-            eng.synchronize()
-            rows = eng.download(0, n)["_pitched"]
-            fastq_write(forward_handle.fileno(), reverse_handle.fileno(), record.id, done, self.cpu_number, n,
-                        eng.read_length, eng.pitch, rows[0], rows[1], rows[2], rows[3], n_threads=writer_threads)
+            if self.device_fastq:
+                # text built on the device, copied and written behind the next batch's generation
+                # (one pwrite stream per file: tmpfs gets slower with concurrent writers to one file)
+                eng.fastq_emit(forward_handle.fileno(), reverse_handle.fileno(), record.id, done, self.cpu_number, 0, n,
+                               n_threads=1)
+            else:
+                eng.synchronize()
+                rows = eng.download(0, n)["_pitched"]
+                fastq_write(forward_handle.fileno(), reverse_handle.fileno(), record.id, done, self.cpu_number, n,
+                            eng.read_length, eng.pitch, rows[0], rows[1], rows[2], rows[3], n_threads=writer_threads)
             self.ordinal += n
             done += n
+        if self.device_fastq and flush:
+            eng.fastq_flush()  # the handles are the caller's again
         return done
 
 
@@ -271,7 +280,8 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
         with forward_handle, reverse_handle, mutation_handle:
             for record, n_pairs, _mode in work:
                 w.simulate_reads(record, n_pairs, forward_handle, reverse_handle, mutation_handle, sequence_type,
-                                 gc_bias)
+                                 gc_bias, flush=False)  # keep the text pipeline running across work items
+            w.engine.fastq_flush()
     finally:
         w.close()
 

@@ -479,3 +479,46 @@ def test_worker_vcf_philox(tmp_path):
             lines.append("\t".join(["%s_%d_2/%d" % (r.id, m["pair"], 1 + int(m["mate"])), str(int(m["position"]) + 1), ".",
                                     ref, alt, qual, "", ""]) + "\n")
     assert open(prefix + ".vcf").read() == "".join(lines) and len(lines) > 50
+
+
+@pytest.mark.parametrize("model,rid,cpu,first_i,counts", [
+    ("novaseq", "genome_A", 0, 0, [1205, 1, 7000]),
+    ("ecoli", "x", 12, 95, [10, 900, 120000]),           # crosses 99|100, 999|1000, 9999|10000, 99999|100000
+    ("miseq", "NZ_" + "k" * 300 + ".1", 3, 999990, [25, 3000]),
+])
+def test_device_fastq_equals_host_formatter(model, rid, cpu, first_i, counts, tmp_path):
+    """iss_fastq_emit (text built on the device, closed-form record offsets, asynchronous copy + pwrite) against
+    iss_fastq_write (host formatter) on the same rows: several appends to the same files, ids that cross digit
+    boundaries, short / long reads and ids."""
+    from helpers import random_genome
+    from insilicoseq_amd.engine import ReadEngine, fastq_write
+
+    dense = dense_model(model)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(random_genome(3, 50000))
+        eng.reserve(max(counts))
+        paths = [str(tmp_path / n) for n in ("d1.fq", "d2.fq", "h1.fq", "h2.fq")]
+        fh = [open(p, "wb") for p in paths]
+        for f in fh[:2]:
+            f.write(b"# existing content\n")  # appended after whatever is in the files
+            f.flush()
+        for f in fh[2:]:
+            f.write(b"# existing content\n")
+            f.flush()
+        i0 = first_i
+        for k, n in enumerate(counts):
+            eng.generate(gid, n, first_ordinal=1000 * k, seed=5)
+            eng.fastq_emit(fh[0].fileno(), fh[1].fileno(), rid, i0, cpu, 0, n, n_threads=3)
+            eng.synchronize()
+            rows = eng.download(0, n)["_pitched"]
+            fastq_write(fh[2].fileno(), fh[3].fileno(), rid, i0, cpu, n, eng.read_length, eng.pitch, rows[0], rows[1],
+                        rows[2], rows[3], n_threads=2)
+            i0 += n
+        eng.fastq_flush()
+        assert os.lseek(fh[0].fileno(), 0, os.SEEK_CUR) == os.path.getsize(paths[0])
+        for f in fh:
+            f.close()
+    assert open(paths[0], "rb").read() == open(paths[2], "rb").read()
+    assert open(paths[1], "rb").read() == open(paths[3], "rb").read()
+    assert os.path.getsize(paths[0]) > 100 * sum(counts) // 4

@@ -38,10 +38,11 @@ def main(src, tag):
     if "k_fill_dword" in acc and "k_read_dwordx2" in acc:
         cal["write_factor"] = (1 << 20) / (acc["k_fill_dword"]["WRITE_SIZE"] / calls["k_fill_dword"]["WRITE_SIZE"])
         cal["fetch_factor"] = (1 << 20) / (acc["k_read_dwordx2"]["FETCH_SIZE"] / calls["k_read_dwordx2"]["FETCH_SIZE"])
-    m = acc["iss::k_main"]
-    n = calls["iss::k_main"]["FETCH_SIZE"]
+    key = [k for k in acc if "k_main" in k][0]  # "iss::k_main" or "void iss::k_main<false>"
+    m = acc[key]
+    n = calls[key]["FETCH_SIZE"]
     fetch = m["FETCH_SIZE"] / n * 1024 * cal.get("fetch_factor", 2.0)
-    write = m["WRITE_SIZE"] / calls["iss::k_main"]["WRITE_SIZE"] * 1024 * cal.get("write_factor", 1.0)
+    write = m["WRITE_SIZE"] / calls[key]["WRITE_SIZE"] * 1024 * cal.get("write_factor", 1.0)
     summary = {"kernel": "iss::k_main", "launches": n, "calibration": cal, "fetch_bytes_per_launch": fetch,
                "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
                "command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline (5,000,000 pairs per step in 5 launches)",
