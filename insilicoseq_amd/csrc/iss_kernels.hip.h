@@ -456,6 +456,7 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
         for (int64_t w = (rs - 3) >> 5; w <= (re - 1) >> 5; ++w) any |= g.mask[w];
         exc |= any ? 32u : 0u;
     }
+    if (!ov_frag) A.flags[i] = 0u;  // first pass: the pair's indel / irregular flags start clean (no separate memset)
     if (irregular && !(A.flags[i] & 3u)) {
         A.flags[i] = 3u;
         const uint32_t at = atomicAdd(A.fix_count, 2u);

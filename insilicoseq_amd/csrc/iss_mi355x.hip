@@ -980,9 +980,13 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
             if (pi.row0 < row0 + n && row0 < pi.row0 + pi.n) HIP_TRY(ctx, hipStreamWaitEvent(s_main, pi.done, 0));
             ++i;
         }
-        uint32_t *counter = ctx->fix_count + (ctx->chunk_seq++ % FIX_SLOTS);
-        HIP_TRY(ctx, hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)n, s_main));
-        HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
+        // fix-list counter of this chunk: a ring of FIX_SLOTS counters.  Everything in order on one stream: the whole
+        // ring is cleared once per FIX_SLOTS chunks; with the indel stream running beside, per chunk.  (The flags
+        // are cleared by k_setup itself.)
+        const unsigned slot_i = (unsigned)(ctx->chunk_seq++ % FIX_SLOTS);
+        uint32_t *counter = ctx->fix_count + slot_i;
+        if (ctx->overlap) HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
+        else if (slot_i == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
         A.mut = ctx->d_pmut;
         A.mut_count = ctx->d_pmut_count;
         A.mut_cap = (uint32_t)ctx->pmut_cap;
