@@ -165,7 +165,7 @@ struct RunArgs {
     int32_t gc_bias;
     uint64_t gc_thr;  // ceil(0.90 * 2^53): accept iff m < gc_thr (generator.py:88)
     uint8_t *out[4];  // rows of this launch: R1 base, R1 qual, R2 base, R2 qual
-    uint32_t *slow_ovf;  // k_main: per-workgroup spill area of the deferred-work queue
+    uint64_t *slow_ovf;  // k_main: per-workgroup spill area of the deferred-work queue
     int32_t slow_every;  // k_main: drain period (iterations), chosen from the model's expected rare-base rate
     int32_t scan_every;  // k_indel_scan: flush period (iterations), chosen from the model's indel probabilities
     // custom fragment length (generator.py:121-123): fragment = int(mu + sd * gaussian), per-pair polar Box-Muller
@@ -499,16 +499,16 @@ __device__ __forceinline__ uint32_t codes_to_ascii4(uint32_t b) {
 }
 
 constexpr int MAIN_THREADS = 1024;
-constexpr int SLOW_QCAP = 1024;  // deferred-work queue entries (one u32 per flagged base) per workgroup in LDS;
-                                 // overflow spills to global
+constexpr int SLOW_QCAP = 512;   // deferred-work queue entries (one u64 per flagged lane-item: item << 8 | base mask) per
+                                 // workgroup in LDS; overflow spills to global
 constexpr int SLOW_EVERY_MAX = 32;  // drain the queue every RunArgs::slow_every (<= this) loop iterations
-constexpr int SLOW_SPILL = 8 * SLOW_EVERY_MAX * MAIN_THREADS;  // global spill entries per workgroup: the worst case of a period
+constexpr int SLOW_SPILL = SLOW_EVERY_MAX * MAIN_THREADS;  // global spill entries (u64) per workgroup: the worst case of a period
 
 // Dynamic LDS of k_main (32-bit words):
 //   [0, mut_words)            error-test table: mut16[q] - 1 (signed), q = 0..n_q
 //   [rows, +tile_words)       compressed quality rows of the position tile: per (mate, bin slot, group)
 //                             GS words = 4 rows of stride_w words + 1 pad word; a row = guide bytes
-//                             (1 << GB of them) then packed entries (t16 << 15 | phred << 2), ascending,
+//                             (1 << GB of them, each the BYTE offset 4 * j of an entry) then packed entries (t16 << 15 | phred << 2), ascending,
 //                             closed by two sentinels
 //   [subst, +subst_words)     substitution table (leading digits + alternatives)
 //   [q_count], [queue]        deferred-work queue
@@ -542,7 +542,7 @@ __device__ __forceinline__ bool main_slow_base(const DevModel &M, const RunArgs 
     const uint32_t gwords = (1u << M.GB) / 4;
     const uint32_t row = T.rows + (((uint32_t)(o * M.NB) + slot) * (uint32_t)M.TG + grp) * (uint32_t)M.GS +
                          (uint32_t)c * (uint32_t)M.stride_w;
-    uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))];
+    uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))] >> 2;  // guide bytes hold 4 * index
     uint32_t e = lds[row + gwords + j];
     while ((e >> 15) < h) e = lds[row + gwords + (++j)];
     uint32_t q = (e >> 2) & 0xffu;
@@ -586,7 +586,7 @@ __device__ __forceinline__ uint32_t hot_lookup(const uint32_t *lds, uint32_t row
     const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds);
     const uint32_t h = wd & 0xffffu;
     const uint32_t j = ldsb[row_b + (h >> gshift)];
-    const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + row_b + gbytes + j * 4);
+    const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + row_b + gbytes + j);  // guide bytes hold 4 * index
     const uint32_t e0 = ent[0], e1 = ent[1];
     const uint32_t hs = h << 15;
     const uint32_t sel = e0 >= hs ? e0 : e1;           // first entry with t16 >= h (if among the two)
@@ -611,9 +611,9 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     T.g0 = tile * M.TG;
     T.tg = (uint32_t)min(M.TG, M.G - T.g0);
     uint32_t *q_count = lds + T.subst16 + M.subst_words;
-    uint32_t *queue = q_count + 4;
+    uint64_t *queue = reinterpret_cast<uint64_t *>(q_count + 4);  // (8-byte aligned: every part before it is a multiple of 4 words)
     // global spill area of this workgroup's queue (only touched when > SLOW_QCAP entries are pending)
-    uint32_t *ovf = A.slow_ovf + (size_t)blockIdx.x * SLOW_SPILL;
+    uint64_t *ovf = A.slow_ovf + (size_t)blockIdx.x * SLOW_SPILL;
     {   // stage this tile's tables in LDS (once per workgroup)
         for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) lds[i] = M.mut16[i] - 1u;
         const uint4 *src = reinterpret_cast<const uint4 *>(M.qrows + (size_t)tile * M.tile_words);
@@ -637,12 +637,20 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     const int gshift = 16 - M.GB;
     const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
     const uint32_t slot_b = (uint32_t)M.TG * (uint32_t)M.GS * 4u;  // bytes per (mate, bin slot)
+    // 32-bit byte offsets, advanced by addition (a chunk is < 2^28 lane-items, so nothing here overflows):
+    // row_g = LDS byte offset of the item's position group; out_b = byte offset of its dword in the four outputs
+    const uint32_t gs_b = (uint32_t)M.GS * 4u;
+    uint32_t row_g = T.rows * 4u + grp * gs_b;
+    uint32_t out_b = (pair * (uint32_t)M.G + (uint32_t)g0 + grp) * 4u;
+    const uint32_t row_step = step_grp * gs_b, row_wrap = tg * gs_b;
+    const uint32_t out_step = (step_pair * (uint32_t)M.G + step_grp) * 4u, out_wrap = ((uint32_t)M.G - tg) * 4u;
+    const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // the leading padding word: offsets >= 0
     uint32_t since_drain = 0;
     MutChunk mchunk = {0u, MUT_CHUNK};  // --store_mutations: forces a reservation at first use
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
         if (it < n_items) {
             const int p0 = (g0 + (int)grp) * 4;
-            const PairDesc d = desc[pair];
+            const PairDesc d = *reinterpret_cast<const PairDesc *>(reinterpret_cast<const char *>(desc) + (size_t)(pair * 16u));
             const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
             // ---- sixteen 16-bit leading digits: (quality, error test) x (fwd, rev) x 4 positions
             const u32x4 wq0 = draw_block(a, K_QM, (uint32_t)(p0 >> 1), 0);
@@ -651,10 +659,10 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             uint32_t fb = 0, rb = 0, fm = 0, rm = 0;
             if (!(A.has_frag && (d.meta & 64u))) {  // irregular pairs are built by the fix-up kernel
                 const int32_t pf = d.fs + p0;
-                const uint32_t *pw = g.packed + (pf >> 4);
+                const uint32_t *pw = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(uint32_t)(((pf >> 4) + 1) << 2));
                 fb = funnel_r(pw[0], pw[1], (uint32_t)(pf & 15) * 2) & 0xffu;
                 const int32_t pr = d.re - 4 - p0;  // lowest genome position of the 4 reverse bases
-                const uint32_t *qw = g.packed + (pr >> 4);
+                const uint32_t *qw = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(uint32_t)(((pr >> 4) + 1) << 2));
                 rb = funnel_r(qw[0], qw[1], (uint32_t)(pr & 15) * 2) & 0xffu;
                 if (d.meta & 0x30u) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
                     const uint32_t *mw = g.mask + (pf >> 5);
@@ -664,13 +672,12 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
                 }
             }
             // ---- phred scores + substitution test, loop-free (hot_lookup); 8 independent lookups
-            const uint32_t rowf_b = (T.rows + grp * (uint32_t)M.GS) * 4u + (d.meta & 3u) * slot_b;
-            const uint32_t rowr_b = (T.rows + grp * (uint32_t)M.GS) * 4u + ((uint32_t)M.NB + ((d.meta >> 2) & 3u)) * slot_b;
-            uint32_t sel[8], rare = 0;
-            const uint32_t lim_b = (uint32_t)(min(RL - p0, 4) - 1) * stride_b;  // padding lanes of the last group reuse the last row
+            const uint32_t rowf_b = row_g + (d.meta & 3u) * slot_b;
+            const uint32_t rowr_b = row_g + ((uint32_t)M.NB + ((d.meta >> 2) & 3u)) * slot_b;
+            uint32_t sel[8], rare = 0;  // (the rows of the last group's padding positions repeat the last position's row)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const uint32_t pc_b = min((uint32_t)c * stride_b, lim_b);
+                const uint32_t pc_b = (uint32_t)c * stride_b;
                 const u32x4 &w = (c >> 1) ? wq1 : wq0;
                 uint32_t x;
                 sel[c] = hot_lookup(lds, rowf_b + pc_b, (c & 1) ? w.z : w.x, gshift, gbytes, x);
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const uint32_t pc_b = min((uint32_t)c * stride_b, lim_b);
+                const uint32_t pc_b = (uint32_t)c * stride_b;
                 const u32x4 &w = (c >> 1) ? wq1 : wq0;
                 uint32_t x;
                 sel[4 + c] = hot_lookup(lds, rowr_b + pc_b, (c & 1) ? w.w : w.y, gshift, gbytes, x);
@@ -703,20 +710,17 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
                     }
                 }
             }
-            const int nvalid = RL - p0;  // zero the padding bytes of the last group
-            const uint32_t keep = nvalid >= 4 ? 0xffffffffu : ((1u << (8 * nvalid)) - 1u);
-            const size_t dw = (size_t)pair * M.G + (size_t)(g0 + grp);
-            reinterpret_cast<uint32_t *>(A.out[0])[dw] = base_f & keep;
-            reinterpret_cast<uint32_t *>(A.out[1])[dw] = qual_f & keep;
-            reinterpret_cast<uint32_t *>(A.out[2])[dw] = base_r & keep;
-            reinterpret_cast<uint32_t *>(A.out[3])[dw] = qual_r & keep;
+            // (the <= 3 padding bytes of the last group hold the clamped last row's values; nothing reads them)
+            *reinterpret_cast<uint32_t *>(A.out[0] + (size_t)out_b) = base_f;
+            *reinterpret_cast<uint32_t *>(A.out[1] + (size_t)out_b) = qual_f;
+            *reinterpret_cast<uint32_t *>(A.out[2] + (size_t)out_b) = base_r;
+            *reinterpret_cast<uint32_t *>(A.out[3] + (size_t)out_b) = qual_r;
             rare &= 0xffu;  // bit (7 - s) <=> base s needs the exact path (~0.3 % of bases)
-            while (rare) {  // one queue entry per flagged base: the deferred pass has no divergence over s
-                const int bit = 31 - __clz(rare);
-                rare &= ~(1u << bit);
+            if (rare) {  // one queue entry per flagged lane-item
                 const uint32_t slot = atomicAdd(q_count, 1u);
-                uint32_t *dst = slot < (uint32_t)SLOW_QCAP ? queue + slot : ovf + (slot - SLOW_QCAP);  // the spill always suffices
-                *dst = (it << 3) | (uint32_t)(7 - bit);
+                const uint64_t ent = ((uint64_t)it << 8) | rare;
+                if (slot < (uint32_t)SLOW_QCAP) queue[slot] = ent;
+                else ovf[slot - SLOW_QCAP] = ent;  // the spill always suffices
             }
         }
         if (++since_drain == (uint32_t)A.slow_every || iter == n_iter - 1) {
@@ -724,10 +728,15 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             __syncthreads();  // also makes this workgroup's global stores visible to all of its lanes
             const uint32_t nq = *q_count;
             for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
-                const uint32_t ent = i < (uint32_t)SLOW_QCAP ? queue[i] : ovf[i - SLOW_QCAP];
-                MutRecord rec;
-                const bool have = main_slow_base(M, A, desc, lds, T, ent >> 3, (int)(ent & 7u), rec);
-                if (STORE_MUT) mut_emit(A, mchunk, have, rec);
+                const uint64_t ent = i < (uint32_t)SLOW_QCAP ? queue[i] : ovf[i - SLOW_QCAP];
+                uint32_t mask = (uint32_t)ent & 0xffu;  // almost always a single bit
+                while (mask) {
+                    const int bit = 31 - __clz(mask);
+                    mask &= ~(1u << bit);
+                    MutRecord rec;
+                    const bool have = main_slow_base(M, A, desc, lds, T, (uint32_t)(ent >> 8), 7 - bit, rec);
+                    if (STORE_MUT) mut_emit(A, mchunk, have, rec);
+                }
             }
             __syncthreads();
             if (threadIdx.x == 0) *q_count = 0;
@@ -736,7 +745,9 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
         it += step;
         pair += step_pair;
         grp += step_grp;
-        if (grp >= tg) { grp -= tg; ++pair; }
+        row_g += row_step;
+        out_b += out_step;
+        if (grp >= tg) { grp -= tg; ++pair; row_g -= row_wrap; out_b += out_wrap; }
     }
 }
 

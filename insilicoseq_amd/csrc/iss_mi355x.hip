@@ -106,7 +106,7 @@ struct iss_ctx {
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
-    uint32_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][SLOW_SPILL]
+    uint64_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][SLOW_SPILL]
     int slow_every = iss::SLOW_EVERY_MAX;
     int scan_every = 8;
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
@@ -335,7 +335,7 @@ int mt_prefetch_commit(iss_ctx *ctx, const MtPrefetch &pf) {
 // dynamic LDS of k_main: quality rows + error-test thresholds + substitution table + deferred-work queue
 size_t main_lds_bytes(const iss::DevModel &M) {
     const size_t mut_words = ((size_t)M.n_q + 1 + 3) & ~(size_t)3;
-    return ((size_t)M.tile_words + mut_words + (size_t)M.subst_words + 4 + (size_t)iss::SLOW_QCAP) * 4;
+    return ((size_t)M.tile_words + mut_words + (size_t)M.subst_words + 4 + 2 * (size_t)iss::SLOW_QCAP) * 4;
 }
 
 int settle_timing(iss_ctx *ctx) {
@@ -512,8 +512,8 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
-    HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * iss::SLOW_SPILL * sizeof(uint32_t)));
-    ctx->slow_ovf = static_cast<uint32_t *>(p);
+    HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * iss::SLOW_SPILL * sizeof(uint64_t)));
+    ctx->slow_ovf = static_cast<uint64_t *>(p);
     *out = ctx;
     return 0;
 }
@@ -553,8 +553,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     if (t->read_length < 2 || t->read_length > iss::FIX_MAX_RL)
         return fail(ctx, ISS_E_INVALID, "read_length must be in [2, 1024]");
     if (t->n_isize > 8000) return fail(ctx, ISS_E_INVALID, "insert-size CDF longer than 8000 entries");
-    if (t->n_isize < 1 || t->n_q < 1 || t->n_q > 63)
-        return fail(ctx, ISS_E_INVALID, "bad table sizes (per-position quality CDFs must have 1..63 entries)");
+    if (t->n_isize < 1 || t->n_q < 1 || t->n_q > 60)
+        return fail(ctx, ISS_E_INVALID, "bad table sizes (per-position quality CDFs must have 1..60 entries)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     free_model(ctx);
@@ -711,7 +711,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     size_t j = 0;
                     for (uint32_t b = 0; b < (1u << M.GB); ++b) {
                         while ((entries[j] >> 15) < (b << (16 - M.GB))) ++j;
-                        guide[b] = (uint8_t)j;
+                        guide[b] = (uint8_t)(4 * j);  // byte offset of the entry (<= 4 * 63)
                     }
                     std::copy(entries.begin(), entries.end(), dst + gwords);
                     for (size_t k = gwords + entries.size(); k < (size_t)M.stride_w; ++k) dst[k] = entries.back();

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
                     const uint32_t h = (uint32_t)(m >> 37);
                     const uint32_t row = ((uint32_t)(o * M.NB + slot) * (uint32_t)M.TG + (uint32_t)(p >> 2)) * (uint32_t)M.GS +
                                          (uint32_t)(p & 3) * (uint32_t)M.stride_w;
-                    uint32_t j = reinterpret_cast<const uint8_t *>(rows)[row * 4 + (h >> (16 - M.GB))];
+                    uint32_t j = reinterpret_cast<const uint8_t *>(rows)[row * 4 + (h >> (16 - M.GB))] >> 2;
                     uint32_t e = rows[row + gbytes / 4 + j];
                     while ((e >> 15) < h) e = rows[row + gbytes / 4 + (++j)];
                     q = (int)((e >> 2) & 0xffu);

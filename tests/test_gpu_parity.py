@@ -310,7 +310,7 @@ def test_api_misuse_is_reported_not_crashed():
             eng.generate(gid, 10, sequence_type="shotgun")
         with pytest.raises(_native.EngineError):  # numpy's legacy seeding range
             eng.seed_mt(2**32)
-        # a model the engine cannot hold: more than 63 entries per quality CDF
+        # a model the engine cannot hold: more than 60 entries per quality CDF
         big = DenseModel(d.read_length, d.isize_cdf, d.bin_cdf, d.bin_nonempty,
                          np.concatenate([d.qcdf, np.ones(d.qcdf.shape[:3] + (30,))], axis=3), d.subst_cdf, d.subst_alt,
                          d.ins, d.ins_letter, d.dele, np.concatenate([d.phred_thr, np.ones(30)]))
