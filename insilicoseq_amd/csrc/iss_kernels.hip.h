@@ -755,13 +755,13 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
 // Conservative: flags mate o of a pair when some indel uniform's leading digit is <= the leading
 // digit of a non-zero threshold (max over bases for deletions).  No flag  =>  provably no indel
 // event (the first event in loop order would have been flagged), so k_main's output stands.
-// One lane per (pair, group of 4 loop steps with a non-zero indel probability): one K_DEL block
-// serves the whole group, one K_INS block each step (both mates).  The per-step limits
-// (digit < lim  <=>  candidate; lim = (thr >> 37) + 1, 0 = never) sit in LDS.  Flagged reads go to a
-// workgroup-local LDS list that is flushed to the global fix list with ONE atomic per flush.
-constexpr int SCAN_W = 41;        // words per group entry (odd: bank-conflict free): [0] group | step flags,
-                                  // then per step c: [1+10c .. +7] insertion limits (digit mate*4+slot),
-                                  // [9+10c], [10+10c] deletion limits fwd / rev
+// One lane per (pair, Philox block holding a digit that can matter): exactly one block and eight
+// compares per lane-item, no divergence between the lanes of a wavefront whatever mix of table
+// entries they hold.  The limits (digit < lim  <=>  candidate; lim = (thr >> 37) + 1, 0 = never) sit in
+// LDS.  Flagged reads go to a workgroup-local LDS list that is flushed to the global fix list with ONE
+// atomic per flush.
+constexpr int SCAN_W = 9;         // words per table entry (odd: bank-conflict free): [0] kind << 24 | index,
+                                  // [1..8] limits of the block's 8 digits
 constexpr int SCAN_THREADS = 512;
 constexpr int SCAN_LIST = 8192;   // LDS list entries; flushed every RunArgs::scan_every iterations, chosen on the
                                   // host so that a period cannot overflow it (2 * scan_every * SCAN_THREADS <= SCAN_LIST
@@ -788,26 +788,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
         if (it < n_items) {
             const uint32_t *tab = tab0 + e * SCAN_W;
-            const uint32_t head = tab[0];
-            const uint32_t grp = head & 0xffffu;
+            const uint32_t c2 = tab[0];
             // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
             const Addr a = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
-            uint32_t cand = 0;
-            if (head & 0x00f00000u) {  // some step of the group has a deletion probability
-                const u32x4 w = draw_block(a, K_DEL, grp, 0);
+            const u32x4 w = philox4x32_10(a.c0, a.c1, c2, 0u, a.k0, a.k1);
+            uint32_t hit = 0;  // bit d: digit d is below its limit
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (digit16(w, c * 2) < tab[9 + 10 * c]) cand |= 1u;
-                    if (digit16(w, c * 2 + 1) < tab[10 + 10 * c]) cand |= 2u;
-                }
-            }
-            for (int c = 0; c < 4; ++c) {
-                if (!((head >> (16 + c)) & 1u)) continue;  // no insertion probability at this step
-                const u32x4 w = draw_block(a, K_INS, grp * 4 + (uint32_t)c, 0);
-#pragma unroll
-                for (int dgt = 0; dgt < 8; ++dgt)
-                    if (digit16(w, dgt) < tab[1 + 10 * c + dgt]) cand |= 1u << (dgt >> 2);
-            }
+            for (int dgt = 0; dgt < 8; ++dgt) hit |= (digit16(w, dgt) < tab[1 + dgt] ? 1u : 0u) << dgt;
+            // digit -> mate: K_DEL (n & 3) * 2 + mate, K_INS mate * 4 + slot
+            const uint32_t cand = (c2 >> 24) == K_DEL ? (((hit & 0x55u) ? 1u : 0u) | ((hit & 0xaau) ? 2u : 0u))
+                                                      : (((hit & 0x0fu) ? 1u : 0u) | ((hit & 0xf0u) ? 2u : 0u));
             if (cand) {
                 const uint32_t old = atomicOr(&flags[pair], cand);
                 uint32_t fresh = cand & ~old;

@@ -741,35 +741,35 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             del_max[e] = dm;
             ins_any[e] = im ? 1 : 0;
         }
-    // k_indel_scan table: one entry per group of 4 loop steps n <= RL-2 (__init__.py:187) with any non-zero threshold
+    // k_indel_scan table: one entry per Philox block that holds a digit with a non-zero limit -- the K_DEL block of a
+    // group of 4 loop steps n <= RL-2 (__init__.py:187; digit (n & 3) * 2 + mate) or the K_INS block of one step
+    // (digit mate * 4 + letter slot).  Entry = [kind << 24 | index, 8 limits]; limit = (thr >> 37) + 1, 0 = never.
     std::vector<uint32_t> scan_tab;
     auto lim = [](uint64_t T) { return T ? (uint32_t)(T >> 37) + 1u : 0u; };
+    auto push_block = [&](uint32_t kind, uint32_t index, const uint32_t lims[8]) {
+        bool any = false;
+        for (int k = 0; k < 8; ++k) any |= lims[k] != 0;
+        if (!any) return;
+        scan_tab.push_back((kind << 24) | index);
+        scan_tab.insert(scan_tab.end(), lims, lims + 8);
+    };
     for (int gI = 0; gI * 4 <= RL - 2; ++gI) {
-        uint32_t ent[iss::SCAN_W] = {0};
-        uint32_t head = (uint32_t)gI;
-        for (int c = 0; c < 4; ++c) {
-            const int n = gI * 4 + c;
-            if (n > RL - 2) break;
-            for (int o = 0; o < 2; ++o) {
-                const size_t e = (size_t)o * RL + n;
-                for (int x = 0; x < 4; ++x) {
-                    ent[1 + 10 * c + o * 4 + x] = lim(t->ins_thr[e * 4 + x]);
-                    if (ent[1 + 10 * c + o * 4 + x]) head |= 1u << (16 + c);
-                }
-                ent[9 + 10 * c + o] = lim(del_max[e]);
-                if (ent[9 + 10 * c + o]) head |= 1u << (20 + c);
-            }
+        uint32_t dl[8] = {0};
+        for (int c = 0; c < 4 && gI * 4 + c <= RL - 2; ++c)
+            for (int o = 0; o < 2; ++o) dl[c * 2 + o] = lim(del_max[(size_t)o * RL + gI * 4 + c]);
+        push_block(iss::K_DEL, (uint32_t)gI, dl);
+        for (int c = 0; c < 4 && gI * 4 + c <= RL - 2; ++c) {
+            uint32_t il[8];
+            for (int o = 0; o < 2; ++o)
+                for (int x = 0; x < 4; ++x) il[o * 4 + x] = lim(t->ins_thr[((size_t)o * RL + gI * 4 + c) * 4 + x]);
+            push_block(iss::K_INS, (uint32_t)(gI * 4 + c), il);
         }
-        if (!(head & 0x00ff0000u)) continue;
-        ent[0] = head;
-        scan_tab.insert(scan_tab.end(), ent, ent + iss::SCAN_W);
     }
     M.n_scan = (int32_t)(scan_tab.size() / iss::SCAN_W);
     {   // expected flagged mates per scan item -> flush period of the LDS list (half-full on average)
         double rate = 0;
         for (size_t e = 0; e + iss::SCAN_W <= scan_tab.size(); e += iss::SCAN_W)
-            for (int c = 0; c < 4; ++c)
-                for (int k = 1; k <= 10; ++k) rate += (double)scan_tab[e + 10 * c + k] / 65536.0;
+            for (int k = 1; k <= 8; ++k) rate += (double)scan_tab[e + k] / 65536.0;
         rate = M.n_scan ? rate / M.n_scan : 0.0;
         const double per_iter = std::max(rate, 1e-6) * iss::SCAN_THREADS;
         ctx->scan_every = (int)std::max(8.0, std::min(512.0, 0.5 * iss::SCAN_LIST / per_iter));
