@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libiss_mi355x.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("ISS_MI355X_LIB") or os.path.join(_HERE, LIB_NAME)  # override: A/B builds (tools/ab_bench.sh)
 
 E_INVALID, E_HIP, E_NOMEM, E_SHORT_RECORD, E_IO = -1, -2, -3, -4, -5
 SEQ_TYPES = {"metagenomics": 0, "amplicon": 1}

@@ -670,6 +670,10 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     }
                 }
         const double rare = more_rate(M.GB) + err / (double)std::max<size_t>(rows, 1) + 2e-4;
+        if (getenv("ISS_DEBUG_MODEL"))
+            fprintf(stderr, "[model] per base: P(> 2 thresholds below in the guide bucket) %.5f (GB 6: %.5f, 7: %.5f, 8: %.5f), "
+                            "P(substitution test fires) %.5f, s_max %zu\n", more_rate(M.GB), more_rate(6), more_rate(7), more_rate(8),
+                    err / (double)std::max<size_t>(rows, 1), s_max);
         const double per_iter = rare * 8.0 * iss::MAIN_THREADS;
         ctx->slow_every = (int)std::max(2.0, std::min((double)iss::SLOW_EVERY_MAX, 65536.0 / std::max(per_iter, 1.0)));
     }
@@ -698,6 +702,10 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     if (!M.n_tiles) return fail(ctx, ISS_E_INVALID, "quality tables do not fit the LDS even for one position group");
     (void)fits(M.n_tiles, one_per_cu);
     M.n_tiles = (M.G + M.TG - 1) / M.TG;
+    if (getenv("ISS_DEBUG_MODEL"))
+        fprintf(stderr, "[model] RL %d G %d NB %d GB %d stride_w %d GS %d TG %d n_tiles %d tile %.1f KB (k_main LDS %.1f KB) slow_every %d\n",
+                M.RL, M.G, M.NB, M.GB, M.stride_w, M.GS, M.TG, M.n_tiles, M.tile_words * 4 / 1024.0,
+                main_lds_bytes(M) / 1024.0, ctx->slow_every);
     std::vector<uint32_t> qrows((size_t)M.n_tiles * M.tile_words, 0);
     for (int tl = 0; tl < M.n_tiles; ++tl)
         for (int o = 0; o < 2; ++o)
