@@ -165,8 +165,6 @@ struct RunArgs {
     int32_t gc_bias;
     uint64_t gc_thr;  // ceil(0.90 * 2^53): accept iff m < gc_thr (generator.py:88)
     uint8_t *out[4];  // rows of this launch: R1 base, R1 qual, R2 base, R2 qual
-    uint64_t *slow_ovf;  // k_main: per-workgroup spill area of the deferred-work queue
-    int32_t slow_every;  // k_main: drain period (iterations), chosen from the model's expected rare-base rate
     int32_t scan_every;  // k_indel_scan: flush period (iterations), chosen from the model's indel probabilities
     // custom fragment length (generator.py:121-123): fragment = int(mu + sd * gaussian), per-pair polar Box-Muller
     int32_t has_frag;
@@ -499,11 +497,8 @@ __device__ __forceinline__ uint32_t codes_to_ascii4(uint32_t b) {
 }
 
 constexpr int MAIN_THREADS = 1024;
-constexpr int SLOW_QCAP = 512;   // deferred-work queue entries (one u64 per flagged lane-item: item << 8 | base mask) per
-                                 // workgroup in LDS; overflow spills to global
-constexpr int SLOW_EVERY_MAX = 32;  // drain the queue every RunArgs::slow_every (<= this) loop iterations
-constexpr int SLOW_SPILL = SLOW_EVERY_MAX * MAIN_THREADS;  // global spill entries (u64) per workgroup: the worst case of a period
-
+constexpr int SLOW_RING = 128;  // entries of a wavefront's private ring of deferred lane-items (LDS): a wavefront pushes
+                                // <= 64 per iteration and drains a round of 64 as soon as it has one
 // Dynamic LDS of k_main (32-bit words):
 //   [0, mut_words)            error-test table: mut16[q] - 1 (signed), q = 0..n_q
 //   [rows, +tile_words)       compressed quality rows of the position tile: per (mate, bin slot, group)
@@ -511,7 +506,7 @@ constexpr int SLOW_SPILL = SLOW_EVERY_MAX * MAIN_THREADS;  // global spill entri
 //                             (1 << GB of them, each the BYTE offset 4 * j of an entry) then packed entries (t16 << 15 | phred << 2), ascending,
 //                             closed by two sentinels
 //   [subst, +subst_words)     substitution table (leading digits + alternatives)
-//   [q_count], [queue]        deferred-work queue
+//   [rings]                   MAIN_THREADS / 64 private rings of SLOW_RING deferred lane-items
 struct MainTile {  // per-workgroup constants of k_main (word offsets into the dynamic LDS array)
     uint32_t rows;
     uint32_t subst16;
@@ -610,10 +605,11 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     T.subst16 = (uint32_t)(mut_words + M.tile_words);
     T.g0 = tile * M.TG;
     T.tg = (uint32_t)min(M.TG, M.G - T.g0);
-    uint32_t *q_count = lds + T.subst16 + M.subst_words;
-    uint64_t *queue = reinterpret_cast<uint64_t *>(q_count + 4);  // (8-byte aligned: every part before it is a multiple of 4 words)
-    // global spill area of this workgroup's queue (only touched when > SLOW_QCAP entries are pending)
-    uint64_t *ovf = A.slow_ovf + (size_t)blockIdx.x * SLOW_SPILL;
+    // Deferred lane-items (a base needs the exact path): a private ring per wavefront -- no atomics, no barriers.
+    // Entry = iteration << 14 | lane << 8 | base mask; head / tail are wave-uniform.
+    uint32_t *ring = lds + T.subst16 + M.subst_words + (threadIdx.x >> 6) * SLOW_RING;
+    uint32_t q_head = 0, q_tail = 0;
+    const uint32_t lane = threadIdx.x & 63u;
     {   // stage this tile's tables in LDS (once per workgroup)
         for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) lds[i] = M.mut16[i] - 1u;
         const uint4 *src = reinterpret_cast<const uint4 *>(M.qrows + (size_t)tile * M.tile_words);
@@ -621,16 +617,17 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
         for (int i = threadIdx.x; i < M.tile_words / 4; i += blockDim.x) dst[i] = src[i];
         const uint32_t *ssrc = M.subst16 + (size_t)tile * M.subst_words;
         for (int i = threadIdx.x; i < M.subst_words; i += blockDim.x) lds[T.subst16 + i] = ssrc[i];
-        if (threadIdx.x == 0) *q_count = 0;
     }
     __syncthreads();
     const uint32_t tg = T.tg;
     const int g0 = T.g0;
     const uint32_t n_items = (uint32_t)A.n_pairs * tg;
     const uint32_t step = n_wg * blockDim.x;
-    const uint32_t step_pair = step / tg, step_grp = step - step_pair * tg;
+    // (uniform values that come out of a division live in vector registers unless told otherwise: the kernel has none to spare)
+    auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    const uint32_t step_pair = sgpr(step / tg), step_grp = sgpr(step - step_pair * tg);
     const uint32_t first = wg * blockDim.x;
-    const uint32_t n_iter = n_items > first ? (n_items - first + step - 1) / step : 0;  // uniform in the workgroup
+    const uint32_t n_iter = sgpr(n_items > first ? (n_items - first + step - 1) / step : 0);  // uniform in the workgroup
     uint32_t it = first + threadIdx.x;
     uint32_t pair = it / tg, grp = it - pair * tg;
     const int RL = M.RL;
@@ -642,12 +639,29 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     const uint32_t gs_b = (uint32_t)M.GS * 4u;
     uint32_t row_g = T.rows * 4u + grp * gs_b;
     uint32_t out_b = (pair * (uint32_t)M.G + (uint32_t)g0 + grp) * 4u;
-    const uint32_t row_step = step_grp * gs_b, row_wrap = tg * gs_b;
-    const uint32_t out_step = (step_pair * (uint32_t)M.G + step_grp) * 4u, out_wrap = ((uint32_t)M.G - tg) * 4u;
+    const uint32_t row_step = sgpr(step_grp * gs_b), row_wrap = sgpr(tg * gs_b);
+    const uint32_t out_step = sgpr((step_pair * (uint32_t)M.G + step_grp) * 4u), out_wrap = sgpr(((uint32_t)M.G - tg) * 4u);
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // the leading padding word: offsets >= 0
-    uint32_t since_drain = 0;
     MutChunk mchunk = {0u, MUT_CHUNK};  // --store_mutations: forces a reservation at first use
+    // one round of the exact path: lane k takes the k-th pending entry of this wavefront (n <= 64 of them)
+    auto drain_round = [&](uint32_t n) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's output dwords have reached the L2
+        if (lane < n) {
+            const uint32_t ent = ring[(q_head + lane) & (SLOW_RING - 1)];
+            const uint32_t it_e = first + (threadIdx.x & ~63u) + ((ent >> 8) & 63u) + (ent >> 14) * step;
+            uint32_t mask = ent & 0xffu;  // almost always a single bit
+            while (mask) {
+                const int bit = 31 - __clz(mask);
+                mask &= ~(1u << bit);
+                MutRecord rec;
+                const bool have = main_slow_base(M, A, desc, lds, T, it_e, 7 - bit, rec);
+                if (STORE_MUT) mut_emit(A, mchunk, have, rec);
+            }
+        }
+        q_head += n;
+    };
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
+        uint32_t rare = 0;
         if (it < n_items) {
             const int p0 = (g0 + (int)grp) * 4;
             const PairDesc d = *reinterpret_cast<const PairDesc *>(reinterpret_cast<const char *>(desc) + (size_t)(pair * 16u));
@@ -674,7 +688,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             // ---- phred scores + substitution test, loop-free (hot_lookup); 8 independent lookups
             const uint32_t rowf_b = row_g + (d.meta & 3u) * slot_b;
             const uint32_t rowr_b = row_g + ((uint32_t)M.NB + ((d.meta >> 2) & 3u)) * slot_b;
-            uint32_t sel[8], rare = 0;  // (the rows of the last group's padding positions repeat the last position's row)
+            uint32_t sel[8];  // (the rows of the last group's padding positions repeat the last position's row)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t pc_b = (uint32_t)c * stride_b;
@@ -715,32 +729,16 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             *reinterpret_cast<uint32_t *>(A.out[1] + (size_t)out_b) = qual_f;
             *reinterpret_cast<uint32_t *>(A.out[2] + (size_t)out_b) = base_r;
             *reinterpret_cast<uint32_t *>(A.out[3] + (size_t)out_b) = qual_r;
-            rare &= 0xffu;  // bit (7 - s) <=> base s needs the exact path (~0.3 % of bases)
-            if (rare) {  // one queue entry per flagged lane-item
-                const uint32_t slot = atomicAdd(q_count, 1u);
-                const uint64_t ent = ((uint64_t)it << 8) | rare;
-                if (slot < (uint32_t)SLOW_QCAP) queue[slot] = ent;
-                else ovf[slot - SLOW_QCAP] = ent;  // the spill always suffices
-            }
+            rare &= 0xffu;  // bit (7 - s) <=> base s needs the exact path (~1 % of bases: mostly substitution events)
         }
-        if (++since_drain == (uint32_t)A.slow_every || iter == n_iter - 1) {
-            since_drain = 0;
-            __syncthreads();  // also makes this workgroup's global stores visible to all of its lanes
-            const uint32_t nq = *q_count;
-            for (uint32_t i = threadIdx.x; i < nq; i += blockDim.x) {
-                const uint64_t ent = i < (uint32_t)SLOW_QCAP ? queue[i] : ovf[i - SLOW_QCAP];
-                uint32_t mask = (uint32_t)ent & 0xffu;  // almost always a single bit
-                while (mask) {
-                    const int bit = 31 - __clz(mask);
-                    mask &= ~(1u << bit);
-                    MutRecord rec;
-                    const bool have = main_slow_base(M, A, desc, lds, T, (uint32_t)(ent >> 8), 7 - bit, rec);
-                    if (STORE_MUT) mut_emit(A, mchunk, have, rec);
-                }
+        const unsigned long long rm = __ballot(rare != 0u);
+        if (rm) {
+            if (rare) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
+                ring[(q_tail + rank) & (SLOW_RING - 1)] = (iter << 14) | (lane << 8) | rare;
             }
-            __syncthreads();
-            if (threadIdx.x == 0) *q_count = 0;
-            __syncthreads();
+            q_tail += (uint32_t)__popcll(rm);
+            if (q_tail - q_head >= 64u) drain_round(64u);
         }
         it += step;
         pair += step_pair;
@@ -749,6 +747,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
         out_b += out_step;
         if (grp >= tg) { grp -= tg; ++pair; row_g -= row_wrap; out_b += out_wrap; }
     }
+    if (q_tail != q_head) drain_round(q_tail - q_head);
 }
 
 // ================================================================== k_indel_scan

@@ -106,8 +106,6 @@ struct iss_ctx {
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
-    uint64_t *slow_ovf = nullptr;   // k_main deferred-queue spill: [max grid][SLOW_SPILL]
-    int slow_every = iss::SLOW_EVERY_MAX;
     int scan_every = 8;
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
     // custom fragment length on the Philox path
@@ -335,7 +333,7 @@ int mt_prefetch_commit(iss_ctx *ctx, const MtPrefetch &pf) {
 // dynamic LDS of k_main: quality rows + error-test thresholds + substitution table + deferred-work queue
 size_t main_lds_bytes(const iss::DevModel &M) {
     const size_t mut_words = ((size_t)M.n_q + 1 + 3) & ~(size_t)3;
-    return ((size_t)M.tile_words + mut_words + (size_t)M.subst_words + 4 + 2 * (size_t)iss::SLOW_QCAP) * 4;
+    return ((size_t)M.tile_words + mut_words + (size_t)M.subst_words + (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING) * 4;
 }
 
 int settle_timing(iss_ctx *ctx) {
@@ -512,8 +510,6 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
-    HIP_TRY(ctx, hipMalloc(&p, (size_t)ctx->max_main_grid * iss::SLOW_SPILL * sizeof(uint64_t)));
-    ctx->slow_ovf = static_cast<uint64_t *>(p);
     *out = ctx;
     return 0;
 }
@@ -530,7 +526,6 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     free_outputs(ctx);
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
-    if (ctx->slow_ovf) (void)hipFree(ctx->slow_ovf);
     if (ctx->d_amb) (void)hipFree(ctx->d_amb);
     if (ctx->d_pmut) (void)hipFree(ctx->d_pmut);
     if (ctx->d_ov_pairs) (void)hipFree(ctx->d_ov_pairs);
@@ -655,7 +650,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     M.GB = 6;
     if (const char *e = getenv("ISS_GUIDE_BITS")) M.GB = std::min(8, std::max(6, atoi(e)));
     else while (M.GB < 8 && more_rate(M.GB) > 0.004) ++M.GB;
-    {   // drain period of k_main's deferred queue: aim at <= 64 k entries per period and workgroup
+    if (getenv("ISS_DEBUG_MODEL")) {  // expected share of bases that leave the hot loop
         double err = 0;
         size_t rows = 0;
         for (int o = 0; o < 2; ++o)
@@ -669,13 +664,9 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                         prev = c;
                     }
                 }
-        const double rare = more_rate(M.GB) + err / (double)std::max<size_t>(rows, 1) + 2e-4;
-        if (getenv("ISS_DEBUG_MODEL"))
-            fprintf(stderr, "[model] per base: P(> 2 thresholds below in the guide bucket) %.5f (GB 6: %.5f, 7: %.5f, 8: %.5f), "
-                            "P(substitution test fires) %.5f, s_max %zu\n", more_rate(M.GB), more_rate(6), more_rate(7), more_rate(8),
-                    err / (double)std::max<size_t>(rows, 1), s_max);
-        const double per_iter = rare * 8.0 * iss::MAIN_THREADS;
-        ctx->slow_every = (int)std::max(2.0, std::min((double)iss::SLOW_EVERY_MAX, 65536.0 / std::max(per_iter, 1.0)));
+        fprintf(stderr, "[model] per base: P(> 2 thresholds below in the guide bucket) %.5f (GB 6: %.5f, 7: %.5f, 8: %.5f), "
+                        "P(substitution test fires) %.5f, s_max %zu\n", more_rate(M.GB), more_rate(6), more_rate(7), more_rate(8),
+                err / (double)std::max<size_t>(rows, 1), s_max);
     }
     const int gwords = (1 << M.GB) / 4;
     M.stride_w = (int32_t)(gwords + s_max);
@@ -703,9 +694,9 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     (void)fits(M.n_tiles, one_per_cu);
     M.n_tiles = (M.G + M.TG - 1) / M.TG;
     if (getenv("ISS_DEBUG_MODEL"))
-        fprintf(stderr, "[model] RL %d G %d NB %d GB %d stride_w %d GS %d TG %d n_tiles %d tile %.1f KB (k_main LDS %.1f KB) slow_every %d\n",
+        fprintf(stderr, "[model] RL %d G %d NB %d GB %d stride_w %d GS %d TG %d n_tiles %d tile %.1f KB (k_main LDS %.1f KB)\n",
                 M.RL, M.G, M.NB, M.GB, M.stride_w, M.GS, M.TG, M.n_tiles, M.tile_words * 4 / 1024.0,
-                main_lds_bytes(M) / 1024.0, ctx->slow_every);
+                main_lds_bytes(M) / 1024.0);
     std::vector<uint32_t> qrows((size_t)M.n_tiles * M.tile_words, 0);
     for (int tl = 0; tl < M.n_tiles; ++tl)
         for (int o = 0; o < 2; ++o)
@@ -961,8 +952,6 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         A.gc_bias = gc_bias ? 1 : 0;
         A.gc_thr = 8106479329266893ull;  // ceil(0.90 * 2^53), 0.90 being the f64 nearest to 0.9
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
-        A.slow_ovf = ctx->slow_ovf;
-        A.slow_every = ctx->slow_every;
         A.scan_every = ctx->scan_every;
         iss::PairDesc *desc = ctx->desc + row0;
         uint32_t *flags = ctx->flags + row0;
