@@ -106,6 +106,35 @@ def exponential(record_list):
 ABUNDANCE = {"lognormal": lognormal, "uniform": uniform, "exponential": exponential}
 
 
+def compress_file(path, block_bytes=32 << 20, threads=None):
+    """gzip `path` to `path + ".gz"` and remove it, like iss/util.py:255-268, but block-parallel: every block of the
+    file becomes one gzip member compressed on its own thread (zlib releases the GIL); concatenated members are
+    one valid gzip stream with the same content as the reference's single-member file."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    threads = threads or min(32, os.cpu_count() or 1)
+
+    def member(block):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31)  # wbits 31: gzip container
+        return c.compress(block) + c.flush()
+
+    with open(path, "rb") as fi, open(path + ".gz", "wb") as fo, ThreadPoolExecutor(threads) as pool:
+        pending = []
+        while True:
+            block = fi.read(block_bytes)
+            if block:
+                pending.append(pool.submit(member, block))
+            while pending and (not block or len(pending) >= 2 * threads):
+                fo.write(pending.pop(0).result())
+            if not block:
+                break
+        if os.path.getsize(path) == 0:
+            fo.write(member(b""))
+    os.remove(path)
+    return path + ".gz"
+
+
 def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias, rng, store_mutations,
             fragment):
     """One pool process == one GPU.  Records are re-read from the concatenated FASTA (the reference
@@ -172,11 +201,9 @@ def generate_reads(args):
     else:
         concatenate_rank_files(args.output, workers)  # raises if a worker had no chunk (util.py:233)
     os.remove(genome_file)
-    if args.compress:
+    if args.compress:  # util.compress (iss/util.py:255-268): <file>.gz next to the file, original removed
         for suffix in ("_R1.fastq", "_R2.fastq") + ((".vcf",) if args.store_mutations else ()):
-            with open(args.output + suffix, "rb") as fi, gzip.open(args.output + suffix + ".gz", "wb") as fo:
-                shutil.copyfileobj(fi, fo)
-            os.remove(args.output + suffix)
+            compress_file(args.output + suffix)
     logger.info("Read generation complete")
 
 

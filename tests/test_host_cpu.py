@@ -166,3 +166,21 @@ def test_oracle_vcf_rows_match_reference():
             qual = str(int(m["quality"])) if m["type"] == 0 else "."
             lines.append("\t".join([read_id, str(int(m["position"]) + 1), ".", ref, alt, qual, "", ""]) + "\n")
     assert "".join(lines).encode() == z["vcf"].tobytes()
+
+
+def test_compress_file_is_one_gzip_stream(tmp_path):
+    """--compress (iss/util.py:255-268): block-parallel gzip members must read back as the original bytes."""
+    import gzip
+
+    from insilicoseq_amd.app import compress_file
+
+    rng = np.random.RandomState(3)
+    for n in (0, 17, 3_000_000):
+        data = rng.randint(33, 74, size=n).astype(np.uint8).tobytes()
+        path = str(tmp_path / ("reads_%d.fastq" % n))
+        with open(path, "wb") as fh:
+            fh.write(data)
+        gz = compress_file(path, block_bytes=1 << 20, threads=3)
+        assert gz == path + ".gz" and not os.path.exists(path)
+        with gzip.open(gz, "rb") as fh:
+            assert fh.read() == data
