@@ -522,3 +522,43 @@ def test_device_fastq_equals_host_formatter(model, rid, cpu, first_i, counts, tm
     assert open(paths[0], "rb").read() == open(paths[2], "rb").read()
     assert open(paths[1], "rb").read() == open(paths[3], "rb").read()
     assert os.path.getsize(paths[0]) > 100 * sum(counts) // 4
+
+
+@pytest.mark.parametrize("model,n_genomes,pairs_total", [("novaseq", 5, 5_000_000), ("hiseq", 7, 6_250_000)])
+def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total):
+    """BASELINE.json's full sizes (configs[2]: 10 M NovaSeq reads over 5 x 5 Mbp; one rank's 6.25 M-pair share of
+    configs[3]: HiSeq, 5 Mbp genomes): the whole work list is generated on the GPU as bench.py does it, and --
+    every pair being a pure function of (seed, ordinal, genome) -- windows of consecutive ordinals spread over
+    every work item are recomputed by the CPU oracle and compared byte for byte, coordinates included."""
+    from insilicoseq_amd.engine import ReadEngine
+    from insilicoseq_amd.generator import lognormal_abundance
+    from oracle import oracle as O
+
+    dense = dense_model(model)
+    rng = np.random.RandomState(123)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genomes = [letters[rng.randint(0, 4, size=5_000_000)].tobytes().decode() for _ in range(n_genomes)]
+    ab = lognormal_abundance(list(range(n_genomes)), np.random.RandomState(123))
+    counts = [int(pairs_total * ab[k]) for k in range(n_genomes)]
+    orc = O.Oracle(dense)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gids = [eng.add_genome(g) for g in genomes]
+        eng.reserve(sum(counts))
+        row, ordinal, items = 0, 0, []
+        for gid, n in zip(gids, counts):
+            eng.generate(gid, n, first_ordinal=ordinal, seed=42, out_first_pair=row)
+            items.append((gid, n, row, ordinal))
+            row += n
+            ordinal += n
+        eng.synchronize()
+        pick = np.random.RandomState(7)
+        for k, (gid, n, row0, ord0) in enumerate(items):
+            for start in sorted(set([0, max(n - 64, 0)] + list(pick.randint(0, max(n - 64, 1), size=6)))):
+                w = min(64, n - start)
+                got = eng.download(row0 + start, w)
+                cg = eng.coords(row0 + start, w)
+                exp = orc.simulate(O.Rng().seed_philox(42), genomes[k], w, first_ordinal=ord0 + start, want_coords=True)
+                for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                    assert np.array_equal(got[key], exp[key]), (k, start, key)
+                assert np.array_equal(np.asarray(cg), exp["coords"]), (k, start)
