@@ -1264,16 +1264,19 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     {
         const char *force = getenv("ISS_MT_PATH");  // "walk": sequential walker only (testing aid)
         const bool allowed = !(force && !strcmp(force, "walk")) && !m.has_frag && !m.d_mut && ctx->mt_bounce_rate < 0.05 &&
-                             iss::mt_res_need_np(M.RL) <= 2048u && M.n_isize <= 4096;
+                             M.n_isize <= 4096;
         const size_t budget = 160 * 1024 - 256;
-        const uint32_t need = iss::mt_res_need_py(M.RL);
-        struct Cand { int pyv; bool rows; resolve_fn fn; };
-        const Cand cands[4] = {{8, true, iss::k_mt_resolve<8, 2, true>}, {4, true, iss::k_mt_resolve<4, 2, true>},
-                               {8, false, iss::k_mt_resolve<8, 2, false>}, {4, false, iss::k_mt_resolve<4, 2, false>}};
+        const uint32_t need_py = iss::mt_res_need_py(M.RL), need_np = iss::mt_res_need_np(M.RL);
+        struct Cand { int pyv, npv; bool rows; resolve_fn fn; };
+        const Cand cands[8] = {  // digit rows in LDS first, then the smallest rings that show a whole pair
+            {8, 2, true, iss::k_mt_resolve<8, 2, true>},   {4, 2, true, iss::k_mt_resolve<4, 2, true>},
+            {8, 4, true, iss::k_mt_resolve<8, 4, true>},   {4, 4, true, iss::k_mt_resolve<4, 4, true>},
+            {8, 2, false, iss::k_mt_resolve<8, 2, false>}, {4, 2, false, iss::k_mt_resolve<4, 2, false>},
+            {8, 4, false, iss::k_mt_resolve<8, 4, false>}, {4, 4, false, iss::k_mt_resolve<4, 4, false>}};
         for (const Cand &c : cands) {
             if (!allowed || resolve) break;
-            if (need > (uint32_t)c.pyv * 1024u) continue;
-            const size_t b = iss::mt_res_lds_bytes(M, c.pyv, 2, c.rows);
+            if (need_py > (uint32_t)c.pyv * 1024u || need_np > (uint32_t)c.npv * 1024u) continue;
+            const size_t b = iss::mt_res_lds_bytes(M, c.pyv, c.npv, c.rows);
             if (b > budget) continue;
             resolve = c.fn;
             resolve_lds = b;
@@ -1352,7 +1355,7 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         A.gc_thr = 8106479329266893ull;
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
         A.res = m.d_res;
-        A.use_rows = use_rows ? 1 : 0;
+        A.use_rows = use_rows && n > 64 ? 1 : 0;  // staging the rows (one wavefront, tens of KB) only pays for a real batch
         A.mut = m.d_mut;
         A.mut_cap = m.mut_cap;
         A.mut_base = m.mut_n;
@@ -1364,7 +1367,8 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         A.ov_frag = ov_frag;
         A.guard = getenv("ISS_MT_GUARD") ? atof(getenv("ISS_MT_GUARD")) : 1e-6;
         A.gauss = m.d_gauss;
-        hipLaunchKernelGGL(iss::k_mt_walk, dim3(1), dim3(64), lds_bytes, ctx->stream, M, dg, A, ctx->desc + row0);
+        hipLaunchKernelGGL(iss::k_mt_walk, dim3(1), dim3(64), A.use_rows ? lds_bytes : fixed_lds, ctx->stream, M, dg, A,
+                           ctx->desc + row0);
         HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipGetLastError());

@@ -43,14 +43,16 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// grid = 2 (stream 0: CPython random, stream 1: numpy), block = 256.
+// grid = 2 (stream 0: CPython random, stream 1: numpy), block = 320: four wavefronts produce words 0..622 (three
+// per lane), the fifth only word 623 -- its chain of old words is as long as the others' work, so it runs beside
+// them instead of behind one of them (measured: 1.08 s vs 1.31 s per 2.1e9 words with lane 169 doing both).
 // Every word of the next block is written in terms of the OLD block only, so a block costs one barrier:
 // with F(k) = twist(o[k], o[k+1]),
 //   n[k]       = o[k+397] ^ F(k)                               k < 227
 //   n[227 + j] = n[j] ^ F(227 + j) = o[j+397] ^ F(j) ^ F(227 + j)        j < 227
 //   n[454 + j] = n[227 + j] ^ F(454 + j)                                  j < 169
-//   n[623]     = n[396] ^ twist(o[623], n[0])    (lane 169 holds n[396]; n[0] costs it one more twist)
-constexpr int FILL_THREADS = 256;
+//   n[623]     = n[396] ^ twist(o[623], n[0])
+constexpr int FILL_THREADS = 320;
 __global__ __launch_bounds__(FILL_THREADS) void k_mt_fill(MtState *states, uint32_t *out0, uint32_t *out1, uint32_t blocks0,
                                                           uint32_t blocks1) {
     __shared__ uint32_t buf[2][624];
@@ -76,12 +78,14 @@ __global__ __launch_bounds__(FILL_THREADS) void k_mt_fill(MtState *states, uint3
                 const uint32_t e = c ^ mt_twist(o[454 + tid], o[455 + tid]);         // n[454 + tid]
                 n[454 + tid] = e;
                 ob[454 + tid] = mt_temper(e);
-            } else if (tid == 169) {
-                const uint32_t n0 = o[397] ^ mt_twist(o[0], o[1]);
-                const uint32_t e = c ^ mt_twist(o[623], n0);                          // n[623]
-                n[623] = e;
-                ob[623] = mt_temper(e);
             }
+        } else if (tid == 256) {
+            const uint32_t n0 = o[397] ^ mt_twist(o[0], o[1]);
+            const uint32_t n169 = o[566] ^ mt_twist(o[169], o[170]);
+            const uint32_t n396 = n169 ^ mt_twist(o[396], o[397]);
+            const uint32_t e = n396 ^ mt_twist(o[623], n0);
+            n[623] = e;
+            ob[623] = mt_temper(e);
         }
         cur ^= 1;
         lds_barrier();
@@ -460,9 +464,10 @@ struct MtResolveArgs {
     MtPairRec *rec;
 };
 
-constexpr int RES_THREADS = 256;
-__host__ __device__ inline uint32_t mt_res_need_py(int RL) { return 64u + 10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL; }  // per mate
-__host__ __device__ inline uint32_t mt_res_need_np(int RL) { return 8u + 4u * (uint32_t)RL; }
+constexpr int RES_THREADS = 512;  // two groups of four wavefronts: the mates of a pair are worked on side by side
+// the rings must show a whole pair at once (both mates are read concurrently)
+__host__ __device__ inline uint32_t mt_res_need_py(int RL) { return 128u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
+__host__ __device__ inline uint32_t mt_res_need_np(int RL) { return 16u + 8u * (uint32_t)RL; }
 __host__ __device__ inline size_t mt_res_lds_bytes(const DevModel &M, int pyv, int npv, bool rows_lds) {
     size_t b = (size_t)(2 * pyv + 2 * npv) * 1024 * 4 + 2 * 16 * 4;  // rings + their 16-word mirrors
     b += (size_t)(64 + 8 + M.n_isize) * 8;                           // mut_thr, bin_thr, isize_thr
@@ -475,7 +480,10 @@ template <int PYV, int NPV, bool ROWS_LDS>
 __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenome g, MtResolveArgs A, PairDesc *desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t HPY = PYV * 1024u, WPY = 2u * HPY, HNP = NPV * 1024u, WNP = 2u * HNP;
+    constexpr uint32_t CHUNK = RES_THREADS * 4u;  // words one load / store instruction of the workgroup moves
+    static_assert(HPY % CHUNK == 0 && HNP % CHUNK == 0, "ring halves are whole chunks");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, gw = wave & 3, tid_g = tid & 255;  // mate group, wavefront and lane index inside it
     const int RL = M.RL, nq = M.n_q;
     // ring[W .. W + 16) mirrors ring[0 .. 16): a run of <= 16 words starting anywhere needs no wrap-around
     uint32_t *ring_py = lds;
@@ -497,31 +505,32 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
         for (int i = tid; i < 2 * M.NB * RL * M.mt_row_w; i += RES_THREADS) dst[i] = src[i];
     }
     // ---- stream rings: halves kpy, kpy + 1 are in the ring, half kpy + 2 is on its way in registers
-    uint4 pv[PYV], nv[NPV];
+    constexpr int PYL = (int)(HPY / CHUNK), NPL = (int)(HNP / CHUNK);
+    uint4 pv[PYL], nv[NPL];
     auto fetch_py = [&](uint32_t half) {
 #pragma unroll
-        for (int v = 0; v < PYV; ++v) {
-            const uint32_t idx = half * HPY + (uint32_t)v * 1024u + (uint32_t)tid * 4u;
+        for (int v = 0; v < PYL; ++v) {
+            const uint32_t idx = half * HPY + (uint32_t)v * CHUNK + (uint32_t)tid * 4u;
             pv[v] = idx + 4u <= A.py_cap ? *reinterpret_cast<const uint4 *>(A.py_base + idx) : make_uint4(0, 0, 0, 0);
         }
     };
     auto fetch_np = [&](uint32_t half) {
 #pragma unroll
-        for (int v = 0; v < NPV; ++v) {
-            const uint32_t idx = half * HNP + (uint32_t)v * 1024u + (uint32_t)tid * 4u;
+        for (int v = 0; v < NPL; ++v) {
+            const uint32_t idx = half * HNP + (uint32_t)v * CHUNK + (uint32_t)tid * 4u;
             nv[v] = idx + 4u <= A.np_cap ? *reinterpret_cast<const uint4 *>(A.np_base + idx) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_py = [&](uint32_t half) {
 #pragma unroll
-        for (int v = 0; v < PYV; ++v)
-            *reinterpret_cast<uint4 *>(ring_py + (half & 1u) * HPY + (uint32_t)v * 1024u + (uint32_t)tid * 4u) = pv[v];
+        for (int v = 0; v < PYL; ++v)
+            *reinterpret_cast<uint4 *>(ring_py + (half & 1u) * HPY + (uint32_t)v * CHUNK + (uint32_t)tid * 4u) = pv[v];
         if (!(half & 1u) && tid < 4) *reinterpret_cast<uint4 *>(ring_py + WPY + (uint32_t)tid * 4u) = pv[0];
     };
     auto store_np = [&](uint32_t half) {
 #pragma unroll
-        for (int v = 0; v < NPV; ++v)
-            *reinterpret_cast<uint4 *>(ring_np + (half & 1u) * HNP + (uint32_t)v * 1024u + (uint32_t)tid * 4u) = nv[v];
+        for (int v = 0; v < NPL; ++v)
+            *reinterpret_cast<uint4 *>(ring_np + (half & 1u) * HNP + (uint32_t)v * CHUNK + (uint32_t)tid * 4u) = nv[v];
         if (!(half & 1u) && tid < 4) *reinterpret_cast<uint4 *>(ring_np + WNP + (uint32_t)tid * 4u) = nv[0];
     };
     uint32_t opy = A.py_off, onp = A.np_off;
@@ -543,16 +552,17 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
 
     uint32_t slots = 0;  // bin -> slot, 2 bits each, [o][bin]
     for (int k = 0; k < 8; ++k) slots |= ((uint32_t)M.bin_slot[k] & 3u) << (2 * k);
-    const bool spare_wave = RL <= RES_THREADS - 64;  // the last wavefront has no position: it checks the indel draws
+    const bool spare_wave = RL <= 192;  // a group's last wavefront has no position: it checks the indel draws
+    const uint32_t C_MATE = 10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL;  // py words of a plain mate
 
-    // one mate on the fast path: returns substitution events, sets hit when the mate is not plain
-    auto mate_fast = [&](int o, uint32_t opy_m, uint32_t onp_m, int &slot_out, bool &hit_out) -> uint32_t {
+    // One mate on the fast path, worked on by the four wavefronts of group o: every wavefront leaves
+    // (substitution events | bin slot << 16 | not-plain << 31) of its lanes in the scratch slot.
+    auto mate_body = [&](int o, uint32_t opy_m, uint32_t onp_m) {
         const uint64_t mb = mk53(npr(onp_m), npr(onp_m + 1));
         const uint64_t *bt = bin_thr + 4 * o;  // np.random.choice: #(cdf <= u), kde.py:74
         int bin = (bt[0] <= mb ? 1 : 0) + (bt[1] <= mb ? 1 : 0) + (bt[2] <= mb ? 1 : 0) + (bt[3] <= mb ? 1 : 0);
         bin = bin > 3 ? 3 : bin;
         const int slot = (int)((slots >> (2 * (o * 4 + bin))) & 3u);
-        slot_out = slot;
         const uint32_t opy_err = opy_m + 10u * (uint32_t)(RL - 1);
         uint32_t nev = 0;
         bool cand = false;
@@ -562,9 +572,9 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
 #pragma unroll
             for (int x = 0; x < 5; ++x) cand |= (w[2 * x] >> 5) <= lm[x];
         };
-        if (spare_wave && wave == RES_THREADS / 64 - 1)
+        if (spare_wave && gw == 3)
             for (int p = lane; p < RL - 1; p += 64) indel_step(p);
-        for (int p = tid; p < RL; p += RES_THREADS) {
+        for (int p = tid_g; p < RL; p += 256) {
             const uint32_t *wq = ring_np + ((onp_m + 2u + 2u * (uint32_t)p) & (WNP - 1u));
             const uint32_t *we = ring_py + ((opy_err + 2u * (uint32_t)p) & (WPY - 1u));
             const uint64_t mq = mk53(wq[0], wq[1]);
@@ -589,7 +599,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
             } else {
                 int c1 = 0;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) {  // keys 6, 13, ... (n_q <= 63); indices past n_q read the 0xffff padding
+                for (int j = 0; j < 9; ++j) {  // keys 6, 13, ... (n_q <= 60); indices past n_q read the 0xffff padding
                     const int k = min(6 + 7 * j, nq);
                     const uint32_t dgt = row[k];
                     c1 += dgt < h ? 1 : 0;
@@ -613,18 +623,20 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
             if (!spare_wave && p < RL - 1) indel_step(p);
         }
         const bool hit = __ballot(cand) != 0ull;
-        if (lane == 0) scratch[sl * 8 + wave] = nev | (hit ? 0x80000000u : 0u);
-        lds_barrier();
-        uint32_t tot = 0, any_hit = 0;
+        if (lane == 0) scratch[sl * 8 + wave] = nev | ((uint32_t)slot << 16) | (hit ? 0x80000000u : 0u);
+    };
+    // after the barrier: what group o's four wavefronts left (events summed, slot, any not-plain)
+    auto mate_result = [&](int o, uint32_t &nev, uint32_t &slot, bool &hit) {
+        nev = 0;
+        uint32_t any = 0, v = 0;
 #pragma unroll
-        for (int w = 0; w < RES_THREADS / 64; ++w) {
-            const uint32_t v = scratch[sl * 8 + w];
-            tot += v & 0xffffu;
-            any_hit |= v >> 31;
+        for (int w = 0; w < 4; ++w) {
+            v = scratch[sl * 8 + 4 * o + w];
+            nev += v & 0xffffu;
+            any |= v >> 31;
         }
-        sl ^= 1u;  // the next barrier uses the other slot (a fast wave may write before a slow one has read)
-        hit_out = any_hit != 0u;
-        return tot;
+        slot = (v >> 16) & 3u;
+        hit = any != 0u;
     };
     while (i < A.n_pairs) {
         if (opy + py_need > A.py_fill || onp + np_need > A.np_fill) { starved = 1; break; }
@@ -653,18 +665,18 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
         const int64_t frag = isz + 2 * (int64_t)RL;
         int64_t fs = 0;
         bool odd = false;  // this pair goes to the sequential walker
-        auto randbelow1 = [&](uint32_t n) -> uint32_t {  // one round of 64 candidate words
+        auto randbelow_at = [&](uint32_t &off, uint32_t n) -> uint32_t {  // one round of 64 candidate words from py[off ..]
             const int k = 32 - __clz(n);
-            const uint32_t r = pyr(opy + (uint32_t)lane) >> (32 - k);
+            const uint32_t r = pyr(off + (uint32_t)lane) >> (32 - k);
             const unsigned long long ok = __ballot(r < n);
             if (!ok) { odd = true; return 0u; }
             const int t = __ffsll(ok) - 1;
-            opy += (uint32_t)t + 1u;
+            off += (uint32_t)t + 1u;
             return (uint32_t)__shfl((int)r, t);
         };
         if (A.sequence_type == 0) {  // generator.py:134-135, 142-144
             const int64_t width = L - frag;
-            fs = randbelow1((uint32_t)(width > 0 ? width : L - RL));
+            fs = randbelow_at(opy, (uint32_t)(width > 0 ? width : L - RL));
         }
         const int64_t fe = fs + RL;
         auto exceptions_in = [&](int64_t lo, int64_t hi) -> bool {  // any letter outside ACGT in [lo, hi)
@@ -679,46 +691,48 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
             }
             return __ballot(any) != 0ull;
         };
+        // the py words of the second mate do not depend on the first mate's outcome: its start, incl. the
+        // reverse-end fallback randrange drawn between the mates, is known now; only its np offset is not
+        uint32_t opy1 = opy + C_MATE;
+        int64_t rs, re;
+        if (A.sequence_type == 0) { rs = fe + isz; re = rs + RL; }  // generator.py:164-177
+        else { rs = L - RL; re = L; }
+        if (!odd && re > L) { re = RL + (int64_t)randbelow_at(opy1, (uint32_t)(L - RL)); rs = re - RL; }
+        if (!odd) odd = exceptions_in(fs, fe) || exceptions_in(rs, re);
         PairDesc d;
         d.fs = (int32_t)fs;
+        d.re = (int32_t)re;
         d.isz = (int32_t)isz;
         d.meta = 0;
         MtPairRec rc;
-        int64_t re = 0;
-        if (!odd) odd = exceptions_in(fs, fe);
         if (!odd) {
-            int slot;
-            bool hit;
-            const uint32_t nev = mate_fast(0, opy, onp, slot, hit);
-            odd = hit;
-            d.meta |= (uint32_t)slot;
+            // both mates at once: group 0 the first, group 1 the second ASSUMING the first has no substitution event
+            const uint32_t onp1_guess = onp + 2u + 2u * (uint32_t)RL;
+            if (grp == 0) mate_body(0, opy, onp);
+            else mate_body(1, opy1, onp1_guess);
+            lds_barrier();
+            uint32_t nev0, slot0, nev1, slot1;
+            bool hit0, hit1;
+            mate_result(0, nev0, slot0, hit0);
+            mate_result(1, nev1, slot1, hit1);
+            sl ^= 1u;  // the next barrier uses the other slot (a fast wave may write before a slow one has read)
+            const uint32_t onp1 = onp1_guess + 2u * nev0;
+            if (!hit0 && nev0 != 0u) {  // the guess was wrong: the second mate again, from its true np offset
+                if (grp == 1) mate_body(1, opy1, onp1);
+                lds_barrier();
+                mate_result(1, nev1, slot1, hit1);
+                sl ^= 1u;
+            }
+            odd = hit0 || hit1;
+            d.meta = slot0 | (slot1 << 2);
             rc.opy_err[0] = opy + 10u * (uint32_t)(RL - 1);
             rc.onp_bin[0] = onp;
-            opy += 10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL;
-            onp += 2u + 2u * (uint32_t)RL + 2u * nev;
-        }
-        if (!odd) {
-            if (opy >= (kpy + 1) * HPY) { store_py(kpy + 2); ++kpy; lds_barrier(); fetch_py(kpy + 2); }
-            if (onp >= (knp + 1) * HNP) { store_np(knp + 2); ++knp; lds_barrier(); fetch_np(knp + 2); }
-            int64_t rs;
-            if (A.sequence_type == 0) { rs = fe + isz; re = rs + RL; }  // generator.py:164-177
-            else { rs = L - RL; re = L; }
-            if (re > L) { re = RL + (int64_t)randbelow1((uint32_t)(L - RL)); rs = re - RL; }
-            if (!odd) odd = exceptions_in(rs, re);
-        }
-        if (!odd) {
-            int slot;
-            bool hit;
-            const uint32_t nev = mate_fast(1, opy, onp, slot, hit);
-            odd = hit;
-            d.meta |= (uint32_t)slot << 2;
-            rc.opy_err[1] = opy + 10u * (uint32_t)(RL - 1);
-            rc.onp_bin[1] = onp;
-            opy += 10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL;
-            onp += 2u + 2u * (uint32_t)RL + 2u * nev;
+            rc.opy_err[1] = opy1 + 10u * (uint32_t)(RL - 1);
+            rc.onp_bin[1] = onp1;
+            opy = opy1 + C_MATE;
+            onp = onp1 + 2u + 2u * (uint32_t)RL + 2u * nev1;
         }
         if (odd) { opy = opy0; onp = onp0; need_generic = 1; break; }
-        d.re = (int32_t)re;
         bool keep = true;
         if (A.gc_bias) {  // generator.py:82-92
             keep = mk53(npr(onp), npr(onp + 1)) < A.gc_thr;
