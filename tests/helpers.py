@@ -43,3 +43,35 @@ def mixed_genome(seed, n):
     ambl = np.frombuffer(b"nrywsmkhbvd", dtype=np.uint8)[rng.randint(0, 11, n)]
     out = np.where(x < 0.8, plain, np.where(x < 0.92, lower, np.where(x < 0.97, amb, ambl)))
     return out.astype(np.uint8).tobytes().decode()
+
+
+def synthetic_model(read_length, n_q, n_isize, seed, indel=(1e-3, 2e-3), nonempty=((1, 1, 1, 1), (1, 0, 1, 1))):
+    """A random but valid dense model at arbitrary sizes (limits of the engine: read_length 1024, 60 phred entries,
+    8000 insert sizes).  phred_thr follows util.phred_to_prob like the real profiles."""
+    rng = np.random.RandomState(seed)
+    RL = read_length
+
+    def cdf(shape):
+        w = rng.gamma(0.3, size=shape) + 1e-12
+        c = np.cumsum(w, axis=-1)
+        c /= c[..., -1:]
+        c[..., -1] = 1.0
+        return c
+
+    isize = cdf((n_isize,))
+    bin_w = rng.random_sample((2, 4)) * np.asarray(nonempty, dtype=np.float64) + 1e-9 * np.asarray(nonempty)
+    bin_cdf = np.cumsum(bin_w, axis=1)
+    bin_cdf /= bin_cdf[:, -1:]
+    qcdf = cdf((2, 4, RL, n_q))
+    subst_cdf = cdf((2, RL, 4, 3))
+    alts = {0: b"TCG", 1: b"ACG", 2: b"ATG", 3: b"ATC"}  # base order A, T, C, G
+    subst_alt = np.zeros((2, RL, 4, 3), dtype=np.uint8)
+    for b in range(4):
+        subst_alt[:, :, b, :] = np.frombuffer(alts[b], dtype=np.uint8)
+    ins = np.full((2, RL, 4), indel[0]) * rng.random_sample((2, RL, 4))
+    dele = np.full((2, RL, 4), indel[1]) * rng.random_sample((2, RL, 4))
+    ins_letter = np.zeros((2, RL, 4), dtype=np.uint8)
+    ins_letter[:] = np.frombuffer(b"ATCG", dtype=np.uint8)
+    phred_thr = 1.0 - 10.0 ** (-np.arange(n_q + 1) / 10.0)
+    return DenseModel(RL, isize, bin_cdf, np.asarray(nonempty, dtype=np.uint8), qcdf, subst_cdf, subst_alt, ins, ins_letter,
+                      dele, phred_thr)

@@ -562,3 +562,31 @@ def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total):
                 for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
                     assert np.array_equal(got[key], exp[key]), (k, start, key)
                 assert np.array_equal(np.asarray(cg), exp["coords"]), (k, start)
+
+
+@pytest.mark.parametrize("RL,n_q,n_isize,n", [(1024, 60, 8000, 300), (997, 41, 1000, 300), (2, 1, 1, 500), (5, 3, 7, 500)])
+def test_engine_limits_match_oracle(RL, n_q, n_isize, n):
+    """The engine's size limits (read_length 1024, 60 phred entries, 8000 insert sizes) and its smallest shapes,
+    random valid tables with indels: Philox path and MT walker against the oracle."""
+    from helpers import synthetic_model
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    dense = synthetic_model(RL, n_q, n_isize, seed=RL + n_q)
+    genome = mixed_genome(RL, max(6 * RL + n_isize, 64))
+    orc = O.Oracle(dense)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        eng.generate(gid, n, first_ordinal=3, seed=9)
+        eng.synchronize()
+        got = eng.download(0, n)
+        exp = orc.simulate(O.Rng().seed_philox(9), genome, n, first_ordinal=3)
+        for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(got[key], exp[key]), ("philox", key)
+        eng.seed_mt(1234)
+        assert eng.generate_mt(gid, n) == n
+        got = eng.download(0, n)
+        exp = orc.simulate(O.Rng().seed_mt(1234), genome, n)
+        for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(got[key], exp[key]), ("mt", key)
