@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ISS_ABI_VERSION 1
+#define ISS_ABI_VERSION 2
 
 #define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
 #define ISS_E_HIP (-2)         /* HIP runtime failure (message has the hip error)  */
@@ -73,6 +73,15 @@ typedef struct {
     const uint8_t *ins_letter;   /* [2][RL][4]       ASCII, in the dict's iteration order              */
     const uint64_t *del_thr;     /* [2][RL][4]       ceil : delete iff m < thr       __init__.py:209   */
     const uint64_t *mut_thr;     /* [n_q+1]          floor(phred_to_prob(q)*2^53): error iff m > thr   */
+    /* BasicErrorModel (iss/error_models/basic.py:18-63), quality_mode 1: constant insert size, phred scores
+     * int(round(-10 * log10(1 - min(np.random.normal(basic_mean, basic_sd), basic_cap)))) per position; the
+     * insert-size / bin / quality tables above are then unused (n_q + 1 must cover the phreds: 41 -> 0..41).
+     * Runs in the reference-compatible mode (iss_generate_mt) only; iss_generate refuses such a model. */
+    int32_t quality_mode;        /* 0: KDE tables (kde.py), 1: basic                                     */
+    int32_t basic_insert_size;   /* basic.py:21 (200)                                                    */
+    double basic_mean;           /* util.phred_to_prob(30), basic.py:24, :52                             */
+    double basic_sd;             /* 0.01, basic.py:52                                                     */
+    double basic_cap;            /* 0.9999, basic.py:52                                                   */
 } iss_model_tables;
 
 int iss_model_upload(iss_ctx *ctx, const iss_model_tables *tables);

@@ -40,6 +40,8 @@ class ModelTables(C.Structure):
         ("isize_thr", C.c_void_p), ("bin_thr", C.c_void_p), ("bin_nonempty", C.c_void_p), ("q_thr", C.c_void_p),
         ("subst_thr", C.c_void_p), ("subst_alt", C.c_void_p), ("ins_thr", C.c_void_p), ("ins_letter", C.c_void_p),
         ("del_thr", C.c_void_p), ("mut_thr", C.c_void_p),
+        ("quality_mode", C.c_int32), ("basic_insert_size", C.c_int32), ("basic_mean", C.c_double),
+        ("basic_sd", C.c_double), ("basic_cap", C.c_double),
     ]
 
 

@@ -23,7 +23,7 @@ import numpy as np
 
 from .distributed import VCF_HEADER, concatenate_rank_files, temp_prefix
 from .generator import generate_work_divider, parse_fasta, worker_iterator
-from .model import KDErrorModel
+from .model import BasicErrorModel, KDErrorModel
 
 PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 # names of iss/generator.py:377-387 -> dense files converted from the reference's profiles
@@ -43,8 +43,8 @@ def convert_n_reads(unit):
 def load_error_model(mode, seed, model, fragment_length, fragment_length_sd, store_mutations, rng="philox"):
     """iss/generator.py:359-421 for what the device path covers (kde)."""
     logger = logging.getLogger(__name__)
-    if mode != "kde":
-        logger.error("--mode %s is not available on the GPU path (kde only)" % mode)
+    if mode == "perfect":  # (the reference's PerfectErrorModel fails at its first error draw: SURVEY.md Appendix A-8)
+        logger.error("--mode perfect is not available on the GPU path")
         sys.exit(1)
     if fragment_length is not None and fragment_length_sd is not None:
         logger.info("Using custom fragment length %s and default fragment length sd %s" % (fragment_length,
@@ -52,12 +52,16 @@ def load_error_model(mode, seed, model, fragment_length, fragment_length_sd, sto
     elif bool(fragment_length) ^ bool(fragment_length_sd):  # generator.py:393-395
         logger.error("fragment_length and fragment_length_sd must be specified together")
         sys.exit(1)
-    if model is None:
-        logger.error("--model is required in --mode kde")
-        sys.exit(1)
     if seed:  # generator.py:397-400 (seed 0 leaves the parent unseeded)
         random.seed(seed)
         np.random.seed(seed)
+    if mode == "basic":  # generator.py:412-416
+        if model is not None:
+            logger.warning("--model %s will be ignored in --mode %s" % (model, mode))
+        return BasicErrorModel(fragment_length, fragment_length_sd, store_mutations)
+    if model is None:
+        logger.error("--model is required in --mode kde")
+        sys.exit(1)
     if model.lower() in PRECOMPUTED:
         npz = os.path.join(PROFILES, PRECOMPUTED[model.lower()] + ".dense.npz")
     else:
@@ -141,7 +145,10 @@ def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_ty
     pickles them; same content)."""
     logging.basicConfig(level=logging.WARNING)
     records = {r.id: r for r in parse_fasta(genome_file)}
-    model = KDErrorModel(npz, fragment[0], fragment[1], store_mutations)
+    if npz is None:  # --mode basic
+        model = BasicErrorModel(fragment[0], fragment[1], store_mutations)
+    else:
+        model = KDErrorModel(npz, fragment[0], fragment[1], store_mutations)
     work = [(records[rid], n, "default") for rid, n in work_spec]
     worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device, rng=rng)
 
@@ -150,6 +157,9 @@ def generate_reads(args):
     logger = logging.getLogger(__name__)
     error_model = load_error_model(args.mode, args.seed, args.model, args.fragment_length, args.fragment_length_sd,
                                    args.store_mutations, args.rng)
+    if args.mode == "basic" and args.rng != "mt":
+        logger.info("--mode basic runs in the reference-compatible RNG mode (--rng mt)")
+        args.rng = "mt"
     if not args.genomes:
         logger.error("One of --genomes/-g is required")
         sys.exit(1)

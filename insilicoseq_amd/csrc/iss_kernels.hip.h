@@ -113,7 +113,10 @@ struct DevModel {
     // reference-compatible MT mode, k_mt_resolve (iss_mt_compat.hip.h)
     int32_t mt_row_w;             // 32-bit words per row of mt_rows (odd)
     const uint16_t *mt_rows;      // [2][NB][RL] rows of n_q leading digits min(q_thr >> 37, 0xffff) (no merging: index == phred)
-    const uint32_t *mt_lim;       // [2][RL][5] thr >> 26 of the 4 insertion thresholds and the largest deletion threshold
+    const uint32_t *mt_lim;       // [2][RL][5] thr >> 26 of the 4 insertion thresholds and the largest deletion threshold    // BasicErrorModel (iss/error_models/basic.py), reference-compatible mode only
+    int32_t quality_mode;         // 0 KDE tables; 1 basic: phred = round(-10 log10(1 - min(N(basic_mean, basic_sd), basic_cap)))
+    int32_t basic_insert_size;    // basic.py:21, :56-63 (no draw)
+    double basic_mean, basic_sd, basic_cap;
 };
 
 struct DevGenome {

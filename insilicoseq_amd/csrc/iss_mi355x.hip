@@ -137,6 +137,7 @@ struct iss_ctx {
         iss::MutRecord *d_mut = nullptr;  // --store_mutations rows of the last iss_generate_mt call
         int64_t mut_cap = 0, mut_n = 0;
         hipEvent_t ev_main = nullptr, ev_fill = nullptr;  // ordering between ctx->stream and the fill stream
+        iss::MtPhredAmb *d_amb = nullptr;  // BasicErrorModel: [0, CAP) phreds for the host, [CAP, 2 CAP) its answers
         iss::MtPairRec *d_rec = nullptr;  // k_mt_resolve -> k_mt_emit: stream offsets of one launch's pairs
         int64_t n_resolved = 0, n_walked = 0;  // pairs by path (statistics, iss_mt_path_counts)
     } mt;
@@ -196,6 +197,8 @@ void free_mt(iss_ctx *ctx) {
     if (ctx->mt.d_gauss) (void)hipFree(ctx->mt.d_gauss);
     if (ctx->mt.d_rec) (void)hipFree(ctx->mt.d_rec);
     ctx->mt.d_rec = nullptr;
+    if (ctx->mt.d_amb) (void)hipFree(ctx->mt.d_amb);
+    ctx->mt.d_amb = nullptr;
     if (ctx->mt.ev_main) (void)hipEventDestroy(ctx->mt.ev_main);
     if (ctx->mt.ev_fill) (void)hipEventDestroy(ctx->mt.ev_fill);
     ctx->mt.ev_main = ctx->mt.ev_fill = nullptr;
@@ -264,6 +267,25 @@ int mt_fill_async(iss_ctx *ctx, uint32_t *const dst[2], const uint32_t blocks[2]
 int mt_fill_join(iss_ctx *ctx) {
     if (ctx->mt.ev_fill) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->mt.ev_fill, 0));
     return 0;
+}
+
+// BasicErrorModel phred of one gaussian exactly as the reference computes it (libm, no contraction):
+// legacy_gauss value f*x2 (fresh) / f*x1 (cached), loc + scale*g, min(q, cap), int(round(-10*log10(1 - p))).
+int host_basic_phred(double x1v, double x2v, bool cached, double loc, double scale, double cap) {
+    volatile double x1 = x1v, x2 = x2v;
+    volatile double r2 = x1 * x1;
+    volatile double t2 = x2 * x2;
+    r2 = r2 + t2;
+    volatile double f = -2.0 * log(r2);
+    f = f / r2;
+    f = sqrt(f);
+    volatile double gval = cached ? f * x1 : f * x2;
+    volatile double sc = scale * gval;
+    volatile double p = loc + sc;
+    if (p > cap) p = cap;
+    volatile double y = 1.0 - p;
+    volatile double x = -10.0 * log10(y);
+    return (int)nearbyint(x);  // round-half-even, like Python's round() on a float
 }
 
 // make at least `want[s]` unconsumed words available in stream s (capacity permitting)
@@ -580,6 +602,12 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     iss::DevModel &M = ctx->M;
     M = iss::DevModel{};
     M.RL = RL; M.n_isize = t->n_isize; M.n_q = nq;
+    if (t->quality_mode != 0 && t->quality_mode != 1) return fail(ctx, ISS_E_INVALID, "quality_mode must be 0 (kde) or 1 (basic)");
+    if (t->quality_mode == 1 && (nq < 41 || !(t->basic_sd >= 0.0) || !(t->basic_cap < 1.0) || t->basic_insert_size < 0))
+        return fail(ctx, ISS_E_INVALID, "basic model: needs phred thresholds 0..41, sd >= 0, cap < 1, insert size >= 0");
+    M.quality_mode = t->quality_mode;
+    M.basic_insert_size = t->basic_insert_size;
+    M.basic_mean = t->basic_mean; M.basic_sd = t->basic_sd; M.basic_cap = t->basic_cap;
     M.G = (RL + 3) / 4; M.pitch = M.G * 4;
     // ---- compressed quality rows for k_main: per (orientation, bin slot, position) the distinct
     // 16-bit leading digits of the thresholds, packed (t16 << 8 | #thresholds below), + a 64-byte
@@ -928,6 +956,8 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
     const Genome &G = ctx->genomes[genome_id];
     const iss::DevModel &M = ctx->M;
+    if (M.quality_mode == 1)
+        return fail(ctx, ISS_E_INVALID, "BasicErrorModel runs in the reference-compatible mode only (iss_generate_mt / rng=\"mt\")");
     if (!(M.RL < G.L)) return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
     if (n_pairs == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1239,22 +1269,25 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     const int64_t CH = 8192;
-    const size_t py_need = iss::mt_py_need(M.RL), np_need = iss::mt_np_need(M.RL);
+    const bool basic = M.quality_mode == 1;
+    const size_t py_need = iss::mt_py_need(M.RL), np_need = iss::mt_np_need(M.RL, basic);
     { int rc_ = mt_reserve(ctx, 3 * ((size_t)(CH + 1) * py_need + 1248), 3 * ((size_t)(CH + 1) * np_need + 1248)); if (rc_) return rc_; }
     auto &m = ctx->mt;
     if (!(M.RL < G.L)) {
         // the reference draws the insert size BEFORE its assertion fails (generator.py:121-126, 130)
         if (m.has_frag)
             return fail(ctx, ISS_E_INVALID, "short record with a custom fragment length: stream alignment not supported");
-        const size_t want[2] = {0, 2};
-        { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
-        m.used[1] += 2;
+        if (!basic) {  // (BasicErrorModel.random_insert_size is a constant: nothing is drawn)
+            const size_t want[2] = {0, 2};
+            { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
+            m.used[1] += 2;
+        }
         return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
     }
     if (n_pairs == 0) return 0;
     const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
     const size_t fixed_lds = iss::mt_walk_fixed_lds_bytes(M.RL);
-    const bool use_rows = M.n_tiles == 1 && (size_t)M.tile_words * 4 + fixed_lds <= 150 * 1024;
+    const bool use_rows = !basic && M.n_tiles == 1 && (size_t)M.tile_words * 4 + fixed_lds <= 150 * 1024;
     const size_t lds_bytes = fixed_lds + (use_rows ? (size_t)M.tile_words * 4 : 0);
     // Resolver path (k_mt_resolve + k_mt_emit) for plain runs; the sequential walker for custom fragment
     // lengths, --store_mutations, indel-heavy models, and for the single pairs the resolver hands back.
@@ -1264,7 +1297,7 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     {
         const char *force = getenv("ISS_MT_PATH");  // "walk": sequential walker only (testing aid)
         const bool allowed = !(force && !strcmp(force, "walk")) && !m.has_frag && !m.d_mut && ctx->mt_bounce_rate < 0.05 &&
-                             M.n_isize <= 4096;
+                             M.n_isize <= 4096 && !basic;
         const size_t budget = 160 * 1024 - 256;
         const uint32_t need_py = iss::mt_res_need_py(M.RL), need_np = iss::mt_res_need_np(M.RL);
         struct Cand { int pyv, npv; bool rows; resolve_fn fn; };
@@ -1291,6 +1324,12 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
             }
         }
     }
+    if (basic && !m.d_amb) {  // phreds the host has to round, and its answers
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, 2 * iss::MT_AMB_CAP * sizeof(iss::MtPhredAmb)));
+        m.d_amb = static_cast<iss::MtPhredAmb *>(p);
+    }
+    std::vector<iss::MtPhredAmb> ovq;  // answers for the pair that restarts
     int64_t done = 0;
     m.mut_n = 0;
     bool ov_valid = false, walk_one = false;
@@ -1366,7 +1405,14 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         A.ov_valid = ov_valid ? 1 : 0;
         A.ov_frag = ov_frag;
         A.guard = getenv("ISS_MT_GUARD") ? atof(getenv("ISS_MT_GUARD")) : 1e-6;
+        if (basic && A.guard > 0.45) A.guard = 0.45;  // (a test aid: > 0.5 would make every phred "ambiguous" twice over)
         A.gauss = m.d_gauss;
+        A.amb = m.d_amb;
+        A.ovq = m.d_amb ? m.d_amb + iss::MT_AMB_CAP : nullptr;
+        A.n_ovq = (int32_t)ovq.size();
+        if (!ovq.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(m.d_amb + iss::MT_AMB_CAP, ovq.data(), ovq.size() * sizeof(iss::MtPhredAmb),
+                                        hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(iss::k_mt_walk, dim3(1), dim3(64), A.use_rows ? lds_bytes : fixed_lds, ctx->stream, M, dg, A,
                            ctx->desc + row0);
         HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
@@ -1378,6 +1424,25 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         done += res.n_done;
         m.n_walked += res.n_done;
         m.mut_n += res.n_mut;
+        // host answers (phreds, fragment length) belong to the attempt that started the launch: they stay only if the
+        // walk stopped again at that very attempt (gc_bias rejections move on to a new attempt of the same pair)
+        const bool same_attempt = res.n_done == 0 && res.py_used == 0 && res.np_used == 0;
+        if (!same_attempt) ovq.clear();
+        if (res.need_host == 2) {
+            // BasicErrorModel: phreds within the guard of a rounding boundary -- evaluated here exactly as numpy / the
+            // reference do (libm): legacy_gauss f = sqrt(-2*log(r2)/r2); loc + scale*g; min(q, 0.9999);
+            // int(round(-10 * log10(1 - p)))  (basic.py:52-53, util.py:44); the same pair restarts with the answers
+            const int n_amb = std::min<int>(res.n_amb, iss::MT_AMB_CAP);
+            std::vector<iss::MtPhredAmb> amb((size_t)n_amb);
+            HIP_TRY(ctx, hipMemcpy(amb.data(), m.d_amb, amb.size() * sizeof(iss::MtPhredAmb), hipMemcpyDeviceToHost));
+            for (auto &e : amb) {
+                e.q = host_basic_phred(e.x1, e.x2, e.cached != 0, M.basic_mean, M.basic_sd, M.basic_cap);
+                ovq.push_back(e);
+            }
+            if (ovq.size() > (size_t)iss::MT_AMB_CAP) return fail(ctx, ISS_E_INVALID, "too many undecidable phred scores in one pair");
+            if (!same_attempt) ov_valid = false;  // (a restart of the SAME attempt keeps its host-evaluated fragment length)
+            continue;
+        }
         ov_valid = false;
         if (res.need_host) {
             // int(np.random.normal(mu, sd)) of the next pair with the host's libm, exactly as numpy's legacy_gauss:

@@ -103,6 +103,14 @@ struct MtWalkResult {
                                 // integer boundary to trust the device's log(): the host evaluates it (libm)
     int32_t host_cached;        // ... from the cached second gaussian (f * x1) instead of the fresh one (f * x2)
     double host_x1, host_x2;    // the polar pair that produced it
+    int32_t n_amb;              // need_host == 2 (BasicErrorModel): phred scores too close to a rounding boundary for the
+    int32_t pad2;               // device's log / log10: MtWalkArgs::amb[0 .. n_amb) lists them, the host evaluates them (libm)
+};
+
+// a BasicErrorModel phred the host has to round (need_host == 2), and the host's answer on the relaunch
+struct MtPhredAmb {
+    int32_t mate, pos, cached, q;  // cached: the value is the second one (f * x1) of its polar pair; q: the answer
+    double x1, x2;                 // the accepted polar candidate
 };
 
 // numpy's legacy gaussian state (polar Box-Muller caches its second value) + what produced the cached value
@@ -130,7 +138,11 @@ struct MtWalkArgs {
     double guard;               // |x - round(x)| below this goes to the host (1e-6; tests widen it)
     int64_t ov_frag;
     MtGauss *gauss;             // persistent across launches
+    MtPhredAmb *amb;            // out: ambiguous phreds of the pair that stopped the walk (capacity MT_AMB_CAP)
+    const MtPhredAmb *ovq;      // in: the host's answers for the FIRST pair of this launch
+    int32_t n_ovq;
 };
+constexpr int MT_AMB_CAP = 512;
 
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
@@ -140,7 +152,11 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // worst-case stream words one attempt at a pair can consume (randrange bounded at 64 words each)
 __host__ __device__ inline uint32_t mt_py_need(int RL) { return 128u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
-__host__ __device__ inline uint32_t mt_np_need(int RL) { return 64u /* polar loop */ + 2u + 2u * (2u + 4u * (uint32_t)RL) + 2u; }
+__host__ __device__ inline uint32_t mt_np_need(int RL, bool basic = false) {
+    // basic: the phreds of a mate are RL gaussians = RL/2 accepted polar candidates of 4 words (acceptance pi/4, expected
+    // 2.55 * RL words); 8 * RL + 1024 is tens of standard deviations above that (k_mt_walk also checks every round)
+    return 64u /* polar loop */ + 2u + 2u * (2u + 4u * (uint32_t)RL) + 2u + (basic ? 2u * (8u * (uint32_t)RL + 1024u) : 0u);
+}
 __host__ __device__ inline size_t mt_walk_fixed_lds_bytes(int RL) {
     const size_t rlp = (size_t)((RL + 63) & ~63);
     return 64 * 8 /* mut_thr */ + (rlp + 64) /* tmpl */ + 3 * rlp /* read, qual, stack */ + (size_t)10 * RL * 4 /* window */;
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
         for (int i = lane; i < M.tile_words; i += 64) rows[i] = M.qrows[i];
     for (int i = lane; i <= M.n_q; i += 64) mut_thr[i] = M.mut_thr[i];
     __syncthreads();
-    const uint32_t py_need = mt_py_need(RL), np_need = mt_np_need(RL);
+    const uint32_t py_need = mt_py_need(RL), np_need = mt_np_need(RL, M.quality_mode == 1);
     const uint32_t *py = A.py, *np = A.np;
     uint32_t opy = 0, onp = 0;
     const int64_t L = g.L;
@@ -196,9 +212,83 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
             A.mut[A.mut_base + at] = r;
         }
     };
+    int n_amb = 0, abort_pair = 0;  // wave-uniform
+    // BasicErrorModel.gen_phred_scores (basic.py:40-54): RL values of np.random.normal(mean, sd) -- numpy's legacy polar
+    // Box-Muller: candidates (x1, x2) of two doubles each until 0 < r2 < 1; an accepted candidate yields f * x2, then
+    // (cached for the next call, across mates and pairs) f * x1 -- capped at 0.9999, then
+    // prob_to_phred = int(round(-10 * log10(1 - p))) (util.py:44).  64 candidates per round, one per lane; ranks by
+    // ballot.  The device's log / log10 are not libm's: a value within `guard` of a rounding boundary is not decided
+    // here but listed for the host (returns 2; the relaunch brings the answers).  Returns 1 when the stream runs dry.
+    auto basic_phreds = [&](int o, bool first_of_launch) -> int {
+        const double mean = M.basic_mean, sd = M.basic_sd, cap = M.basic_cap;
+        int amb_here = 0;
+        auto phred_of = [&](double gval, double x1, double x2, int cached, int pos, bool active) {
+            double p = __dadd_rn(mean, __dmul_rn(sd, gval));
+            if (p > cap) p = cap;  // min(q, 0.9999)
+            const double x = __dmul_rn(-10.0, log10(__dadd_rn(1.0, -p)));
+            const double r = rint(x);
+            int q = (int)r;
+            bool amb = active && !(fabs(x - r) < 0.5 - A.guard);
+            if (amb && first_of_launch)
+                for (int k = 0; k < A.n_ovq; ++k)
+                    if (A.ovq[k].mate == o && A.ovq[k].pos == pos) { q = A.ovq[k].q; amb = false; }
+            const unsigned long long am = __ballot(amb);
+            if (amb) {
+                const int at = n_amb + amb_here + (int)__popcll(am & ((1ull << lane) - 1ull));
+                if (at < MT_AMB_CAP) {
+                    MtPhredAmb e;
+                    e.mate = o; e.pos = pos; e.cached = cached; e.q = 0; e.x1 = x1; e.x2 = x2;
+                    A.amb[at] = e;
+                }
+            }
+            amb_here += (int)__popcll(am);
+            if (active) ql[pos] = (uint8_t)q;
+        };
+        int j = 0;
+        if (gs.has_gauss) {  // the cached second value of an earlier candidate comes first
+            phred_of(gs.gauss, gs.x1, gs.x2, 1, 0, lane == 0);
+            gs.has_gauss = 0;
+            j = 1;
+        }
+        while (j < RL) {
+            if (onp + 256u > A.np_avail) return 1;
+            const uint32_t *w = np + onp + 4u * (uint32_t)lane;
+            const double x1 = __dadd_rn(__dmul_rn(2.0, (double)mk53(w[0], w[1]) * (1.0 / 9007199254740992.0)), -1.0);
+            const double x2 = __dadd_rn(__dmul_rn(2.0, (double)mk53(w[2], w[3]) * (1.0 / 9007199254740992.0)), -1.0);
+            const double r2 = __dadd_rn(__dmul_rn(x1, x1), __dmul_rn(x2, x2));
+            const bool ok = !(r2 >= 1.0 || r2 == 0.0);
+            const unsigned long long m = __ballot(ok);
+            const int k = (int)__popcll(m & ((1ull << lane) - 1ull));  // rank among the accepted candidates
+            const int want = (RL - j + 1) >> 1;                           // accepted candidates still needed
+            const int acc = (int)__popcll(m);
+            const bool use = ok && k < want;
+            const double f = use ? sqrt(__ddiv_rn(__dmul_rn(-2.0, log(r2)), r2)) : 0.0;
+            const double v0 = __dmul_rn(f, x2), v1 = __dmul_rn(f, x1);
+            phred_of(v0, x1, x2, 0, j + 2 * k, use && j + 2 * k < RL);
+            phred_of(v1, x1, x2, 1, j + 2 * k + 1, use && j + 2 * k + 1 < RL);
+            if (acc >= want) {
+                const int last = __ffsll((unsigned long long)__ballot(ok && k == want - 1)) - 1;  // lane of the last one used
+                onp += 4u * (uint32_t)(last + 1);
+                if ((RL - j) & 1) {  // its second value is left over: cached for the next call
+                    gs.has_gauss = 1;
+                    gs.gauss = __shfl(v1, last);
+                    gs.x1 = __shfl(x1, last);
+                    gs.x2 = __shfl(x2, last);
+                }
+                j = RL;
+            } else {
+                onp += 256u;
+                j += 2 * acc;
+            }
+        }
+        n_amb += amb_here;
+        return amb_here ? 2 : 0;
+    };
     while (i < A.n_pairs) {
         const int64_t mut_mark = n_mut;
         if (opy + py_need > A.py_avail || onp + np_need > A.np_avail) { starved = 1; break; }
+        n_amb = 0;
+        abort_pair = 0;
         const uint32_t opy0 = opy, onp0 = onp;
         const MtGauss gs0 = gs;
         int64_t isz, frag;
@@ -241,6 +331,9 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
                 frag = (int64_t)x;  // int(): truncation toward zero
             }
             isz = frag - 2 * (int64_t)RL;
+        } else if (M.quality_mode == 1) {
+            isz = M.basic_insert_size;  // BasicErrorModel.random_insert_size: a constant, no draw (basic.py:56-63)
+            frag = isz + 2 * (int64_t)RL;
         } else {
             // insert size: np.searchsorted(cdf, np.random.rand())  (kde.py:97)
             const uint64_t m = mk53(np[onp], np[onp + 1]);
@@ -344,6 +437,12 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
                 opy += pos;
             }
             __syncthreads();
+            if (M.quality_mode == 1) {
+                abort_pair = basic_phreds(o, opy0 == 0u && onp0 == 0u);
+                if (!abort_pair && onp + 2u * (uint32_t)RL + 4u > A.np_avail) abort_pair = 1;  // room for the substitution picks
+                if (abort_pair) break;
+                __syncthreads();
+            } else {
             // ---- gen_phred_scores: bin choice + one CDF inversion per position (kde.py:72-85)
             int bin;
             {
@@ -374,6 +473,7 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
             }
             onp += 2u * (uint32_t)RL;
             __syncthreads();
+            }
             // ---- mut_sequence: one py double per position, one np double per substitution event, in order
             uint8_t *ob = A.out[2 * o] + (size_t)i * M.pitch;
             uint8_t *oq = A.out[2 * o + 1] + (size_t)i * M.pitch;
@@ -410,6 +510,11 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
             onp += 2u * nev;
             __syncthreads();
         }
+        if (abort_pair) {  // BasicErrorModel: out of stream words (1) or a phred the host has to round (2)
+            if (abort_pair == 1) starved = 1; else need_host = 2;
+            opy = opy0; onp = onp0; gs = gs0; n_mut = mut_mark;
+            break;
+        }
         d.re = (int32_t)re;
         bool keep = true;
         if (A.gc_bias) {  // generator.py:82-92
@@ -433,6 +538,7 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
         A.res->host_cached = host_cached;
         A.res->host_x1 = host_x1;
         A.res->host_x2 = host_x2;
+        A.res->n_amb = n_amb;
         *A.gauss = gs;
     }
 }

@@ -71,7 +71,15 @@ class ReadEngine(object):
         mt.n_q = dense.n_q
         for k, v in keep.items():
             setattr(mt, k, v.ctypes.data)
+        mt.quality_mode = int(getattr(dense, "quality_mode", 0))
+        mt.basic_insert_size = int(getattr(dense, "basic_insert_size", 200))
+        # np.random.normal(util.phred_to_prob(mean_quality), 0.01, read_length); min(q, 0.9999)  (basic.py:52)
+        from .model import phred_to_prob
+        mt.basic_mean = float(phred_to_prob(int(getattr(dense, "basic_mean_quality", 30))))
+        mt.basic_sd = 0.01
+        mt.basic_cap = 0.9999
         self._check(self._lib.iss_model_upload(self._ctx, C.byref(mt)))
+        self.quality_mode = mt.quality_mode
         self.read_length = dense.read_length
         self.pitch = self._lib.iss_output_pitch(self._ctx)
         self._capacity = 0

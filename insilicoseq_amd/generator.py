@@ -156,6 +156,8 @@ class Worker(object):
         self.seed = worker_seed(seed, cpu_number)
         self.engine = ReadEngine(self.cpu_number if device is None else device)
         self.dense = _dense_of(error_model)
+        if getattr(self.dense, "quality_mode", 0) == 1 and rng != "mt":
+            raise ValueError("BasicErrorModel runs in the reference-compatible RNG mode only: rng=\"mt\"")
         self.engine.load_model(self.dense)
         self.store_mutations = False
         self.device_fastq = os.environ.get("ISS_HOST_FASTQ", "") != "1"  # ISS_HOST_FASTQ=1: host formatter (iss_fastq_write)

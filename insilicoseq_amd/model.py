@@ -70,6 +70,11 @@ class DenseModel(object):
         self.ins_letter = np.ascontiguousarray(ins_letter, dtype=np.uint8)
         self.dele = np.ascontiguousarray(dele, dtype=np.float64)
         self.phred_thr = np.ascontiguousarray(phred_thr, dtype=np.float64)
+        # 0: KDE tables.  1: BasicErrorModel (iss/error_models/basic.py) -- constant insert size, phred scores from a
+        # normal distribution around phred_to_prob(mean quality); the quality / bin / insert-size tables are unused.
+        self.quality_mode = 0
+        self.basic_insert_size = 200
+        self.basic_mean_quality = 30
         self.validate()
 
     # ------------------------------------------------------------------ shape
@@ -193,10 +198,32 @@ class DenseModel(object):
             prof["del_reverse"],
         )
 
+    @classmethod
+    def basic(cls, read_length=125, insert_size=200, mean_quality=30):
+        """The tables of ``BasicErrorModel`` (iss/error_models/basic.py:18-38): read length 125, insert size 200,
+        every substitution equally likely (``np.random.choice`` over [1/3, 1/3, 1/3]), no indels."""
+        RL = int(read_length)
+        cdf = _choice_cdf([1 / 3, 1 / 3, 1 / 3])
+        alts = {"A": "TCG", "T": "ACG", "C": "ATG", "G": "ATC"}  # basic.py:27-32
+        subst_alt = np.zeros((2, RL, 4, 3), dtype=np.uint8)
+        for bi, b in enumerate(BASES):
+            subst_alt[:, :, bi, :] = [ord(c) for c in alts[b]]
+        d = cls(RL, np.array([1.0]), np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (2, 1)),
+                np.tile(np.array([0, 0, 0, 1], dtype=np.uint8), (2, 1)), np.ones((2, N_BINS, RL, 41)),
+                np.tile(cdf, (2, RL, 4, 1)), subst_alt, np.zeros((2, RL, 4)),
+                np.tile(np.frombuffer(BASES.encode(), dtype=np.uint8), (2, RL, 1)), np.zeros((2, RL, 4)),
+                np.array([phred_to_prob(q) for q in range(42)]))
+        d.quality_mode = 1
+        d.basic_insert_size = int(insert_size)
+        d.basic_mean_quality = int(mean_quality)
+        return d
+
     # ----------------------------------------------------- dense (pickle-free) io
     def save(self, path):
         np.savez_compressed(
             path, format=np.array("iss-dense-1"), read_length=np.int64(self.read_length),
+            quality_mode=np.int64(self.quality_mode), basic_insert_size=np.int64(self.basic_insert_size),
+            basic_mean_quality=np.int64(self.basic_mean_quality),
             **{k: getattr(self, k) for k in self.FIELDS}
         )
 
@@ -205,7 +232,12 @@ class DenseModel(object):
         d = np.load(path, allow_pickle=False)
         if "format" not in d.files or str(d["format"]) != "iss-dense-1":
             raise ModelError("%s is not a dense iss model" % path)
-        return cls(int(d["read_length"]), *[d[k] for k in cls.FIELDS])
+        m = cls(int(d["read_length"]), *[d[k] for k in cls.FIELDS])
+        if "quality_mode" in d.files:
+            m.quality_mode = int(d["quality_mode"])
+            m.basic_insert_size = int(d["basic_insert_size"])
+            m.basic_mean_quality = int(d["basic_mean_quality"])
+        return m
 
     @classmethod
     def load_any(cls, path):
@@ -357,3 +389,24 @@ class KDErrorModel(object):
             self.quality_reverse, self.subst_choices_for, self.subst_choices_rev, self.ins_for, self.ins_rev,
             self.del_for, self.del_rev,
         )
+
+
+class BasicErrorModel(object):
+    """Host-side mirror of ``iss.error_models.basic.BasicErrorModel`` (basic.py:10-63): same constructor and
+    attributes; ``dense()`` gives the tables the engine uploads.  On the device it runs in the
+    reference-compatible RNG mode (``rng="mt"``)."""
+
+    def __init__(self, fragment_length=None, fragment_sd=None, store_mutations=False):
+        self.read_length = 125
+        self.insert_size = 200
+        self.fragment_length = fragment_length
+        self.fragment_sd = fragment_sd
+        self.store_mutations = store_mutations
+        self.quality_forward = self.quality_reverse = 30
+        self.npz_path = None
+
+    def dense(self):
+        return DenseModel.basic(self.read_length, self.insert_size, self.quality_forward)
+
+    def random_insert_size(self):
+        return self.insert_size

@@ -156,7 +156,12 @@ class Rng(object):
 class Oracle(object):
     """The semantic function on dense tables (insilicoseq_amd.model.DenseModel-shaped object)."""
 
-    def __init__(self, dense, quality_mode=0, basic_insert_size=200, basic_mean_quality=30):
+    def __init__(self, dense, quality_mode=None, basic_insert_size=None, basic_mean_quality=None):
+        # defaults: what the dense model says (DenseModel.basic() marks itself)
+        quality_mode = getattr(dense, "quality_mode", 0) if quality_mode is None else quality_mode
+        basic_insert_size = getattr(dense, "basic_insert_size", 200) if basic_insert_size is None else basic_insert_size
+        basic_mean_quality = (getattr(dense, "basic_mean_quality", 30) if basic_mean_quality is None
+                              else basic_mean_quality)
         self.d = dense
         self._keep = [dense.isize_cdf, dense.bin_cdf, dense.qcdf, dense.subst_cdf, dense.subst_alt, dense.ins,
                       dense.ins_letter, dense.dele, dense.phred_thr]

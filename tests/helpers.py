@@ -11,7 +11,7 @@ PROFILES = os.path.join(os.path.dirname(GOLDEN), "..", "insilicoseq_amd", "profi
 
 
 def dense_model(name, indel=None):
-    d = DenseModel.load(os.path.join(PROFILES, name + ".dense.npz"))
+    d = DenseModel.basic() if name == "basic" else DenseModel.load(os.path.join(PROFILES, name + ".dense.npz"))
     if indel is not None:
         d.ins[:] = indel[0]
         d.dele[:] = indel[1]

@@ -65,7 +65,7 @@ def test_pairs_equal_reference(engine, case):
     assert list(_res53(py)) == list(z["tail_py"]) and list(_res53(npw)) == list(z["tail_np"])
 
 
-@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc"])
+@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc", "genomes_basic_cpu2"])
 def test_worker_files_equal_reference(case, tmp_path):
     from insilicoseq_amd.generator import Record, worker_iterator
 
@@ -78,6 +78,19 @@ def test_worker_files_equal_reference(case, tmp_path):
                     meta["gc_bias"], device=0, rng="mt")
     assert open(prefix + "_R1.fastq", "rb").read() == z["r1"].tobytes()
     assert open(prefix + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+
+
+def test_generate_cli_basic_mode_equals_reference(tmp_path):
+    """`--mode basic` (BasicErrorModel on the device, MT mode implied) == `iss generate --mode basic --cpus 2`."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "run")
+    subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes",
+                           os.path.join(GOLDEN, "genomes.fasta"), "--mode", "basic", "-n", "400", "--seed", "42",
+                           "--cpus", "2", "--devices", "1", "-o", out, "--quiet"], cwd=root)
+    z = np.load(os.path.join(GOLDEN, "generate", "genomes_basic_n400_seed42_cpus2.npz"))
+    assert open(out + "_abundance.txt", "rb").read() == z["abundance"].tobytes()
+    assert open(out + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(out + "_R2.fastq", "rb").read() == z["r2"].tobytes()
 
 
 @pytest.mark.parametrize("cpus", [1, 2, 3])
@@ -222,17 +235,21 @@ def test_config1_scale_short_genomes_miseq(engine):
     assert list(_res53(npw)) == [rng.np_random() for _ in range(4)]
 
 
-def test_store_mutations_vcf_equals_reference(tmp_path):
+@pytest.mark.parametrize("case", ["syn_novaseq_vcf", "genomes_basic_cpu2"])
+def test_store_mutations_vcf_equals_reference(case, tmp_path):
     """--store_mutations in MT mode: the worker's .vcf (and FASTQ) equal the reference's files."""
     from insilicoseq_amd.generator import Record, worker_iterator
-    from insilicoseq_amd.model import KDErrorModel
+    from insilicoseq_amd.model import BasicErrorModel, KDErrorModel
 
-    z = np.load(os.path.join(GOLDEN, "worker", "syn_novaseq_vcf.npz"))
+    z = np.load(os.path.join(GOLDEN, "worker", case + ".npz"))
     meta = json.loads(str(z["meta"]))
     recs = [Record(z["genome_%d" % i].tobytes().decode(), id=rid) for i, rid in enumerate(meta["ids"])]
     work = [(r, n, "default") for r, n in zip(recs, meta["counts"])]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    em = KDErrorModel(os.path.join(root, "insilicoseq_amd", "profiles", "novaseq.dense.npz"), None, None, True)
+    if meta["model"] == "basic":
+        em = BasicErrorModel(None, None, True)
+    else:
+        em = KDErrorModel(os.path.join(root, "insilicoseq_amd", "profiles", "novaseq.dense.npz"), None, None, True)
     prefix = str(tmp_path / "w")
     worker_iterator(work, em, meta["cpu_number"], prefix, meta["seed"], meta["sequence_type"], meta["gc_bias"],
                     device=0, rng="mt")
@@ -271,7 +288,8 @@ def test_fragment_length_host_guard_path(monkeypatch):
     from insilicoseq_amd.engine import ReadEngine
 
     monkeypatch.setenv("ISS_MT_GUARD", "0.6")
-    for case in ("novaseq_frag160", "ecoli_gcbias_frag"):
+    # (BasicErrorModel: the same guard sends nine phred scores out of ten to the host's libm as well)
+    for case in ("novaseq_frag160", "ecoli_gcbias_frag", "basic_frag300", "basic_mixed", "basic_gcbias"):
         z, meta = load_pairs_case(case)
         with ReadEngine(0) as eng:
             eng.load_model(dense_model(meta["model"], meta["indel"]))

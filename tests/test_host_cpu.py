@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(native):
     assert declared == set(native.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.iss_abi_version() == 1
+    assert lib.iss_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure(native):
@@ -61,7 +61,7 @@ def _worker_case(name):
     return z, meta, genomes
 
 
-@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc"])
+@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc", "genomes_basic_cpu2"])
 def test_worker_fastq_matches_reference(native, case, tmp_path):
     """Oracle (MT streams, seeded like worker_iterator: seed + cpu_number) + the product's FASTQ
     formatter reproduce the reference worker's R1/R2 files byte for byte (ids, order, skipped
@@ -144,12 +144,13 @@ def test_parse_fasta_and_work_divider_match_reference_generate():
         assert set(seen) == set(expect)
 
 
-def test_oracle_vcf_rows_match_reference():
+@pytest.mark.parametrize("case", ["syn_novaseq_vcf", "genomes_basic_cpu2"])
+def test_oracle_vcf_rows_match_reference(case):
     """--store_mutations: the oracle's mutation records, formatted like write_mutations
     (iss/generator.py:598-620), reproduce the reference worker's .vcf byte for byte."""
     from oracle import oracle as O
 
-    z, meta, genomes = _worker_case("syn_novaseq_vcf")
+    z, meta, genomes = _worker_case(case)
     assert meta["store_mutations"]
     d = dense_model(meta["model"])
     orc = O.Oracle(d)
@@ -157,6 +158,8 @@ def test_oracle_vcf_rows_match_reference():
     lines = []
     for rid, n, g in zip(meta["ids"], meta["counts"], genomes):
         res = orc.simulate(rng, g, n, store_mutations=True)
+        if res["status"] == O.SKIP_RECORD:
+            continue
         assert res["status"] == 0
         for m in res["mutations"]:
             read_id = "%s_%d_%d/%d" % (rid, m["pair"], meta["cpu_number"], 1 + int(m["mate"]))
