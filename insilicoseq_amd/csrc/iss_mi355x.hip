@@ -677,7 +677,26 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     };
     M.GB = 6;
     if (const char *e = getenv("ISS_GUIDE_BITS")) M.GB = std::min(8, std::max(6, atoi(e)));
-    else while (M.GB < 8 && more_rate(M.GB) > 0.004) ++M.GB;
+    else {
+        while (M.GB < 8 && more_rate(M.GB) > 0.004) ++M.GB;
+        // ... unless a smaller guide is what lets TWO workgroups share a CU with tiles of >= 12 position groups:
+        // measured (MiSeq, 301 x 3 bins), 8 wavefronts / SIMD are worth more than the extra deferred bases
+        // (guide 8 bits, one workgroup / CU: 7.7 ms per 5 M pairs; 6 bits, two: 7.0 ms).
+        auto two_fit = [&](int gb) {
+            const size_t gs = 4 * ((size_t)(1 << gb) / 4 + s_max) + 1;
+            for (int nt = 1; nt <= (RL + 3) / 4; ++nt) {
+                const size_t tg = ((size_t)(RL + 3) / 4 + nt - 1) / nt;
+                if (tg < (size_t)std::min(12, (RL + 3) / 4)) break;
+                const size_t words = (2 * (size_t)M.NB * tg * gs + 3) / 4 * 4 + (((size_t)nq + 1 + 3) & ~(size_t)3) + 2 * tg * 4 * 4 * 2 +
+                                     (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING;
+                if (words * 4 <= 79 * 1024) return true;
+            }
+            return false;
+        };
+        if (!two_fit(M.GB))
+            for (int gb = M.GB - 1; gb >= 6; --gb)
+                if (two_fit(gb)) { M.GB = gb; break; }
+    }
     if (getenv("ISS_DEBUG_MODEL")) {  // expected share of bases that leave the hot loop
         double err = 0;
         size_t rows = 0;
