@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--indel", type=float, nargs=2, default=None, metavar=("P_INS", "P_DEL"),
                     help="override every insertion / deletion probability (BASELINE configs[4]-like indel-heavy model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo: a dry run of "
+                    "the multi-rank logic, e.g. with ISS_BENCH_SHARE_GPU=1 on a single-GPU box)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_500_000)
     args = ap.parse_args()
 
@@ -62,13 +64,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if os.environ.get("ISS_BENCH_SHARE_GPU") == "1":  # dry runs only: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
 
