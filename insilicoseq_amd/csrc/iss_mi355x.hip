@@ -1306,8 +1306,9 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     if (n_pairs == 0) return 0;
     const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
     const size_t fixed_lds = iss::mt_walk_fixed_lds_bytes(M.RL);
-    const bool use_rows = !basic && M.n_tiles == 1 && (size_t)M.tile_words * 4 + fixed_lds <= 150 * 1024;
-    const size_t lds_bytes = fixed_lds + (use_rows ? (size_t)M.tile_words * 4 : 0);
+    const size_t rows_bytes = (((size_t)2 * M.NB * M.RL * M.mt_row_w + 1) & ~(size_t)1) * 4;  // 16-bit digit rows
+    const bool use_rows = !basic && rows_bytes + fixed_lds <= 150 * 1024;
+    const size_t lds_bytes = fixed_lds + (use_rows ? rows_bytes : 0);
     // Resolver path (k_mt_resolve + k_mt_emit) for plain runs; the sequential walker for custom fragment
     // lengths, --store_mutations, indel-heavy models, and for the single pairs the resolver hands back.
     typedef void (*resolve_fn)(iss::DevModel, iss::DevGenome, iss::MtResolveArgs, iss::PairDesc *);

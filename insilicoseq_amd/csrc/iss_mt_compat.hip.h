@@ -127,7 +127,7 @@ struct MtWalkArgs {
     uint64_t gc_thr;
     uint8_t *out[4];
     MtWalkResult *res;
-    int32_t use_rows;  // the compressed quality rows (single tile) are staged in LDS
+    int32_t use_rows;  // the 16-bit digit rows (DevModel::mt_rows) are staged in LDS
     int32_t win_words; // LDS words for the slow indel path's stream window (10 * (RL - 1))
     MutRecord *mut;    // --store_mutations rows (NULL: off)
     int64_t mut_cap, mut_base;  // capacity; rows already written by earlier launches of this call
@@ -184,21 +184,25 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
     const int rlp = (RL + 63) & ~63;
     // LDS carve: [rows (optional)] [mut_thr u64 x 64] [tmpl rlp+64] [read rlp] [qual rlp] [stk rlp] [win]
     uint32_t *rows = lds;
-    uint64_t *mut_thr = reinterpret_cast<uint64_t *>(lds + (A.use_rows ? M.tile_words : 0));
+    const uint32_t rows_words = (uint32_t)(2 * M.NB * RL * M.mt_row_w);
+    uint64_t *mut_thr = reinterpret_cast<uint64_t *>(lds + (A.use_rows ? ((rows_words + 1u) & ~1u) : 0u));
     uint8_t *tmpl = reinterpret_cast<uint8_t *>(mut_thr + 64);
     uint8_t *rd = tmpl + rlp + 64;
     uint8_t *ql = rd + rlp;
     uint8_t *stk = ql + rlp;
     uint32_t *win = reinterpret_cast<uint32_t *>(stk + rlp);
-    if (A.use_rows)
-        for (int i = lane; i < M.tile_words; i += 64) rows[i] = M.qrows[i];
+    if (A.use_rows) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(M.mt_rows);
+        for (uint32_t i = lane; i < rows_words; i += 64) rows[i] = src[i];
+    }
+    const uint16_t *drows = A.use_rows ? reinterpret_cast<const uint16_t *>(rows) : M.mt_rows;
+    const uint32_t row_h = (uint32_t)M.mt_row_w * 2u;  // u16 entries per row
     for (int i = lane; i <= M.n_q; i += 64) mut_thr[i] = M.mut_thr[i];
     __syncthreads();
     const uint32_t py_need = mt_py_need(RL), np_need = mt_np_need(RL, M.quality_mode == 1);
     const uint32_t *py = A.py, *np = A.np;
     uint32_t opy = 0, onp = 0;
     const int64_t L = g.L;
-    const uint32_t gbytes = 1u << M.GB;
     int64_t i = 0;
     int starved = 0, need_host = 0, host_cached = 0, ov_valid = A.ov_valid;
     double host_x1 = 0, host_x2 = 0;
@@ -455,19 +459,29 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
             d.meta |= (uint32_t)slot << (2 * o);
             for (int p = lane; p < RL; p += 64) {
                 const uint64_t m = mk53(np[onp + 2u * (uint32_t)p], np[onp + 2u * (uint32_t)p + 1]);
-                int q;
-                const uint64_t *full = M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * M.n_q;
-                if (A.use_rows) {
-                    const uint32_t h = (uint32_t)(m >> 37);
-                    const uint32_t row = ((uint32_t)(o * M.NB + slot) * (uint32_t)M.TG + (uint32_t)(p >> 2)) * (uint32_t)M.GS +
-                                         (uint32_t)(p & 3) * (uint32_t)M.stride_w;
-                    uint32_t j = reinterpret_cast<const uint8_t *>(rows)[row * 4 + (h >> (16 - M.GB))] >> 2;
-                    uint32_t e = rows[row + gbytes / 4 + j];
-                    while ((e >> 15) < h) e = rows[row + gbytes / 4 + (++j)];
-                    q = (int)((e >> 2) & 0xffu);
-                    if ((e >> 15) == h) q = count_lt(full, M.n_q, m);
-                } else {
-                    q = count_lt(full, M.n_q, m);
+                // leading digits first (two rounds of independent reads: every 7th digit, then the segment), the full
+                // thresholds only among those that share the draw's digit
+                const uint32_t h = (uint32_t)(m >> 37);
+                const uint16_t *row = drows + ((size_t)(o * M.NB + slot) * RL + p) * row_h;
+                const int nq = M.n_q;
+                int c1 = 0;
+                bool tie = false;
+#pragma unroll
+                for (int jk = 0; jk < 9; ++jk) {  // keys 6, 13, ... (n_q <= 60); indices past n_q read the 0xffff padding
+                    const uint32_t dgt = row[min(6 + 7 * jk, nq)];
+                    c1 += dgt < h ? 1 : 0;
+                    tie |= dgt == h;
+                }
+                int q = 7 * c1;
+#pragma unroll
+                for (int jk = 0; jk < 6; ++jk) {
+                    const uint32_t dgt = row[min(7 * c1 + jk, nq)];
+                    q += dgt < h ? 1 : 0;
+                    tie |= dgt == h;
+                }
+                if (tie) {
+                    const uint64_t *full = M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * nq;
+                    while (q < nq && full[q] < m) ++q;
                 }
                 ql[p] = (uint8_t)q;
             }
