@@ -590,3 +590,39 @@ def test_engine_limits_match_oracle(RL, n_q, n_isize, n):
         exp = orc.simulate(O.Rng().seed_mt(1234), genome, n)
         for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
             assert np.array_equal(got[key], exp[key]), ("mt", key)
+
+
+def test_genome_positions_beyond_2_30():
+    """A 1.2 Gbp record (the engine takes genomes below 2^31 bp): 32-bit position arithmetic near its limit, on both RNG
+    paths, against the oracle at the pairs with the largest / smallest coordinates and a random sample."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    L = 1_200_000_000
+    g = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.RandomState(1).randint(0, 4, size=L)]
+    g[L - 5000:L - 4000] = ord("N")
+    gs = g.tobytes()
+    dense = dense_model("novaseq")
+    orc = O.Oracle(dense)
+    n = 200000
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(g)
+        eng.generate(gid, n, first_ordinal=0, seed=3)
+        eng.synchronize()
+        coords = eng.coords(0, n)
+        assert int(coords[:, 2].max()) > (1 << 30) + 100_000_000
+        order = np.argsort(coords[:, 2])
+        picks = list(order[-30:]) + list(order[:10]) + list(np.random.RandomState(2).randint(0, n, 30))
+        for i in picks:
+            got = eng.download(int(i), 1)
+            exp = orc.simulate(O.Rng().seed_philox(3), gs, 1, first_ordinal=int(i), want_coords=True)
+            for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                assert np.array_equal(got[k], exp[k]), (int(i), k)
+            assert np.array_equal(coords[i], exp["coords"][0])
+        eng.seed_mt(9)
+        assert eng.generate_mt(gid, 1500) == 1500
+        got = eng.download(0, 1500)
+        exp = orc.simulate(O.Rng().seed_mt(9), gs, 1500)
+        for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(got[k], exp[k]), ("mt", k)
