@@ -152,7 +152,8 @@ int iss_output_download(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, uint8
 int iss_output_download_coords(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, int64_t *coords);
 
 /* HIP-event timing of the kernels launched by iss_generate (on the launch stream).
- * enable: 1/0.  iss_timing_read synchronises, returns accumulated milliseconds per kernel
+ * enable: 0 off, 1 every kernel, 2 k_main only (an event is a bubble in the stream: the five-kernel timing costs
+ * about 6 % of a step).  iss_timing_read synchronises, returns accumulated milliseconds per kernel
  * (setup, main, indel-scan, indel-fixup) and the number of iss_generate launches, then
  * resets the accumulators. */
 int iss_timing_enable(iss_ctx *ctx, int enable);

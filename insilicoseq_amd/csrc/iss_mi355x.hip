@@ -143,7 +143,7 @@ struct iss_ctx {
     } mt;
     FastqPipe fq;
     // timing
-    bool timing = false;
+    bool timing = false, timing_main_only = false;
     std::vector<TimedLaunch> timed;
     double ms_acc[4] = {0, 0, 0, 0};
     int64_t n_launches = 0;
@@ -362,9 +362,10 @@ int settle_timing(iss_ctx *ctx) {
     static const int first[4] = {0, 1, 3, 5};
     for (auto &t : ctx->timed) {
         HIP_TRY(ctx, hipEventSynchronize(t.ev[2]));
-        if (t.has_scan) HIP_TRY(ctx, hipEventSynchronize(t.ev[6]));
+        if (t.has_scan && t.ev[6]) HIP_TRY(ctx, hipEventSynchronize(t.ev[6]));
         for (int k = 0; k < 4; ++k) {
             if (k >= 2 && !t.has_scan) continue;
+            if (!t.ev[first[k]] || !t.ev[first[k] + 1]) continue;  // k_main-only timing
             float ms = 0.f;
             HIP_TRY(ctx, hipEventElapsedTime(&ms, t.ev[first[k]], t.ev[first[k] + 1]));
             ctx->ms_acc[k] += ms;
@@ -1011,6 +1012,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         hipStream_t s_indel = ctx->overlap ? ctx->indel_stream : ctx->stream;
         auto mark = [&](int k, hipStream_t st) -> hipError_t {
             if (!ctx->timing) return hipSuccess;
+            if (ctx->timing_main_only && k != 1 && k != 2) return hipSuccess;  // (every event costs a bubble in the stream)
             hipError_t e = hipEventCreate(&tl.ev[k]);
             if (e != hipSuccess) return e;
             return hipEventRecord(tl.ev[k], st);
@@ -1198,6 +1200,7 @@ int iss_timing_enable(iss_ctx *ctx, int enable) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
     int rc = settle_timing(ctx);
     ctx->timing = enable != 0;
+    ctx->timing_main_only = enable == 2;
     return rc;
 }
 

@@ -224,7 +224,8 @@ class ReadEngine(object):
 
     # ------------------------------------------------------------------ measurement
     def timing_enable(self, on=True):
-        self._check(self._lib.iss_timing_enable(self._ctx, int(bool(on))))
+        """False / 0: off; True / 1: HIP events around every kernel; 2: around k_main only (cheaper)."""
+        self._check(self._lib.iss_timing_enable(self._ctx, int(on)))
 
     def timing_read(self):
         ms = (C.c_double * 4)()

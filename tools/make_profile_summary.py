@@ -23,7 +23,7 @@ def main(src, tag):
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     stats = glob.glob(src + "/stats/*kernel_stats.csv")[0]
     with open(stats) as fh, open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as out:
-        out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n")
+        out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline\n")
         out.write(fh.read())
     acc, calls = counters(src)
     lines = ["# rocprofv3 --pmc <counters> --kernel-trace (separate passes), same bench command; totals over all dispatches",
@@ -45,7 +45,7 @@ def main(src, tag):
     write = m["WRITE_SIZE"] / calls[key]["WRITE_SIZE"] * 1024 * cal.get("write_factor", 1.0)
     summary = {"kernel": "iss::k_main", "launches": n, "calibration": cal, "fetch_bytes_per_launch": fetch,
                "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
-               "command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline (5,000,000 pairs per step in 5 launches)",
+               "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline (5,000,000 pairs per step in 5 launches)",
                "pairs_per_launch_avg": 1_000_000}
     json.dump(summary, open(os.path.join(out_dir, tag + "_traffic.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
