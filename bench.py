@@ -189,6 +189,12 @@ def main():
                 "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_pair * total_pairs_step / max(len(work), 1),
                 "algorithmic_bytes_per_pair": b_pair, "avg_launch_ms": tm["main_ms"] / max(n_main_launches, 1),
                 "launches": n_main_launches,
+                # what actually bounds k_main: integer VALU issue.  Wavefront-level VALU instructions per launch from the
+                # committed PMC pass; 4 cycles each on one of 1024 SIMDs (256 CUs x 4) at 2.4 GHz
+                "valu": {"insts_per_launch": getattr(committed_traffic, "valu_insts", None),
+                         "issue_busy_frac_est": (getattr(committed_traffic, "valu_insts", None) or 0) * 4.0 / (
+                             1024 * 2.4e9 * (tm["main_ms"] / max(n_main_launches, 1)) / 1e3) if main_s > 0 else None,
+                         "note": "excludes the second issue cycle pair of v_mad_u64_u32 (Philox), ~12 % more"},
             },
             "kernel_ms_per_step": dict(other, main_ms=tm["main_ms"] / args.steps,
                                        note="main_ms: HIP events over the timed region; the others: over the warm-up steps"),
@@ -221,6 +227,7 @@ def committed_traffic():
         return None, "no PMC pass committed"
     with open(files[-1]) as fh:
         t = json.load(fh)
+    committed_traffic.valu_insts = t.get("valu_insts_per_launch")
     return t["traffic_bytes_per_launch"], "bytes per launch (avg 1e6 pairs), from %s" % os.path.basename(files[-1])
 
 

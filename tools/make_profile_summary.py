@@ -43,7 +43,9 @@ def main(src, tag):
     n = calls[key]["FETCH_SIZE"]
     fetch = m["FETCH_SIZE"] / n * 1024 * cal.get("fetch_factor", 2.0)
     write = m["WRITE_SIZE"] / calls[key]["WRITE_SIZE"] * 1024 * cal.get("write_factor", 1.0)
-    summary = {"kernel": "iss::k_main", "launches": n, "calibration": cal, "fetch_bytes_per_launch": fetch,
+    valu = m.get("SQ_INSTS_VALU", 0.0) / max(calls[key].get("SQ_INSTS_VALU", 1), 1)
+    summary = {"kernel": "iss::k_main", "launches": n, "calibration": cal, "valu_insts_per_launch": valu,
+               "fetch_bytes_per_launch": fetch,
                "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
                "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline (5,000,000 pairs per step in 5 launches)",
                "pairs_per_launch_avg": 1_000_000}
