@@ -1312,14 +1312,14 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     const size_t rows_bytes = (((size_t)2 * M.NB * M.RL * M.mt_row_w + 1) & ~(size_t)1) * 4;  // 16-bit digit rows
     const bool use_rows = !basic && rows_bytes + fixed_lds <= 150 * 1024;
     const size_t lds_bytes = fixed_lds + (use_rows ? rows_bytes : 0);
-    // Resolver path (k_mt_resolve + k_mt_emit) for plain runs; the sequential walker for custom fragment
-    // lengths, --store_mutations, indel-heavy models, and for the single pairs the resolver hands back.
+    // Resolver path (k_mt_resolve + k_mt_emit) for plain runs; the sequential walker for --store_mutations,
+    // indel-heavy models, the BasicErrorModel, and for the single pairs the resolver hands back.
     typedef void (*resolve_fn)(iss::DevModel, iss::DevGenome, iss::MtResolveArgs, iss::PairDesc *);
     resolve_fn resolve = nullptr;
     size_t resolve_lds = 0;
     {
         const char *force = getenv("ISS_MT_PATH");  // "walk": sequential walker only (testing aid)
-        const bool allowed = !(force && !strcmp(force, "walk")) && !m.has_frag && !m.d_mut && ctx->mt_bounce_rate < 0.05 &&
+        const bool allowed = !(force && !strcmp(force, "walk")) && !m.d_mut && ctx->mt_bounce_rate < 0.05 &&
                              M.n_isize <= 4096 && !basic;
         const size_t budget = 160 * 1024 - 256;
         const uint32_t need_py = iss::mt_res_need_py(M.RL), need_np = iss::mt_res_need_np(M.RL);
@@ -1386,6 +1386,11 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
             R.gc_thr = 8106479329266893ull;
             R.res = m.d_res;
             R.rec = m.d_rec;
+            R.has_frag = m.has_frag ? 1 : 0;
+            R.frag_mu = m.frag_mu;
+            R.frag_sd = m.frag_sd;
+            R.guard = getenv("ISS_MT_GUARD") ? atof(getenv("ISS_MT_GUARD")) : 1e-6;
+            R.gauss = m.d_gauss;
             hipLaunchKernelGGL(resolve, dim3(1), dim3(iss::RES_THREADS), resolve_lds, ctx->stream, M, dg, R, ctx->desc + row0);
             HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

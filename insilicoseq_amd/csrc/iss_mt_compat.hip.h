@@ -582,12 +582,15 @@ struct MtResolveArgs {
     uint64_t gc_thr;
     MtWalkResult *res;
     MtPairRec *rec;
+    int32_t has_frag;           // custom fragment length: int(np.random.normal(mu, sd)) instead of the insert-size CDF
+    double frag_mu, frag_sd, guard;
+    MtGauss *gauss;             // numpy's cached second gaussian, shared with k_mt_walk
 };
 
 constexpr int RES_THREADS = 512;  // two groups of four wavefronts: the mates of a pair are worked on side by side
 // the rings must show a whole pair at once (both mates are read concurrently)
 __host__ __device__ inline uint32_t mt_res_need_py(int RL) { return 128u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
-__host__ __device__ inline uint32_t mt_res_need_np(int RL) { return 16u + 8u * (uint32_t)RL; }
+__host__ __device__ inline uint32_t mt_res_need_np(int RL) { return 16u + 64u /* polar loop */ + 8u * (uint32_t)RL; }
 __host__ __device__ inline size_t mt_res_lds_bytes(const DevModel &M, int pyv, int npv, bool rows_lds) {
     size_t b = (size_t)(2 * pyv + 2 * npv) * 1024 * 4 + 2 * 16 * 4;  // rings + their 16-word mirrors
     b += (size_t)(64 + 8 + M.n_isize) * 8;                           // mut_thr, bin_thr, isize_thr
@@ -669,6 +672,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
     uint32_t sl = 0;  // scratch slot (alternates per barrier)
     int64_t i = 0;
     int starved = 0, need_generic = 0;
+    MtGauss gs = *A.gauss;  // wave-uniform copy; written back at the end
 
     uint32_t slots = 0;  // bin -> slot, 2 bits each, [o][bin]
     for (int k = 0; k < 8; ++k) slots |= ((uint32_t)M.bin_slot[k] & 3u) << (2 * k);
@@ -763,9 +767,37 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
         const uint32_t opy0 = opy, onp0 = onp;
         if (opy >= (kpy + 1) * HPY) { store_py(kpy + 2); ++kpy; lds_barrier(); fetch_py(kpy + 2); }
         if (onp >= (knp + 1) * HNP) { store_np(knp + 2); ++knp; lds_barrier(); fetch_np(knp + 2); }
-        // ---- insert size: np.searchsorted(cdf, np.random.rand())  (kde.py:97), two-level count in LDS
+        const MtGauss gs0 = gs;
+        bool odd = false;  // this pair goes to the sequential walker
         int64_t isz;
-        {
+        if (A.has_frag) {
+            // int(np.random.normal(mu, sd)), numpy's legacy polar Box-Muller with its cached second value (generator.py:122);
+            // a draw too close to an integer for the device's log(), or more than 16 rejected candidates: the walker
+            double gval;
+            if (gs.has_gauss) {
+                gval = gs.gauss;
+                gs.has_gauss = 0;
+            } else {
+                double x1 = 0, x2 = 0, r2 = 2.0;
+                for (int t = 0; t < 16 && (r2 >= 1.0 || r2 == 0.0); ++t) {
+                    x1 = __dadd_rn(__dmul_rn(2.0, (double)mk53(npr(onp), npr(onp + 1)) * (1.0 / 9007199254740992.0)), -1.0);
+                    x2 = __dadd_rn(__dmul_rn(2.0, (double)mk53(npr(onp + 2), npr(onp + 3)) * (1.0 / 9007199254740992.0)), -1.0);
+                    onp += 4;
+                    r2 = __dadd_rn(__dmul_rn(x1, x1), __dmul_rn(x2, x2));
+                }
+                if (r2 >= 1.0 || r2 == 0.0) { odd = true; r2 = 0.5; }
+                const double f = sqrt(__ddiv_rn(__dmul_rn(-2.0, log(r2)), r2));
+                gs.gauss = __dmul_rn(f, x1);
+                gs.has_gauss = 1;
+                gs.x1 = x1;
+                gs.x2 = x2;
+                gval = __dmul_rn(f, x2);
+            }
+            const double x = __dadd_rn(A.frag_mu, __dmul_rn(A.frag_sd, gval));
+            if (!(fabs(x) < 1e15) || fabs(x - rint(x)) < A.guard) odd = true;
+            isz = (odd ? 0 : (int64_t)x) - 2 * (int64_t)RL;
+        } else {
+            // ---- insert size: np.searchsorted(cdf, np.random.rand())  (kde.py:97), two-level count in LDS
             const uint64_t m = mk53(npr(onp), npr(onp + 1));
             onp += 2;
             const int n = M.n_isize, S = (n + 63) / 64;
@@ -784,7 +816,6 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
         }
         const int64_t frag = isz + 2 * (int64_t)RL;
         int64_t fs = 0;
-        bool odd = false;  // this pair goes to the sequential walker
         auto randbelow_at = [&](uint32_t &off, uint32_t n) -> uint32_t {  // one round of 64 candidate words from py[off ..]
             const int k = 32 - __clz(n);
             const uint32_t r = pyr(off + (uint32_t)lane) >> (32 - k);
@@ -794,7 +825,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
             off += (uint32_t)t + 1u;
             return (uint32_t)__shfl((int)r, t);
         };
-        if (A.sequence_type == 0) {  // generator.py:134-135, 142-144
+        if (A.sequence_type == 0 && !odd) {  // generator.py:134-135, 142-144
             const int64_t width = L - frag;
             fs = randbelow_at(opy, (uint32_t)(width > 0 ? width : L - RL));
         }
@@ -818,6 +849,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
         if (A.sequence_type == 0) { rs = fe + isz; re = rs + RL; }  // generator.py:164-177
         else { rs = L - RL; re = L; }
         if (!odd && re > L) { re = RL + (int64_t)randbelow_at(opy1, (uint32_t)(L - RL)); rs = re - RL; }
+        if (fe > L || rs < 0) odd = true;  // templates cut by the genome ends (short / negative fragments): Python slice rules
         if (!odd) odd = exceptions_in(fs, fe) || exceptions_in(rs, re);
         PairDesc d;
         d.fs = (int32_t)fs;
@@ -852,7 +884,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
             opy = opy1 + C_MATE;
             onp = onp1 + 2u + 2u * (uint32_t)RL + 2u * nev1;
         }
-        if (odd) { opy = opy0; onp = onp0; need_generic = 1; break; }
+        if (odd) { opy = opy0; onp = onp0; gs = gs0; need_generic = 1; break; }
         bool keep = true;
         if (A.gc_bias) {  // generator.py:82-92
             keep = mk53(npr(onp), npr(onp + 1)) < A.gc_thr;
@@ -872,6 +904,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
         A.res->n_mut = 0;
         A.res->need_host = 0;
         A.res->host_cached = 0;
+        *A.gauss = gs;
     }
 }
 
