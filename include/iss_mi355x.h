@@ -177,7 +177,7 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
 int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n);
 /* Pairs produced so far by each device path of iss_generate_mt: the offset resolver + parallel emitter
  * (plain pairs) and the sequential walker (pairs with an indel candidate, letters outside ACGT or a template cut by
- * a genome end; --store_mutations, the BasicErrorModel; everything when ISS_MT_PATH=walk is set in the environment). */
+ * a genome end; indel-heavy models, the BasicErrorModel; everything when ISS_MT_PATH=walk is set in the environment). */
 int iss_mt_path_counts(iss_ctx *ctx, int64_t *n_resolved, int64_t *n_walked);
 /* Custom fragment length in MT mode (--fragment-length / --fragment-length-sd, iss/generator.py:121-123):
  * fragment = int(np.random.normal(mu, sd)) with numpy's legacy polar Box-Muller incl. its cached second value

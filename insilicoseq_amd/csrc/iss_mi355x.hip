@@ -139,6 +139,8 @@ struct iss_ctx {
         hipEvent_t ev_main = nullptr, ev_fill = nullptr;  // ordering between ctx->stream and the fill stream
         iss::MtPhredAmb *d_amb = nullptr;  // BasicErrorModel: [0, CAP) phreds for the host, [CAP, 2 CAP) its answers
         iss::MtPairRec *d_rec = nullptr;  // k_mt_resolve -> k_mt_emit: stream offsets of one launch's pairs
+        int32_t *d_mut_cnt = nullptr;     // k_mt_emit, --store_mutations: rows per (pair, mate), then their offsets
+        int64_t *d_mut_off = nullptr;
         int64_t n_resolved = 0, n_walked = 0;  // pairs by path (statistics, iss_mt_path_counts)
     } mt;
     FastqPipe fq;
@@ -196,7 +198,9 @@ void free_mt(iss_ctx *ctx) {
     if (ctx->mt.d_mut) (void)hipFree(ctx->mt.d_mut);
     if (ctx->mt.d_gauss) (void)hipFree(ctx->mt.d_gauss);
     if (ctx->mt.d_rec) (void)hipFree(ctx->mt.d_rec);
-    ctx->mt.d_rec = nullptr;
+    if (ctx->mt.d_mut_cnt) (void)hipFree(ctx->mt.d_mut_cnt);
+    if (ctx->mt.d_mut_off) (void)hipFree(ctx->mt.d_mut_off);
+    ctx->mt.d_rec = nullptr; ctx->mt.d_mut_cnt = nullptr; ctx->mt.d_mut_off = nullptr;
     if (ctx->mt.d_amb) (void)hipFree(ctx->mt.d_amb);
     ctx->mt.d_amb = nullptr;
     if (ctx->mt.ev_main) (void)hipEventDestroy(ctx->mt.ev_main);
@@ -1312,14 +1316,14 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     const size_t rows_bytes = (((size_t)2 * M.NB * M.RL * M.mt_row_w + 1) & ~(size_t)1) * 4;  // 16-bit digit rows
     const bool use_rows = !basic && rows_bytes + fixed_lds <= 150 * 1024;
     const size_t lds_bytes = fixed_lds + (use_rows ? rows_bytes : 0);
-    // Resolver path (k_mt_resolve + k_mt_emit) for plain runs; the sequential walker for --store_mutations,
-    // indel-heavy models, the BasicErrorModel, and for the single pairs the resolver hands back.
+    // Resolver path (k_mt_resolve + k_mt_emit) for plain runs; the sequential walker for indel-heavy models, the
+    // BasicErrorModel, and for the single pairs the resolver hands back.
     typedef void (*resolve_fn)(iss::DevModel, iss::DevGenome, iss::MtResolveArgs, iss::PairDesc *);
     resolve_fn resolve = nullptr;
     size_t resolve_lds = 0;
     {
         const char *force = getenv("ISS_MT_PATH");  // "walk": sequential walker only (testing aid)
-        const bool allowed = !(force && !strcmp(force, "walk")) && !m.d_mut && ctx->mt_bounce_rate < 0.05 &&
+        const bool allowed = !(force && !strcmp(force, "walk")) && ctx->mt_bounce_rate < 0.05 &&
                              M.n_isize <= 4096 && !basic;
         const size_t budget = 160 * 1024 - 256;
         const uint32_t need_py = iss::mt_res_need_py(M.RL), need_np = iss::mt_res_need_np(M.RL);
@@ -1344,6 +1348,10 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
                 void *p = nullptr;
                 HIP_TRY(ctx, hipMalloc(&p, (size_t)CH * sizeof(iss::MtPairRec)));
                 m.d_rec = static_cast<iss::MtPairRec *>(p);
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)2 * CH * sizeof(int32_t)));
+                m.d_mut_cnt = static_cast<int32_t *>(p);
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)2 * CH * sizeof(int64_t)));
+                m.d_mut_off = static_cast<int64_t *>(p);
             }
         }
     }
@@ -1395,11 +1403,38 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
             HIP_TRY(ctx, hipMemcpyAsync(&res, m.d_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             HIP_TRY(ctx, hipGetLastError());
-            if (res.n_done > 0)
-                hipLaunchKernelGGL(iss::k_mt_emit, dim3((unsigned)((2 * res.n_done + 3) / 4)), dim3(256), 0, ctx->stream, M, dg,
-                                   R.py_base, R.np_base, res.n_done, ctx->desc + row0, m.d_rec,
-                                   ctx->out[0] + (size_t)row0 * M.pitch, ctx->out[1] + (size_t)row0 * M.pitch,
-                                   ctx->out[2] + (size_t)row0 * M.pitch, ctx->out[3] + (size_t)row0 * M.pitch);
+            if (res.n_done > 0) {
+                auto emit = [&](const iss::MtEmitMut &E) {
+                    hipLaunchKernelGGL(iss::k_mt_emit, dim3((unsigned)((2 * res.n_done + 3) / 4)), dim3(256), 0, ctx->stream, M, dg,
+                                       R.py_base, R.np_base, res.n_done, ctx->desc + row0, m.d_rec,
+                                       ctx->out[0] + (size_t)row0 * M.pitch, ctx->out[1] + (size_t)row0 * M.pitch,
+                                       ctx->out[2] + (size_t)row0 * M.pitch, ctx->out[3] + (size_t)row0 * M.pitch, E);
+                };
+                iss::MtEmitMut E{};
+                if (!m.d_mut) {
+                    emit(E);
+                } else {
+                    // --store_mutations: count the rows of every mate, place them with a prefix sum, write them in order
+                    const size_t items = (size_t)(2 * res.n_done);
+                    E.mut_cnt = m.d_mut_cnt;
+                    emit(E);
+                    std::vector<int32_t> cnt(items);
+                    HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), m.d_mut_cnt, items * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    std::vector<int64_t> off(items);
+                    int64_t at = m.mut_n;
+                    for (size_t k = 0; k < items; ++k) { off[k] = at; at += cnt[k]; }
+                    HIP_TRY(ctx, hipMemcpyAsync(m.d_mut_off, off.data(), items * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+                    E.mut_cnt = nullptr;
+                    E.mut_off = m.d_mut_off;
+                    E.mut = m.d_mut;
+                    E.mut_cap = m.mut_cap;
+                    E.pair_base = done;
+                    emit(E);
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `off` is pageable host memory
+                    m.mut_n = at;
+                }
+            }
             m.used[0] += res.py_used;
             m.used[1] += res.np_used;
             { int rc_ = mt_prefetch_commit(ctx, pf); if (rc_) return rc_; }

@@ -910,9 +910,20 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
 
 // reads of the pairs k_mt_resolve resolved: one wavefront per (pair, mate); the read is the template
 // (no indel, only ACGT), phred scores and substitutions come from the recorded stream offsets
+// --store_mutations: the rows of a (pair, mate) are its substituted positions in ascending order, and the file
+// lists the mates in order.  Pass 1 (mut_cnt != NULL) only counts the rows of every mate; the host turns the counts
+// into offsets; pass 2 (mut != NULL) writes each row at its final place mut_off[item] + rank.
+struct MtEmitMut {
+    int32_t *mut_cnt;         // pass 1: [2 * n_pairs] rows per (pair, mate)
+    const int64_t *mut_off;   // pass 2: [2 * n_pairs] first row of (pair, mate) in `mut`
+    MutRecord *mut;
+    int64_t mut_cap;
+    int64_t pair_base;        // pair index (within the call) of this launch's first pair
+};
+
 __global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const uint32_t *py, const uint32_t *np,
                                                  int64_t n_pairs, const PairDesc *desc, const MtPairRec *rec, uint8_t *out0,
-                                                 uint8_t *out1, uint8_t *out2, uint8_t *out3) {
+                                                 uint8_t *out1, uint8_t *out2, uint8_t *out3, MtEmitMut E) {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= 2 * n_pairs) return;
@@ -926,13 +937,15 @@ __global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const 
     bin = bin > 3 ? 3 : bin;
     uint8_t *ob = (o ? out2 : out0) + (size_t)i * M.pitch;
     uint8_t *oq = (o ? out3 : out1) + (size_t)i * M.pitch;
-    uint32_t nev = 0;
+    uint32_t nev = 0, n_rows = 0;
+    const int64_t row0 = E.mut ? E.mut_off[item] : 0;
     for (int p0 = 0; p0 < RL; p0 += 64) {
         const int p = p0 + lane;
         bool err = false;
-        int ch = 0, q = 0, bi = -1;
+        int ch = 0, q = 0, bi = -1, before = 0;
         if (p < RL) {
             ch = o == 0 ? fetch_ascii(g, (int64_t)d.fs + p) : complement_ascii(fetch_ascii(g, (int64_t)d.re - 1 - p));
+            before = ch;
             const uint64_t mq = mk53(np[onp_q + 2u * (uint32_t)p], np[onp_q + 2u * (uint32_t)p + 1u]);
             q = count_lt(M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * M.n_q, M.n_q, mq);
             bi = base_index(ch);
@@ -948,8 +961,22 @@ __global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const 
             ch = M.subst_alt[row + k];
         }
         nev += (uint32_t)__popcll(evm);
+        // a row only if the new letter differs from the original read, which here is the template (__init__.py:98)
+        const bool rowp = err && ch != before;
+        const unsigned long long rm = __ballot(rowp);
+        if (rowp && E.mut) {
+            const int64_t at = row0 + n_rows + (int64_t)__popcll(rm & ((1ull << lane) - 1ull));
+            if (at < E.mut_cap) {
+                MutRecord mr;
+                mr.pair = (int32_t)(E.pair_base + i); mr.mate = (int8_t)o; mr.type = 0; mr.position = (int16_t)p;
+                mr.ref = (uint8_t)before; mr.alt = (uint8_t)ch; mr.quality = (int16_t)q;
+                E.mut[at] = mr;
+            }
+        }
+        n_rows += (uint32_t)__popcll(rm);
         if (p < RL) { ob[p] = (uint8_t)ch; oq[p] = (uint8_t)q; }
     }
+    if (E.mut_cnt && lane == 0) E.mut_cnt[item] = (int32_t)n_rows;
     for (int p = RL + lane; p < M.pitch; p += 64) { ob[p] = 0; oq[p] = 0; }
 }
 

@@ -153,6 +153,8 @@ RESOLVER_CASES = {
     "novaseq_short": dict(model="novaseq", L=400, n=6000),   # width <= 0 and reverse-end fallback randrange
     "novaseq_exceptions": dict(model="novaseq", L=200000, n=20000, exceptions=True),
     "miseq_legacy_indels": dict(model="miseq-legacy", L=200000, n=3000),  # indel candidates everywhere: walker only
+    "novaseq_vcf": dict(model="novaseq", L=300000, n=20000, mut=True),              # --store_mutations rows
+    "hiseq_vcf_exceptions": dict(model="hiseq", L=150000, n=9000, mut=True, exceptions=True),
     "novaseq_frag400": dict(model="novaseq", L=300000, n=12000, frag=(400, 30)),
     "novaseq_frag160": dict(model="novaseq", L=3000, n=6000, frag=(160, 40)),   # negative inserts, templates cut by the ends
     "hiseq_frag_gc": dict(model="hiseq", L=100000, n=8000, frag=(350, 60), gc_bias=True),
@@ -183,16 +185,21 @@ def test_resolver_equals_walker(engine, monkeypatch, case):
         engine.seed_mt(77)
         engine.mt_set_fragment(*c.get("frag", (None, None)))
         engine.reserve(n + 500)
+        engine.mt_mutations_reserve(16 * n if c.get("mut") else 0)
         r0, w0 = engine.mt_path_counts()
         assert engine.generate_mt(gid, n, **kw) == n
+        rows = engine.mt_mutations().copy() if c.get("mut") else None
         # a second work item on the same streams (offsets that do not start at a buffer boundary)
         assert engine.generate_mt(gid, 500, out_first_pair=n, **kw) == 500
         r1, w1 = engine.mt_path_counts()
         got = engine.download(0, n + 500)
         coords = engine.coords(0, n + 500)
-        outs[path] = (got, coords, engine.mt_peek(16), (r1 - r0, w1 - w0))
+        outs[path] = (got, coords, engine.mt_peek(16), (r1 - r0, w1 - w0), rows)
         engine.mt_set_fragment(None, None)
-    (ga, ca, pa, cnt_walk), (gb, cb, pb, cnt_res) = outs["walk"], outs["resolve"]
+        engine.mt_mutations_reserve(0)
+    (ga, ca, pa, cnt_walk, rows_a), (gb, cb, pb, cnt_res, rows_b) = outs["walk"], outs["resolve"]
+    if c.get("mut"):
+        assert len(rows_a) > 0.2 * n and rows_a.tobytes() == rows_b.tobytes()
     for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
         bad = np.argwhere(ga[k] != gb[k])
         assert bad.size == 0, "%s differs at %s (%d cells)" % (k, bad[:5].tolist(), len(bad))
@@ -201,7 +208,7 @@ def test_resolver_equals_walker(engine, monkeypatch, case):
     assert cnt_walk == (0, n + 500)
     if case == "miseq_legacy_indels":
         assert cnt_res == (0, n + 500)
-    elif case in ("novaseq_exceptions", "novaseq_frag160"):
+    elif case in ("novaseq_exceptions", "novaseq_frag160", "hiseq_vcf_exceptions"):
         assert cnt_res[0] > 0.5 * n and cnt_res[1] > 50 and sum(cnt_res) == n + 500
     else:
         assert cnt_res[0] > 0.95 * n and sum(cnt_res) == n + 500
