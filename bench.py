@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--indel", type=float, nargs=2, default=None, metavar=("P_INS", "P_DEL"),
                     help="override every insertion / deletion probability (BASELINE configs[4]-like indel-heavy model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTQ-on-tmpfs leg (rank 0, N = 1 only)")
+    ap.add_argument("--e2e-pairs", type=int, default=5_000_000)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo: a dry run of "
                     "the multi-rank logic, e.g. with ISS_BENCH_SHARE_GPU=1 on a single-GPU box)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_500_000)
@@ -202,6 +204,8 @@ def main():
             "indel_fixup_reads_per_step": stats["fixup_reads"] / max(args.steps, 1),
             "model_broadcast_s": bcast_s,
         }
+        if world == 1 and not args.no_end_to_end:
+            out["end_to_end"] = end_to_end(dense, records, abundance, args.e2e_pairs)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dense, work, args.cpu_sample_pairs)
         print(json.dumps(out))
@@ -229,6 +233,34 @@ def committed_traffic():
         t = json.load(fh)
     committed_traffic.valu_insts = t.get("valu_insts_per_launch")
     return t["traffic_bytes_per_launch"], "bytes per launch (avg 1e6 pairs), from %s" % os.path.basename(files[-1])
+
+
+def end_to_end(dense, records, abundance, n_pairs):
+    """SURVEY.md 8d "report both": one worker from genomes in HBM to FASTQ FILES (worker_iterator: generation, FASTQ text
+    built on the device, copy, pwrite) on tmpfs.  Informational: `value` above stays the kernel-side rate."""
+    import shutil
+    import tempfile
+
+    from insilicoseq_amd.generator import worker_iterator
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = tempfile.mkdtemp(dir=base)
+    try:
+        work = [(r, int(n_pairs * abundance[r.id]), "default") for r in records]
+        prefix = os.path.join(d, "w")
+        worker_iterator([(records[0], 1000, "default")], dense, 0, prefix, SEED, "metagenomics", False, device=0)  # warm-up
+        t0 = time.perf_counter()
+        worker_iterator(work, dense, 0, prefix, SEED, "metagenomics", False, device=0)
+        dt = time.perf_counter() - t0
+        size = os.path.getsize(prefix + "_R1.fastq") + os.path.getsize(prefix + "_R2.fastq")
+        n = sum(k for _, k, _ in work)
+        return {"value": n / dt, "unit": "read-pairs/s", "fastq_GB_per_s": size / dt / 1e9,
+                "sample": "%d pairs -> %.2f GB of FASTQ on %s in %.2f s (incl. engine start-up), one worker" % (
+                    n, size / 1e9, base or "the temp dir", dt)}
+    except Exception as e:  # a leg of extra information must not take the benchmark line down
+        return {"value": None, "error": repr(e)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(dense, work, sample_pairs):

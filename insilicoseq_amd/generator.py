@@ -179,7 +179,10 @@ class Worker(object):
     def genome_id(self, record):
         key = id(record)
         if key not in self._gids:
-            self._gids[key] = self.engine.add_genome(str(record.seq))
+            seq = record.seq  # str / bytes / uint8 array as they are; Bio.Seq and the like through str()
+            if not isinstance(seq, (str, bytes, bytearray, np.ndarray)):
+                seq = str(seq)
+            self._gids[key] = self.engine.add_genome(seq)
         return self._gids[key]
 
     def simulate_reads(self, record, n_pairs, forward_handle, reverse_handle, mutations_handle, sequence_type,
