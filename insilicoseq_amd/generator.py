@@ -69,63 +69,55 @@ def to_coverage(total_n_reads, species_abundance, read_length, genome_size):
     return coverage
 
 
+def _pairs_per_record(records, readcount_dic, abundance_dic, n_reads, coverage_mode, read_length):
+    """(record, read pairs) for every record that gets reads -- the arithmetic of iss/generator.py:288-311: pairs =
+    round(reads / 2) per record, plus one whenever the running sum of the rounded counts falls behind the rounded
+    running sum of the exact ones."""
+    logger = logging.getLogger(__name__)
+    if readcount_dic is None and abundance_dic is None:
+        raise RuntimeError("No readcount or abundance file provided")
+    table, what = (readcount_dic, "readcount") if readcount_dic is not None else (abundance_dic, "abundance")
+    exact_sum, given = 0.0, 0
+    for record in records:
+        if record.id not in table:
+            logger.warning("Record %s not found in %s file" % (record.id, what))
+            continue
+        if readcount_dic is not None:
+            exact = table[record.id] / 2
+        else:
+            share, size = table[record.id], len(record.seq)
+            cov = share if coverage_mode else to_coverage(n_reads, share, read_length, size)
+            exact = ((cov * size) / read_length) / 2
+        n_pairs = round(exact)
+        exact_sum += exact
+        given += n_pairs
+        if round(exact_sum) > given:  # rounding correction
+            n_pairs += 1
+            given += 1
+        logger.debug("%s: %s read pairs" % (record.id, n_pairs))
+        if n_pairs:
+            yield record, n_pairs
+
+
 def generate_work_divider(fasta_file, readcount_dic, abundance_dic, n_reads, coverage, coverage_file, error_model,
                           output, chunk_size):
-    """Yield lists of (record, n_pairs, mode) -- iss/generator.py:254-356.  ``mode`` is always
-    "default": the >2 GiB pickle spill (:313-331) is a transport workaround of the reference's
-    process pool and has no counterpart here (genomes are uploaded to HBM, not pickled)."""
-    logger = logging.getLogger(__name__)
-    current_chunk = 0
-    total_reads_generated = 0
-    total_reads_generated_unrounded = 0
-    chunk_work = []
-    for record in fasta_file:
-        if readcount_dic is not None:
-            if record.id not in readcount_dic:
-                logger.warning("Record %s not found in readcount file" % record.id)
-                continue
-            n_pairs_unrounded = readcount_dic[record.id] / 2
-        elif abundance_dic is not None:
-            if record.id not in abundance_dic:
-                logger.warning("Record %s not found in abundance file" % record.id)
-                continue
-            record_abundance = abundance_dic[record.id]
-            genome_size = len(record.seq)
-            if coverage or coverage_file:
-                record_coverage = record_abundance
-            else:
-                record_coverage = to_coverage(n_reads, record_abundance, error_model.read_length, genome_size)
-            n_pairs_unrounded = ((record_coverage * len(record.seq)) / error_model.read_length) / 2
-        else:
-            raise RuntimeError("No readcount or abundance file provided")
-        n_pairs = round(n_pairs_unrounded)
-        total_reads_generated_unrounded += n_pairs_unrounded
-        total_reads_generated += n_pairs
-        if round(total_reads_generated_unrounded) > total_reads_generated:
-            logger.debug("Adding a pair to correct rounding error")
-            n_pairs += 1
-            total_reads_generated += 1
-        logger.debug("Will generate %s read pairs for %s" % (n_pairs, record.id))
-        if n_pairs == 0:
-            continue
-        mode = "default"
-        n_pairs_remaining = n_pairs
-        while n_pairs_remaining > 0:
-            chunk_remaining = chunk_size - current_chunk
-            if n_pairs_remaining <= chunk_remaining:
-                chunk_work.append((record, n_pairs_remaining, mode))
-                n_pairs_added = n_pairs_remaining
-            else:
-                chunk_work.append((record, chunk_remaining, mode))
-                n_pairs_added = chunk_remaining
-            n_pairs_remaining -= n_pairs_added
-            current_chunk += n_pairs_added
-            if current_chunk == chunk_size:
-                yield chunk_work
-                chunk_work = []
-                current_chunk = 0
-    if chunk_work:
-        yield chunk_work
+    """Lists of (record, n_pairs, mode), each list worth ``chunk_size`` pairs (the last one possibly less): the
+    flattened (record, pairs) sequence cut into consecutive chunks, a record straddling a boundary being split --
+    iss/generator.py:254-356.  ``mode`` is always "default": the > 2 GiB pickle spill (:313-331) is a transport
+    workaround of the reference's process pool and has no counterpart here (genomes go to HBM, not through pickle)."""
+    chunk, room = [], chunk_size
+    for record, todo in _pairs_per_record(fasta_file, readcount_dic, abundance_dic, n_reads, bool(coverage or coverage_file),
+                                          error_model.read_length):
+        while todo:
+            take = min(todo, room)
+            chunk.append((record, take, "default"))
+            todo -= take
+            room -= take
+            if room == 0:
+                yield chunk
+                chunk, room = [], chunk_size
+    if chunk:
+        yield chunk
 
 
 def _dense_of(error_model):
