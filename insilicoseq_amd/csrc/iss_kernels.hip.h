@@ -852,13 +852,15 @@ constexpr int16_t FIX_NONE = 0x7fff;
 __host__ __device__ inline int fix_rlp(int RL) { return (RL + 63) & ~63; }
 __host__ __device__ inline size_t fix_wave_bytes(int RL) {
     const size_t rlp = (size_t)fix_rlp(RL);
-    return rlp * 4 /* ev, stk, qual, (pad) */ + (rlp + 64) /* tmpl */ + 3 * 2 * (rlp + 64) /* map, rec_n0, rec_k0 */;
+    return rlp * 4 /* ev, stk, qual, (pad) */ + (rlp + 64) /* tmpl */ + 3 * 2 * (rlp + 64) /* map, rec_n0, rec_k0 */ +
+           2 * 2 * rlp /* ddel, dqm: the mate's deletion / error-test digits, one Philox block per lane */ +
+           (FIX_MAX_RL / 64) * 8 /* act: the steps with an event, one 64-bit mask per chunk (wave-uniform, out of the registers) */;
 }
 __host__ __device__ inline size_t fix_lds_bytes(int RL) {
     return (size_t)2 * RL * 8 * 4 + 64 * 4 + FIX_WAVES * fix_wave_bytes(RL);
 }
 
-__global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevGenome g, RunArgs A,
+__global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, DevGenome g, RunArgs A,
                                                                 const PairDesc *__restrict__ desc,
                                                                 const uint32_t *__restrict__ fix_list,
                                                                 const uint32_t *__restrict__ fix_count,
@@ -883,6 +885,9 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
     int16_t *map = reinterpret_cast<int16_t *>(tmpl + rlp + 64);
     int16_t *rec_n0 = map + (rlp + 64);
     int16_t *rec_k0 = rec_n0 + (rlp + 64);
+    uint16_t *ddel = reinterpret_cast<uint16_t *>(rec_k0 + (rlp + 64));  // [rlp] deletion digit of step n (K_DEL)
+    uint16_t *dqm = ddel + rlp;                                           // [rlp] error-test digit of position j (K_QM)
+    uint64_t *act = reinterpret_cast<uint64_t *>(dqm + rlp);              // [FIX_MAX_RL / 64] steps with an event
     const int n_pre = RL + 64;
     const int n_chunks = rlp / 64;  // 64-step chunks covering indices 0 .. RL-1
     MutChunk mchunk = {0u, MUT_CHUNK};
@@ -895,8 +900,21 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
         const MateGeom geo = mate_geom(o, d, RL, g.L);
         uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.pitch;
         const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.pitch;
+        // ---- phase 0: the digits that several steps / positions share, one Philox block per LANE (a K_DEL block holds
+        //      the deletion digits of 4 steps, a K_QM block the error-test digits of 2 positions)
+        for (int b = lane; b * 4 < RL - 1; b += 64) {
+            const u32x4 w = draw_block(a, K_DEL, (uint32_t)b, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ddel[b * 4 + c] = (uint16_t)digit16(w, c * 2 + o);
+        }
+        for (int b = lane; b * 2 < RL; b += 64) {
+            const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 0);
+            dqm[b * 2] = (uint16_t)digit16(w, 2 * o + 1);
+            dqm[b * 2 + 1] = (uint16_t)digit16(w, 4 + 2 * o + 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // ---- phase 1: event masks, template, phred row
-        uint64_t act[FIX_MAX_RL / 64];
 #pragma unroll 1
         for (int c = 0; c < n_chunks; ++c) {
             const int n = c * 64 + lane;
@@ -918,8 +936,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
                     }
                 }
                 if (t8[4] | t8[5] | t8[6] | t8[7]) {  // :209-210
-                    const u32x4 w = draw_block(a, K_DEL, (uint32_t)n >> 2, 0);
-                    const uint32_t h = digit16(w, (n & 3) * 2 + o);
+                    const uint32_t h = ddel[n];
                     for (int b = 0; b < 4; ++b) {
                         if (!t8[4 + b]) continue;
                         const uint32_t th = t8[4 + b] - 1u;
@@ -930,7 +947,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
                 }
             }
             if (n < RL) { ev[n] = (uint8_t)m8; map[n] = FIX_NONE; qual[n] = out_qual[n]; }
-            act[c] = __ballot(m8 != 0);
+            { const uint64_t am = __ballot(m8 != 0); if (lane == 0) act[c] = am; }
         }
         for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)geom_base(g, o, geo, k);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1005,8 +1022,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_indel_fixup(DevModel M, DevG
                 tok = rec_k0[r] + (j - rec_n0[r]);
             }
             int base = tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : geom_base(g, o, geo, tok));
-            const u32x4 w = draw_block(a, K_QM, (uint32_t)j >> 1, 0);
-            const uint32_t h = digit16(w, (j & 1) * 4 + 2 * o + 1);
+            const uint32_t h = dqm[j];
             const int q = qual[j];
             const uint32_t t = mut16[q];
             bool err = h > t;
