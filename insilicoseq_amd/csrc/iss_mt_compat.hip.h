@@ -510,7 +510,8 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
                     const size_t row = ((size_t)(o * RL + p) * 4 + bi) * 3;
                     const int k = (ms >= M.subst_thr[row]) + (ms >= M.subst_thr[row + 1]);
                     const int alt = M.subst_alt[row + k];
-                    rec = alt != (int)tmpl[p];  // only if it differs from the ORIGINAL read (:98)
+                    rec = p >= t_len || alt != (int)tmpl[p];  // only if it differs from the ORIGINAL read (:98); past a cut-short
+                                                              // template the reference raises IndexError: the row is kept
                     ref_ch = ch;
                     ch = alt;
                 }

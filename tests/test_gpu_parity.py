@@ -626,3 +626,86 @@ def test_genome_positions_beyond_2_30():
         exp = orc.simulate(O.Rng().seed_mt(9), gs, 1500)
         for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
             assert np.array_equal(got[k], exp[k]), ("mt", k)
+
+
+def _fuzz_config(k):
+    """Random but reproducible (model shape, tables, genome, options) for the differential test below."""
+    from helpers import synthetic_model
+
+    r = np.random.RandomState(1000 + k)
+    RL = int(r.choice([2, 3, 7, 20, 36, 75, 100, 126, 151, 200, 251, 301]))
+    n_q = int(r.choice([1, 2, 8, 41, 41, 41, 60]))
+    n_isize = int(r.choice([1, 5, 300, 1000, 2000]))
+    scale = float(r.choice([0.0, 0.0, 1e-5, 1e-3, 3e-2, 0.3]))
+    bins = [tuple(int(x) for x in r.randint(0, 2, size=4)) for _ in range(2)]
+    bins = [b if any(b) else (0, 0, 1, 0) for b in bins]
+    dense = synthetic_model(RL, n_q, n_isize, seed=2000 + k, indel=(scale, 2 * scale), nonempty=tuple(bins))
+    kind = r.randint(0, 4)
+    L = int(r.choice([RL + 1, RL + 5, 3 * RL + 10, 10 * RL + n_isize, 20000]))
+    L = max(L, RL + 1)
+    genome = (random_genome if kind else mixed_genome)(3000 + k, L)
+    frag = None
+    if r.rand() < 0.35:
+        frag = (float(r.choice([RL // 2 + 1, 2 * RL, 2 * RL + 150, 3 * RL])), float(r.choice([1, 10, 60])))
+    return dict(dense=dense, genome=genome, n=int(r.choice([1, 17, 200, 700])), seed=int(r.randint(0, 2**31)),
+                first=int(r.choice([0, 5, 2**33])), seq_type="amplicon" if r.rand() < 0.2 else "metagenomics",
+                gc_bias=bool(r.rand() < 0.3), frag=frag, mut=bool(r.rand() < 0.5))
+
+
+@pytest.mark.parametrize("k", range(200))
+def test_randomized_differential_both_paths(k):
+    """Random model shapes (read length 2..301, 1..60 phred entries, arbitrary non-empty bins, indel rates from 0 to
+    30 %), genomes (plain, mixed case + IUPAC, barely longer than a read), options (amplicon, gc_bias, custom fragment
+    lengths incl. shorter than a read, --store_mutations): the Philox path and the MT path against the oracle --
+    bases, phreds, coordinates, mutation rows."""
+    from insilicoseq_amd import _native
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    c = _fuzz_config(k)
+    dense, genome, n = c["dense"], c["genome"], c["n"]
+    orc = O.Oracle(dense)
+    fl, fsd = c["frag"] if c["frag"] else (None, None)
+    kw = dict(sequence_type=c["seq_type"], gc_bias=c["gc_bias"])
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        # ---- Philox
+        exp = orc.simulate(O.Rng().seed_philox(c["seed"]), genome, n, first_ordinal=c["first"], fragment_length=fl,
+                           fragment_sd=fsd, store_mutations=c["mut"], want_coords=True, **kw)
+        eng.set_fragment(fl, fsd)
+        eng.mutations_reserve(max(64 * n * dense.read_length, 1 << 21) if c["mut"] else 0)  # (rows are reserved in 256-slot chunks per wavefront)
+        eng.generate(gid, n, first_ordinal=c["first"], seed=c["seed"], **kw)
+        eng.synchronize()
+        got = eng.download(0, n)
+        assert exp["status"] == 0 and exp["n_done"] == n
+        for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(got[key], exp[key]), ("philox", key)
+        assert np.array_equal(np.asarray(eng.coords(0, n)), exp["coords"])
+        if c["mut"]:
+            rows = eng.mutations()
+            assert len(rows) == len(exp["mutations"])
+            for f in ("pair", "mate", "type", "position", "ref", "alt", "quality"):
+                assert np.array_equal(rows[f], exp["mutations"][f]), ("philox rows", f)
+        eng.mutations_reserve(0)
+        eng.set_fragment(None, None)
+        # ---- MT (resolver + walker, whatever the model allows)
+        s32 = c["seed"] & 0x7FFFFFFF
+        exp = orc.simulate(O.Rng().seed_mt(s32), genome, n, fragment_length=fl, fragment_sd=fsd, store_mutations=c["mut"], **kw)
+        eng.seed_mt(s32)
+        eng.mt_set_fragment(fl, fsd)
+        eng.mt_mutations_reserve(64 * n * dense.read_length if c["mut"] else 0)
+        try:
+            assert eng.generate_mt(gid, n, **kw) == n
+        except _native.EngineError:
+            assert c["frag"] is not None and exp["status"] != 0  # (a record the reference skips mid-stream)
+            return
+        got = eng.download(0, n)
+        assert exp["status"] == 0
+        for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(got[key], exp[key]), ("mt", key)
+        if c["mut"]:
+            rows = eng.mt_mutations()
+            assert len(rows) == len(exp["mutations"])
+            for f in ("pair", "mate", "type", "position", "ref", "alt", "quality"):
+                assert np.array_equal(rows[f], exp["mutations"][f]), ("mt rows", f)
