@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
                 sub.pair = (int32_t)(A.pair_base + pair); sub.mate = (int8_t)o; sub.type = (int8_t)32; sub.position = (int16_t)j;
                 sub.ref = (uint8_t)before; sub.alt = (uint8_t)base; sub.quality = (int16_t)q;
                 // (a read position past a template the genome end cut short has no "original" letter: the reference raises
-                //  IndexError there; the row is kept, as in the oracle)
+                //  IndexError there; the row is kept)
                 mut_emit(A, mchunk, err && base_index(before) >= 0 && (j >= geo.t_len || base != (int)tmpl[j]), sub);
             }
         }
