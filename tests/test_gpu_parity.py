@@ -709,3 +709,72 @@ def test_randomized_differential_both_paths(k):
             assert len(rows) == len(exp["mutations"])
             for f in ("pair", "mate", "type", "position", "ref", "alt", "quality"):
                 assert np.array_equal(rows[f], exp["mutations"][f]), ("mt rows", f)
+
+
+def _expected_worker_files(dense, recs, counts, seed, cpu, rng_mode, seq_type, gc_bias, frag, tmp_path):
+    """worker_iterator's three files as the oracle + the host formatter + the reference's VCF line format give them."""
+    from insilicoseq_amd.engine import fastq_write
+    from oracle import oracle as O
+
+    orc = O.Oracle(dense)
+    rng = O.Rng().seed_philox(seed + cpu) if rng_mode == "philox" else O.Rng().seed_mt(seed + cpu)
+    fl, fsd = frag if frag else (None, None)
+    p1, p2 = tmp_path / "e1", tmp_path / "e2"
+    lines, ordinal = [], 0
+    with open(p1, "wb") as f1, open(p2, "wb") as f2:
+        for r, n in zip(recs, counts):
+            kw = dict(first_ordinal=ordinal) if rng_mode == "philox" else {}
+            res = orc.simulate(rng, r.seq, n, sequence_type=seq_type, gc_bias=gc_bias, fragment_length=fl, fragment_sd=fsd,
+                               store_mutations=True, **kw)
+            if res["status"] == O.SKIP_RECORD:
+                continue
+            assert res["status"] == 0
+            k = res["n_done"]
+            if k:
+                fastq_write(f1.fileno(), f2.fileno(), r.id, 0, cpu, k, dense.read_length, dense.read_length, res["r1_base"],
+                            res["r1_qual"], res["r2_base"], res["r2_qual"], 1)
+            ordinal += n
+            for m in res["mutations"]:
+                ref, alt = chr(m["ref"]), chr(m["alt"])
+                alt = ref + alt if m["type"] == 1 else alt
+                qual = str(int(m["quality"])) if m["type"] == 0 else "."
+                lines.append("\t".join(["%s_%d_%d/%d" % (r.id, m["pair"], cpu, 1 + int(m["mate"])), str(int(m["position"]) + 1),
+                                        ".", ref, alt, qual, "", ""]) + "\n")
+    return p1.read_bytes(), p2.read_bytes(), "".join(lines)
+
+
+@pytest.mark.parametrize("k", range(24))
+def test_randomized_worker_lists(k, tmp_path):
+    """Random work lists through worker_iterator (records of assorted lengths incl. some the reference skips, zero /
+    one / many pairs, stream and ordinal carry-over between items, device FASTQ text, VCF) on both RNG paths."""
+    from insilicoseq_amd.generator import Record, worker_iterator
+    from insilicoseq_amd.model import BasicErrorModel
+
+    r = np.random.RandomState(500 + k)
+    rng_mode = "philox" if k % 2 == 0 else "mt"
+    model = str(r.choice(["novaseq", "hiseq", "ecoli", "miseq-36"] + (["basic"] if rng_mode == "mt" else [])))
+    dense = dense_model(model)
+    RL = dense.read_length
+    recs, counts = [], []
+    for i in range(int(r.randint(2, 7))):
+        L = int(r.choice([RL - 3, RL, RL + 1, 2 * RL, 5 * RL, 4000, 30000]))
+        g = (mixed_genome if r.rand() < 0.3 else random_genome)(700 + 10 * k + i, max(L, 4))
+        recs.append(Record(g, id="rec%d.%d" % (k, i)))
+        counts.append(int(r.choice([0, 1, 2, 63, 64, 65, 300, 1500])))
+    frag = (float(r.choice([2 * RL + 80, 3 * RL])), float(r.choice([5, 40]))) if r.rand() < 0.3 else None
+    if frag and rng_mode == "mt" and any(len(x.seq) <= RL for x in recs):
+        frag = None  # (skipping a record under a custom fragment length is not supported in MT mode)
+    seq_type = "amplicon" if r.rand() < 0.15 else "metagenomics"
+    gc_bias = bool(r.rand() < 0.3)
+    seed, cpu = int(r.randint(0, 10**6)), int(r.randint(0, 40))
+    em = BasicErrorModel(*(frag or (None, None)), True) if model == "basic" else dense
+    if model != "basic":
+        em.store_mutations = True
+        em.fragment_length, em.fragment_sd = frag if frag else (None, None)
+    prefix = str(tmp_path / "w")
+    worker_iterator([(x, n, "default") for x, n in zip(recs, counts)], em, cpu, prefix, seed, seq_type, gc_bias, device=0,
+                    rng=rng_mode)
+    e1, e2, evcf = _expected_worker_files(dense, recs, counts, seed, cpu, rng_mode, seq_type, gc_bias, frag, tmp_path)
+    assert open(prefix + "_R1.fastq", "rb").read() == e1
+    assert open(prefix + "_R2.fastq", "rb").read() == e2
+    assert open(prefix + ".vcf").read() == evcf
