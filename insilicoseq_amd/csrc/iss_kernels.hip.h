@@ -596,7 +596,9 @@ __device__ __forceinline__ uint32_t hot_lookup(const uint32_t *lds, uint32_t row
 }
 
 // STORE_MUT: --store_mutations variant (keeps the row bookkeeping out of the common kernel's register budget)
-template <bool STORE_MUT>
+// PLAIN: the record holds nothing but A/C/G/T and there is no custom fragment length (no irregular pairs) -- the
+// common case runs without the tests, masks and zero-initialisations of the other two.
+template <bool STORE_MUT, bool PLAIN>
 __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -674,14 +676,14 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             const u32x4 wq1 = draw_block(a, K_QM, (uint32_t)(p0 >> 1) + 1, 0);
             // ---- template bases: forward g[fs+p0 .. +3]; reverse comp(g[re-1-p0 .. -3])
             uint32_t fb = 0, rb = 0, fm = 0, rm = 0;
-            if (!(A.has_frag && (d.meta & 64u))) {  // irregular pairs are built by the fix-up kernel
+            if (PLAIN || !(A.has_frag && (d.meta & 64u))) {  // irregular pairs are built by the fix-up kernel
                 const int32_t pf = d.fs + p0;
                 const uint32_t *pw = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(uint32_t)(((pf >> 4) + 1) << 2));
                 fb = funnel_r(pw[0], pw[1], (uint32_t)(pf & 15) * 2) & 0xffu;
                 const int32_t pr = d.re - 4 - p0;  // lowest genome position of the 4 reverse bases
                 const uint32_t *qw = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(uint32_t)(((pr >> 4) + 1) << 2));
                 rb = funnel_r(qw[0], qw[1], (uint32_t)(pr & 15) * 2) & 0xffu;
-                if (d.meta & 0x30u) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
+                if (!PLAIN && (d.meta & 0x30u)) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
                     const uint32_t *mw = g.mask + (pf >> 5);
                     fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xfu;
                     const uint32_t *nw = g.mask + (pr >> 5);
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
                                       __builtin_amdgcn_perm(sel[7], sel[6], 0x04000c0cu)) >> 2) & 0x3f3f3f3fu;
             uint32_t base_f = codes_to_ascii4(fb);
             uint32_t base_r = __builtin_amdgcn_perm(0u, codes_to_ascii4(rb ^ 0x55u), 0x00010203u);  // complement, reversed
-            if (fm | rm) {  // IUPAC / lower-case letters: patch from the ASCII copy
+            if (!PLAIN && (fm | rm)) {  // IUPAC / lower-case letters: patch from the ASCII copy
                 for (int c = 0; c < 4; ++c) {
                     if ((fm >> c) & 1u) {
                         const uint32_t ch = g.ascii[(int64_t)d.fs + p0 + c];

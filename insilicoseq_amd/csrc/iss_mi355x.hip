@@ -516,10 +516,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, device_ordinal));
         ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_main<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_main<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        const void *mains[4] = {reinterpret_cast<const void *>(iss::k_main<false, false>), reinterpret_cast<const void *>(iss::k_main<false, true>),
+                                reinterpret_cast<const void *>(iss::k_main<true, false>), reinterpret_cast<const void *>(iss::k_main<true, true>)};
+        for (const void *f : mains) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_mt_walk),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_fixup),
@@ -1111,12 +1110,12 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
             unsigned per_tile = std::max(1u, per_cu * (unsigned)ctx->n_cu / (unsigned)M.n_tiles);
             per_tile = (unsigned)std::min<uint64_t>(per_tile, (items + iss::MAIN_THREADS - 1) / iss::MAIN_THREADS);
             per_tile = std::max(1u, std::min(per_tile, ctx->max_main_grid / (unsigned)M.n_tiles));
-            if (A.mut)
-                hipLaunchKernelGGL(iss::k_main<true>, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes,
-                                   s_main, M, dg, A, desc);
-            else
-                hipLaunchKernelGGL(iss::k_main<false>, dim3(per_tile * (unsigned)M.n_tiles), dim3(iss::MAIN_THREADS), lds_bytes,
-                                   s_main, M, dg, A, desc);
+            const dim3 grid(per_tile * (unsigned)M.n_tiles), block(iss::MAIN_THREADS);
+            const bool plain = !G.has_exceptions && !ctx->has_frag;
+#define ISS_LAUNCH_MAIN(MUT, PLAIN) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN>), grid, block, lds_bytes, s_main, M, dg, A, desc)
+            if (A.mut) { if (plain) ISS_LAUNCH_MAIN(true, true); else ISS_LAUNCH_MAIN(true, false); }
+            else { if (plain) ISS_LAUNCH_MAIN(false, true); else ISS_LAUNCH_MAIN(false, false); }
+#undef ISS_LAUNCH_MAIN
         }
         HIP_TRY(ctx, mark(2, s_main));
         const bool indel_pass = M.n_scan > 0 || ctx->has_frag;

@@ -83,20 +83,51 @@ def temp_prefix(output, rank):
 VCF_HEADER = "##fileformat=VCFv4.1\n" + "\t".join(["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO"])
 
 
+def _append_file(src_path, out):
+    """Append a file to the open binary file ``out`` (in-kernel copy where the platform has it)."""
+    with open(src_path, "rb") as fh:
+        size = os.fstat(fh.fileno()).st_size
+        out.flush()
+        try:
+            off = 0
+            while off < size:
+                n = os.sendfile(out.fileno(), fh.fileno(), off, min(size - off, 1 << 30))
+                if n == 0:
+                    break
+                off += n
+            if off == size:
+                return
+            fh.seek(off)
+        except (AttributeError, OSError):
+            fh.seek(0)
+            out.seek(0, os.SEEK_END)
+        shutil.copyfileobj(fh, out, 1 << 22)
+
+
 def concatenate_rank_files(output, world, suffixes=("_R1.fastq", "_R2.fastq"), cleanup=True, headers=None):
     """util.concatenate over the per-rank temp files, in rank order (iss/app.py:123-133).  Like the
     reference, a missing temp file (fewer chunks than workers) is an error (iss/util.py:233).
-    ``headers``: optional {suffix: header text} written first, followed by a newline (util.py:229-230)."""
+    ``headers``: optional {suffix: header text} written first, followed by a newline (util.py:229-230).
+    Same bytes as the reference's copy loop; rank 0's file is renamed instead of copied when it is going to be
+    removed anyway and nothing precedes it (tens of GB at BASELINE's sizes)."""
     for suffix in suffixes:
-        with open(output + suffix, "wb") as out:
-            if headers and suffix in headers:
-                out.write((headers[suffix] + "\n").encode())
-            for r in range(world):
-                with open(temp_prefix(output, r) + suffix, "rb") as fh:
-                    shutil.copyfileobj(fh, out, 1 << 22)
+        paths = [temp_prefix(output, r) + suffix for r in range(world)]
+        for path in paths:
+            if not os.path.exists(path):
+                raise FileNotFoundError(path)
+        header = headers.get(suffix) if headers else None
+        first = 0
+        if cleanup and header is None and world > 0:
+            os.replace(paths[0], output + suffix)
+            first = 1
+        with open(output + suffix, "ab" if first else "wb") as out:
+            if header is not None:
+                out.write((header + "\n").encode())
+            for path in paths[first:]:
+                _append_file(path, out)
     if cleanup:
         for r in range(world):
             for suffix in tuple(suffixes) + (".vcf",):
-                path = temp_prefix(output, r) + (suffix if suffix != ".vcf" else ".vcf")
+                path = temp_prefix(output, r) + suffix
                 if os.path.exists(path):
                     os.remove(path)
