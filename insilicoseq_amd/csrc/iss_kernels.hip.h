@@ -506,7 +506,7 @@ constexpr int SLOW_RING = 128;  // entries of a wavefront's private ring of defe
 //   [0, mut_words)            error-test table: mut16[q] - 1 (signed), q = 0..n_q
 //   [rows, +tile_words)       compressed quality rows of the position tile: per (mate, bin slot, group)
 //                             GS words = 4 rows of stride_w words + 1 pad word; a row = guide bytes
-//                             (1 << GB of them, each the BYTE offset 4 * j of an entry) then packed entries (t16 << 15 | phred << 2), ascending,
+//                             (1 << GB of them, each the BYTE offset 4 * j of an entry) then packed entries (t16 << 15 | phred << 8 | phred << 2), ascending,
 //                             closed by two sentinels
 //   [subst, +subst_words)     substitution table (leading digits + alternatives)
 //   [rings]                   MAIN_THREADS / 64 private rings of SLOW_RING deferred lane-items
@@ -543,7 +543,7 @@ __device__ __forceinline__ bool main_slow_base(const DevModel &M, const RunArgs 
     uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))] >> 2;  // guide bytes hold 4 * index
     uint32_t e = lds[row + gwords + j];
     while ((e >> 15) < h) e = lds[row + gwords + (++j)];
-    uint32_t q = (e >> 2) & 0xffu;
+    uint32_t q = (e >> 2) & 0x3fu;
     if ((e >> 15) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
     A.out[2 * o + 1][byte_off] = (uint8_t)q;
     // substitution test (__init__.py:94)
@@ -575,8 +575,8 @@ __device__ __forceinline__ bool main_slow_base(const DevModel &M, const RunArgs 
 }
 
 // One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive
-// entries -> select.  Entry = (t16 << 15) | (phred << 2): < 2^31, so differences carry their sign; the
-// low byte is the byte offset of the phred's error-test threshold.  Returns the selected entry and
+// entries -> select.  Entry = (t16 << 15) | (phred << 8) | (phred << 2): < 2^31, so differences carry their sign;
+// the low byte is the byte offset of the phred's error-test threshold, bits 8-13 the phred (< 64) for the output.  Returns the selected entry and
 // ORs into `x` a word whose SIGN BIT is set when the base needs the exact path (tie, > 2 thresholds
 // in the guide bucket, substitution test fires or ties).
 __device__ __forceinline__ uint32_t hot_lookup(const uint32_t *lds, uint32_t row_b, uint32_t wd, int gshift,
@@ -691,8 +691,8 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
                 }
             }
             // ---- phred scores + substitution test, loop-free (hot_lookup); 8 independent lookups
-            const uint32_t rowf_b = row_g + (d.meta & 3u) * slot_b;
-            const uint32_t rowr_b = row_g + ((uint32_t)M.NB + ((d.meta >> 2) & 3u)) * slot_b;
+            const uint32_t rowf_b = row_g + __umul24(d.meta & 3u, slot_b);  // (slot_b < 160 KB: 24-bit operands)
+            const uint32_t rowr_b = row_g + __umul24((uint32_t)M.NB + ((d.meta >> 2) & 3u), slot_b);
             uint32_t sel[8];  // (the rows of the last group's padding positions repeat the last position's row)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -710,11 +710,11 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
                 sel[4 + c] = hot_lookup(lds, rowr_b + pc_b, (c & 1) ? w.w : w.y, gshift, gbytes, x);
                 rare = __builtin_amdgcn_alignbit(rare, x, 31);
             }
-            // phred bytes: (low byte of each selected entry) >> 2
-            const uint32_t qual_f = ((__builtin_amdgcn_perm(sel[1], sel[0], 0x0c0c0400u) |
-                                      __builtin_amdgcn_perm(sel[3], sel[2], 0x04000c0cu)) >> 2) & 0x3f3f3f3fu;
-            const uint32_t qual_r = ((__builtin_amdgcn_perm(sel[5], sel[4], 0x0c0c0400u) |
-                                      __builtin_amdgcn_perm(sel[7], sel[6], 0x04000c0cu)) >> 2) & 0x3f3f3f3fu;
+            // phred bytes: bits 8-13 of each selected entry
+            const uint32_t qual_f = (__builtin_amdgcn_perm(sel[1], sel[0], 0x0c0c0501u) |
+                                     __builtin_amdgcn_perm(sel[3], sel[2], 0x05010c0cu)) & 0x3f3f3f3fu;
+            const uint32_t qual_r = (__builtin_amdgcn_perm(sel[5], sel[4], 0x0c0c0501u) |
+                                     __builtin_amdgcn_perm(sel[7], sel[6], 0x05010c0cu)) & 0x3f3f3f3fu;
             uint32_t base_f = codes_to_ascii4(fb);
             uint32_t base_r = __builtin_amdgcn_perm(0u, codes_to_ascii4(rb ^ 0x55u), 0x00010203u);  // complement, reversed
             if (!PLAIN && (fm | rm)) {  // IUPAC / lower-case letters: patch from the ASCII copy

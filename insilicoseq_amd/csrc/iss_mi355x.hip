@@ -638,11 +638,11 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         entries.clear();
         for (int i = 0; i < nq; ++i) {
             const uint32_t v = (uint32_t)std::min<uint64_t>(row[i] >> 37, 0xffffu);  // 2^53 (cdf == 1.0) clamps: a tie
-            if (entries.empty() || (entries.back() >> 15) != v) entries.push_back((v << 15) | ((uint32_t)i << 2));
+            if (entries.empty() || (entries.back() >> 15) != v) entries.push_back((v << 15) | ((uint32_t)i << 8) | ((uint32_t)i << 2));
         }
         // two closing sentinels (the hot loop reads entries j and j + 1 unconditionally); digit 0xffff
         // "ties" with them and is resolved exactly
-        if ((entries.back() >> 15) != 0xffffu) entries.push_back((0xffffu << 15) | ((uint32_t)nq << 2));
+        if ((entries.back() >> 15) != 0xffffu) entries.push_back((0xffffu << 15) | ((uint32_t)nq << 8) | ((uint32_t)nq << 2));
         entries.push_back(entries.back());
         entries.push_back(entries.back());
     };
