@@ -139,6 +139,7 @@ class Worker(object):
     """State of one reference worker on one GPU: engine + uploaded genomes + running ordinal."""
 
     BATCH_PAIRS = 1 << 20  # rows generated / downloaded / formatted per step of the streaming loop
+    GENOME_BUDGET = 96 << 30  # letters kept resident in HBM (1.4 B each incl. the packed copies) before all are dropped
 
     def __init__(self, error_model, cpu_number, seed, device=None, rng="philox"):
         if rng not in ("philox", "mt"):
@@ -163,19 +164,27 @@ class Worker(object):
             self.engine.set_fragment(getattr(error_model, "fragment_length", None),
                                      getattr(error_model, "fragment_sd", None))
         self.ordinal = 0
-        self._gids = {}
+        self._gids = {}  # id(record) -> (record, genome id on the device)
+        self._resident = 0
 
     def close(self):
         self.engine.close()
 
     def genome_id(self, record):
         key = id(record)
-        if key not in self._gids:
+        hit = self._gids.get(key)
+        if hit is None or hit[0] is not record:
             seq = record.seq  # str / bytes / uint8 array as they are; Bio.Seq and the like through str()
             if not isinstance(seq, (str, bytes, bytearray, np.ndarray)):
                 seq = str(seq)
-            self._gids[key] = self.engine.add_genome(seq)
-        return self._gids[key]
+            if self._gids and self._resident + len(seq) > self.GENOME_BUDGET:
+                # a work list visits a record in one or two consecutive items: nothing uploaded so far is needed again
+                self.engine.clear_genomes()  # (waits for the device and the FASTQ pipeline first)
+                self._gids.clear()
+                self._resident = 0
+            hit = self._gids[key] = (record, self.engine.add_genome(seq))
+            self._resident += len(seq)
+        return hit[1]
 
     def simulate_reads(self, record, n_pairs, forward_handle, reverse_handle, mutations_handle, sequence_type,
                        gc_bias=False, writer_threads=4, flush=True):

@@ -778,3 +778,21 @@ def test_randomized_worker_lists(k, tmp_path):
     assert open(prefix + "_R1.fastq", "rb").read() == e1
     assert open(prefix + "_R2.fastq", "rb").read() == e2
     assert open(prefix + ".vcf").read() == evcf
+
+
+def test_worker_drops_resident_genomes_over_budget(tmp_path, monkeypatch):
+    """A work list larger than the HBM budget for genomes: uploaded records are dropped and the files do not change."""
+    from insilicoseq_amd import generator as G
+
+    dense = dense_model("novaseq")
+    recs = [G.Record(random_genome(900 + i, 3000 + 500 * i), id="r%d" % i) for i in range(5)]
+    work = [(recs[0], 40, "default"), (recs[1], 70, "default"), (recs[1], 5, "default"), (recs[2], 0, "default"),
+            (recs[3], 64, "default"), (recs[0], 9, "default"), (recs[4], 33, "default")]
+    outs = []
+    for budget in (None, 7000):
+        if budget:
+            monkeypatch.setattr(G.Worker, "GENOME_BUDGET", budget)
+        prefix = str(tmp_path / ("w%s" % budget))
+        G.worker_iterator(work, dense, 2, prefix, 11, "metagenomics", False, device=0)
+        outs.append((open(prefix + "_R1.fastq", "rb").read(), open(prefix + "_R2.fastq", "rb").read()))
+    assert outs[0] == outs[1] and outs[0][0].count(b"\n") == 4 * (40 + 70 + 5 + 64 + 9 + 33)
