@@ -648,22 +648,31 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     const uint32_t out_step = sgpr((step_pair * (uint32_t)M.G + step_grp) * 4u), out_wrap = sgpr(((uint32_t)M.G - tg) * 4u);
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // the leading padding word: offsets >= 0
     MutChunk mchunk = {0u, MUT_CHUNK};  // --store_mutations: forces a reservation at first use
-    // one round of the exact path: lane k takes the k-th pending entry of this wavefront (n <= 64 of them)
+    // one round of the exact path: lane k takes ONE base of the k-th pending entry of this wavefront (n <= 64 of them);
+    // an entry with more bases (noisy models: NextSeq, MiSeq) goes back into the ring, so every round runs full
+    // instead of looping until the lane with the most bases is done (at most 64 come back for the 64 taken out)
     auto drain_round = [&](uint32_t n) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's output dwords have reached the L2
+        uint32_t rest = 0;
         if (lane < n) {
             const uint32_t ent = ring[(q_head + lane) & (SLOW_RING - 1)];
             const uint32_t it_e = first + (threadIdx.x & ~63u) + ((ent >> 8) & 63u) + (ent >> 14) * step;
-            uint32_t mask = ent & 0xffu;  // almost always a single bit
-            while (mask) {
-                const int bit = 31 - __clz(mask);
-                mask &= ~(1u << bit);
-                MutRecord rec;
-                const bool have = main_slow_base(M, A, desc, lds, T, it_e, 7 - bit, rec);
-                if (STORE_MUT) mut_emit(A, mchunk, have, rec);
-            }
+            const uint32_t mask = ent & 0xffu;  // never empty
+            const int bit = 31 - __clz(mask);
+            if (mask & (mask - 1u)) rest = ent & ~(1u << bit);
+            MutRecord rec;
+            const bool have = main_slow_base(M, A, desc, lds, T, it_e, 7 - bit, rec);
+            if (STORE_MUT) mut_emit(A, mchunk, have, rec);
         }
         q_head += n;
+        const unsigned long long again = __ballot(rest != 0u);
+        if (again) {
+            if (rest) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
+                ring[(q_tail + rank) & (SLOW_RING - 1)] = rest;
+            }
+            q_tail += (uint32_t)__popcll(again);
+        }
     };
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
         uint32_t rare = 0;
@@ -743,7 +752,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
                 ring[(q_tail + rank) & (SLOW_RING - 1)] = (iter << 14) | (lane << 8) | rare;
             }
             q_tail += (uint32_t)__popcll(rm);
-            if (q_tail - q_head >= 64u) drain_round(64u);
+            while (q_tail - q_head >= 64u) drain_round(64u);
         }
         it += step;
         pair += step_pair;
@@ -752,7 +761,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
         out_b += out_step;
         if (grp >= tg) { grp -= tg; ++pair; row_g -= row_wrap; out_b += out_wrap; }
     }
-    if (q_tail != q_head) drain_round(q_tail - q_head);
+    while (q_tail != q_head) drain_round(min(64u, q_tail - q_head));
 }
 
 // ================================================================== k_indel_scan
