@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ISS_ABI_VERSION 2
+#define ISS_ABI_VERSION 3
 
 #define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
 #define ISS_E_HIP (-2)         /* HIP runtime failure (message has the hip error)  */
@@ -204,6 +204,24 @@ int iss_mt_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity,
 int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, int64_t first_i, int32_t cpu_number,
                    int64_t first_pair, int64_t n_pairs, int32_t n_threads);
 int iss_fastq_flush(iss_ctx *ctx);
+
+/*
+ * `--compress` (iss/app.py:134-143 -> util.compress, iss/util.py:255-268: gzip of the finished FASTQ files) moved in
+ * front of the files: with mode 1 every iss_fastq_emit appends ONE GZIP MEMBER per file (RFC 1952) holding the
+ * batch's text instead of the text -- DEFLATE blocks with a dynamic Huffman code and run matches, built on the device
+ * from the batch's own token histogram, so only the compressed bytes (about 1/3.5) cross PCIe and reach the file
+ * system.  Concatenated members are one valid .gz file whose content is the text mode 0 writes.  mode 0 (default):
+ * plain text.  Changing the mode flushes.
+ */
+int iss_fastq_compress(iss_ctx *ctx, int32_t mode);
+
+/*
+ * The code builder of the compressed mode as a host function (tests, tools): hist[263] token counts (literals
+ * 0..255, [256] the number of blocks, [257..262] runs of length 3..8 at distance 1) -> entry[s] = bit-reversed code |
+ * length << 16 for the 263 symbols, and the dynamic-block header (BFINAL = 0 ... both code-length tables; one distance
+ * code, one bit long) as hdr_bits bits, least significant first, in hdr_words[64].  No GPU needed.
+ */
+int iss_deflate_code_build(const uint32_t *hist, uint32_t *entry, uint32_t *hdr_bits, uint32_t *hdr_words);
 
 /*
  * FASTQ emission, replaces SeqIO.write(record, handle, "fastq-sanger") in

@@ -20,7 +20,7 @@ EXPORTS = (
     "iss_output_download_coords", "iss_timing_enable", "iss_timing_read", "iss_stats_read", "iss_fastq_write",
     "iss_mt_seed", "iss_generate_mt", "iss_mt_peek", "iss_mt_mutations_reserve", "iss_mt_mutations_download",
     "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
-    "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush",
+    "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush", "iss_fastq_compress", "iss_deflate_code_build",
 )
 
 
@@ -94,6 +94,8 @@ def lib():
     L.iss_mt_mutations_download.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.iss_fastq_emit.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i64, i32]
     L.iss_fastq_flush.argtypes = [vp]
+    L.iss_fastq_compress.argtypes = [vp, i32]
+    L.iss_deflate_code_build.argtypes = [vp, vp, vp, vp]
     L.iss_fastq_write.argtypes = [C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i32, i32, vp, vp, vp, vp, i32]
     for name in EXPORTS:
         if name not in ("iss_ctx_destroy", "iss_last_error"):

@@ -1,0 +1,470 @@
+// iss_deflate.hip.h -- gzip members built on the device (`--compress`, iss/util.py:255-268).
+//
+// The reference gzips the finished FASTQ files on the host (gzip.open + copyfileobj).  At the kernel's rate the FASTQ
+// text is the bottleneck twice over (PCIe, then the file system), so with compression on the text never leaves the
+// device: every batch of FASTQ text becomes one gzip member made of DEFLATE blocks with a dynamic Huffman code whose
+// only matches are runs (distance 1, found inside 8-byte chunks, so no search and no dependency between lanes).
+// FASTQ is bases (2 bits of entropy), phreds (runs of the top quality) and headers; this reaches about 3.5x on it
+// (zlib level 6: 4-4.5x).  The decompressed bytes are exactly the text k_fastq_format wrote (the compressed bytes
+// differ from the reference's, like any two gzip implementations' do).
+//
+// Per batch and mate:  k_deflate_hist (byte histogram of the text) -> k_deflate_build (ONE lane: length-limited
+// Huffman code, canonical codes, the dynamic-block header bits -- the same code any host would build, here without a
+// round trip) -> k_deflate_len (bits and raw CRC-32 of every 32 KB block) -> k_deflate_scan (byte offsets) ->
+// k_deflate_encode (bit packing through LDS).  Every block ends with an empty stored block (the "sync flush" of
+// zlib), which byte-aligns the next one, so blocks are written independently.  The host adds the 10-byte member
+// header, the final empty block, CRC-32 and ISIZE (RFC 1952), combining the per-block CRCs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace iss {
+
+constexpr int DEFLATE_SYMS = 263;      // literals 0..255, end of block, lengths 3..8 (codes 257..262, no extra bits)
+constexpr int DEFLATE_BLOCK = 32768;   // text bytes per DEFLATE block
+constexpr int DEFLATE_HDR_WORDS = 64;  // room for the dynamic-block header (<= 3 + 14 + 57 + 258 * 7 + ... bits)
+constexpr int DEFLATE_THREADS = 256;
+
+struct DeflateCode {
+    uint32_t entry[DEFLATE_SYMS];      // bit-reversed code | length << 16
+    uint32_t hdr_bits;                 // length of the block header: BFINAL, BTYPE, HLIT, HDIST, HCLEN, both code tables
+    uint32_t hdr[DEFLATE_HDR_WORDS];   // its bits, least significant first
+    uint32_t crc_shift[8][32];         // GF(2) operators "append 128 << k zero bytes" for the in-block CRC tree
+};
+
+// ---------------------------------------------------------------- code construction (host and device)
+// Huffman code lengths of n <= 288 symbols, limited to maxbits; symbols with count 0 get length 0.  The code is
+// complete (Kraft sum exactly 1), as inflate requires, whenever at least two symbols are in use.
+__host__ __device__ inline void deflate_lengths(const uint32_t *cnt, int n, int maxbits, uint8_t *len) {
+    // binary heap of (weight, node); nodes 0..n-1 leaves, n.. internal
+    uint64_t heap[2 * 288];
+    int16_t parent[2 * 288];
+    int hn = 0;
+    auto push = [&](uint64_t key) {
+        int i = hn++;
+        while (i > 0 && heap[(i - 1) / 2] > key) { heap[i] = heap[(i - 1) / 2]; i = (i - 1) / 2; }
+        heap[i] = key;
+    };
+    auto pop = [&]() {
+        const uint64_t top = heap[0], last = heap[--hn];
+        int i = 0;
+        for (;;) {
+            int c = 2 * i + 1;
+            if (c >= hn) break;
+            if (c + 1 < hn && heap[c + 1] < heap[c]) ++c;
+            if (heap[c] >= last) break;
+            heap[i] = heap[c];
+            i = c;
+        }
+        if (hn) heap[i] = last;
+        return top;
+    };
+    int used = 0;
+    for (int s = 0; s < n; ++s) {
+        len[s] = 0;
+        if (cnt[s]) { push(((uint64_t)cnt[s] << 16) | (uint64_t)s); ++used; }
+    }
+    if (used == 0) return;
+    if (used == 1) {  // one symbol: one bit, paired with a second symbol so the code is complete
+        const int s = (int)(heap[0] & 0xffffu);
+        len[s] = 1;
+        len[s == 0 ? 1 : 0] = 1;
+        return;
+    }
+    int next = n;
+    while (hn > 1) {
+        const uint64_t a = pop(), b = pop();
+        parent[a & 0xffffu] = (int16_t)next;
+        parent[b & 0xffffu] = (int16_t)next;
+        push((((a >> 16) + (b >> 16)) << 16) | (uint64_t)next);
+        ++next;
+    }
+    const int root = (int)(heap[0] & 0xffffu);
+    for (int s = 0; s < n; ++s) {
+        if (!cnt[s]) continue;
+        int d = 0;
+        for (int v = s; v != root; v = parent[v]) ++d;
+        len[s] = (uint8_t)(d > maxbits ? maxbits : d);
+    }
+    // Kraft sum in units of 2^-maxbits; clamping may have pushed it over 1
+    const uint32_t one = 1u << maxbits;
+    uint32_t k = 0;
+    for (int s = 0; s < n; ++s) if (len[s]) k += one >> len[s];
+    while (k > one) {  // lengthen the longest code that still can be lengthened (cheapest in expected bits)
+        int best = -1;
+        for (int s = 0; s < n; ++s)
+            if (len[s] && len[s] < maxbits && (best < 0 || len[s] > len[best] || (len[s] == len[best] && cnt[s] < cnt[best])))
+                best = s;
+        k -= one >> (len[best] + 1);
+        ++len[best];
+    }
+    while (k < one) {  // shorten the longest code that fits into what is left
+        int best = -1;
+        for (int s = 0; s < n; ++s)
+            if (len[s] > 1 && (one >> len[s]) <= one - k && (best < 0 || len[s] > len[best] || (len[s] == len[best] && cnt[s] > cnt[best])))
+                best = s;
+        if (best < 0) break;
+        k += one >> len[best];
+        --len[best];
+    }
+}
+
+// canonical codes (RFC 1951 3.2.2), bit-reversed for a least-significant-bit-first stream
+__host__ __device__ inline void deflate_codes(const uint8_t *len, int n, uint16_t *code) {
+    uint32_t bl_count[16] = {0}, next_code[16] = {0};
+    for (int s = 0; s < n; ++s) ++bl_count[len[s]];
+    bl_count[0] = 0;
+    uint32_t c = 0;
+    for (int b = 1; b < 16; ++b) { c = (c + bl_count[b - 1]) << 1; next_code[b] = c; }
+    for (int s = 0; s < n; ++s) {
+        uint32_t v = 0;
+        if (len[s]) {
+            const uint32_t x = next_code[len[s]]++;
+            for (int b = 0; b < len[s]; ++b) v |= ((x >> b) & 1u) << (len[s] - 1 - b);
+        }
+        code[s] = (uint16_t)v;
+    }
+}
+
+struct BitSink {
+    uint32_t *w;
+    uint32_t n;  // bits so far
+    __host__ __device__ void put(uint32_t v, int bits) {
+        for (int b = 0; b < bits; ++b, ++n)
+            if ((v >> b) & 1u) w[n >> 5] |= 1u << (n & 31);
+    }
+};
+
+// hist[s]: token counts of the text (literals, hist[256] = number of blocks, run lengths 3..8 at 257..262).  Every
+// symbol gets a code (count + 1, and at least 2^-15 of the total so that the tree stays shallow): a batch is
+// compressed with the code of its own text, but nothing breaks if a symbol shows up that the histogram missed.
+__host__ __device__ inline void deflate_build_code(const uint32_t *hist, DeflateCode *out) {
+    uint32_t cnt[DEFLATE_SYMS];
+    uint64_t total = 0;
+    for (int s = 0; s < DEFLATE_SYMS; ++s) total += hist[s];
+    const uint32_t floor_cnt = (uint32_t)(total >> 15);
+    for (int s = 0; s < DEFLATE_SYMS; ++s) cnt[s] = hist[s] + 1u > floor_cnt ? hist[s] + 1u : floor_cnt;
+    uint8_t len[DEFLATE_SYMS + 1];
+    uint16_t code[DEFLATE_SYMS];
+    deflate_lengths(cnt, DEFLATE_SYMS, 15, len);
+    deflate_codes(len, DEFLATE_SYMS, code);
+    for (int s = 0; s < DEFLATE_SYMS; ++s) out->entry[s] = (uint32_t)code[s] | ((uint32_t)len[s] << 16);
+    // ---- header: the literal/length code lengths + one distance code of length 1, run-length coded (3.2.7)
+    len[DEFLATE_SYMS] = 1;
+    uint8_t sym[DEFLATE_SYMS + 1], extra[DEFLATE_SYMS + 1];
+    int ns = 0;
+    for (int i = 0; i <= DEFLATE_SYMS;) {
+        int r = 1;
+        while (i + r <= DEFLATE_SYMS && len[i + r] == len[i]) ++r;
+        sym[ns] = len[i]; extra[ns] = 0; ++ns;  // the value itself
+        int rem = r - 1;
+        if (len[i] != 0)
+            while (rem >= 3) { const int t = rem > 6 ? 6 : rem; sym[ns] = 16; extra[ns] = (uint8_t)(t - 3); ++ns; rem -= t; }
+        for (; rem > 0; --rem) { sym[ns] = len[i]; extra[ns] = 0; ++ns; }
+        i += r;
+    }
+    uint32_t ccnt[19] = {0};
+    for (int i = 0; i < ns; ++i) ++ccnt[sym[i]];
+    uint8_t clen[19];
+    uint16_t ccode[19];
+    deflate_lengths(ccnt, 19, 7, clen);
+    deflate_codes(clen, 19, ccode);
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int hclen = 19;
+    while (hclen > 4 && clen[order[hclen - 1]] == 0) --hclen;
+    for (int i = 0; i < DEFLATE_HDR_WORDS; ++i) out->hdr[i] = 0;
+    BitSink bs{out->hdr, 0};
+    bs.put(0, 1);  // BFINAL = 0 (the member is closed by an empty final block)
+    bs.put(2, 2);  // BTYPE = 10: dynamic Huffman codes
+    bs.put(DEFLATE_SYMS - 257, 5);  // HLIT
+    bs.put(0, 5);                   // HDIST: one distance code (distance 1), one bit long
+    bs.put((uint32_t)(hclen - 4), 4);
+    for (int i = 0; i < hclen; ++i) bs.put(clen[order[i]], 3);
+    for (int i = 0; i < ns; ++i) {
+        bs.put(ccode[sym[i]], clen[sym[i]]);
+        if (sym[i] == 16) bs.put(extra[i], 2);
+    }
+    out->hdr_bits = bs.n;
+}
+
+// ---------------------------------------------------------------- CRC-32 (reflected 0xEDB88320), raw: initial value 0, no final xor
+__host__ __device__ inline uint32_t crc_table_entry(uint32_t i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+    return c;
+}
+__host__ __device__ inline uint32_t gf2_times(const uint32_t *mat, uint32_t vec) {
+    uint32_t sum = 0;
+    for (int i = 0; vec; vec >>= 1, ++i) if (vec & 1u) sum ^= mat[i];
+    return sum;
+}
+inline void gf2_square(uint32_t *sq, const uint32_t *mat) { for (int n = 0; n < 32; ++n) sq[n] = gf2_times(mat, mat[n]); }
+// operator "append n zero bytes" (zlib's crc32_combine construction), n >= 1
+inline void crc_shift_operator(uint64_t n_bytes, uint32_t *op) {
+    uint32_t even[32], odd[32];
+    odd[0] = 0xEDB88320u;  // one zero bit
+    for (int n = 1; n < 32; ++n) odd[n] = 1u << (n - 1);
+    gf2_square(even, odd);   // two bits
+    gf2_square(odd, even);   // four bits
+    uint32_t acc[32];
+    for (int n = 0; n < 32; ++n) acc[n] = 1u << n;  // identity
+    // the first squaring below yields the one-byte operator
+    uint32_t *cur = odd, *nxt = even;
+    for (uint64_t n = n_bytes; n; n >>= 1) {
+        gf2_square(nxt, cur);
+        uint32_t *t = cur; cur = nxt; nxt = t;  // cur = operator for 2^k bytes
+        if (n & 1u) {
+            uint32_t tmp[32];
+            for (int i = 0; i < 32; ++i) tmp[i] = gf2_times(cur, acc[i]);
+            for (int i = 0; i < 32; ++i) acc[i] = tmp[i];
+        }
+    }
+    for (int n = 0; n < 32; ++n) op[n] = acc[n];
+}
+
+// ---------------------------------------------------------------- tokens
+// The text is cut into 8-byte chunks (aligned to the text's start; blocks are multiples of 8).  Inside a chunk a byte
+// that repeats its predecessor at least three times becomes a match (length 3..8, distance 1); everything else is a
+// literal.  The predecessor of a chunk's first byte is the text byte before it (none at offset 0), which may belong to
+// the previous block: DEFLATE's window does not care.  f(symbol, is_match) is called per token.
+template <typename F>
+__host__ __device__ inline void deflate_tokens(uint64_t raw, uint32_t m, int prev, F &&f) {
+    uint32_t i = 0;
+    while (i < m) {
+        const int c = (int)((raw >> (8 * i)) & 0xffu);
+        if (c == prev) {
+            uint32_t r = 1;
+            while (i + r < m && (int)((raw >> (8 * (i + r))) & 0xffu) == c) ++r;
+            if (r >= 3u) { f(254u + r, true); i += r; continue; }  // lengths 3..8 -> codes 257..262
+        }
+        f((uint32_t)c, false);
+        prev = c;
+        ++i;
+    }
+}
+
+// ---------------------------------------------------------------- kernels
+struct DeflateArgs {
+    const uint8_t *text[2];     // [mate]
+    uint64_t n_bytes;           // per mate
+    uint32_t n_blocks;          // ceil(n_bytes / DEFLATE_BLOCK)
+    uint32_t *hist[2];          // [mate][DEFLATE_SYMS]
+    DeflateCode *code[2];
+    uint32_t *block_bytes[2];   // [mate][n_blocks] compressed size of each block
+    uint32_t *block_crc[2];     // [mate][n_blocks] raw CRC-32 of each block's text
+    uint64_t *block_off[2];     // [mate][n_blocks + 1] byte offsets in `out` (exclusive scan), [n_blocks] = total
+    uint8_t *out[2];
+    uint64_t out_cap;
+};
+
+// chunk `c` of the text: its bytes (little endian), how many there are, and the byte before it (-1: none)
+__device__ __forceinline__ uint64_t deflate_chunk(const uint8_t *t, uint64_t n_bytes, uint64_t c, uint32_t &m, int &prev) {
+    const uint64_t at = c * 8u;
+    m = (uint32_t)min((uint64_t)8, n_bytes - at);
+    prev = at ? (int)t[at - 1] : -1;
+    if (m == 8u) return *reinterpret_cast<const uint64_t *>(t + at);  // (the text buffer is 8-byte aligned)
+    uint64_t raw = 0;
+    for (uint32_t k = 0; k < m; ++k) raw |= (uint64_t)t[at + k] << (8 * k);
+    return raw;
+}
+
+__global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_hist(DeflateArgs A) {
+    __shared__ uint32_t h[DEFLATE_SYMS];
+    const int mate = blockIdx.y;
+    for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS) h[s] = 0;
+    __syncthreads();
+    const uint8_t *t = A.text[mate];
+    const uint64_t n_chunks = (A.n_bytes + 7) / 8;
+    for (uint64_t c = (uint64_t)blockIdx.x * DEFLATE_THREADS + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * DEFLATE_THREADS) {
+        uint32_t m;
+        int prev;
+        const uint64_t raw = deflate_chunk(t, A.n_bytes, c, m, prev);
+        deflate_tokens(raw, m, prev, [&](uint32_t sym, bool) { atomicAdd(&h[sym], 1u); });
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS)
+        if (h[s]) atomicAdd(&A.hist[mate][s], h[s]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.hist[mate][256], A.n_blocks);
+}
+
+__global__ void k_deflate_build(DeflateArgs A) {
+    if (threadIdx.x == 0) deflate_build_code(A.hist[blockIdx.x], A.code[blockIdx.x]);
+}
+
+// One workgroup per block: compressed size in bytes and the raw CRC-32 of the block's text.  For the CRC, lane t of
+// the workgroup owns the 128 bytes that END (256 - t) * 128 bytes before the end of the block (a short block is
+// padded with zeros in FRONT, which a raw CRC does not see), so the tree of "append 128 << k bytes" operators is the
+// same for every block.
+__global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) {
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t lens[DEFLATE_SYMS];
+    __shared__ uint32_t red[DEFLATE_THREADS];
+    __shared__ uint32_t crcs[DEFLATE_THREADS];
+    const int mate = blockIdx.y;
+    const uint32_t b = blockIdx.x;
+    const DeflateCode *C = A.code[mate];
+    tab[threadIdx.x] = crc_table_entry(threadIdx.x);
+    for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS) lens[s] = C->entry[s] >> 16;
+    __syncthreads();
+    const uint64_t start = (uint64_t)b * DEFLATE_BLOCK;
+    const uint32_t n = (uint32_t)min((uint64_t)DEFLATE_BLOCK, A.n_bytes - start);
+    uint32_t bits = 0;
+    for (uint32_t c = threadIdx.x; c * 8u < n; c += DEFLATE_THREADS) {
+        uint32_t m;
+        int prev;
+        const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, start / 8u + c, m, prev);
+        deflate_tokens(raw, m, prev, [&](uint32_t sym, bool match) { bits += lens[sym] + (match ? 1u : 0u); });
+    }
+    const uint8_t *t = A.text[mate] + start;
+    const int64_t lo = (int64_t)n - (int64_t)(DEFLATE_THREADS - threadIdx.x) * 128;  // may be negative: zeros in front
+    uint32_t crc = 0;
+    for (int64_t i = lo < 0 ? 0 : lo; i < lo + 128; ++i) crc = tab[(crc ^ t[i]) & 0xffu] ^ (crc >> 8);
+    red[threadIdx.x] = bits;
+    crcs[threadIdx.x] = crc;
+    __syncthreads();
+    for (int k = 0, s = 1; s < DEFLATE_THREADS; s <<= 1, ++k) {
+        if ((threadIdx.x & (2 * s - 1)) == 0) {
+            red[threadIdx.x] += red[threadIdx.x + s];
+            crcs[threadIdx.x] = gf2_times(C->crc_shift[k], crcs[threadIdx.x]) ^ crcs[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t total = C->hdr_bits + red[0] + lens[256] + 3u;  // + end of block + header of the empty stored block
+        A.block_bytes[mate][b] = (total + 7u) / 8u + 4u;                 // + LEN = 0, NLEN = 0xffff
+        A.block_crc[mate][b] = crcs[0];
+    }
+}
+
+// exclusive scan of the block sizes (one workgroup per mate)
+__global__ __launch_bounds__(1024) void k_deflate_scan(DeflateArgs A) {
+    __shared__ uint64_t part[1024];
+    const int mate = blockIdx.x;
+    const uint32_t per = (A.n_blocks + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = min(A.n_blocks, lo + per);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += A.block_bytes[mate][i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint64_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) { A.block_off[mate][i] = run; run += A.block_bytes[mate][i]; }
+    if (threadIdx.x == 1023) A.block_off[mate][A.n_blocks] = part[1023];
+}
+
+// One workgroup per block.  Tiles of 256 lanes x 8 bytes: each lane concatenates the codes of its chunk (<= 120 bits), a
+// workgroup scan places them, the bits are ORed into an LDS window, whole words of the window go out and the
+// unfinished last word starts the next tile.  The block starts on a byte of `out`, not on a word: the window is
+// bit-shifted by the misalignment and the first / last word are merged with atomicOr (the buffer is zeroed).
+constexpr int DEFLATE_WIN_WORDS = DEFLATE_THREADS * 120 / 32 + 4;
+
+__global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_encode(DeflateArgs A) {
+    __shared__ uint32_t ent[DEFLATE_SYMS];
+    __shared__ uint32_t win[DEFLATE_WIN_WORDS];
+    __shared__ uint32_t wsum[DEFLATE_THREADS / 64];
+    const int mate = blockIdx.y;
+    const uint32_t b = blockIdx.x;
+    const DeflateCode *C = A.code[mate];
+    for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS) ent[s] = C->entry[s];
+    for (int i = threadIdx.x; i < DEFLATE_WIN_WORDS; i += DEFLATE_THREADS) win[i] = 0;
+    __syncthreads();
+    const uint64_t start = (uint64_t)b * DEFLATE_BLOCK;
+    const uint32_t n = (uint32_t)min((uint64_t)DEFLATE_BLOCK, A.n_bytes - start);
+    const uint64_t off = A.block_off[mate][b];
+    if (off + A.block_bytes[mate][b] > A.out_cap) return;  // (the host reports the overflow from block_off[n_blocks])
+    uint32_t *outw = reinterpret_cast<uint32_t *>(A.out[mate] + (off & ~3ull));
+    uint32_t wpos = 0;                            // words of this block already written
+    uint32_t fill = (uint32_t)(off & 3ull) * 8u;  // bits in the window so far (the first tile starts misaligned)
+    auto or_bits = [&](uint32_t at, uint64_t v) {  // OR <= 64 bits at bit `at` of the window
+        if (!v) return;
+        const uint32_t w = at >> 5, sh = at & 31u;
+        atomicOr(&win[w], (uint32_t)(v << sh));
+        const uint64_t hi = sh ? v >> (32 - sh) : v >> 32;
+        if (hi) {
+            atomicOr(&win[w + 1], (uint32_t)hi);
+            if (hi >> 32) atomicOr(&win[w + 2], (uint32_t)(hi >> 32));
+        }
+    };
+    auto flush = [&](bool last) {  // whole words of the window -> out; the partial last word moves to the front
+        __syncthreads();
+        const uint32_t nw = last ? (fill + 31u) >> 5 : fill >> 5;
+        for (uint32_t i = threadIdx.x; i < nw; i += DEFLATE_THREADS) {
+            const uint32_t v = win[i];
+            if ((wpos + i == 0) || (last && i == nw - 1)) { if (v) atomicOr(&outw[wpos + i], v); }
+            else outw[wpos + i] = v;
+        }
+        __syncthreads();
+        const uint32_t keep = last ? 0u : win[nw];
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i <= nw + 4 && i < DEFLATE_WIN_WORDS; i += DEFLATE_THREADS) win[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) win[0] = keep;
+        wpos += nw;
+        fill &= last ? 0u : 31u;
+        __syncthreads();
+    };
+    // ---- block header
+    for (uint32_t i = threadIdx.x; i * 32u < C->hdr_bits; i += DEFLATE_THREADS) {
+        const uint32_t left = C->hdr_bits - i * 32u;
+        const uint32_t v = left >= 32u ? C->hdr[i] : (C->hdr[i] & ((1u << left) - 1u));
+        or_bits(fill + i * 32u, v);
+    }
+    fill += C->hdr_bits;
+    flush(false);
+    // ---- literals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n; base += DEFLATE_THREADS * 8) {
+        const uint32_t at = base + threadIdx.x * 8u;
+        uint64_t lo = 0, hi = 0;
+        uint32_t nb = 0;
+        if (at < n) {
+            uint32_t m;
+            int prev;
+            const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, (start + at) / 8u, m, prev);
+            deflate_tokens(raw, m, prev, [&](uint32_t sym, bool match) {
+                const uint32_t e = ent[sym];
+                const uint64_t c = e & 0xffffu;                    // (a match: its distance bit, 0, follows the length code)
+                const uint32_t l = (e >> 16) + (match ? 1u : 0u);
+                if (nb < 64u) {
+                    lo |= c << nb;
+                    if (nb + l > 64u) hi |= c >> (64u - nb);
+                } else {
+                    hi |= c << (nb - 64u);
+                }
+                nb += l;
+            });
+        }
+        // exclusive scan of nb over the workgroup
+        uint32_t x = nb;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t pre = x - nb, tile_bits = 0;
+        for (int w = 0; w < DEFLATE_THREADS / 64; ++w) {
+            if (w < wave) pre += wsum[w];
+            tile_bits += wsum[w];
+        }
+        or_bits(fill + pre, lo);
+        if (nb > 64u) or_bits(fill + pre + 64u, hi);
+        fill += tile_bits;
+        flush(false);
+    }
+    // ---- end of block, then an empty stored block: 3 header bits, padding to a byte, LEN = 0, NLEN = 0xffff
+    if (threadIdx.x == 0) or_bits(fill, ent[256] & 0xffffu);
+    fill += ent[256] >> 16;
+    fill += 3u;
+    fill = (fill + 7u) & ~7u;
+    if (threadIdx.x == 0) or_bits(fill + 16u, 0xffffull);
+    fill += 32u;
+    flush(true);
+}
+
+}  // namespace iss

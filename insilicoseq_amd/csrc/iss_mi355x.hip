@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "iss_fastq.hip.h"
+#include "iss_deflate.hip.h"
 #include "iss_kernels.hip.h"
 #include "iss_mt_compat.hip.h"
 
@@ -54,10 +55,12 @@ constexpr int FIX_SLOTS = 16;  // ring of fix-list counters (one per chunk in fl
 // format kernel runs on the context's stream, the copy back on a copy stream, the file writes on a writer thread.
 struct FastqJob {
     int slot;
-    size_t bytes;
+    size_t bytes;     // text bytes per file
     int fd[2];
-    int64_t off[2];
+    int64_t off[2];   // plain text: final offsets of this job's bytes (compressed: the writer keeps the running offsets)
     int threads;
+    bool gzip;
+    uint32_t n_blocks;
 };
 struct FastqPipe {
     bool ready = false;
@@ -78,6 +81,20 @@ struct FastqPipe {
     bool busy[2] = {false, false};
     bool stop = false;
     std::string error;
+    // compressed mode (iss_fastq_compress): per slot and mate the device-side state of iss_deflate.hip.h, the
+    // compressed bytes land in h_text; the writer thread fetches exactly the bytes a member has
+    int gzip = 0;
+    hipStream_t data_stream = nullptr;
+    size_t comp_cap = 0;                 // bytes of d_comp / h_text per (slot, mate)
+    uint32_t blocks_cap = 0;
+    uint8_t *d_comp[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint32_t *d_hist[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    iss::DeflateCode *d_code[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint32_t *d_bbytes[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *d_bcrc[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint64_t *d_boff[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint32_t *h_bcrc[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // pinned
+    uint64_t *h_total[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // pinned, one value
+    uint32_t op_block[32];               // CRC operator "append DEFLATE_BLOCK zero bytes"
 };
 constexpr size_t FASTQ_ID_MAX = 4096;
 
@@ -414,7 +431,52 @@ void fastq_writer_loop(iss_ctx *ctx) {
         const auto t0 = std::chrono::steady_clock::now();
         if (hipEventSynchronize(q.ev_copy[job.slot]) != hipSuccess) err = "device copy of the FASTQ text failed";
         const auto t1 = std::chrono::steady_clock::now();
-        if (err.empty()) {
+        if (err.empty() && job.gzip) {
+            // one gzip member per file: header, the DEFLATE blocks (fetched now that their size is known), an empty
+            // final block, CRC-32 and ISIZE of the text (RFC 1952)
+            for (int mate = 0; mate < 2 && err.empty(); ++mate) {
+                const uint64_t total = *q.h_total[job.slot][mate];
+                if (total > q.comp_cap) { err = "compressed FASTQ larger than its buffer"; break; }
+                if (hipMemcpyAsync(q.h_text[job.slot][mate], q.d_comp[job.slot][mate], total, hipMemcpyDeviceToHost,
+                                   q.data_stream) != hipSuccess) err = "device copy of the compressed FASTQ failed";
+            }
+            if (err.empty() && hipStreamSynchronize(q.data_stream) != hipSuccess) err = "device copy of the compressed FASTQ failed";
+            if (err.empty()) {
+                std::thread th[2];
+                int rc[2] = {0, 0};
+                uint64_t wrote[2] = {0, 0};
+                for (int mate = 0; mate < 2; ++mate) {
+                    th[mate] = std::thread([&, mate] {
+                        const uint64_t total = *q.h_total[job.slot][mate];
+                        // raw CRC of the text from the per-block raw CRCs, then the initial / final conditioning
+                        uint32_t raw = 0;
+                        const uint32_t *bc = q.h_bcrc[job.slot][mate];
+                        const uint64_t last_len = job.bytes - (uint64_t)(job.n_blocks - 1) * iss::DEFLATE_BLOCK;
+                        uint32_t op_last[32], op_all[32];
+                        iss::crc_shift_operator(last_len, op_last);
+                        iss::crc_shift_operator(job.bytes, op_all);
+                        for (uint32_t b = 0; b < job.n_blocks; ++b)
+                            raw = iss::gf2_times(b + 1 == job.n_blocks ? op_last : q.op_block, raw) ^ bc[b];
+                        const uint32_t crc = raw ^ iss::gf2_times(op_all, 0xffffffffu) ^ 0xffffffffu;
+                        const uint8_t head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+                        uint8_t tail[10] = {0x03, 0x00};
+                        const uint32_t isize = (uint32_t)job.bytes;
+                        memcpy(tail + 2, &crc, 4);
+                        memcpy(tail + 6, &isize, 4);
+                        int64_t at = q.off[mate];
+                        if (pwrite_all(job.fd[mate], head, 10, at) || pwrite_all(job.fd[mate], q.h_text[job.slot][mate], total, at + 10) ||
+                            pwrite_all(job.fd[mate], tail, 10, at + 10 + (int64_t)total))
+                            rc[mate] = errno;
+                        wrote[mate] = 20 + total;
+                    });
+                }
+                for (auto &t : th) t.join();
+                for (int mate = 0; mate < 2; ++mate) {
+                    if (rc[mate]) err = std::string("write failed: ") + strerror(rc[mate]);
+                    q.off[mate] += (int64_t)wrote[mate];  // (only this thread moves the offsets in compressed mode)
+                }
+            }
+        } else if (err.empty()) {
             // both files in parallel, each cut into pieces written with pwrite at their final offsets
             const size_t piece = std::max<size_t>((job.bytes + (size_t)job.threads - 1) / (size_t)job.threads, 1 << 20);
             std::vector<std::thread> th;
@@ -468,11 +530,27 @@ int fastq_flush(iss_ctx *ctx) {
     return 0;
 }
 
+// the same, but the files stay attached (buffers are about to be reallocated in the middle of a run)
+int fastq_flush_keep(iss_ctx *ctx) {
+    FastqPipe &q = ctx->fq;
+    const int fd_keep[2] = {q.fd[0], q.fd[1]};
+    { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
+    q.fd[0] = fd_keep[0]; q.fd[1] = fd_keep[1];  // (q.off is where the writer left it)
+    return 0;
+}
+
 void fastq_free_buffers(iss_ctx *ctx) {
     FastqPipe &q = ctx->fq;
     for (auto &sl : q.d_text) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
     for (auto &sl : q.h_text) for (auto &p : sl) { if (p) (void)hipHostFree(p); p = nullptr; }
+    for (auto &sl : q.d_comp) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto &sl : q.d_bbytes) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto &sl : q.d_bcrc) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto &sl : q.d_boff) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto &sl : q.h_bcrc) for (auto &p : sl) { if (p) (void)hipHostFree(p); p = nullptr; }
     q.cap = 0;
+    q.comp_cap = 0;
+    q.blocks_cap = 0;
 }
 
 void fastq_shutdown(iss_ctx *ctx) {
@@ -486,6 +564,10 @@ void fastq_shutdown(iss_ctx *ctx) {
     q.cv.notify_all();
     if (q.writer.joinable()) q.writer.join();
     fastq_free_buffers(ctx);
+    for (auto &sl : q.d_hist) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto &sl : q.d_code) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
+    for (auto &sl : q.h_total) for (auto &p : sl) { if (p) (void)hipHostFree(p); p = nullptr; }
+    if (q.data_stream) (void)hipStreamDestroy(q.data_stream);
     if (q.d_id) (void)hipFree(q.d_id);
     for (auto &e : q.ev_fmt) if (e) (void)hipEventDestroy(e);
     for (auto &e : q.ev_copy) if (e) (void)hipEventDestroy(e);
@@ -1685,15 +1767,47 @@ int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, in
             q.off[m] = at;
         }
     }
-    if (bytes > q.cap) {
-        const int fd_keep[2] = {q.fd[0], q.fd[1]};
-        const int64_t off_keep[2] = {q.off[0], q.off[1]};
-        { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
-        q.fd[0] = fd_keep[0]; q.fd[1] = fd_keep[1]; q.off[0] = off_keep[0]; q.off[1] = off_keep[1];
+    const uint32_t n_blocks = (uint32_t)((bytes + iss::DEFLATE_BLOCK - 1) / iss::DEFLATE_BLOCK);
+    // compressed bytes of a batch: its own Huffman code never needs more than 8 bits per byte plus rounding; the
+    // smoothing of the counts (every symbol keeps a code) and the block headers are covered by the margin
+    auto comp_bytes = [](size_t text, size_t blocks) { return text + text / 8 + blocks * 320 + 64; };
+    if (bytes > q.cap || (q.gzip && (comp_bytes(bytes, n_blocks) > q.comp_cap || n_blocks > q.blocks_cap))) {
+        { int rc_ = fastq_flush_keep(ctx); if (rc_) return rc_; }
         fastq_free_buffers(ctx);
-        for (auto &sl : q.d_text) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipMalloc(&v, bytes)); p = static_cast<uint8_t *>(v); }
-        for (auto &sl : q.h_text) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipHostMalloc(&v, bytes, hipHostMallocDefault)); p = static_cast<uint8_t *>(v); }
-        q.cap = bytes;
+        // (pinned allocations are slow: leave room for longer ids and pair numbers instead of growing batch by batch)
+        const size_t cap = bytes + bytes / 8 + (1u << 20);
+        const size_t cap_blocks = (cap + iss::DEFLATE_BLOCK - 1) / iss::DEFLATE_BLOCK;
+        const size_t comp_cap = comp_bytes(cap, cap_blocks);
+        const size_t host_bytes = q.gzip ? comp_cap : cap;
+        for (auto &sl : q.d_text) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipMalloc(&v, cap + 16)); p = static_cast<uint8_t *>(v); }
+        for (auto &sl : q.h_text) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipHostMalloc(&v, host_bytes, hipHostMallocDefault)); p = static_cast<uint8_t *>(v); }
+        q.cap = cap;
+        if (q.gzip) {
+            for (auto &sl : q.d_comp) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipMalloc(&v, comp_cap)); p = static_cast<uint8_t *>(v); }
+            for (auto &sl : q.d_bbytes) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipMalloc(&v, cap_blocks * 4)); p = static_cast<uint32_t *>(v); }
+            for (auto &sl : q.d_bcrc) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipMalloc(&v, cap_blocks * 4)); p = static_cast<uint32_t *>(v); }
+            for (auto &sl : q.d_boff) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipMalloc(&v, (cap_blocks + 1) * 8)); p = static_cast<uint64_t *>(v); }
+            for (auto &sl : q.h_bcrc) for (auto &p : sl) { void *v = nullptr; HIP_TRY(ctx, hipHostMalloc(&v, cap_blocks * 4, hipHostMallocDefault)); p = static_cast<uint32_t *>(v); }
+            q.comp_cap = comp_cap;
+            q.blocks_cap = (uint32_t)cap_blocks;
+        }
+    }
+    if (q.gzip && !q.d_code[0][0]) {  // fixed-size state of the compressed mode, once
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&q.data_stream, hipStreamNonBlocking));
+        iss::crc_shift_operator(iss::DEFLATE_BLOCK, q.op_block);
+        iss::DeflateCode init{};
+        for (int k = 0; k < 8; ++k) iss::crc_shift_operator((uint64_t)128 << k, init.crc_shift[k]);
+        for (int sl = 0; sl < 2; ++sl)
+            for (int m = 0; m < 2; ++m) {
+                void *v = nullptr;
+                HIP_TRY(ctx, hipMalloc(&v, (iss::DEFLATE_SYMS + 7) * 4));
+                q.d_hist[sl][m] = static_cast<uint32_t *>(v);
+                HIP_TRY(ctx, hipMalloc(&v, sizeof(iss::DeflateCode)));
+                q.d_code[sl][m] = static_cast<iss::DeflateCode *>(v);
+                HIP_TRY(ctx, hipMemcpy(v, &init, sizeof init, hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipHostMalloc(&v, 64, hipHostMallocDefault));
+                q.h_total[sl][m] = static_cast<uint64_t *>(v);
+            }
     }
     const int slot = q.next;
     {
@@ -1712,21 +1826,53 @@ int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, in
     }
     hipLaunchKernelGGL(iss::k_fastq_format, dim3((unsigned)((n_pairs + iss::FASTQ_WAVES - 1) / iss::FASTQ_WAVES), 2),
                        dim3(64 * iss::FASTQ_WAVES), 0, ctx->stream, A);
+    if (q.gzip) {  // the text stays on the device: histogram -> code -> block sizes + CRCs -> offsets -> bits (iss_deflate.hip.h)
+        iss::DeflateArgs D{};
+        D.n_bytes = bytes;
+        D.n_blocks = n_blocks;
+        D.out_cap = q.comp_cap;
+        for (int m = 0; m < 2; ++m) {
+            D.text[m] = q.d_text[slot][m];
+            D.hist[m] = q.d_hist[slot][m];
+            D.code[m] = q.d_code[slot][m];
+            D.block_bytes[m] = q.d_bbytes[slot][m];
+            D.block_crc[m] = q.d_bcrc[slot][m];
+            D.block_off[m] = q.d_boff[slot][m];
+            D.out[m] = q.d_comp[slot][m];
+            HIP_TRY(ctx, hipMemsetAsync(q.d_hist[slot][m], 0, iss::DEFLATE_SYMS * 4, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(q.d_comp[slot][m], 0, std::min(q.comp_cap, comp_bytes(bytes, n_blocks)), ctx->stream));
+        }
+        const unsigned hist_grid = (unsigned)std::min<uint64_t>(2048, (bytes / 16 + iss::DEFLATE_THREADS - 1) / iss::DEFLATE_THREADS + 1);
+        hipLaunchKernelGGL(iss::k_deflate_hist, dim3(hist_grid, 2), dim3(iss::DEFLATE_THREADS), 0, ctx->stream, D);
+        hipLaunchKernelGGL(iss::k_deflate_build, dim3(2), dim3(64), 0, ctx->stream, D);
+        hipLaunchKernelGGL(iss::k_deflate_len, dim3(n_blocks, 2), dim3(iss::DEFLATE_THREADS), 0, ctx->stream, D);
+        hipLaunchKernelGGL(iss::k_deflate_scan, dim3(2), dim3(1024), 0, ctx->stream, D);
+        hipLaunchKernelGGL(iss::k_deflate_encode, dim3(n_blocks, 2), dim3(iss::DEFLATE_THREADS), 0, ctx->stream, D);
+    }
     HIP_TRY(ctx, hipEventRecord(q.ev_fmt[slot], ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(q.copy_stream, q.ev_fmt[slot], 0));
-    for (int m = 0; m < 2; ++m)
-        HIP_TRY(ctx, hipMemcpyAsync(q.h_text[slot][m], q.d_text[slot][m], bytes, hipMemcpyDeviceToHost, q.copy_stream));
+    for (int m = 0; m < 2; ++m) {
+        if (q.gzip) {  // sizes and CRCs now; the writer thread fetches the bytes once it knows how many there are
+            HIP_TRY(ctx, hipMemcpyAsync(q.h_total[slot][m], q.d_boff[slot][m] + n_blocks, 8, hipMemcpyDeviceToHost, q.copy_stream));
+            HIP_TRY(ctx, hipMemcpyAsync(q.h_bcrc[slot][m], q.d_bcrc[slot][m], (size_t)n_blocks * 4, hipMemcpyDeviceToHost, q.copy_stream));
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(q.h_text[slot][m], q.d_text[slot][m], bytes, hipMemcpyDeviceToHost, q.copy_stream));
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(q.ev_copy[slot], q.copy_stream));
     {
         std::lock_guard<std::mutex> lk(q.mu);
         if (const char *e = getenv("ISS_FASTQ_PIECES")) n_threads = atoi(e);  // tuning aid
-        FastqJob job{slot, bytes, {q.fd[0], q.fd[1]}, {q.off[0], q.off[1]}, std::max(1, std::min<int>(n_threads, 128))};
+        FastqJob job{slot, bytes, {q.fd[0], q.fd[1]}, {q.off[0], q.off[1]}, std::max(1, std::min<int>(n_threads, 128)),
+                     q.gzip != 0, n_blocks};
         q.jobs.push_back(job);
         q.busy[slot] = true;
     }
     q.cv.notify_all();
-    q.off[0] += (int64_t)bytes;
-    q.off[1] += (int64_t)bytes;
+    if (!q.gzip) {  // (compressed members: the writer thread advances the offsets by what it wrote)
+        q.off[0] += (int64_t)bytes;
+        q.off[1] += (int64_t)bytes;
+    }
     q.next ^= 1;
     return 0;
 }
@@ -1734,6 +1880,29 @@ int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, in
 int iss_fastq_flush(iss_ctx *ctx) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
     return fastq_flush(ctx);
+}
+
+int iss_fastq_compress(iss_ctx *ctx, int32_t mode) {
+    if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
+    if (mode != 0 && mode != 1) return fail(ctx, ISS_E_INVALID, "iss_fastq_compress: mode must be 0 (text) or 1 (gzip members)");
+    if (ctx->fq.gzip == mode) return 0;
+    { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    fastq_free_buffers(ctx);  // the host buffers have another size in the other mode
+    ctx->fq.gzip = mode;
+    return 0;
+}
+
+int iss_deflate_code_build(const uint32_t *hist, uint32_t *entry, uint32_t *hdr_bits, uint32_t *hdr_words) {
+    if (!hist || !entry || !hdr_bits || !hdr_words) return ISS_E_INVALID;
+    static iss::DeflateCode c;  // (large for a stack frame; the function is a test hook, not re-entrant)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    iss::deflate_build_code(hist, &c);
+    memcpy(entry, c.entry, sizeof c.entry);
+    *hdr_bits = c.hdr_bits;
+    memcpy(hdr_words, c.hdr, sizeof c.hdr);
+    return 0;
 }
 
 static int write_all(int fd, const char *p, size_t n) {

@@ -188,6 +188,10 @@ class ReadEngine(object):
         self._check(self._lib.iss_fastq_emit(self._ctx, int(fd_r1), int(fd_r2), str(record_id).encode(), int(first_i),
                                              int(cpu_number), int(first_pair), int(n_pairs), int(n_threads)))
 
+    def fastq_compress(self, on=True):
+        """`--compress` on the device: every fastq_emit appends one gzip member per file instead of text."""
+        self._check(self._lib.iss_fastq_compress(self._ctx, 1 if on else 0))
+
     def fastq_flush(self):
         self._check(self._lib.iss_fastq_flush(self._ctx))
 

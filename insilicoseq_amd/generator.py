@@ -141,7 +141,7 @@ class Worker(object):
     BATCH_PAIRS = 1 << 20  # rows generated / downloaded / formatted per step of the streaming loop
     GENOME_BUDGET = 96 << 30  # letters kept resident in HBM (1.4 B each incl. the packed copies) before all are dropped
 
-    def __init__(self, error_model, cpu_number, seed, device=None, rng="philox"):
+    def __init__(self, error_model, cpu_number, seed, device=None, rng="philox", compress=False):
         if rng not in ("philox", "mt"):
             raise ValueError("rng must be 'philox' (parallel, default) or 'mt' (reference-identical, sequential)")
         self.rng = rng
@@ -154,6 +154,11 @@ class Worker(object):
         self.engine.load_model(self.dense)
         self.store_mutations = False
         self.device_fastq = os.environ.get("ISS_HOST_FASTQ", "") != "1"  # ISS_HOST_FASTQ=1: host formatter (iss_fastq_write)
+        self.compress = bool(compress)
+        if self.compress:
+            if not self.device_fastq:
+                raise ValueError("compress=True needs the device FASTQ path (unset ISS_HOST_FASTQ)")
+            self.engine.fastq_compress(True)  # the FASTQ handles receive gzip members instead of text
         if rng == "mt":
             # random.seed(seed + cpu_number); np.random.seed(seed + cpu_number)  (generator.py:234-236);
             # unseeded workers draw an OS-entropy seed (the reference is then not reproducible either)
@@ -260,10 +265,12 @@ def simulate_reads(record, error_model, n_pairs, cpu_number, forward_handle, rev
 
 
 def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence_type, gc_bias, device=None,
-                    rng="philox"):
+                    rng="philox", compress=False):
     """iss/generator.py:223-251 on GPU ``device`` (default: ``cpu_number``).  ``rng="mt"`` consumes the
     reference's two Mersenne-Twister streams on the device: the files then equal the reference's byte for
-    byte (sequential, ~1e5 pairs/s); ``rng="philox"`` is the parallel path."""
+    byte (sequential, ~1e5 pairs/s); ``rng="philox"`` is the parallel path.  ``compress=True``: the two FASTQ files
+    (same names) hold gzip members built on the device instead of text -- `--compress` without the text ever leaving
+    the GPU; gunzipped they are the files ``compress=False`` writes."""
     logger = logging.getLogger(__name__)
     store_mutations = bool(getattr(error_model, "store_mutations", False))
     if sequence_type not in _native.SEQ_TYPES:
@@ -275,7 +282,7 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
     except PermissionError as e:
         logger.error("Failed to write temporary output file(s): %s" % e)
         sys.exit(1)
-    w = Worker(error_model, cpu_number, seed, device=device, rng=rng)
+    w = Worker(error_model, cpu_number, seed, device=device, rng=rng, compress=compress)
     if store_mutations:
         w.store_mutations = True
         if rng == "mt":

@@ -796,3 +796,55 @@ def test_worker_drops_resident_genomes_over_budget(tmp_path, monkeypatch):
         G.worker_iterator(work, dense, 2, prefix, 11, "metagenomics", False, device=0)
         outs.append((open(prefix + "_R1.fastq", "rb").read(), open(prefix + "_R2.fastq", "rb").read()))
     assert outs[0] == outs[1] and outs[0][0].count(b"\n") == 4 * (40 + 70 + 5 + 64 + 9 + 33)
+
+
+@pytest.mark.parametrize("rng_mode", ["philox", "mt"])
+def test_device_gzip_members_hold_the_same_text(rng_mode, tmp_path, monkeypatch):
+    """`--compress` on the device (iss_fastq_compress, iss_deflate.hip.h): the gunzipped files are the text files, for
+    single and multiple batches, several records (one member per batch), blocks of every size class and ids of
+    changing width."""
+    import gzip
+
+    from insilicoseq_amd import generator as G
+
+    dense = dense_model("novaseq" if rng_mode == "philox" else "hiseq")
+    recs = [G.Record(random_genome(40 + i, 30000), id="contig.%d" % i) for i in range(3)] + [G.Record(mixed_genome(44, 9000), id="m")]
+    work = [(recs[0], 1, "default"), (recs[1], 3000, "default"), (recs[2], 0, "default"), (recs[3], 77, "default"),
+            (recs[0], 1234, "default"), (recs[1], 99, "default")]
+    if rng_mode == "mt":
+        work = [(r, min(n, 300), m) for r, n, m in work]
+    monkeypatch.setattr(G.Worker, "BATCH_PAIRS", 1000)  # 3000 pairs: three batches = three members
+    out = {}
+    for compress in (False, True):
+        prefix = str(tmp_path / ("c%d" % compress))
+        G.worker_iterator(work, dense, 3, prefix, 5, "metagenomics", False, device=0, rng=rng_mode, compress=compress)
+        out[compress] = [open(prefix + s, "rb").read() for s in ("_R1.fastq", "_R2.fastq")]
+    for plain, packed in zip(out[False], out[True]):
+        assert packed[:4] == b"\x1f\x8b\x08\x00" and gzip.decompress(packed) == plain
+        assert len(packed) < 0.4 * len(plain)  # (tiny members: the block headers weigh in)
+
+
+def test_device_gzip_full_batch(tmp_path):
+    """A full-size batch (2^20 pairs, 10 000 DEFLATE blocks per file) and a tail batch through the compressed path."""
+    import gzip
+    import hashlib
+
+    from insilicoseq_amd import generator as G
+
+    dense = dense_model("novaseq")
+    rec = G.Record(random_genome(8, 200000), id="big_genome")
+    work = [(rec, (1 << 20) + 12345, "default")]
+    sums = {}
+    for compress in (False, True):
+        prefix = str(tmp_path / ("f%d" % compress))
+        G.worker_iterator(work, dense, 0, prefix, 9, "metagenomics", False, device=0, compress=compress)
+        for s in ("_R1.fastq", "_R2.fastq"):
+            h = hashlib.sha256()
+            with (gzip.open if compress else open)(prefix + s, "rb") as fh:
+                for chunk in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(chunk)
+            sums[(compress, s)] = (h.hexdigest(), os.path.getsize(prefix + s))
+            os.remove(prefix + s)
+    for s in ("_R1.fastq", "_R2.fastq"):
+        assert sums[(True, s)][0] == sums[(False, s)][0]
+        assert sums[(True, s)][1] < 0.33 * sums[(False, s)][1]

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(native):
     assert declared == set(native.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.iss_abi_version() == 2
+    assert lib.iss_abi_version() == 3
 
 
 def test_no_gpu_means_loud_failure(native):
@@ -187,3 +187,88 @@ def test_compress_file_is_one_gzip_stream(tmp_path):
         assert gz == path + ".gz" and not os.path.exists(path)
         with gzip.open(gz, "rb") as fh:
             assert fh.read() == data
+
+
+def _tokens(data):
+    """The device's tokens (iss_deflate.hip.h, deflate_tokens): 8-byte chunks; a byte repeating its predecessor >= 3
+    times inside the chunk is a run (symbol 254 + length, distance 1), everything else a literal."""
+    out = []
+    for at in range(0, len(data), 8):
+        chunk = data[at:at + 8]
+        prev = data[at - 1] if at else -1
+        i = 0
+        while i < len(chunk):
+            c = chunk[i]
+            if c == prev:
+                r = 1
+                while i + r < len(chunk) and chunk[i + r] == c:
+                    r += 1
+                if r >= 3:
+                    out.append((254 + r, True))
+                    i += r
+                    continue
+            out.append((c, False))
+            prev = c
+            i += 1
+    return out
+
+
+def _deflate_block(native, data, hist=None):
+    """One DEFLATE block of `data` built on the CPU with the code tables of iss_deflate_code_build (what the device
+    kernels pack): header bits, the tokens' codes, end of block, then an empty stored block and a final empty block."""
+    import ctypes as C
+
+    toks = _tokens(data)
+    if hist is None:
+        hist = np.bincount(np.array([t[0] for t in toks] + [256], dtype=np.int64), minlength=263).astype(np.uint32)
+    hist = np.ascontiguousarray(hist, dtype=np.uint32)
+    assert hist.size == 263
+    entry = np.zeros(263, dtype=np.uint32)
+    hdr = np.zeros(64, dtype=np.uint32)
+    nbits = C.c_uint32(0)
+    assert native.lib().iss_deflate_code_build(hist.ctypes.data, entry.ctypes.data, C.byref(nbits), hdr.ctypes.data) == 0
+    lens = (entry >> 16).astype(np.int64)
+    assert lens.min() >= 1 and lens.max() <= 15
+    assert sum(2.0 ** -int(x) for x in lens) == 1.0  # complete code (inflate rejects anything else)
+    acc = 0
+    for w in range((nbits.value + 31) // 32):
+        acc |= int(hdr[w]) << (32 * w)
+    acc &= (1 << nbits.value) - 1
+    n = nbits.value
+    for sym, match in toks:
+        acc |= (int(entry[sym]) & 0xffff) << n
+        n += int(lens[sym]) + (1 if match else 0)  # a match: one zero bit for its distance code
+    acc |= (int(entry[256]) & 0xffff) << n
+    n += int(lens[256])
+    n += 3                      # empty stored block: BFINAL 0, BTYPE 00
+    n = (n + 7) // 8 * 8
+    acc |= 0xffff0000 << n      # LEN 0, NLEN 0xffff
+    n += 32
+    return acc.to_bytes(n // 8, "little") + b"\x03\x00", lens
+
+
+def test_deflate_code_builder_makes_valid_streams(native):
+    """The code builder shared by the host and the device (iss_deflate.hip.h): length-limited complete Huffman codes
+    and the dynamic-block header, checked by inflating CPU-packed blocks with zlib."""
+    import zlib
+
+    rng = np.random.RandomState(5)
+    fastq = b"".join(b"@genome_%d_%d_0/1\n" % (i % 3, i) + bytes(rng.choice(list(b"ACGT"), 151)) + b"\n+\n" +
+                     bytes(rng.choice(list(b"#-8F"), 151, p=[0.01, 0.04, 0.1, 0.85])) + b"\n" for i in range(300))
+    cases = [fastq, b"A", b"", bytes(range(256)) * 3, bytes(rng.randint(0, 256, 5000).astype(np.uint8)),
+             b"\x00" * 4000 + b"\x01", b"FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF", b"ab" + b"c" * 9 + b"dd" + b"e" * 3]
+    for data in cases:
+        block, lens = _deflate_block(native, data)
+        assert zlib.decompressobj(-15).decompress(block) == data
+    block, lens = _deflate_block(native, fastq)
+    assert len(block) < 0.30 * len(fastq)
+    # a code built from one histogram still encodes symbols the histogram never saw
+    hist = np.bincount(np.array([t[0] for t in _tokens(fastq)] + [256]), minlength=263).astype(np.uint32)
+    other = b"nnnnNNNN@@@\xff\x00" * 50
+    block, _ = _deflate_block(native, other, hist=hist)
+    assert zlib.decompressobj(-15).decompress(block) == other
+    # extreme counts (a long batch) keep the 15-bit limit
+    hist = np.ones(263, dtype=np.uint32)
+    hist[65], hist[67], hist[10] = 4_000_000_000, 200_000_000, 3
+    block, lens = _deflate_block(native, b"ACCA\n", hist=hist)
+    assert zlib.decompressobj(-15).decompress(block) == b"ACCA\n" and lens[65] == 1

@@ -20,6 +20,7 @@ ap.add_argument("--pairs", type=int, default=5_000_000)
 ap.add_argument("--mt-pairs", type=int, default=500_000)
 ap.add_argument("--model", default="novaseq")
 ap.add_argument("--dir", default="/dev/shm")
+ap.add_argument("--compress", action="store_true", help="gzip members built on the device (iss_fastq_compress)")
 args = ap.parse_args()
 
 dense = dense_model(args.model)
@@ -31,12 +32,14 @@ for rng, total in (("philox", args.pairs), ("mt", args.mt_pairs)):
     d = tempfile.mkdtemp(dir=args.dir)
     try:
         prefix = os.path.join(d, "w")
-        worker_iterator([(recs[0], 1000, "default")], dense, 0, prefix, 42, "metagenomics", False, device=0, rng=rng)  # warm-up
+        worker_iterator([(recs[0], 1000, "default")], dense, 0, prefix, 42, "metagenomics", False, device=0, rng=rng,
+                        compress=args.compress)  # warm-up
         t0 = time.perf_counter()
-        worker_iterator(work, dense, 0, prefix, 42, "metagenomics", False, device=0, rng=rng)
+        worker_iterator(work, dense, 0, prefix, 42, "metagenomics", False, device=0, rng=rng, compress=args.compress)
         dt = time.perf_counter() - t0
         size = os.path.getsize(prefix + "_R1.fastq") + os.path.getsize(prefix + "_R2.fastq")
-        print("%s rng=%s: %d pairs -> %.2f GB of FASTQ in %.2f s = %.3g pairs/s end to end (%.2f GB/s of text)" % (
-            args.model, rng, sum(counts), size / 1e9, dt, sum(counts) / dt, size / 1e9 / dt), flush=True)
+        print("%s rng=%s%s: %d pairs -> %.2f GB of %s in %.2f s = %.3g pairs/s end to end (%.2f GB/s written)" % (
+            args.model, rng, " compress" if args.compress else "", sum(counts), size / 1e9,
+            "gzip members" if args.compress else "FASTQ", dt, sum(counts) / dt, size / 1e9 / dt), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
