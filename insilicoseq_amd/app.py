@@ -140,7 +140,7 @@ def compress_file(path, block_bytes=32 << 20, threads=None):
 
 
 def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias, rng, store_mutations,
-            fragment):
+            fragment, compress=False):
     """One pool process == one GPU.  Records are re-read from the concatenated FASTA (the reference
     pickles them; same content)."""
     logging.basicConfig(level=logging.WARNING)
@@ -150,7 +150,7 @@ def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_ty
     else:
         model = KDErrorModel(npz, fragment[0], fragment[1], store_mutations)
     work = [(records[rid], n, "default") for rid, n in work_spec]
-    worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device, rng=rng)
+    worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device, rng=rng, compress=compress)
 
 
 def generate_reads(args):
@@ -190,6 +190,10 @@ def generate_reads(args):
             logger.error("Could not get abundance, or coverage or readcount information")
             sys.exit(1)
     workers = args.gpus
+    # --compress: the workers' FASTQ files already hold gzip members built on the device (one per batch); concatenated
+    # they are the .gz files util.compress would have made from the text (iss/util.py:255-268), which never exists
+    device_gzip = bool(args.compress) and os.environ.get("ISS_HOST_FASTQ", "") != "1"
+    gz = {"_R1.fastq": "_R1.fastq.gz", "_R2.fastq": "_R2.fastq.gz"} if device_gzip else None
     chunk_size = -((n_reads // 2) // -workers)  # ceildiv, app.py:82
     chunks = list(generate_work_divider(records, readcount_dic, abundance_dic, n_reads, None, None, error_model,
                                         args.output, chunk_size))
@@ -198,7 +202,7 @@ def generate_reads(args):
         spec = [(rec.id, n) for rec, n, _ in chunk]
         jobs.append((rank, rank % max(args.devices, 1), genome_file, spec, error_model.npz_path, args.seed,
                      temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng, args.store_mutations,
-                     (args.fragment_length, args.fragment_length_sd)))
+                     (args.fragment_length, args.fragment_length_sd), device_gzip))
     if workers == 1:
         for j in jobs:
             _worker(*j)
@@ -207,12 +211,12 @@ def generate_reads(args):
             pool.starmap(_worker, jobs)
     if args.store_mutations:  # app.py:128-133
         concatenate_rank_files(args.output, workers, suffixes=("_R1.fastq", "_R2.fastq", ".vcf"),
-                               headers={".vcf": VCF_HEADER})
+                               headers={".vcf": VCF_HEADER}, out_suffixes=gz)
     else:
-        concatenate_rank_files(args.output, workers)  # raises if a worker had no chunk (util.py:233)
+        concatenate_rank_files(args.output, workers, out_suffixes=gz)  # raises if a worker had no chunk (util.py:233)
     os.remove(genome_file)
     if args.compress:  # util.compress (iss/util.py:255-268): <file>.gz next to the file, original removed
-        for suffix in ("_R1.fastq", "_R2.fastq") + ((".vcf",) if args.store_mutations else ()):
+        for suffix in (() if device_gzip else ("_R1.fastq", "_R2.fastq")) + ((".vcf",) if args.store_mutations else ()):
             compress_file(args.output + suffix)
     logger.info("Read generation complete")
 

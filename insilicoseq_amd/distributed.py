@@ -104,23 +104,27 @@ def _append_file(src_path, out):
         shutil.copyfileobj(fh, out, 1 << 22)
 
 
-def concatenate_rank_files(output, world, suffixes=("_R1.fastq", "_R2.fastq"), cleanup=True, headers=None):
+def concatenate_rank_files(output, world, suffixes=("_R1.fastq", "_R2.fastq"), cleanup=True, headers=None,
+                           out_suffixes=None):
     """util.concatenate over the per-rank temp files, in rank order (iss/app.py:123-133).  Like the
     reference, a missing temp file (fewer chunks than workers) is an error (iss/util.py:233).
     ``headers``: optional {suffix: header text} written first, followed by a newline (util.py:229-230).
     Same bytes as the reference's copy loop; rank 0's file is renamed instead of copied when it is going to be
-    removed anyway and nothing precedes it (tens of GB at BASELINE's sizes)."""
+    removed anyway and nothing precedes it (tens of GB at BASELINE's sizes).  ``out_suffixes``: optional
+    {suffix: suffix of the assembled file} (workers that wrote gzip members: "_R1.fastq" -> "_R1.fastq.gz")."""
+    out_suffixes = out_suffixes or {}
     for suffix in suffixes:
         paths = [temp_prefix(output, r) + suffix for r in range(world)]
         for path in paths:
             if not os.path.exists(path):
                 raise FileNotFoundError(path)
         header = headers.get(suffix) if headers else None
+        target = output + out_suffixes.get(suffix, suffix)
         first = 0
         if cleanup and header is None and world > 0:
-            os.replace(paths[0], output + suffix)
+            os.replace(paths[0], target)
             first = 1
-        with open(output + suffix, "ab" if first else "wb") as out:
+        with open(target, "ab" if first else "wb") as out:
             if header is not None:
                 out.write((header + "\n").encode())
             for path in paths[first:]:

@@ -107,6 +107,26 @@ def test_generate_cli_equals_reference(cpus, tmp_path):
     assert open(out + "_R2.fastq", "rb").read() == z["r2"].tobytes()
 
 
+@pytest.mark.parametrize("cpus", [1, 2])
+def test_generate_cli_compress_equals_reference(cpus, tmp_path):
+    """`--compress` (gzip members built on the device, one per worker batch, concatenated in worker order; the .vcf
+    through the host path): the gunzipped files are the reference's `iss generate --cpus N` files and no text file is left."""
+    import gzip
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "run")
+    subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes",
+                           os.path.join(GOLDEN, "genomes.fasta"), "--model", "hiseq", "-n", "600", "--seed", "42",
+                           "--cpus", str(cpus), "--devices", "1", "--rng", "mt", "--compress", "--store_mutations",
+                           "-o", out, "--quiet"], cwd=root)
+    z = np.load(os.path.join(GOLDEN, "generate", "genomes_hiseq_n600_seed42_cpus%d.npz" % cpus))
+    assert gzip.open(out + "_R1.fastq.gz", "rb").read() == z["r1"].tobytes()
+    assert gzip.open(out + "_R2.fastq.gz", "rb").read() == z["r2"].tobytes()
+    assert gzip.open(out + ".vcf.gz", "rb").read().startswith(b"##fileformat=VCFv4.1")
+    left = sorted(os.listdir(str(tmp_path)))
+    assert left == ["run.vcf.gz", "run_R1.fastq.gz", "run_R2.fastq.gz", "run_abundance.txt"], left
+
+
 def test_mt_mode_large_equals_oracle(engine):
     """20k pairs (several stream refills) against the CPU oracle in MT mode, plus the stream positions."""
     from helpers import random_genome
