@@ -35,10 +35,18 @@ struct DeflateCode {
 // ---------------------------------------------------------------- code construction (host and device)
 // Huffman code lengths of n <= 288 symbols, limited to maxbits; symbols with count 0 get length 0.  The code is
 // complete (Kraft sum exactly 1), as inflate requires, whenever at least two symbols are in use.
-__host__ __device__ inline void deflate_lengths(const uint32_t *cnt, int n, int maxbits, uint8_t *len) {
-    // binary heap of (weight, node); nodes 0..n-1 leaves, n.. internal
+struct DeflateWork {  // scratch of the code builder: in LDS on the device (private arrays would live in scratch memory)
     uint64_t heap[2 * 288];
     int16_t parent[2 * 288];
+    uint32_t cnt[288];
+    uint8_t len[288 + 1], sym[288 + 1], extra[288 + 1];
+    uint16_t code[288];
+};
+
+__host__ __device__ inline void deflate_lengths(const uint32_t *cnt, int n, int maxbits, uint8_t *len, DeflateWork *ws) {
+    // binary heap of (weight, node); nodes 0..n-1 leaves, n.. internal
+    uint64_t *heap = ws->heap;
+    int16_t *parent = ws->parent;
     int hn = 0;
     auto push = [&](uint64_t key) {
         int i = hn++;
@@ -138,20 +146,20 @@ struct BitSink {
 // hist[s]: token counts of the text (literals, hist[256] = number of blocks, run lengths 3..8 at 257..262).  Every
 // symbol gets a code (count + 1, and at least 2^-15 of the total so that the tree stays shallow): a batch is
 // compressed with the code of its own text, but nothing breaks if a symbol shows up that the histogram missed.
-__host__ __device__ inline void deflate_build_code(const uint32_t *hist, DeflateCode *out) {
-    uint32_t cnt[DEFLATE_SYMS];
+__host__ __device__ inline void deflate_build_code(const uint32_t *hist, DeflateCode *out, DeflateWork *ws) {
+    uint32_t *cnt = ws->cnt;
     uint64_t total = 0;
     for (int s = 0; s < DEFLATE_SYMS; ++s) total += hist[s];
     const uint32_t floor_cnt = (uint32_t)(total >> 15);
     for (int s = 0; s < DEFLATE_SYMS; ++s) cnt[s] = hist[s] + 1u > floor_cnt ? hist[s] + 1u : floor_cnt;
-    uint8_t len[DEFLATE_SYMS + 1];
-    uint16_t code[DEFLATE_SYMS];
-    deflate_lengths(cnt, DEFLATE_SYMS, 15, len);
+    uint8_t *len = ws->len;
+    uint16_t *code = ws->code;
+    deflate_lengths(cnt, DEFLATE_SYMS, 15, len, ws);
     deflate_codes(len, DEFLATE_SYMS, code);
     for (int s = 0; s < DEFLATE_SYMS; ++s) out->entry[s] = (uint32_t)code[s] | ((uint32_t)len[s] << 16);
     // ---- header: the literal/length code lengths + one distance code of length 1, run-length coded (3.2.7)
     len[DEFLATE_SYMS] = 1;
-    uint8_t sym[DEFLATE_SYMS + 1], extra[DEFLATE_SYMS + 1];
+    uint8_t *sym = ws->sym, *extra = ws->extra;
     int ns = 0;
     for (int i = 0; i <= DEFLATE_SYMS;) {
         int r = 1;
@@ -167,7 +175,7 @@ __host__ __device__ inline void deflate_build_code(const uint32_t *hist, Deflate
     for (int i = 0; i < ns; ++i) ++ccnt[sym[i]];
     uint8_t clen[19];
     uint16_t ccode[19];
-    deflate_lengths(ccnt, 19, 7, clen);
+    deflate_lengths(ccnt, 19, 7, clen, ws);
     deflate_codes(clen, 19, ccode);
     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     int hclen = 19;
@@ -257,6 +265,13 @@ struct DeflateArgs {
     uint64_t out_cap;
 };
 
+// text bytes of block b.  (Written with 32-bit block numbers on purpose: hipcc 7.2 lowers the obvious
+// min(DEFLATE_BLOCK, n_bytes - start) on uniform 64-bit values to a v_cmp followed by an s_cselect on a stale SCC.)
+__device__ __forceinline__ uint32_t deflate_block_len(uint64_t n_bytes, uint32_t b) {
+    const uint32_t full = (uint32_t)(n_bytes / DEFLATE_BLOCK);
+    return b < full ? (uint32_t)DEFLATE_BLOCK : (uint32_t)(n_bytes - (uint64_t)full * DEFLATE_BLOCK);
+}
+
 // chunk `c` of the text: its bytes (little endian), how many there are, and the byte before it (-1: none)
 __device__ __forceinline__ uint64_t deflate_chunk(const uint8_t *t, uint64_t n_bytes, uint64_t c, uint32_t &m, int &prev) {
     const uint64_t at = c * 8u;
@@ -288,37 +303,71 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_hist(DeflateArgs A)
 }
 
 __global__ void k_deflate_build(DeflateArgs A) {
-    if (threadIdx.x == 0) deflate_build_code(A.hist[blockIdx.x], A.code[blockIdx.x]);
+    __shared__ DeflateWork ws;
+    __shared__ uint32_t hist[DEFLATE_SYMS];
+    for (int s = threadIdx.x; s < DEFLATE_SYMS; s += blockDim.x) hist[s] = A.hist[blockIdx.x][s];
+    __syncthreads();
+    if (threadIdx.x == 0) deflate_build_code(hist, A.code[blockIdx.x], &ws);
 }
 
 // One workgroup per block: compressed size in bytes and the raw CRC-32 of the block's text.  For the CRC, lane t of
 // the workgroup owns the 128 bytes that END (256 - t) * 128 bytes before the end of the block (a short block is
 // padded with zeros in FRONT, which a raw CRC does not see), so the tree of "append 128 << k bytes" operators is the
-// same for every block.
+// same for every block.  A full block is staged in LDS with coalesced loads first (pieces of 32 words at a stride of
+// 33, so that the lanes' sequential walks over their pieces hit distinct banks); the last, shorter block of a text
+// takes the plain path.
 __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[4][256];  // slicing-by-4 tables
     __shared__ uint32_t lens[DEFLATE_SYMS];
     __shared__ uint32_t red[DEFLATE_THREADS];
     __shared__ uint32_t crcs[DEFLATE_THREADS];
+    __shared__ uint32_t stage[DEFLATE_THREADS * 33];
     const int mate = blockIdx.y;
     const uint32_t b = blockIdx.x;
     const DeflateCode *C = A.code[mate];
-    tab[threadIdx.x] = crc_table_entry(threadIdx.x);
+    tab[0][threadIdx.x] = crc_table_entry(threadIdx.x);
     for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS) lens[s] = C->entry[s] >> 16;
     __syncthreads();
-    const uint64_t start = (uint64_t)b * DEFLATE_BLOCK;
-    const uint32_t n = (uint32_t)min((uint64_t)DEFLATE_BLOCK, A.n_bytes - start);
-    uint32_t bits = 0;
-    for (uint32_t c = threadIdx.x; c * 8u < n; c += DEFLATE_THREADS) {
-        uint32_t m;
-        int prev;
-        const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, start / 8u + c, m, prev);
-        deflate_tokens(raw, m, prev, [&](uint32_t sym, bool match) { bits += lens[sym] + (match ? 1u : 0u); });
+    for (int k = 1; k < 4; ++k) {
+        const uint32_t v = tab[k - 1][threadIdx.x];
+        tab[k][threadIdx.x] = (v >> 8) ^ tab[0][v & 0xffu];
+        __syncthreads();
     }
+    const uint64_t start = (uint64_t)b * DEFLATE_BLOCK;
+    const uint32_t n = deflate_block_len(A.n_bytes, b);
     const uint8_t *t = A.text[mate] + start;
-    const int64_t lo = (int64_t)n - (int64_t)(DEFLATE_THREADS - threadIdx.x) * 128;  // may be negative: zeros in front
-    uint32_t crc = 0;
-    for (int64_t i = lo < 0 ? 0 : lo; i < lo + 128; ++i) crc = tab[(crc ^ t[i]) & 0xffu] ^ (crc >> 8);
+    uint32_t bits = 0, crc = 0;
+    if (n == (uint32_t)DEFLATE_BLOCK) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(t);
+        for (int j = 0; j < DEFLATE_BLOCK / 16 / DEFLATE_THREADS; ++j) {
+            const uint32_t q = threadIdx.x + j * DEFLATE_THREADS;  // 16-byte unit
+            const uint4 v = src[q];
+            uint32_t *d = stage + (q >> 3) * 33u + (q & 7u) * 4u;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        const int before = start ? (int)t[-1] : -1;
+        for (uint32_t c = threadIdx.x; c < (uint32_t)DEFLATE_BLOCK / 8u; c += DEFLATE_THREADS) {
+            const uint32_t w = (c >> 4) * 33u + (c & 15u) * 2u;
+            const uint64_t raw = (uint64_t)stage[w] | ((uint64_t)stage[w + 1] << 32);
+            const int prev = c ? (int)(stage[(c & 15u) ? w - 1 : w - 2] >> 24) : before;
+            deflate_tokens(raw, 8u, prev, [&](uint32_t sym, bool match) { bits += lens[sym] + (match ? 1u : 0u); });
+        }
+        const uint32_t *mine = stage + threadIdx.x * 33u;
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t x = crc ^ mine[i];
+            crc = tab[3][x & 0xffu] ^ tab[2][(x >> 8) & 0xffu] ^ tab[1][(x >> 16) & 0xffu] ^ tab[0][x >> 24];
+        }
+    } else {
+        for (uint32_t c = threadIdx.x; c * 8u < n; c += DEFLATE_THREADS) {
+            uint32_t m;
+            int prev;
+            const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, start / 8u + c, m, prev);
+            deflate_tokens(raw, m, prev, [&](uint32_t sym, bool match) { bits += lens[sym] + (match ? 1u : 0u); });
+        }
+        const int64_t lo = (int64_t)n - (int64_t)(DEFLATE_THREADS - threadIdx.x) * 128;  // may be negative: zeros in front
+        for (int64_t i = lo < 0 ? 0 : lo; i < lo + 128; ++i) crc = tab[0][(crc ^ t[i]) & 0xffu] ^ (crc >> 8);
+    }
     red[threadIdx.x] = bits;
     crcs[threadIdx.x] = crc;
     __syncthreads();
@@ -374,7 +423,7 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_encode(DeflateArgs 
     for (int i = threadIdx.x; i < DEFLATE_WIN_WORDS; i += DEFLATE_THREADS) win[i] = 0;
     __syncthreads();
     const uint64_t start = (uint64_t)b * DEFLATE_BLOCK;
-    const uint32_t n = (uint32_t)min((uint64_t)DEFLATE_BLOCK, A.n_bytes - start);
+    const uint32_t n = deflate_block_len(A.n_bytes, b);
     const uint64_t off = A.block_off[mate][b];
     if (off + A.block_bytes[mate][b] > A.out_cap) return;  // (the host reports the overflow from block_off[n_blocks])
     uint32_t *outw = reinterpret_cast<uint32_t *>(A.out[mate] + (off & ~3ull));

@@ -1896,9 +1896,10 @@ int iss_fastq_compress(iss_ctx *ctx, int32_t mode) {
 int iss_deflate_code_build(const uint32_t *hist, uint32_t *entry, uint32_t *hdr_bits, uint32_t *hdr_words) {
     if (!hist || !entry || !hdr_bits || !hdr_words) return ISS_E_INVALID;
     static iss::DeflateCode c;  // (large for a stack frame; the function is a test hook, not re-entrant)
+    static iss::DeflateWork ws;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    iss::deflate_build_code(hist, &c);
+    iss::deflate_build_code(hist, &c, &ws);
     memcpy(entry, c.entry, sizeof c.entry);
     *hdr_bits = c.hdr_bits;
     memcpy(hdr_words, c.hdr, sizeof c.hdr);
