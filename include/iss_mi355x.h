@@ -208,7 +208,7 @@ int iss_fastq_flush(iss_ctx *ctx);
 /*
  * `--compress` (iss/app.py:134-143 -> util.compress, iss/util.py:255-268: gzip of the finished FASTQ files) moved in
  * front of the files: with mode 1 every iss_fastq_emit appends ONE GZIP MEMBER per file (RFC 1952) holding the
- * batch's text instead of the text -- DEFLATE blocks with a dynamic Huffman code and run matches, built on the device
+ * batch's text instead of the text -- DEFLATE blocks with a dynamic Huffman code, run and previous-record matches, built on the device
  * from the batch's own token histogram, so only the compressed bytes (about 1/3.5) cross PCIe and reach the file
  * system.  Concatenated members are one valid .gz file whose content is the text mode 0 writes.  mode 0 (default):
  * plain text.  Changing the mode flushes.
@@ -217,11 +217,15 @@ int iss_fastq_compress(iss_ctx *ctx, int32_t mode);
 
 /*
  * The code builder of the compressed mode as a host function (tests, tools): hist[263] token counts (literals
- * 0..255, [256] the number of blocks, [257..262] runs of length 3..8 at distance 1) -> entry[s] = bit-reversed code |
- * length << 16 for the 263 symbols, and the dynamic-block header (BFINAL = 0 ... both code-length tables; one distance
- * code, one bit long) as hdr_bits bits, least significant first, in hdr_words[64].  No GPU needed.
+ * 0..255, [256] the number of blocks, [257..262] matches of length 3..8) and the batch's record length (the
+ * distance of the "previous record" matches; 0: only runs, distance 1) -> entry[s] = bit-reversed code | length << 16
+ * for the 263 symbols, the dynamic-block header (BFINAL = 0 ... both code-length tables) as hdr_bits bits, least
+ * significant first, in hdr_words[64], and dist_code[3] = {distance symbol, extra bits, their value} of the record
+ * length: a run's length code is followed by the bit 0, a previous-record match's by the bit 1 and the extra bits.
+ * No GPU needed.
  */
-int iss_deflate_code_build(const uint32_t *hist, uint32_t *entry, uint32_t *hdr_bits, uint32_t *hdr_words);
+int iss_deflate_code_build(const uint32_t *hist, uint32_t record_distance, uint32_t *entry, uint32_t *hdr_bits,
+                           uint32_t *hdr_words, uint32_t *dist_code);
 
 /*
  * FASTQ emission, replaces SeqIO.write(record, handle, "fastq-sanger") in

@@ -95,7 +95,7 @@ def lib():
     L.iss_fastq_emit.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i64, i32]
     L.iss_fastq_flush.argtypes = [vp]
     L.iss_fastq_compress.argtypes = [vp, i32]
-    L.iss_deflate_code_build.argtypes = [vp, vp, vp, vp]
+    L.iss_deflate_code_build.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
     L.iss_fastq_write.argtypes = [C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i32, i32, vp, vp, vp, vp, i32]
     for name in EXPORTS:
         if name not in ("iss_ctx_destroy", "iss_last_error"):

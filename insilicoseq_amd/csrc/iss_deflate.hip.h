@@ -3,12 +3,13 @@
 // The reference gzips the finished FASTQ files on the host (gzip.open + copyfileobj).  At the kernel's rate the FASTQ
 // text is the bottleneck twice over (PCIe, then the file system), so with compression on the text never leaves the
 // device: every batch of FASTQ text becomes one gzip member made of DEFLATE blocks with a dynamic Huffman code whose
-// only matches are runs (distance 1, found inside 8-byte chunks, so no search and no dependency between lanes).
-// FASTQ is bases (2 bits of entropy), phreds (runs of the top quality) and headers; this reaches about 3.5x on it
-// (zlib level 6: 4-4.5x).  The decompressed bytes are exactly the text k_fastq_format wrote (the compressed bytes
+// only matches are runs (distance 1) and copies of the previous record (distance = the batch's record length), both
+// found inside 8-byte chunks, so there is no search and no dependency between lanes.  FASTQ is bases (2 bits of
+// entropy), phreds (runs of the top quality) and headers; this reaches 3.7x on NovaSeq text (zlib level 1: 3.9x,
+// level 6: 5x).  The decompressed bytes are exactly the text k_fastq_format wrote (the compressed bytes
 // differ from the reference's, like any two gzip implementations' do).
 //
-// Per batch and mate:  k_deflate_hist (byte histogram of the text) -> k_deflate_build (ONE lane: length-limited
+// Per batch and mate:  k_deflate_hist (token histogram of the text) -> k_deflate_build (ONE lane: length-limited
 // Huffman code, canonical codes, the dynamic-block header bits -- the same code any host would build, here without a
 // round trip) -> k_deflate_len (bits and raw CRC-32 of every 32 KB block) -> k_deflate_scan (byte offsets) ->
 // k_deflate_encode (bit packing through LDS).  Every block ends with an empty stored block (the "sync flush" of
@@ -39,7 +40,7 @@ struct DeflateWork {  // scratch of the code builder: in LDS on the device (priv
     uint64_t heap[2 * 288];
     int16_t parent[2 * 288];
     uint32_t cnt[288];
-    uint8_t len[288 + 1], sym[288 + 1], extra[288 + 1];
+    uint8_t len[320], sym[320], extra[320];
     uint16_t code[288];
 };
 
@@ -146,7 +147,8 @@ struct BitSink {
 // hist[s]: token counts of the text (literals, hist[256] = number of blocks, run lengths 3..8 at 257..262).  Every
 // symbol gets a code (count + 1, and at least 2^-15 of the total so that the tree stays shallow): a batch is
 // compressed with the code of its own text, but nothing breaks if a symbol shows up that the histogram missed.
-__host__ __device__ inline void deflate_build_code(const uint32_t *hist, DeflateCode *out, DeflateWork *ws) {
+// dist_sym: distance symbol of the batch's record length (0: distance 1 is the only distance in use)
+__host__ __device__ inline void deflate_build_code(const uint32_t *hist, DeflateCode *out, DeflateWork *ws, uint32_t dist_sym = 0) {
     uint32_t *cnt = ws->cnt;
     uint64_t total = 0;
     for (int s = 0; s < DEFLATE_SYMS; ++s) total += hist[s];
@@ -157,13 +159,17 @@ __host__ __device__ inline void deflate_build_code(const uint32_t *hist, Deflate
     deflate_lengths(cnt, DEFLATE_SYMS, 15, len, ws);
     deflate_codes(len, DEFLATE_SYMS, code);
     for (int s = 0; s < DEFLATE_SYMS; ++s) out->entry[s] = (uint32_t)code[s] | ((uint32_t)len[s] << 16);
-    // ---- header: the literal/length code lengths + one distance code of length 1, run-length coded (3.2.7)
+    // ---- header: the literal/length code lengths, then the distance code lengths -- distance 1 ("0") and, with
+    // dist_sym, the record distance ("1"), one bit each -- run-length coded together (3.2.7)
+    const int n_all = DEFLATE_SYMS + 1 + (int)dist_sym;
+    for (int i = DEFLATE_SYMS; i < n_all; ++i) len[i] = 0;
     len[DEFLATE_SYMS] = 1;
+    len[n_all - 1] = 1;
     uint8_t *sym = ws->sym, *extra = ws->extra;
     int ns = 0;
-    for (int i = 0; i <= DEFLATE_SYMS;) {
+    for (int i = 0; i < n_all;) {
         int r = 1;
-        while (i + r <= DEFLATE_SYMS && len[i + r] == len[i]) ++r;
+        while (i + r < n_all && len[i + r] == len[i]) ++r;
         sym[ns] = len[i]; extra[ns] = 0; ++ns;  // the value itself
         int rem = r - 1;
         if (len[i] != 0)
@@ -185,7 +191,7 @@ __host__ __device__ inline void deflate_build_code(const uint32_t *hist, Deflate
     bs.put(0, 1);  // BFINAL = 0 (the member is closed by an empty final block)
     bs.put(2, 2);  // BTYPE = 10: dynamic Huffman codes
     bs.put(DEFLATE_SYMS - 257, 5);  // HLIT
-    bs.put(0, 5);                   // HDIST: one distance code (distance 1), one bit long
+    bs.put(dist_sym, 5);            // HDIST: distance codes 0 .. dist_sym
     bs.put((uint32_t)(hclen - 4), 4);
     for (int i = 0; i < hclen; ++i) bs.put(clen[order[i]], 3);
     for (int i = 0; i < ns; ++i) {
@@ -231,24 +237,47 @@ inline void crc_shift_operator(uint64_t n_bytes, uint32_t *op) {
 }
 
 // ---------------------------------------------------------------- tokens
-// The text is cut into 8-byte chunks (aligned to the text's start; blocks are multiples of 8).  Inside a chunk a byte
-// that repeats its predecessor at least three times becomes a match (length 3..8, distance 1); everything else is a
-// literal.  The predecessor of a chunk's first byte is the text byte before it (none at offset 0), which may belong to
-// the previous block: DEFLATE's window does not care.  f(symbol, is_match) is called per token.
+// The text is cut into 8-byte chunks (aligned to the text's start; blocks are multiples of 8).  Inside a chunk, at
+// every position two matches are tried: the run (the byte repeats its predecessor: distance 1) and the previous
+// record (the same bytes `dist` earlier -- a batch's records have one length but for the digits of the pair number,
+// so the constant parts of the header line, "+" and most of a top-quality phred line are found there); the longer
+// one wins if it has >= 3 (run) / >= 4 (previous record) bytes (lengths 3..8: codes 257..262), otherwise the byte is a literal.  The predecessor of a
+// chunk's first byte and the bytes `dist` earlier may belong to the previous block: DEFLATE's window does not care.
+// f(symbol, kind) is called per token: kind 0 literal, 1 run, 2 previous record.
 template <typename F>
-__host__ __device__ inline void deflate_tokens(uint64_t raw, uint32_t m, int prev, F &&f) {
+__host__ __device__ inline void deflate_tokens(uint64_t raw, uint32_t m, int prev, uint64_t src, bool has_src, F &&f) {
+    const uint64_t same = has_src ? ~(raw ^ src) : 0;  // byte k all ones <=> equal to the byte `dist` earlier
     uint32_t i = 0;
     while (i < m) {
         const int c = (int)((raw >> (8 * i)) & 0xffu);
+        uint32_t r1 = 0, rd = 0;
         if (c == prev) {
-            uint32_t r = 1;
-            while (i + r < m && (int)((raw >> (8 * (i + r))) & 0xffu) == c) ++r;
-            if (r >= 3u) { f(254u + r, true); i += r; continue; }  // lengths 3..8 -> codes 257..262
+            r1 = 1;
+            while (i + r1 < m && (int)((raw >> (8 * (i + r1))) & 0xffu) == c) ++r1;
         }
-        f((uint32_t)c, false);
+        while (i + rd < m && ((same >> (8 * (i + rd))) & 0xffu) == 0xffu) ++rd;
+        if (r1 >= 3u && r1 >= rd) { f(254u + r1, 1); i += r1; continue; }  // (a run is the cheaper match)
+        if (rd >= 4u) {  // (its distance costs 8-14 bits: three bytes are not worth it)
+            f(254u + rd, 2);
+            i += rd;
+            prev = (int)((raw >> (8 * (i - 1))) & 0xffu);
+            continue;
+        }
+        f((uint32_t)c, 0);
         prev = c;
         ++i;
     }
+}
+
+// DEFLATE distance code of `dist` (RFC 1951 3.2.5): symbol, number of extra bits, their value
+__host__ __device__ inline void deflate_dist_code(uint32_t dist, uint32_t *sym, uint32_t *ebits, uint32_t *eval) {
+    if (dist <= 4u) { *sym = dist - 1u; *ebits = 0; *eval = 0; return; }
+    uint32_t d = dist - 1u, hb = 31u;
+    while (!((d >> hb) & 1u)) --hb;           // highest set bit of dist - 1 (>= 2)
+    const uint32_t second = (d >> (hb - 1u)) & 1u;
+    *sym = 2u * hb + second;
+    *ebits = hb - 1u;
+    *eval = d & ((1u << (hb - 1u)) - 1u);
 }
 
 // ---------------------------------------------------------------- kernels
@@ -263,6 +292,8 @@ struct DeflateArgs {
     uint64_t *block_off[2];     // [mate][n_blocks + 1] byte offsets in `out` (exclusive scan), [n_blocks] = total
     uint8_t *out[2];
     uint64_t out_cap;
+    uint32_t dist;              // record length of the batch (0: only runs are matched)
+    uint32_t dist_sym, dist_ebits, dist_eval;
 };
 
 // text bytes of block b.  (Written with 32-bit block numbers on purpose: hipcc 7.2 lowers the obvious
@@ -272,11 +303,25 @@ __device__ __forceinline__ uint32_t deflate_block_len(uint64_t n_bytes, uint32_t
     return b < full ? (uint32_t)DEFLATE_BLOCK : (uint32_t)(n_bytes - (uint64_t)full * DEFLATE_BLOCK);
 }
 
-// chunk `c` of the text: its bytes (little endian), how many there are, and the byte before it (-1: none)
-__device__ __forceinline__ uint64_t deflate_chunk(const uint8_t *t, uint64_t n_bytes, uint64_t c, uint32_t &m, int &prev) {
+// the eight bytes that stand `dist` before text offset `at` (at >= dist; the buffer has 16 bytes of padding)
+__device__ __forceinline__ uint64_t deflate_source(const uint8_t *t, uint64_t at, uint32_t dist) {
+    const uint64_t p = at - dist, a = p & ~7ull;
+    const uint32_t sh = (uint32_t)(p & 7ull) * 8u;
+    const uint64_t lo = *reinterpret_cast<const uint64_t *>(t + a);
+    if (!sh) return lo;
+    const uint64_t hi = *reinterpret_cast<const uint64_t *>(t + a + 8);
+    return (lo >> sh) | (hi << (64u - sh));
+}
+
+// chunk `c` of the text: its bytes (little endian), how many there are, the byte before it (-1: none) and the bytes
+// `dist` earlier
+__device__ __forceinline__ uint64_t deflate_chunk(const uint8_t *t, uint64_t n_bytes, uint64_t c, uint32_t dist, uint32_t &m,
+                                                  int &prev, uint64_t &src, bool &has_src) {
     const uint64_t at = c * 8u;
     m = (uint32_t)min((uint64_t)8, n_bytes - at);
     prev = at ? (int)t[at - 1] : -1;
+    has_src = dist && at >= dist;
+    src = has_src ? deflate_source(t, at, dist) : 0;
     if (m == 8u) return *reinterpret_cast<const uint64_t *>(t + at);  // (the text buffer is 8-byte aligned)
     uint64_t raw = 0;
     for (uint32_t k = 0; k < m; ++k) raw |= (uint64_t)t[at + k] << (8 * k);
@@ -293,8 +338,10 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_hist(DeflateArgs A)
     for (uint64_t c = (uint64_t)blockIdx.x * DEFLATE_THREADS + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * DEFLATE_THREADS) {
         uint32_t m;
         int prev;
-        const uint64_t raw = deflate_chunk(t, A.n_bytes, c, m, prev);
-        deflate_tokens(raw, m, prev, [&](uint32_t sym, bool) { atomicAdd(&h[sym], 1u); });
+        uint64_t src;
+        bool has_src;
+        const uint64_t raw = deflate_chunk(t, A.n_bytes, c, A.dist, m, prev, src, has_src);
+        deflate_tokens(raw, m, prev, src, has_src, [&](uint32_t sym, int) { atomicAdd(&h[sym], 1u); });
     }
     __syncthreads();
     for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS)
@@ -307,7 +354,7 @@ __global__ void k_deflate_build(DeflateArgs A) {
     __shared__ uint32_t hist[DEFLATE_SYMS];
     for (int s = threadIdx.x; s < DEFLATE_SYMS; s += blockDim.x) hist[s] = A.hist[blockIdx.x][s];
     __syncthreads();
-    if (threadIdx.x == 0) deflate_build_code(hist, A.code[blockIdx.x], &ws);
+    if (threadIdx.x == 0) deflate_build_code(hist, A.code[blockIdx.x], &ws, A.dist ? A.dist_sym : 0u);
 }
 
 // One workgroup per block: compressed size in bytes and the raw CRC-32 of the block's text.  For the CRC, lane t of
@@ -337,6 +384,8 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) 
     const uint32_t n = deflate_block_len(A.n_bytes, b);
     const uint8_t *t = A.text[mate] + start;
     uint32_t bits = 0, crc = 0;
+    // bits after the length code: a run's distance code (1 bit), the record distance's code (1 bit) + extra bits
+    const uint32_t kind_bits[3] = {0u, 1u, 1u + A.dist_ebits};
     if (n == (uint32_t)DEFLATE_BLOCK) {
         const uint4 *src = reinterpret_cast<const uint4 *>(t);
         for (int j = 0; j < DEFLATE_BLOCK / 16 / DEFLATE_THREADS; ++j) {
@@ -351,7 +400,10 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) 
             const uint32_t w = (c >> 4) * 33u + (c & 15u) * 2u;
             const uint64_t raw = (uint64_t)stage[w] | ((uint64_t)stage[w + 1] << 32);
             const int prev = c ? (int)(stage[(c & 15u) ? w - 1 : w - 2] >> 24) : before;
-            deflate_tokens(raw, 8u, prev, [&](uint32_t sym, bool match) { bits += lens[sym] + (match ? 1u : 0u); });
+            const uint64_t at = start + (uint64_t)c * 8u;
+            const bool has_src = A.dist && at >= A.dist;
+            const uint64_t src = has_src ? deflate_source(A.text[mate], at, A.dist) : 0;
+            deflate_tokens(raw, 8u, prev, src, has_src, [&](uint32_t sym, int kind) { bits += lens[sym] + kind_bits[kind]; });
         }
         const uint32_t *mine = stage + threadIdx.x * 33u;
         for (int i = 0; i < 32; ++i) {
@@ -362,8 +414,10 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) 
         for (uint32_t c = threadIdx.x; c * 8u < n; c += DEFLATE_THREADS) {
             uint32_t m;
             int prev;
-            const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, start / 8u + c, m, prev);
-            deflate_tokens(raw, m, prev, [&](uint32_t sym, bool match) { bits += lens[sym] + (match ? 1u : 0u); });
+            uint64_t src;
+            bool has_src;
+            const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, start / 8u + c, A.dist, m, prev, src, has_src);
+            deflate_tokens(raw, m, prev, src, has_src, [&](uint32_t sym, int kind) { bits += lens[sym] + kind_bits[kind]; });
         }
         const int64_t lo = (int64_t)n - (int64_t)(DEFLATE_THREADS - threadIdx.x) * 128;  // may be negative: zeros in front
         for (int64_t i = lo < 0 ? 0 : lo; i < lo + 128; ++i) crc = tab[0][(crc ^ t[i]) & 0xffu] ^ (crc >> 8);
@@ -474,11 +528,16 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_encode(DeflateArgs 
         if (at < n) {
             uint32_t m;
             int prev;
-            const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, (start + at) / 8u, m, prev);
-            deflate_tokens(raw, m, prev, [&](uint32_t sym, bool match) {
+            uint64_t src;
+            bool has_src;
+            const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, (start + at) / 8u, A.dist, m, prev, src, has_src);
+            deflate_tokens(raw, m, prev, src, has_src, [&](uint32_t sym, int kind) {
                 const uint32_t e = ent[sym];
-                const uint64_t c = e & 0xffffu;                    // (a match: its distance bit, 0, follows the length code)
-                const uint32_t l = (e >> 16) + (match ? 1u : 0u);
+                uint64_t c = e & 0xffffu;
+                uint32_t l = e >> 16;
+                // after a length code: the distance code -- "0" for distance 1, "1" + extra bits for the record distance
+                if (kind == 1) l += 1u;
+                if (kind == 2) { c |= (uint64_t)(1u | (A.dist_eval << 1)) << l; l += 1u + A.dist_ebits; }
                 if (nb < 64u) {
                     lo |= c << nb;
                     if (nb + l > 64u) hi |= c >> (64u - nb);

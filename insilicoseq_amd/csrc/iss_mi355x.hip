@@ -1831,6 +1831,15 @@ int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, in
         D.n_bytes = bytes;
         D.n_blocks = n_blocks;
         D.out_cap = q.comp_cap;
+        {   // the record length most records of this batch have: the distance of the "previous record" matches
+            int dg = 1;
+            for (uint64_t v = A.first_i + (uint64_t)n_pairs - 1; v >= 10; v /= 10) ++dg;
+            const size_t rec = C + (size_t)dg;
+            if (rec >= 8 && rec <= 32768 && !getenv("ISS_DEFLATE_RUNS_ONLY")) {
+                D.dist = (uint32_t)rec;
+                iss::deflate_dist_code(D.dist, &D.dist_sym, &D.dist_ebits, &D.dist_eval);
+            }
+        }
         for (int m = 0; m < 2; ++m) {
             D.text[m] = q.d_text[slot][m];
             D.hist[m] = q.d_hist[slot][m];
@@ -1893,13 +1902,16 @@ int iss_fastq_compress(iss_ctx *ctx, int32_t mode) {
     return 0;
 }
 
-int iss_deflate_code_build(const uint32_t *hist, uint32_t *entry, uint32_t *hdr_bits, uint32_t *hdr_words) {
-    if (!hist || !entry || !hdr_bits || !hdr_words) return ISS_E_INVALID;
+int iss_deflate_code_build(const uint32_t *hist, uint32_t record_distance, uint32_t *entry, uint32_t *hdr_bits,
+                           uint32_t *hdr_words, uint32_t *dist_code) {
+    if (!hist || !entry || !hdr_bits || !hdr_words || !dist_code || record_distance > 32768) return ISS_E_INVALID;
+    dist_code[0] = dist_code[1] = dist_code[2] = 0;
+    if (record_distance) iss::deflate_dist_code(record_distance, &dist_code[0], &dist_code[1], &dist_code[2]);
     static iss::DeflateCode c;  // (large for a stack frame; the function is a test hook, not re-entrant)
     static iss::DeflateWork ws;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    iss::deflate_build_code(hist, &c, &ws);
+    iss::deflate_build_code(hist, &c, &ws, dist_code[0]);
     memcpy(entry, c.entry, sizeof c.entry);
     *hdr_bits = c.hdr_bits;
     memcpy(hdr_words, c.hdr, sizeof c.hdr);

@@ -189,44 +189,56 @@ def test_compress_file_is_one_gzip_stream(tmp_path):
             assert fh.read() == data
 
 
-def _tokens(data):
-    """The device's tokens (iss_deflate.hip.h, deflate_tokens): 8-byte chunks; a byte repeating its predecessor >= 3
-    times inside the chunk is a run (symbol 254 + length, distance 1), everything else a literal."""
+def _tokens(data, dist=0):
+    """The device's tokens (iss_deflate.hip.h, deflate_tokens): 8-byte chunks; at every position the run (the byte
+    repeats its predecessor) and the previous record (the same bytes `dist` earlier) are tried, the longer one wins
+    with >= 3 (run) / >= 4 (previous record) bytes inside the chunk (symbol 254 + length; kind 1 run, 2 previous
+    record), else a literal (kind 0)."""
     out = []
     for at in range(0, len(data), 8):
         chunk = data[at:at + 8]
         prev = data[at - 1] if at else -1
+        has_src = bool(dist) and at >= dist
         i = 0
         while i < len(chunk):
             c = chunk[i]
+            r1 = rd = 0
             if c == prev:
-                r = 1
-                while i + r < len(chunk) and chunk[i + r] == c:
-                    r += 1
-                if r >= 3:
-                    out.append((254 + r, True))
-                    i += r
-                    continue
-            out.append((c, False))
-            prev = c
-            i += 1
+                r1 = 1
+                while i + r1 < len(chunk) and chunk[i + r1] == c:
+                    r1 += 1
+            while has_src and i + rd < len(chunk) and chunk[i + rd] == data[at + i + rd - dist]:
+                rd += 1
+            if r1 >= 3 and r1 >= rd:
+                out.append((254 + r1, 1))
+                i += r1
+            elif rd >= 4:
+                out.append((254 + rd, 2))
+                i += rd
+                prev = chunk[i - 1]
+            else:
+                out.append((c, 0))
+                prev = c
+                i += 1
     return out
 
 
-def _deflate_block(native, data, hist=None):
+def _deflate_block(native, data, hist=None, dist=0):
     """One DEFLATE block of `data` built on the CPU with the code tables of iss_deflate_code_build (what the device
     kernels pack): header bits, the tokens' codes, end of block, then an empty stored block and a final empty block."""
     import ctypes as C
 
-    toks = _tokens(data)
+    toks = _tokens(data, dist)
     if hist is None:
         hist = np.bincount(np.array([t[0] for t in toks] + [256], dtype=np.int64), minlength=263).astype(np.uint32)
     hist = np.ascontiguousarray(hist, dtype=np.uint32)
     assert hist.size == 263
     entry = np.zeros(263, dtype=np.uint32)
     hdr = np.zeros(64, dtype=np.uint32)
+    dcode = np.zeros(3, dtype=np.uint32)
     nbits = C.c_uint32(0)
-    assert native.lib().iss_deflate_code_build(hist.ctypes.data, entry.ctypes.data, C.byref(nbits), hdr.ctypes.data) == 0
+    assert native.lib().iss_deflate_code_build(hist.ctypes.data, dist, entry.ctypes.data, C.byref(nbits), hdr.ctypes.data,
+                                               dcode.ctypes.data) == 0
     lens = (entry >> 16).astype(np.int64)
     assert lens.min() >= 1 and lens.max() <= 15
     assert sum(2.0 ** -int(x) for x in lens) == 1.0  # complete code (inflate rejects anything else)
@@ -235,9 +247,14 @@ def _deflate_block(native, data, hist=None):
         acc |= int(hdr[w]) << (32 * w)
     acc &= (1 << nbits.value) - 1
     n = nbits.value
-    for sym, match in toks:
+    for sym, kind in toks:
         acc |= (int(entry[sym]) & 0xffff) << n
-        n += int(lens[sym]) + (1 if match else 0)  # a match: one zero bit for its distance code
+        n += int(lens[sym])
+        if kind == 1:      # distance 1: the bit 0
+            n += 1
+        elif kind == 2:    # the record distance: the bit 1, then its extra bits
+            acc |= (1 | (int(dcode[2]) << 1)) << n
+            n += 1 + int(dcode[1])
     acc |= (int(entry[256]) & 0xffff) << n
     n += int(lens[256])
     n += 3                      # empty stored block: BFINAL 0, BTYPE 00
@@ -253,19 +270,24 @@ def test_deflate_code_builder_makes_valid_streams(native):
     import zlib
 
     rng = np.random.RandomState(5)
-    fastq = b"".join(b"@genome_%d_%d_0/1\n" % (i % 3, i) + bytes(rng.choice(list(b"ACGT"), 151)) + b"\n+\n" +
-                     bytes(rng.choice(list(b"#-8F"), 151, p=[0.01, 0.04, 0.1, 0.85])) + b"\n" for i in range(300))
-    cases = [fastq, b"A", b"", bytes(range(256)) * 3, bytes(rng.randint(0, 256, 5000).astype(np.uint8)),
-             b"\x00" * 4000 + b"\x01", b"FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF", b"ab" + b"c" * 9 + b"dd" + b"e" * 3]
-    for data in cases:
-        block, lens = _deflate_block(native, data)
-        assert zlib.decompressobj(-15).decompress(block) == data
-    block, lens = _deflate_block(native, fastq)
-    assert len(block) < 0.30 * len(fastq)
+    acgt, quals = np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(b"#-8F", dtype=np.uint8)
+    fastq = b"".join(b"@genome_%d_%d_0/1\n" % (7, 1000 + i) + rng.choice(acgt, 151).tobytes() + b"\n+\n" +
+                     rng.choice(quals, 151, p=[0.005, 0.015, 0.03, 0.95]).tobytes() + b"\n" for i in range(300))
+    rec = len(fastq) // 300
+    cases = [(fastq, 0), (fastq, rec), (fastq, rec + 1), (b"A", 0), (b"", 0), (bytes(range(256)) * 3, 256), (bytes(range(256)) * 3, 5),
+             (bytes(rng.randint(0, 256, 5000).astype(np.uint8)), 1000), (b"\x00" * 4000 + b"\x01", 8),
+             (b"FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF", 0), (b"ab" + b"c" * 9 + b"dd" + b"e" * 3, 4), (fastq[:5000] * 8, 5000),
+             (fastq[:4097] * 9, 4097), (fastq[:1000] * 40, 32768)]
+    for data, dist in cases:
+        block, lens = _deflate_block(native, data, dist=dist)
+        assert zlib.decompressobj(-15).decompress(block) == data, dist
+    runs_only, _ = _deflate_block(native, fastq)
+    block, lens = _deflate_block(native, fastq, dist=rec)
+    assert len(block) < 0.9 * len(runs_only) < 0.31 * len(fastq)
     # a code built from one histogram still encodes symbols the histogram never saw
     hist = np.bincount(np.array([t[0] for t in _tokens(fastq)] + [256]), minlength=263).astype(np.uint32)
     other = b"nnnnNNNN@@@\xff\x00" * 50
-    block, _ = _deflate_block(native, other, hist=hist)
+    block, _ = _deflate_block(native, other, hist=hist, dist=13)
     assert zlib.decompressobj(-15).decompress(block) == other
     # extreme counts (a long batch) keep the 15-bit limit
     hist = np.ones(263, dtype=np.uint32)
