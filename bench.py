@@ -53,7 +53,7 @@ def main():
                     help="override every insertion / deletion probability (BASELINE configs[4]-like indel-heavy model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTQ-on-tmpfs leg (rank 0, N = 1 only)")
-    ap.add_argument("--e2e-pairs", type=int, default=5_000_000)
+    ap.add_argument("--e2e-pairs", type=int, default=20_000_000)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo: a dry run of "
                     "the multi-rank logic, e.g. with ISS_BENCH_SHARE_GPU=1 on a single-GPU box)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_500_000)
