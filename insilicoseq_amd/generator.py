@@ -138,7 +138,9 @@ def worker_seed(seed, cpu_number):
 class Worker(object):
     """State of one reference worker on one GPU: engine + uploaded genomes + running ordinal."""
 
-    BATCH_PAIRS = 1 << 20  # rows generated / downloaded / formatted per step of the streaming loop
+    # rows generated / formatted / written per step of the streaming loop (ISS_BATCH_PAIRS: tuning aid).  2^18: the
+    # kernels still run at their full rate, the (pinned) buffers are allocated in a quarter of the time of 2^20
+    BATCH_PAIRS = int(os.environ.get("ISS_BATCH_PAIRS", 1 << 18))
     GENOME_BUDGET = 96 << 30  # letters kept resident in HBM (1.4 B each incl. the packed copies) before all are dropped
 
     def __init__(self, error_model, cpu_number, seed, device=None, rng="philox", compress=False):

@@ -825,7 +825,7 @@ def test_device_gzip_members_hold_the_same_text(rng_mode, tmp_path, monkeypatch)
 
 
 def test_device_gzip_full_batch(tmp_path):
-    """A full-size batch (2^20 pairs, 10 000 DEFLATE blocks per file) and a tail batch through the compressed path."""
+    """Full-size batches (2 600 DEFLATE blocks per file each) and a tail batch through the compressed path."""
     import gzip
     import hashlib
 
