@@ -427,6 +427,7 @@ void fastq_writer_loop(iss_ctx *ctx) {
             job = q.jobs.front();
         }
         std::string err;
+        int64_t gz_wrote[2] = {0, 0};  // compressed mode: only this thread moves the file offsets (under the mutex)
         const bool dbg = getenv("ISS_FASTQ_DEBUG") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         if (hipEventSynchronize(q.ev_copy[job.slot]) != hipSuccess) err = "device copy of the FASTQ text failed";
@@ -445,6 +446,12 @@ void fastq_writer_loop(iss_ctx *ctx) {
                 std::thread th[2];
                 int rc[2] = {0, 0};
                 uint64_t wrote[2] = {0, 0};
+                int64_t gz_at[2];
+                {
+                    std::lock_guard<std::mutex> lk(q.mu);
+                    gz_at[0] = q.off[0];
+                    gz_at[1] = q.off[1];
+                }
                 for (int mate = 0; mate < 2; ++mate) {
                     th[mate] = std::thread([&, mate] {
                         const uint64_t total = *q.h_total[job.slot][mate];
@@ -463,7 +470,7 @@ void fastq_writer_loop(iss_ctx *ctx) {
                         const uint32_t isize = (uint32_t)job.bytes;
                         memcpy(tail + 2, &crc, 4);
                         memcpy(tail + 6, &isize, 4);
-                        int64_t at = q.off[mate];
+                        const int64_t at = gz_at[mate];
                         if (pwrite_all(job.fd[mate], head, 10, at) || pwrite_all(job.fd[mate], q.h_text[job.slot][mate], total, at + 10) ||
                             pwrite_all(job.fd[mate], tail, 10, at + 10 + (int64_t)total))
                             rc[mate] = errno;
@@ -473,7 +480,7 @@ void fastq_writer_loop(iss_ctx *ctx) {
                 for (auto &t : th) t.join();
                 for (int mate = 0; mate < 2; ++mate) {
                     if (rc[mate]) err = std::string("write failed: ") + strerror(rc[mate]);
-                    q.off[mate] += (int64_t)wrote[mate];  // (only this thread moves the offsets in compressed mode)
+                    gz_wrote[mate] = (int64_t)wrote[mate];
                 }
             }
         } else if (err.empty()) {
@@ -506,6 +513,8 @@ void fastq_writer_loop(iss_ctx *ctx) {
             std::lock_guard<std::mutex> lk(q.mu);
             q.jobs.pop_front();
             q.busy[job.slot] = false;
+            q.off[0] += gz_wrote[0];
+            q.off[1] += gz_wrote[1];
             if (!err.empty() && q.error.empty()) q.error = err;
         }
         q.cv.notify_all();
