@@ -848,3 +848,23 @@ def test_device_gzip_full_batch(tmp_path):
     for s in ("_R1.fastq", "_R2.fastq"):
         assert sums[(True, s)][0] == sums[(False, s)][0]
         assert sums[(True, s)][1] < 0.33 * sums[(False, s)][1]
+
+
+@pytest.mark.parametrize("model,id_len", [("miseq", 3), ("miseq", 700), ("miseq-36", 4000), ("novaseq", 64)])
+def test_device_gzip_record_distances(model, id_len, tmp_path):
+    """Record lengths from 100 bytes to 4.7 KB (distance codes 12 .. 24 of the previous-record matches), pair numbers
+    that change their digit count inside a batch."""
+    import gzip
+
+    from insilicoseq_amd import generator as G
+
+    dense = dense_model(model)
+    rec = G.Record(random_genome(77, 20000), id=("x" * id_len)[:id_len - 1] + "7")
+    out = {}
+    for compress in (False, True):
+        prefix = str(tmp_path / ("d%d" % compress))
+        G.worker_iterator([(rec, 1205, "default")], dense, 12, prefix, 3, "metagenomics", False, device=0, compress=compress)
+        out[compress] = [open(prefix + s, "rb").read() for s in ("_R1.fastq", "_R2.fastq")]
+    for plain, packed in zip(out[False], out[True]):
+        assert gzip.decompress(packed) == plain
+        assert len(packed) < 0.45 * len(plain)
