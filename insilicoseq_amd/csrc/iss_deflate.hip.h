@@ -42,79 +42,127 @@ struct DeflateWork {  // scratch of the code builder: in LDS on the device (priv
     uint32_t cnt[288];
     uint8_t len[320], sym[320], extra[320];
     uint16_t code[288];
+    uint32_t prop[64], ccnt[19], ns;   // per-lane proposals of a repair step; code-length alphabet counts; RLE symbols
+    uint8_t clen[19];
+    uint16_t ccode[19];
+    uint32_t entry[288];               // results, copied to the DeflateCode by the caller (all lanes on the device)
+    uint32_t hdr[64];
+    uint32_t hdr_bits;
 };
 
-__host__ __device__ inline void deflate_lengths(const uint32_t *cnt, int n, int maxbits, uint8_t *len, DeflateWork *ws) {
-    // binary heap of (weight, node); nodes 0..n-1 leaves, n.. internal
-    uint64_t *heap = ws->heap;
+// The builder is written for `nl` cooperating lanes (lane = 0 .. nl-1; `sync` separates the phases): the host runs it
+// with one, the device with one wavefront.  Every choice is made on a total order (weight, then symbol / node number),
+// so the result does not depend on nl.
+struct DeflateNoSync { __host__ __device__ void operator()() const {} };
+
+// Huffman code lengths of n <= 288 symbols, limited to maxbits; symbols with count 0 get length 0.  The code is
+// complete (Kraft sum exactly 1), as inflate requires, whenever at least two symbols are in use.
+//   1. keys (count << 16 | symbol) are rank-sorted -- each lane counts the smaller keys of its symbols;
+//   2. lane 0 merges with two queues (sorted leaves, internal nodes in creation order: both ascending in the key);
+//   3. depths: every lane walks its leaves up to the root;  4. the 15-bit limit: lengths are clamped and the Kraft
+//   sum repaired one step at a time, the candidate of each step found by all lanes.
+template <typename Sync>
+__host__ __device__ inline void deflate_lengths(const uint32_t *cnt, int n, int maxbits, uint8_t *len, DeflateWork *ws,
+                                                int lane, int nl, Sync sync) {
+    uint64_t *key = ws->heap, *sorted = ws->heap + 288;
     int16_t *parent = ws->parent;
-    int hn = 0;
-    auto push = [&](uint64_t key) {
-        int i = hn++;
-        while (i > 0 && heap[(i - 1) / 2] > key) { heap[i] = heap[(i - 1) / 2]; i = (i - 1) / 2; }
-        heap[i] = key;
-    };
-    auto pop = [&]() {
-        const uint64_t top = heap[0], last = heap[--hn];
-        int i = 0;
-        for (;;) {
-            int c = 2 * i + 1;
-            if (c >= hn) break;
-            if (c + 1 < hn && heap[c + 1] < heap[c]) ++c;
-            if (heap[c] >= last) break;
-            heap[i] = heap[c];
-            i = c;
-        }
-        if (hn) heap[i] = last;
-        return top;
-    };
-    int used = 0;
-    for (int s = 0; s < n; ++s) {
+    const uint64_t none = ~0ull;
+    for (int s = lane; s < n; s += nl) {
+        key[s] = cnt[s] ? ((uint64_t)cnt[s] << 16) | (uint64_t)s : none;
         len[s] = 0;
-        if (cnt[s]) { push(((uint64_t)cnt[s] << 16) | (uint64_t)s); ++used; }
     }
+    sync();
+    int used = 0;
+    for (int t = 0; t < n; ++t) used += cnt[t] != 0;
+    for (int s = lane; s < n; s += nl) {
+        const uint64_t k = key[s];
+        if (k == none) continue;
+        int r = 0;
+        for (int t = 0; t < n; ++t) r += key[t] < k;
+        sorted[r] = k;
+    }
+    sync();
     if (used == 0) return;
     if (used == 1) {  // one symbol: one bit, paired with a second symbol so the code is complete
-        const int s = (int)(heap[0] & 0xffffu);
-        len[s] = 1;
-        len[s == 0 ? 1 : 0] = 1;
+        if (lane == 0) {
+            const int s = (int)(sorted[0] & 0xffffu);
+            len[s] = 1;
+            len[s == 0 ? 1 : 0] = 1;
+        }
+        sync();
         return;
     }
-    int next = n;
-    while (hn > 1) {
-        const uint64_t a = pop(), b = pop();
-        parent[a & 0xffffu] = (int16_t)next;
-        parent[b & 0xffffu] = (int16_t)next;
-        push((((a >> 16) + (b >> 16)) << 16) | (uint64_t)next);
-        ++next;
+    if (lane == 0) {
+        uint64_t *iq = key;  // internal nodes, in creation order (the keys are not needed any more)
+        int li = 0, qh = 0, qt = 0, next = n;
+        uint64_t lh = sorted[0], ih = none;
+        for (int m = 0; m + 1 < used; ++m) {
+            uint64_t ab[2];
+            for (int k = 0; k < 2; ++k) {
+                if (lh < ih) { ab[k] = lh; ++li; lh = li < used ? sorted[li] : none; }
+                else { ab[k] = ih; ++qh; ih = qh < qt ? iq[qh] : none; }
+            }
+            parent[ab[0] & 0xffffu] = (int16_t)next;
+            parent[ab[1] & 0xffffu] = (int16_t)next;
+            const uint64_t nk = (((ab[0] >> 16) + (ab[1] >> 16)) << 16) | (uint64_t)next;
+            iq[qt++] = nk;
+            if (ih == none) ih = iq[qh];
+            ++next;
+        }
+        parent[next - 1] = -1;
     }
-    const int root = (int)(heap[0] & 0xffffu);
-    for (int s = 0; s < n; ++s) {
+    sync();
+    for (int s = lane; s < n; s += nl) {
         if (!cnt[s]) continue;
         int d = 0;
-        for (int v = s; v != root; v = parent[v]) ++d;
+        for (int v = s; parent[v] >= 0; v = parent[v]) ++d;
         len[s] = (uint8_t)(d > maxbits ? maxbits : d);
     }
+    sync();
     // Kraft sum in units of 2^-maxbits; clamping may have pushed it over 1
     const uint32_t one = 1u << maxbits;
     uint32_t k = 0;
     for (int s = 0; s < n; ++s) if (len[s]) k += one >> len[s];
-    while (k > one) {  // lengthen the longest code that still can be lengthened (cheapest in expected bits)
+    // candidate of a repair step: the longest code that qualifies; among equals the rarer (lengthen) / more frequent
+    // (shorten) symbol, then the lower symbol number.  Every lane proposes its best, lane order breaks no tie.
+    uint32_t *prop = ws->prop;
+    auto better = [&](int a, int b, bool lengthen) {  // is symbol a a better candidate than b (b may be -1)?
+        if (b < 0) return true;
+        if (len[a] != len[b]) return len[a] > len[b];
+        if (cnt[a] != cnt[b]) return lengthen ? cnt[a] < cnt[b] : cnt[a] > cnt[b];
+        return a < b;
+    };
+    auto pick = [&](bool lengthen, uint32_t room) {
         int best = -1;
-        for (int s = 0; s < n; ++s)
-            if (len[s] && len[s] < maxbits && (best < 0 || len[s] > len[best] || (len[s] == len[best] && cnt[s] < cnt[best])))
-                best = s;
+        for (int s = lane; s < n; s += nl) {
+            const bool ok = lengthen ? (len[s] && len[s] < maxbits) : (len[s] > 1 && (one >> len[s]) <= room);
+            if (ok && better(s, best, lengthen)) best = s;
+        }
+        if (nl == 1) return best;
+        prop[lane] = (uint32_t)best;
+        sync();
+        best = -1;
+        for (int l = 0; l < nl; ++l) {
+            const int c = (int)prop[l];
+            if (c >= 0 && better(c, best, lengthen)) best = c;
+        }
+        sync();
+        return best;
+    };
+    while (k > one) {  // lengthen the longest code that still can be lengthened (cheapest in expected bits)
+        const int best = pick(true, 0);
         k -= one >> (len[best] + 1);
-        ++len[best];
+        sync();
+        if (lane == 0) ++len[best];
+        sync();
     }
     while (k < one) {  // shorten the longest code that fits into what is left
-        int best = -1;
-        for (int s = 0; s < n; ++s)
-            if (len[s] > 1 && (one >> len[s]) <= one - k && (best < 0 || len[s] > len[best] || (len[s] == len[best] && cnt[s] > cnt[best])))
-                best = s;
+        const int best = pick(false, one - k);
         if (best < 0) break;
         k += one >> len[best];
-        --len[best];
+        sync();
+        if (lane == 0) --len[best];
+        sync();
     }
 }
 
@@ -135,70 +183,96 @@ __host__ __device__ inline void deflate_codes(const uint8_t *len, int n, uint16_
     }
 }
 
-struct BitSink {
+struct BitSink {  // least-significant-bit-first stream, whole words written as they fill
     uint32_t *w;
-    uint32_t n;  // bits so far
-    __host__ __device__ void put(uint32_t v, int bits) {
-        for (int b = 0; b < bits; ++b, ++n)
-            if ((v >> b) & 1u) w[n >> 5] |= 1u << (n & 31);
+    uint32_t n;    // bits so far
+    uint64_t acc;  // bits not yet written (below n & 31)
+    __host__ __device__ void put(uint32_t v, int bits) {  // bits <= 16
+        acc |= (uint64_t)(v & ((1u << bits) - 1u)) << (n & 31u);
+        const uint32_t before = n >> 5;
+        n += (uint32_t)bits;
+        if ((n >> 5) != before) { w[before] = (uint32_t)acc; acc >>= 32; }
     }
+    __host__ __device__ void finish() { if (n & 31u) w[n >> 5] = (uint32_t)acc; }
 };
 
-// hist[s]: token counts of the text (literals, hist[256] = number of blocks, run lengths 3..8 at 257..262).  Every
+// hist[s]: token counts of the text (literals, hist[256] = number of blocks, match lengths 3..8 at 257..262).  Every
 // symbol gets a code (count + 1, and at least 2^-15 of the total so that the tree stays shallow): a batch is
 // compressed with the code of its own text, but nothing breaks if a symbol shows up that the histogram missed.
-// dist_sym: distance symbol of the batch's record length (0: distance 1 is the only distance in use)
-__host__ __device__ inline void deflate_build_code(const uint32_t *hist, DeflateCode *out, DeflateWork *ws, uint32_t dist_sym = 0) {
+// dist_sym: distance symbol of the batch's record length (0: distance 1 is the only distance in use).
+// Called by all nl lanes; results in ws->entry, ws->hdr, ws->hdr_bits (see deflate_store_code).
+template <typename Sync>
+__host__ __device__ inline void deflate_build_code(const uint32_t *hist, DeflateWork *ws, uint32_t dist_sym, int lane, int nl,
+                                                   Sync sync) {
     uint32_t *cnt = ws->cnt;
     uint64_t total = 0;
     for (int s = 0; s < DEFLATE_SYMS; ++s) total += hist[s];
     const uint32_t floor_cnt = (uint32_t)(total >> 15);
-    for (int s = 0; s < DEFLATE_SYMS; ++s) cnt[s] = hist[s] + 1u > floor_cnt ? hist[s] + 1u : floor_cnt;
+    for (int s = lane; s < DEFLATE_SYMS; s += nl) cnt[s] = hist[s] + 1u > floor_cnt ? hist[s] + 1u : floor_cnt;
+    sync();
     uint8_t *len = ws->len;
-    uint16_t *code = ws->code;
-    deflate_lengths(cnt, DEFLATE_SYMS, 15, len, ws);
-    deflate_codes(len, DEFLATE_SYMS, code);
-    for (int s = 0; s < DEFLATE_SYMS; ++s) out->entry[s] = (uint32_t)code[s] | ((uint32_t)len[s] << 16);
-    // ---- header: the literal/length code lengths, then the distance code lengths -- distance 1 ("0") and, with
-    // dist_sym, the record distance ("1"), one bit each -- run-length coded together (3.2.7)
-    const int n_all = DEFLATE_SYMS + 1 + (int)dist_sym;
-    for (int i = DEFLATE_SYMS; i < n_all; ++i) len[i] = 0;
-    len[DEFLATE_SYMS] = 1;
-    len[n_all - 1] = 1;
-    uint8_t *sym = ws->sym, *extra = ws->extra;
-    int ns = 0;
-    for (int i = 0; i < n_all;) {
-        int r = 1;
-        while (i + r < n_all && len[i + r] == len[i]) ++r;
-        sym[ns] = len[i]; extra[ns] = 0; ++ns;  // the value itself
-        int rem = r - 1;
-        if (len[i] != 0)
-            while (rem >= 3) { const int t = rem > 6 ? 6 : rem; sym[ns] = 16; extra[ns] = (uint8_t)(t - 3); ++ns; rem -= t; }
-        for (; rem > 0; --rem) { sym[ns] = len[i]; extra[ns] = 0; ++ns; }
-        i += r;
+    deflate_lengths(cnt, DEFLATE_SYMS, 15, len, ws, lane, nl, sync);
+    sync();
+    if (lane == 0) {
+        uint16_t *code = ws->code;
+        deflate_codes(len, DEFLATE_SYMS, code);
+        for (int s = 0; s < DEFLATE_SYMS; ++s) ws->entry[s] = (uint32_t)code[s] | ((uint32_t)len[s] << 16);
+        // ---- header: the literal/length code lengths, then the distance code lengths -- distance 1 ("0") and, with
+        // dist_sym, the record distance ("1"), one bit each -- run-length coded together (3.2.7)
+        const int n_all = DEFLATE_SYMS + 1 + (int)dist_sym;
+        for (int i = DEFLATE_SYMS; i < n_all; ++i) len[i] = 0;
+        len[DEFLATE_SYMS] = 1;
+        len[n_all - 1] = 1;
+        uint8_t *sym = ws->sym, *extra = ws->extra;
+        int ns = 0;
+        for (int i = 0; i < n_all;) {
+            int r = 1;
+            while (i + r < n_all && len[i + r] == len[i]) ++r;
+            sym[ns] = len[i]; extra[ns] = 0; ++ns;  // the value itself
+            int rem = r - 1;
+            if (len[i] != 0)
+                while (rem >= 3) { const int t = rem > 6 ? 6 : rem; sym[ns] = 16; extra[ns] = (uint8_t)(t - 3); ++ns; rem -= t; }
+            for (; rem > 0; --rem) { sym[ns] = len[i]; extra[ns] = 0; ++ns; }
+            i += r;
+        }
+        ws->ns = (uint32_t)ns;
+        for (int i = 0; i < 19; ++i) ws->ccnt[i] = 0;
+        for (int i = 0; i < ns; ++i) ++ws->ccnt[sym[i]];
     }
-    uint32_t ccnt[19] = {0};
-    for (int i = 0; i < ns; ++i) ++ccnt[sym[i]];
-    uint8_t clen[19];
-    uint16_t ccode[19];
-    deflate_lengths(ccnt, 19, 7, clen, ws);
-    deflate_codes(clen, 19, ccode);
-    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    int hclen = 19;
-    while (hclen > 4 && clen[order[hclen - 1]] == 0) --hclen;
-    for (int i = 0; i < DEFLATE_HDR_WORDS; ++i) out->hdr[i] = 0;
-    BitSink bs{out->hdr, 0};
-    bs.put(0, 1);  // BFINAL = 0 (the member is closed by an empty final block)
-    bs.put(2, 2);  // BTYPE = 10: dynamic Huffman codes
-    bs.put(DEFLATE_SYMS - 257, 5);  // HLIT
-    bs.put(dist_sym, 5);            // HDIST: distance codes 0 .. dist_sym
-    bs.put((uint32_t)(hclen - 4), 4);
-    for (int i = 0; i < hclen; ++i) bs.put(clen[order[i]], 3);
-    for (int i = 0; i < ns; ++i) {
-        bs.put(ccode[sym[i]], clen[sym[i]]);
-        if (sym[i] == 16) bs.put(extra[i], 2);
+    sync();
+    deflate_lengths(ws->ccnt, 19, 7, ws->clen, ws, lane, nl, sync);
+    sync();
+    if (lane == 0) {
+        const uint8_t *clen = ws->clen, *sym = ws->sym, *extra = ws->extra;
+        uint16_t *ccode = ws->ccode;
+        deflate_codes(clen, 19, ccode);
+        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        int hclen = 19;
+        while (hclen > 4 && clen[order[hclen - 1]] == 0) --hclen;
+        for (int i = 0; i < DEFLATE_HDR_WORDS; ++i) ws->hdr[i] = 0;
+        BitSink bs{ws->hdr, 0, 0};
+        bs.put(0, 1);  // BFINAL = 0 (the member is closed by an empty final block)
+        bs.put(2, 2);  // BTYPE = 10: dynamic Huffman codes
+        bs.put(DEFLATE_SYMS - 257, 5);  // HLIT
+        bs.put(dist_sym, 5);            // HDIST: distance codes 0 .. dist_sym
+        bs.put((uint32_t)(hclen - 4), 4);
+        for (int i = 0; i < hclen; ++i) bs.put(clen[order[i]], 3);
+        const int ns = (int)ws->ns;
+        for (int i = 0; i < ns; ++i) {
+            bs.put(ccode[sym[i]], clen[sym[i]]);
+            if (sym[i] == 16) bs.put(extra[i], 2);
+        }
+        bs.finish();
+        ws->hdr_bits = bs.n;
     }
-    out->hdr_bits = bs.n;
+    sync();
+}
+
+// the part of a DeflateCode the builder makes; lanes `lane`, `lane + n_lanes`, ... of the caller copy
+__host__ __device__ inline void deflate_store_code(const DeflateWork *ws, DeflateCode *out, int lane, int n_lanes) {
+    for (int s = lane; s < DEFLATE_SYMS; s += n_lanes) out->entry[s] = ws->entry[s];
+    for (int i = lane; i < DEFLATE_HDR_WORDS; i += n_lanes) out->hdr[i] = ws->hdr[i];
+    if (lane == 0) out->hdr_bits = ws->hdr_bits;
 }
 
 // ---------------------------------------------------------------- CRC-32 (reflected 0xEDB88320), raw: initial value 0, no final xor
@@ -244,28 +318,29 @@ inline void crc_shift_operator(uint64_t n_bytes, uint32_t *op) {
 // one wins if it has >= 3 (run) / >= 4 (previous record) bytes (lengths 3..8: codes 257..262), otherwise the byte is a literal.  The predecessor of a
 // chunk's first byte and the bytes `dist` earlier may belong to the previous block: DEFLATE's window does not care.
 // f(symbol, kind) is called per token: kind 0 literal, 1 run, 2 previous record.
+// bit k of the result <=> byte k of v is not zero
+__host__ __device__ inline uint32_t deflate_nonzero_bytes(uint64_t v) {
+    const uint64_t low7 = 0x7f7f7f7f7f7f7f7full;
+    const uint64_t top = (((v & low7) + low7) | v) & ~low7;  // bit 7 of every non-zero byte
+    return (uint32_t)((top * 0x0002040810204081ull) >> 56);   // the eight bits 7, 15, ... 63 gathered
+}
+
 template <typename F>
 __host__ __device__ inline void deflate_tokens(uint64_t raw, uint32_t m, int prev, uint64_t src, bool has_src, F &&f) {
-    const uint64_t same = has_src ? ~(raw ^ src) : 0;  // byte k all ones <=> equal to the byte `dist` earlier
+    // differs[k]: byte k differs from the byte before it (run) / from the byte `dist` earlier (previous record);
+    // a stop bit at position m ends every match at the chunk's end
+    const uint64_t before = (raw << 8) | (uint64_t)(prev & 0xff);
+    uint32_t diff_run = deflate_nonzero_bytes(raw ^ before) | (prev < 0 ? 1u : 0u) | (1u << m);
+    uint32_t diff_rec = (has_src ? deflate_nonzero_bytes(raw ^ src) : 0xffu) | (1u << m);
     uint32_t i = 0;
     while (i < m) {
-        const int c = (int)((raw >> (8 * i)) & 0xffu);
-        uint32_t r1 = 0, rd = 0;
-        if (c == prev) {
-            r1 = 1;
-            while (i + r1 < m && (int)((raw >> (8 * (i + r1))) & 0xffu) == c) ++r1;
-        }
-        while (i + rd < m && ((same >> (8 * (i + rd))) & 0xffu) == 0xffu) ++rd;
-        if (r1 >= 3u && r1 >= rd) { f(254u + r1, 1); i += r1; continue; }  // (a run is the cheaper match)
-        if (rd >= 4u) {  // (its distance costs 8-14 bits: three bytes are not worth it)
-            f(254u + rd, 2);
-            i += rd;
-            prev = (int)((raw >> (8 * (i - 1))) & 0xffu);
-            continue;
-        }
-        f((uint32_t)c, 0);
-        prev = c;
-        ++i;
+        const uint32_t r1 = (uint32_t)__builtin_ctz(diff_run >> i), rd = (uint32_t)__builtin_ctz(diff_rec >> i);
+        uint32_t step = 1, sym = (uint32_t)((raw >> (8 * i)) & 0xffu);
+        int kind = 0;
+        if (r1 >= 3u && r1 >= rd) { step = r1; sym = 254u + r1; kind = 1; }  // (a run is the cheaper match)
+        else if (rd >= 4u) { step = rd; sym = 254u + rd; kind = 2; }         // (its distance costs 8-14 bits: three bytes are not worth it)
+        f(sym, kind);
+        i += step;
     }
 }
 
@@ -349,12 +424,16 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_hist(DeflateArgs A)
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&A.hist[mate][256], A.n_blocks);
 }
 
-__global__ void k_deflate_build(DeflateArgs A) {
+struct DeflateBlockSync { __device__ void operator()() const { __syncthreads(); } };
+
+// one wavefront per mate
+__global__ __launch_bounds__(64) void k_deflate_build(DeflateArgs A) {
     __shared__ DeflateWork ws;
     __shared__ uint32_t hist[DEFLATE_SYMS];
     for (int s = threadIdx.x; s < DEFLATE_SYMS; s += blockDim.x) hist[s] = A.hist[blockIdx.x][s];
     __syncthreads();
-    if (threadIdx.x == 0) deflate_build_code(hist, A.code[blockIdx.x], &ws, A.dist ? A.dist_sym : 0u);
+    deflate_build_code(hist, &ws, A.dist ? A.dist_sym : 0u, (int)threadIdx.x, (int)blockDim.x, DeflateBlockSync());
+    deflate_store_code(&ws, A.code[blockIdx.x], (int)threadIdx.x, (int)blockDim.x);
 }
 
 // One workgroup per block: compressed size in bytes and the raw CRC-32 of the block's text.  For the CRC, lane t of
@@ -369,9 +448,11 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) 
     __shared__ uint32_t red[DEFLATE_THREADS];
     __shared__ uint32_t crcs[DEFLATE_THREADS];
     __shared__ uint32_t stage[DEFLATE_THREADS * 33];
+    __shared__ uint32_t shift[8][32];
     const int mate = blockIdx.y;
     const uint32_t b = blockIdx.x;
     const DeflateCode *C = A.code[mate];
+    shift[threadIdx.x >> 5][threadIdx.x & 31] = C->crc_shift[threadIdx.x >> 5][threadIdx.x & 31];
     tab[0][threadIdx.x] = crc_table_entry(threadIdx.x);
     for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS) lens[s] = C->entry[s] >> 16;
     __syncthreads();
@@ -428,7 +509,7 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) 
     for (int k = 0, s = 1; s < DEFLATE_THREADS; s <<= 1, ++k) {
         if ((threadIdx.x & (2 * s - 1)) == 0) {
             red[threadIdx.x] += red[threadIdx.x + s];
-            crcs[threadIdx.x] = gf2_times(C->crc_shift[k], crcs[threadIdx.x]) ^ crcs[threadIdx.x + s];
+            crcs[threadIdx.x] = gf2_times(shift[k], crcs[threadIdx.x]) ^ crcs[threadIdx.x + s];
         }
         __syncthreads();
     }

@@ -1920,7 +1920,8 @@ int iss_deflate_code_build(const uint32_t *hist, uint32_t record_distance, uint3
     static iss::DeflateWork ws;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    iss::deflate_build_code(hist, &c, &ws, dist_code[0]);
+    iss::deflate_build_code(hist, &ws, dist_code[0], 0, 1, iss::DeflateNoSync());
+    iss::deflate_store_code(&ws, &c, 0, 1);
     memcpy(entry, c.entry, sizeof c.entry);
     *hdr_bits = c.hdr_bits;
     memcpy(hdr_words, c.hdr, sizeof c.hdr);
