@@ -294,3 +294,39 @@ def test_deflate_code_builder_makes_valid_streams(native):
     hist[65], hist[67], hist[10] = 4_000_000_000, 200_000_000, 3
     block, lens = _deflate_block(native, b"ACCA\n", hist=hist)
     assert zlib.decompressobj(-15).decompress(block) == b"ACCA\n" and lens[65] == 1
+
+
+def test_deflate_code_builder_randomized(native):
+    """Random token statistics (flat, geometric, one-symbol, zero-heavy, huge counts) through the code builder: every
+    block inflates, the code is complete and within 15 bits."""
+    import zlib
+
+    rng = np.random.RandomState(11)
+    for case in range(120):
+        kind = case % 6
+        n_sym = int(rng.choice([1, 2, 3, 5, 17, 64, 200, 256]))
+        alphabet = rng.choice(256, size=n_sym, replace=False).astype(np.uint8)
+        if kind == 0:
+            p = np.ones(n_sym)
+        elif kind == 1:
+            p = 0.5 ** np.arange(n_sym)
+        elif kind == 2:
+            p = rng.rand(n_sym) ** 8 + 1e-12
+        elif kind == 3:
+            p = 1.0 / (1 + np.arange(n_sym)) ** 3
+        elif kind == 4:
+            p = np.where(np.arange(n_sym) == 0, 1.0, 1e-4)
+        else:
+            p = rng.rand(n_sym)
+        p = p / p.sum()
+        size = int(rng.choice([0, 1, 7, 8, 9, 100, 3000]))
+        data = alphabet[rng.choice(n_sym, size=size, p=p)].tobytes()
+        if case % 4 == 1 and size >= 100:  # periodic data: previous-record matches
+            data = (data[:37] * (size // 37 + 1))[:size]
+        dist = int(rng.choice([0, 0, 5, 37, 300, 4000, 32768]))
+        scale = int(rng.choice([1, 1, 1000, 1_000_000]))  # the same statistics at a long batch's counts
+        toks = _tokens(data, dist)
+        hist = np.bincount(np.array([t[0] for t in toks] + [256], dtype=np.int64), minlength=263) * scale
+        hist = np.minimum(hist, 2**32 - 2).astype(np.uint32)
+        block, lens = _deflate_block(native, data, hist=hist, dist=dist)
+        assert zlib.decompressobj(-15).decompress(block) == data, case
