@@ -868,3 +868,29 @@ def test_device_gzip_record_distances(model, id_len, tmp_path):
     for plain, packed in zip(out[False], out[True]):
         assert gzip.decompress(packed) == plain
         assert len(packed) < 0.45 * len(plain)
+
+
+@pytest.mark.parametrize("k", range(10))
+def test_device_gzip_randomized(k, tmp_path, monkeypatch):
+    """Random work lists, batch sizes, record ids and models through the compressed path: gunzip == the text path."""
+    import gzip
+
+    from insilicoseq_amd import generator as G
+
+    r = np.random.RandomState(900 + k)
+    dense = dense_model(str(r.choice(["novaseq", "hiseq", "miseq-36", "ecoli"])))
+    monkeypatch.setattr(G.Worker, "BATCH_PAIRS", int(r.choice([7, 100, 999, 5000])))
+    recs, work = [], []
+    for i in range(int(r.randint(1, 5))):
+        rid = "".join(chr(int(c)) for c in r.choice(list(range(48, 58)) + list(range(65, 91)) + [46, 95, 124], size=int(r.randint(1, 40))))
+        gen = (mixed_genome if r.rand() < 0.3 else random_genome)(60 + 7 * k + i, int(r.choice([400, 5000, 40000])))
+        recs.append(G.Record(gen, id=rid))
+        work.append((recs[-1], int(r.choice([0, 1, 8, 9, 10, 99, 100, 1001, 12000])), "default"))
+    out = {}
+    for compress in (False, True):
+        prefix = str(tmp_path / ("r%d" % compress))
+        G.worker_iterator(work, dense, 5, prefix, 17 + k, "metagenomics", False, device=0,
+                          compress=compress)
+        out[compress] = [open(prefix + s, "rb").read() for s in ("_R1.fastq", "_R2.fastq")]
+    for plain, packed in zip(out[False], out[True]):
+        assert gzip.decompress(packed) == plain
