@@ -107,7 +107,49 @@ def exponential(record_list):
     return {r: a for r, a in zip(record_list, scaled)}
 
 
-ABUNDANCE = {"lognormal": lognormal, "uniform": uniform, "exponential": exponential}
+def halfnormal(record_list):
+    """iss/abundance.py:97-114: scipy's half-normal variates (drawn from numpy's global stream, like the reference's)."""
+    from scipy import stats
+
+    dist = stats.halfnorm.rvs(loc=0.00, scale=1.00, size=len(record_list))
+    scaled = dist / sum(dist)
+    return {r: a for r, a in zip(record_list, scaled)}
+
+
+def zero_inflated_lognormal(record_list):
+    """iss/abundance.py:157-175: a fifth of the records (Bernoulli 0.2) get no reads at all."""
+    from scipy import stats
+
+    zero_inflated = stats.bernoulli.rvs(p=0.2, size=len(record_list))
+    dist = (1 - zero_inflated) * np.random.lognormal(size=len(record_list))
+    scaled = dist / sum(dist)
+    return {r: a for r, a in zip(record_list, scaled)}
+
+
+ABUNDANCE = {"lognormal": lognormal, "uniform": uniform, "exponential": exponential, "halfnormal": halfnormal,
+             "zero_inflated_lognormal": zero_inflated_lognormal}
+
+
+def coverage_scaling(total_n_reads, coverage_dic, records, read_length):
+    """iss/abundance.py:196-228: scale a coverage distribution so that it adds up to the requested number of reads."""
+    logger = logging.getLogger(__name__)
+    total_reads = 0
+    for record in records:
+        if record.id not in coverage_dic:
+            logger.error("Fasta record not found in abundance file: %r" % record.id)
+            sys.exit(1)
+        total_reads += coverage_dic[record.id] * len(record.seq) / read_length / 2
+    scale_factor = total_n_reads / total_reads
+    for key in coverage_dic:
+        coverage_dic[key] *= scale_factor
+    return coverage_dic
+
+
+def _write_distribution(dic, output, mode):
+    """abundance.to_file (iss/abundance.py:231-251): <out>_abundance.txt or <out>_coverage.txt"""
+    with open(output + ("_abundance.txt" if mode == "abundance" else "_coverage.txt"), "w") as fh:
+        for rid, a in dic.items():
+            fh.write("%s\t%s\n" % (rid, a))
 
 
 def compress_file(path, block_bytes=32 << 20, threads=None):
@@ -173,19 +215,27 @@ def generate_reads(args):
         logger.error("Genome(s) file seems empty: %s" % genome_file)
         sys.exit(1)
     ids = [r.id for r in records]
+    # load_readcount_or_abundance (iss/generator.py:497-594), in the reference's order of precedence
     readcount_dic = abundance_dic = None
     if args.readcount_file:
+        logger.warning("--readcount_file disables --n_reads, n_reads will be calculated from the readcount file")
         readcount_dic = parse_readcount_file(args.readcount_file)
         n_reads = sum(readcount_dic.values())
     else:
         n_reads = convert_n_reads(args.n_reads)
         if args.abundance_file:
             abundance_dic = parse_abundance_file(args.abundance_file)
+        elif args.coverage_file:  # coverages instead of shares: the reads per record no longer depend on --n_reads
+            logger.warning("--coverage_file disables --n_reads")
+            abundance_dic = parse_abundance_file(args.coverage_file)
+        elif args.coverage in ABUNDANCE:
+            abundance_dic = ABUNDANCE[args.coverage](ids)
+            if args.n_reads:
+                abundance_dic = coverage_scaling(n_reads, abundance_dic, records, error_model.read_length)
+            _write_distribution(abundance_dic, args.output, "coverage")
         elif args.abundance in ABUNDANCE:
             abundance_dic = ABUNDANCE[args.abundance](ids)
-            with open(args.output + "_abundance.txt", "w") as fh:  # abundance.to_file, abundance.py:231-251
-                for rid, a in abundance_dic.items():
-                    fh.write("%s\t%s\n" % (rid, a))
+            _write_distribution(abundance_dic, args.output, "abundance")
         else:
             logger.error("Could not get abundance, or coverage or readcount information")
             sys.exit(1)
@@ -195,8 +245,8 @@ def generate_reads(args):
     device_gzip = bool(args.compress) and os.environ.get("ISS_HOST_FASTQ", "") != "1"
     gz = {"_R1.fastq": "_R1.fastq.gz", "_R2.fastq": "_R2.fastq.gz"} if device_gzip else None
     chunk_size = -((n_reads // 2) // -workers)  # ceildiv, app.py:82
-    chunks = list(generate_work_divider(records, readcount_dic, abundance_dic, n_reads, None, None, error_model,
-                                        args.output, chunk_size))
+    chunks = list(generate_work_divider(records, readcount_dic, abundance_dic, n_reads, args.coverage, args.coverage_file,
+                                        error_model, args.output, chunk_size))
     jobs = []
     for rank, chunk in enumerate(chunks[:workers]):  # zip(work_chunks, temp_file_list), app.py:104
         spec = [(rec.id, n) for rec, n, _ in chunk]
@@ -234,6 +284,8 @@ def main(argv=None):
     g.add_argument("--devices", type=int, default=0, help="visible GPUs (default: one per worker)")
     g.add_argument("--abundance", "-a", default="lognormal", choices=sorted(ABUNDANCE))
     g.add_argument("--abundance_file", "-b")
+    g.add_argument("--coverage", "-C", default=None, choices=sorted(ABUNDANCE))
+    g.add_argument("--coverage_file", "-D")
     g.add_argument("--readcount_file", "-R")
     g.add_argument("--gc_bias", "-c", action="store_true")
     g.add_argument("--sequence_type", "-t", default="metagenomics", choices=["metagenomics", "amplicon"])

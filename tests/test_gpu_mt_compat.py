@@ -127,6 +127,32 @@ def test_generate_cli_compress_equals_reference(cpus, tmp_path):
     assert left == ["run.vcf.gz", "run_R1.fastq.gz", "run_R2.fastq.gz", "run_abundance.txt"], left
 
 
+@pytest.mark.parametrize("case", ["halfnormal", "zero_inflated_lognormal", "exponential", "uniform", "coverage_lognormal",
+                                  "coverage_halfnormal", "abundance_file", "coverage_file", "readcount_file"])
+def test_generate_cli_abundance_inputs_equal_reference(case, tmp_path):
+    """The abundance / coverage / read-count inputs of `iss generate` (iss/generator.py:497-594): the distribution file
+    the run writes and the FASTQ files equal the reference's (`--cpus 2`, goldens of make_golden_cli.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(GOLDEN, "generate", "cli_%s.npz" % case))
+    flags = str(z["flags"]).split()
+    given = str(tmp_path / "given.txt")
+    with open(given, "wb") as fh:
+        fh.write(z["given"].tobytes())
+    flags = [given if f.startswith("@") else f for f in flags]
+    out = str(tmp_path / "run")
+    subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes",
+                           os.path.join(GOLDEN, "genomes.fasta"), "--model", "hiseq", "--seed", "42", "--cpus", "2",
+                           "--devices", "1", "--rng", "mt", "-o", out, "--quiet"] + flags, cwd=root)
+    assert open(out + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(out + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+    assert os.path.exists(out + "_abundance.txt") == bool(z["has_abundance"])
+    assert os.path.exists(out + "_coverage.txt") == bool(z["has_coverage"])
+    if z["has_abundance"]:
+        assert open(out + "_abundance.txt", "rb").read() == z["abundance"].tobytes()
+    if z["has_coverage"]:
+        assert open(out + "_coverage.txt", "rb").read() == z["coverage"].tobytes()
+
+
 def test_mt_mode_large_equals_oracle(engine):
     """20k pairs (several stream refills) against the CPU oracle in MT mode, plus the stream positions."""
     from helpers import random_genome

@@ -330,3 +330,30 @@ def test_deflate_code_builder_randomized(native):
         hist = np.minimum(hist, 2**32 - 2).astype(np.uint32)
         block, lens = _deflate_block(native, data, hist=hist, dist=dist)
         assert zlib.decompressobj(-15).decompress(block) == data, case
+
+
+@pytest.mark.parametrize("case", ["halfnormal", "zero_inflated_lognormal", "exponential", "uniform", "coverage_lognormal",
+                                  "coverage_halfnormal"])
+def test_abundance_distributions_match_reference(case, tmp_path):
+    """The abundance / coverage distributions of the CLI (iss/abundance.py:80-175, 196-228) drawn after the reference's
+    seeding (generator.py:397-400): the file the reference's `iss generate --seed 42` wrote, byte for byte."""
+    import random
+
+    from insilicoseq_amd import app
+    from insilicoseq_amd.generator import parse_fasta
+
+    z = np.load(os.path.join(GOLDEN, "generate", "cli_%s.npz" % case))
+    flags = str(z["flags"]).split()
+    records = list(parse_fasta(os.path.join(GOLDEN, "genomes.fasta")))
+    ids = [r.id for r in records]
+    random.seed(42)
+    np.random.seed(42)
+    out = str(tmp_path / "o")
+    if flags[0] == "--abundance":
+        dic = app.ABUNDANCE[flags[1]](ids)
+        app._write_distribution(dic, out, "abundance")
+        assert open(out + "_abundance.txt", "rb").read() == z["abundance"].tobytes()
+    else:
+        dic = app.coverage_scaling(int(flags[3]), app.ABUNDANCE[flags[1]](ids), records, dense_model("hiseq").read_length)
+        app._write_distribution(dic, out, "coverage")
+        assert open(out + "_coverage.txt", "rb").read() == z["coverage"].tobytes()
