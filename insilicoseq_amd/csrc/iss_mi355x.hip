@@ -36,7 +36,45 @@ struct Genome {
     uint8_t *ascii = nullptr;
     int64_t L = 0;
     bool has_exceptions = false;
+    bool in_arena = false;  // small record: its three buffers are slices of a GenomeArena slab
 };
+
+// Records of a long work list (draft genomes: thousands of contigs) are small: their buffers are cut from slabs
+// instead of three hipMallocs each, and their letters are checked on the host instead of waiting for the pack kernel.
+constexpr int64_t SMALL_RECORD = 1 << 20;
+constexpr size_t ARENA_SLAB = 64u << 20;
+struct GenomeArena {
+    std::vector<uint8_t *> slabs;
+    size_t used = ARENA_SLAB;  // of the last slab
+    uint8_t *take(size_t bytes, hipError_t *err) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (used + bytes > ARENA_SLAB) {
+            void *p = nullptr;
+            *err = hipMalloc(&p, ARENA_SLAB);
+            if (*err != hipSuccess) return nullptr;
+            slabs.push_back(static_cast<uint8_t *>(p));
+            used = 0;
+        }
+        uint8_t *r = slabs.back() + used;
+        used += bytes;
+        return r;
+    }
+    void clear() {
+        for (auto *p : slabs) (void)hipFree(p);
+        slabs.clear();
+        used = ARENA_SLAB;
+    }
+};
+
+// 0: outside util.rev_comp's alphabet (iss/util.py:57-88), 1: plain A/C/G/T, 2: IUPAC or lower case (an "exception")
+inline int letter_class(uint8_t c) {
+    if (c == 'A' || c == 'T' || c == 'C' || c == 'G') return 1;
+    const bool letter = (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+    const uint8_t u = c & ~0x20u;
+    const bool ok = letter && (u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'Y' || u == 'R' || u == 'W' || u == 'S' ||
+                               u == 'K' || u == 'M' || u == 'N' || u == 'B' || u == 'V' || u == 'D' || u == 'H');
+    return ok ? 2 : 0;
+}
 
 struct TimedLaunch {
     // main stream: ev0 setup ev1 main ev2;  indel stream: ev3 scan ev4 ... ev5 fixup ev6
@@ -108,6 +146,7 @@ struct iss_ctx {
     hipStream_t indel_stream = nullptr;  // indel scan + fix-up of a chunk run beside the next chunk's main kernel
     bool overlap = false;  // ISS_OVERLAP=1: run the indel passes beside the next chunk (measured: no gain, k_main is VALU-bound)
     std::vector<PendingIndel> pending;
+    GenomeArena arena;
     uint64_t chunk_seq = 0;
     std::string last_error;
     // model
@@ -484,14 +523,19 @@ void fastq_writer_loop(iss_ctx *ctx) {
                 }
             }
         } else if (err.empty()) {
-            // both files in parallel, each cut into pieces written with pwrite at their final offsets
+            // both files in parallel, each cut into pieces written with pwrite at their final offsets (a small job --
+            // one record of a long work list -- is written by this thread: spawning threads would cost more)
+            const bool small_job = job.bytes <= (1u << 20);
+            for (int mate = 0; small_job && mate < 2 && err.empty(); ++mate)
+                if (pwrite_all(job.fd[mate], q.h_text[job.slot][mate], job.bytes, job.off[mate]))
+                    err = std::string("write failed: ") + strerror(errno);
             const size_t piece = std::max<size_t>((job.bytes + (size_t)job.threads - 1) / (size_t)job.threads, 1 << 20);
             std::vector<std::thread> th;
             std::vector<int> rc;
-            for (int mate = 0; mate < 2; ++mate)
+            for (int mate = 0; mate < 2 && !small_job; ++mate)
                 for (size_t at = 0; at < job.bytes; at += piece) rc.push_back(0);
             size_t k = 0;
-            for (int mate = 0; mate < 2; ++mate)
+            for (int mate = 0; mate < 2 && !small_job; ++mate)
                 for (size_t at = 0; at < job.bytes; at += piece, ++k) {
                     const size_t n = std::min(piece, job.bytes - at);
                     const uint8_t *src = q.h_text[job.slot][mate] + at;
@@ -980,35 +1024,66 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     const size_t n_mk = (size_t)(length + 31) / 32, n_pk = 2 * n_mk;
     Genome G;
     G.L = length;
-    void *p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, (n_pk + 4) * sizeof(uint32_t)));
-    G.packed_alloc = static_cast<uint32_t *>(p);
-    HIP_TRY(ctx, hipMalloc(&p, (n_mk + 4) * sizeof(uint32_t)));
-    G.mask_alloc = static_cast<uint32_t *>(p);
-    HIP_TRY(ctx, hipMalloc(&p, (size_t)length));
-    G.ascii = static_cast<uint8_t *>(p);
-    auto release = [&]() { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); };
     unsigned long long *status = reinterpret_cast<unsigned long long *>(ctx->fix_count) + 24;  // 3 words at +192 B
-    const unsigned long long init[3] = {0ull, (unsigned long long)length, 0ull};
-    hipError_t he = hipMemcpyAsync(G.ascii, ascii, (size_t)length, hipMemcpyHostToDevice, ctx->stream);
-    if (he == hipSuccess) he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + 4) * sizeof(uint32_t), ctx->stream);
-    if (he == hipSuccess) he = hipMemsetAsync(G.mask_alloc, 0, (n_mk + 4) * sizeof(uint32_t), ctx->stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(status, init, sizeof init, hipMemcpyHostToDevice, ctx->stream);
-    if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he)); }
-    hipLaunchKernelGGL(iss::k_pack_genome, dim3((unsigned)((n_mk + 255) / 256)), dim3(256), 0, ctx->stream, G.ascii, length,
-                       G.packed_alloc + 1, G.mask_alloc + 1, status);
-    unsigned long long res[3] = {0, 0, 0};
-    he = hipMemcpyAsync(res, status, sizeof res, hipMemcpyDeviceToHost, ctx->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-    if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome pack: ") + hipGetErrorString(he)); }
-    if (res[0]) {
-        release();
-        char buf[200];
-        snprintf(buf, sizeof buf, "genome letter 0x%02x at offset %llu is outside the rev_comp alphabet (%llu such letters; "
-                 "the reference raises KeyError, iss/util.py:90)", ascii[res[1]], res[1], res[0]);
-        return fail(ctx, ISS_E_INVALID, buf);
+    if (length <= SMALL_RECORD) {
+        // small record: letters checked here (no wait for the device), buffers cut from the arena
+        bool exceptions = false;
+        for (int64_t i = 0; i < length; ++i) {
+            const int cls = letter_class(ascii[i]);
+            if (cls == 0) {
+                int64_t bad = 0;
+                for (int64_t j = i; j < length; ++j) bad += letter_class(ascii[j]) == 0;
+                char buf[200];
+                snprintf(buf, sizeof buf, "genome letter 0x%02x at offset %llu is outside the rev_comp alphabet (%llu such letters; "
+                         "the reference raises KeyError, iss/util.py:90)", ascii[i], (unsigned long long)i, (unsigned long long)bad);
+                return fail(ctx, ISS_E_INVALID, buf);
+            }
+            exceptions |= cls == 2;
+        }
+        hipError_t he = hipSuccess;
+        uint8_t *blk = ctx->arena.take((n_pk + 4) * 4 + 256 + (n_mk + 4) * 4 + 256 + (size_t)length, &he);
+        if (!blk) return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he));
+        const size_t pk_bytes = ((n_pk + 4) * 4 + 255) & ~(size_t)255, mk_bytes = ((n_mk + 4) * 4 + 255) & ~(size_t)255;
+        G.packed_alloc = reinterpret_cast<uint32_t *>(blk);
+        G.mask_alloc = reinterpret_cast<uint32_t *>(blk + pk_bytes);
+        G.ascii = blk + pk_bytes + mk_bytes;
+        G.in_arena = true;
+        he = hipMemcpyAsync(G.ascii, ascii, (size_t)length, hipMemcpyHostToDevice, ctx->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(blk, 0, pk_bytes + mk_bytes, ctx->stream);
+        if (he != hipSuccess) return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he));
+        hipLaunchKernelGGL(iss::k_pack_genome, dim3((unsigned)((n_mk + 255) / 256)), dim3(256), 0, ctx->stream, G.ascii, length,
+                           G.packed_alloc + 1, G.mask_alloc + 1, status);
+        G.has_exceptions = exceptions;
+    } else {
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, (n_pk + 4) * sizeof(uint32_t)));
+        G.packed_alloc = static_cast<uint32_t *>(p);
+        HIP_TRY(ctx, hipMalloc(&p, (n_mk + 4) * sizeof(uint32_t)));
+        G.mask_alloc = static_cast<uint32_t *>(p);
+        HIP_TRY(ctx, hipMalloc(&p, (size_t)length));
+        G.ascii = static_cast<uint8_t *>(p);
+        auto release = [&]() { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); };
+        const unsigned long long init[3] = {0ull, (unsigned long long)length, 0ull};
+        hipError_t he = hipMemcpyAsync(G.ascii, ascii, (size_t)length, hipMemcpyHostToDevice, ctx->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + 4) * sizeof(uint32_t), ctx->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(G.mask_alloc, 0, (n_mk + 4) * sizeof(uint32_t), ctx->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(status, init, sizeof init, hipMemcpyHostToDevice, ctx->stream);
+        if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he)); }
+        hipLaunchKernelGGL(iss::k_pack_genome, dim3((unsigned)((n_mk + 255) / 256)), dim3(256), 0, ctx->stream, G.ascii, length,
+                           G.packed_alloc + 1, G.mask_alloc + 1, status);
+        unsigned long long res[3] = {0, 0, 0};
+        he = hipMemcpyAsync(res, status, sizeof res, hipMemcpyDeviceToHost, ctx->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+        if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome pack: ") + hipGetErrorString(he)); }
+        if (res[0]) {
+            release();
+            char buf[200];
+            snprintf(buf, sizeof buf, "genome letter 0x%02x at offset %llu is outside the rev_comp alphabet (%llu such letters; "
+                     "the reference raises KeyError, iss/util.py:90)", ascii[res[1]], res[1], res[0]);
+            return fail(ctx, ISS_E_INVALID, buf);
+        }
+        G.has_exceptions = res[2] != 0;
     }
-    G.has_exceptions = res[2] != 0;
     G.packed = G.packed_alloc + 1;
     G.mask = G.mask_alloc + 1;
     ctx->genomes.push_back(G);
@@ -1019,8 +1094,10 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
 int iss_genome_clear(iss_ctx *ctx) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
     (void)sync_all(ctx);
-    for (auto &G : ctx->genomes) { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); }
+    for (auto &G : ctx->genomes)
+        if (!G.in_arena) { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); }
     ctx->genomes.clear();
+    ctx->arena.clear();
     return 0;
 }
 
