@@ -894,3 +894,27 @@ def test_device_gzip_randomized(k, tmp_path, monkeypatch):
         out[compress] = [open(prefix + s, "rb").read() for s in ("_R1.fastq", "_R2.fastq")]
     for plain, packed in zip(out[False], out[True]):
         assert gzip.decompress(packed) == plain
+
+
+@pytest.mark.parametrize("length", [3000, (1 << 20) + 4096])
+def test_letters_outside_the_rev_comp_alphabet_are_rejected(length):
+    """util.rev_comp raises KeyError on such letters (iss/util.py:90); the upload refuses the record -- small records
+    are checked on the host, large ones by the pack kernel -- and names the first offender."""
+    from insilicoseq_amd import _native
+    from insilicoseq_amd.engine import ReadEngine
+
+    eng = ReadEngine(0)
+    try:
+        eng.load_model(dense_model("ecoli"))
+        g = bytearray(random_genome(3, length).encode())
+        ok = eng.add_genome(bytes(g))
+        assert eng.genome_length(ok) == length
+        g[length - 17] = ord("x")
+        g[length // 2] = ord("-")
+        with pytest.raises(_native.EngineError) as exc:
+            eng.add_genome(bytes(g))
+        assert "0x2d at offset %d" % (length // 2) in str(exc.value) and "2 such letters" in str(exc.value)
+        g[length - 17], g[length // 2] = ord("n"), ord("y")  # IUPAC / lower case are fine
+        eng.add_genome(bytes(g))
+    finally:
+        eng.close()
