@@ -248,6 +248,11 @@ def end_to_end(dense, records, abundance, n_pairs, compress=False):
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     d = tempfile.mkdtemp(dir=base)
     try:
+        # keep well inside the free space of the file system (2 files x ~330 B per pair as text)
+        need = 2 * 340 * n_pairs * (0.4 if compress else 1.0)
+        free = shutil.disk_usage(d).free
+        if need > 0.5 * free:
+            n_pairs = max(1000, int(n_pairs * 0.5 * free / need))
         work = [(r, int(n_pairs * abundance[r.id]), "default") for r in records]
         prefix = os.path.join(d, "w")
         worker_iterator([(records[0], 1000, "default")], dense, 0, prefix, SEED, "metagenomics", False, device=0,
