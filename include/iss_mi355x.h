@@ -216,13 +216,13 @@ int iss_fastq_flush(iss_ctx *ctx);
 int iss_fastq_compress(iss_ctx *ctx, int32_t mode);
 
 /*
- * The code builder of the compressed mode as a host function (tests, tools): hist[263] token counts (literals
- * 0..255, [256] the number of blocks, [257..262] matches of length 3..8) and the batch's record length (the
- * distance of the "previous record" matches; 0: only runs, distance 1) -> entry[s] = bit-reversed code | length << 16
- * for the 263 symbols, the dynamic-block header (BFINAL = 0 ... both code-length tables) as hdr_bits bits, least
- * significant first, in hdr_words[64], and dist_code[3] = {distance symbol, extra bits, their value} of the record
- * length: a run's length code is followed by the bit 0, a previous-record match's by the bit 1 and the extra bits.
- * No GPU needed.
+ * The code builder of the compressed mode as a host function (tests, tools): hist[273] token counts (literals
+ * 0..255, [256] the number of blocks, [257..272] the length codes of matches of 3..32 bytes) and the batch's record
+ * length (the distance of the "previous record" matches; 0: only runs, distance 1) -> entry[s] = bit-reversed code |
+ * length << 16 for the 273 symbols, the dynamic-block header (BFINAL = 0 ... both code-length tables) as hdr_bits
+ * bits, least significant first, in hdr_words[64], and dist_code[3] = {distance symbol, extra bits, their value} of
+ * the record length: a run's length code (+ its extra bits) is followed by the bit 0, a previous-record match's by the
+ * bit 1 and the distance's extra bits.  No GPU needed.
  */
 int iss_deflate_code_build(const uint32_t *hist, uint32_t record_distance, uint32_t *entry, uint32_t *hdr_bits,
                            uint32_t *hdr_words, uint32_t *dist_code);

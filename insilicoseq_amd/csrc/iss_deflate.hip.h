@@ -4,8 +4,8 @@
 // text is the bottleneck twice over (PCIe, then the file system), so with compression on the text never leaves the
 // device: every batch of FASTQ text becomes one gzip member made of DEFLATE blocks with a dynamic Huffman code whose
 // only matches are runs (distance 1) and copies of the previous record (distance = the batch's record length), both
-// found inside 8-byte chunks, so there is no search and no dependency between lanes.  FASTQ is bases (2 bits of
-// entropy), phreds (runs of the top quality) and headers; this reaches 3.7x on NovaSeq text (zlib level 1: 3.9x,
+// found inside 32-byte chunks, so there is no search and no dependency between lanes.  FASTQ is bases (2 bits of
+// entropy), phreds (runs of the top quality) and headers; this reaches 4.0x on NovaSeq text (zlib level 1: 3.9x,
 // level 6: 5x).  The decompressed bytes are exactly the text k_fastq_format wrote (the compressed bytes
 // differ from the reference's, like any two gzip implementations' do).
 //
@@ -21,7 +21,9 @@
 
 namespace iss {
 
-constexpr int DEFLATE_SYMS = 263;      // literals 0..255, end of block, lengths 3..8 (codes 257..262, no extra bits)
+constexpr int DEFLATE_SYMS = 273;      // literals 0..255, end of block, lengths 3..32 (codes 257..272)
+constexpr int DEFLATE_CHUNK = 32;      // bytes of text a lane tokenizes on its own
+constexpr int DEFLATE_NQ = DEFLATE_CHUNK / 8;
 constexpr int DEFLATE_BLOCK = 32768;   // text bytes per DEFLATE block
 constexpr int DEFLATE_HDR_WORDS = 64;  // room for the dynamic-block header (<= 3 + 14 + 57 + 258 * 7 + ... bits)
 constexpr int DEFLATE_THREADS = 256;
@@ -311,13 +313,23 @@ inline void crc_shift_operator(uint64_t n_bytes, uint32_t *op) {
 }
 
 // ---------------------------------------------------------------- tokens
-// The text is cut into 8-byte chunks (aligned to the text's start; blocks are multiples of 8).  Inside a chunk, at
+// The text is cut into 32-byte chunks (aligned to the text's start; blocks are multiples of 32).  Inside a chunk, at
 // every position two matches are tried: the run (the byte repeats its predecessor: distance 1) and the previous
 // record (the same bytes `dist` earlier -- a batch's records have one length but for the digits of the pair number,
 // so the constant parts of the header line, "+" and most of a top-quality phred line are found there); the longer
-// one wins if it has >= 3 (run) / >= 4 (previous record) bytes (lengths 3..8: codes 257..262), otherwise the byte is a literal.  The predecessor of a
-// chunk's first byte and the bytes `dist` earlier may belong to the previous block: DEFLATE's window does not care.
-// f(symbol, kind) is called per token: kind 0 literal, 1 run, 2 previous record.
+// one wins if it has >= 3 (run) / >= 4 (previous record) bytes (lengths 3..32: codes 257..272, RFC 1951 3.2.5),
+// otherwise the byte is a literal.  The predecessor of a chunk's first byte and the bytes `dist` earlier may belong to
+// the previous block: DEFLATE's window does not care.  Match lengths come from byte-difference masks and a count of
+// trailing zeros, so a chunk costs the same whatever it holds.
+// f(symbol, kind, extra bits of the length code, their value) is called per token: kind 0 literal, 1 run, 2 previous record.
+struct DeflateChunk {
+    uint64_t raw[DEFLATE_NQ];  // the bytes, little endian
+    uint64_t src[DEFLATE_NQ];  // the bytes `dist` earlier (has_src)
+    uint32_t m;                // bytes in the chunk (< DEFLATE_CHUNK only at the end of the text)
+    int prev;                  // the byte before the chunk, -1: none
+    bool has_src;
+};
+
 // bit k of the result <=> byte k of v is not zero
 __host__ __device__ inline uint32_t deflate_nonzero_bytes(uint64_t v) {
     const uint64_t low7 = 0x7f7f7f7f7f7f7f7full;
@@ -325,21 +337,35 @@ __host__ __device__ inline uint32_t deflate_nonzero_bytes(uint64_t v) {
     return (uint32_t)((top * 0x0002040810204081ull) >> 56);   // the eight bits 7, 15, ... 63 gathered
 }
 
+__host__ __device__ inline void deflate_length_code(uint32_t len, uint32_t *sym, uint32_t *xbits, uint32_t *xval) {
+    if (len <= 10u) { *sym = 254u + len; *xbits = 0; *xval = 0; return; }
+    const uint32_t k = len - 11u;
+    if (k < 8u) { *sym = 265u + (k >> 1); *xbits = 1; *xval = k & 1u; return; }    // 11 .. 18
+    *sym = 269u + ((k - 8u) >> 2); *xbits = 2; *xval = (k - 8u) & 3u;              // 19 .. 34 (here <= 32)
+}
+
 template <typename F>
-__host__ __device__ inline void deflate_tokens(uint64_t raw, uint32_t m, int prev, uint64_t src, bool has_src, F &&f) {
+__host__ __device__ inline void deflate_tokens(const DeflateChunk &C, F &&f) {
     // differs[k]: byte k differs from the byte before it (run) / from the byte `dist` earlier (previous record);
     // a stop bit at position m ends every match at the chunk's end
-    const uint64_t before = (raw << 8) | (uint64_t)(prev & 0xff);
-    uint32_t diff_run = deflate_nonzero_bytes(raw ^ before) | (prev < 0 ? 1u : 0u) | (1u << m);
-    uint32_t diff_rec = (has_src ? deflate_nonzero_bytes(raw ^ src) : 0xffu) | (1u << m);
+    uint64_t diff_run = 0, diff_rec = 0;
+    for (int q = 0; q < DEFLATE_NQ; ++q) {
+        const uint64_t before = (C.raw[q] << 8) | (q ? C.raw[q - 1] >> 56 : (uint64_t)(C.prev & 0xff));
+        diff_run |= (uint64_t)deflate_nonzero_bytes(C.raw[q] ^ before) << (8 * q);
+        diff_rec |= (uint64_t)(C.has_src ? deflate_nonzero_bytes(C.raw[q] ^ C.src[q]) : 0xffu) << (8 * q);
+    }
+    if (C.prev < 0) diff_run |= 1u;
+    diff_run |= 1ull << C.m;
+    diff_rec |= 1ull << C.m;
     uint32_t i = 0;
-    while (i < m) {
-        const uint32_t r1 = (uint32_t)__builtin_ctz(diff_run >> i), rd = (uint32_t)__builtin_ctz(diff_rec >> i);
-        uint32_t step = 1, sym = (uint32_t)((raw >> (8 * i)) & 0xffu);
+    while (i < C.m) {
+        const uint32_t r1 = (uint32_t)__builtin_ctzll(diff_run >> i), rd = (uint32_t)__builtin_ctzll(diff_rec >> i);
+        uint32_t step = 1, sym = (uint32_t)((C.raw[i >> 3] >> (8 * (i & 7u))) & 0xffu), xbits = 0, xval = 0;
         int kind = 0;
-        if (r1 >= 3u && r1 >= rd) { step = r1; sym = 254u + r1; kind = 1; }  // (a run is the cheaper match)
-        else if (rd >= 4u) { step = rd; sym = 254u + rd; kind = 2; }         // (its distance costs 8-14 bits: three bytes are not worth it)
-        f(sym, kind);
+        if (r1 >= 3u && r1 >= rd) { step = r1; kind = 1; }   // (a run is the cheaper match)
+        else if (rd >= 4u) { step = rd; kind = 2; }          // (its distance costs 8-14 bits: three bytes are not worth it)
+        if (kind) deflate_length_code(step, &sym, &xbits, &xval);
+        f(sym, kind, xbits, xval);
         i += step;
     }
 }
@@ -388,19 +414,23 @@ __device__ __forceinline__ uint64_t deflate_source(const uint8_t *t, uint64_t at
     return (lo >> sh) | (hi << (64u - sh));
 }
 
-// chunk `c` of the text: its bytes (little endian), how many there are, the byte before it (-1: none) and the bytes
-// `dist` earlier
-__device__ __forceinline__ uint64_t deflate_chunk(const uint8_t *t, uint64_t n_bytes, uint64_t c, uint32_t dist, uint32_t &m,
-                                                  int &prev, uint64_t &src, bool &has_src) {
-    const uint64_t at = c * 8u;
-    m = (uint32_t)min((uint64_t)8, n_bytes - at);
-    prev = at ? (int)t[at - 1] : -1;
-    has_src = dist && at >= dist;
-    src = has_src ? deflate_source(t, at, dist) : 0;
-    if (m == 8u) return *reinterpret_cast<const uint64_t *>(t + at);  // (the text buffer is 8-byte aligned)
-    uint64_t raw = 0;
-    for (uint32_t k = 0; k < m; ++k) raw |= (uint64_t)t[at + k] << (8 * k);
-    return raw;
+// chunk `c` of the text
+__device__ __forceinline__ void deflate_chunk(const uint8_t *t, uint64_t n_bytes, uint64_t c, uint32_t dist, DeflateChunk &C) {
+    const uint64_t at = c * DEFLATE_CHUNK;
+    C.m = (uint32_t)min((uint64_t)DEFLATE_CHUNK, n_bytes - at);
+    C.prev = at ? (int)t[at - 1] : -1;
+    C.has_src = dist && at >= dist;
+    for (int q = 0; q < DEFLATE_NQ; ++q) C.src[q] = C.has_src ? deflate_source(t, at + 8u * q, dist) : 0;
+    if (C.m == (uint32_t)DEFLATE_CHUNK) {  // (the text buffer is 16-byte aligned)
+        for (int q = 0; q < DEFLATE_NQ; q += 2) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(t + at + 8 * q);
+            C.raw[q] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            C.raw[q + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        }
+    } else {
+        for (int q = 0; q < DEFLATE_NQ; ++q) C.raw[q] = 0;
+        for (uint32_t k = 0; k < C.m; ++k) C.raw[k >> 3] |= (uint64_t)t[at + k] << (8 * (k & 7u));
+    }
 }
 
 __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_hist(DeflateArgs A) {
@@ -409,14 +439,11 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_hist(DeflateArgs A)
     for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS) h[s] = 0;
     __syncthreads();
     const uint8_t *t = A.text[mate];
-    const uint64_t n_chunks = (A.n_bytes + 7) / 8;
+    const uint64_t n_chunks = (A.n_bytes + DEFLATE_CHUNK - 1) / DEFLATE_CHUNK;
     for (uint64_t c = (uint64_t)blockIdx.x * DEFLATE_THREADS + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * DEFLATE_THREADS) {
-        uint32_t m;
-        int prev;
-        uint64_t src;
-        bool has_src;
-        const uint64_t raw = deflate_chunk(t, A.n_bytes, c, A.dist, m, prev, src, has_src);
-        deflate_tokens(raw, m, prev, src, has_src, [&](uint32_t sym, int) { atomicAdd(&h[sym], 1u); });
+        DeflateChunk C;
+        deflate_chunk(t, A.n_bytes, c, A.dist, C);
+        deflate_tokens(C, [&](uint32_t sym, int, uint32_t, uint32_t) { atomicAdd(&h[sym], 1u); });
     }
     __syncthreads();
     for (int s = threadIdx.x; s < DEFLATE_SYMS; s += DEFLATE_THREADS)
@@ -477,14 +504,16 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) 
         }
         __syncthreads();
         const int before = start ? (int)t[-1] : -1;
-        for (uint32_t c = threadIdx.x; c < (uint32_t)DEFLATE_BLOCK / 8u; c += DEFLATE_THREADS) {
-            const uint32_t w = (c >> 4) * 33u + (c & 15u) * 2u;
-            const uint64_t raw = (uint64_t)stage[w] | ((uint64_t)stage[w + 1] << 32);
-            const int prev = c ? (int)(stage[(c & 15u) ? w - 1 : w - 2] >> 24) : before;
-            const uint64_t at = start + (uint64_t)c * 8u;
-            const bool has_src = A.dist && at >= A.dist;
-            const uint64_t src = has_src ? deflate_source(A.text[mate], at, A.dist) : 0;
-            deflate_tokens(raw, 8u, prev, src, has_src, [&](uint32_t sym, int kind) { bits += lens[sym] + kind_bits[kind]; });
+        for (uint32_t c = threadIdx.x; c < (uint32_t)(DEFLATE_BLOCK / DEFLATE_CHUNK); c += DEFLATE_THREADS) {
+            const uint32_t w = (c >> 2) * 33u + (c & 3u) * 8u;  // four chunks per 128-byte piece
+            DeflateChunk C;
+            for (int q = 0; q < DEFLATE_NQ; ++q) C.raw[q] = (uint64_t)stage[w + 2 * q] | ((uint64_t)stage[w + 2 * q + 1] << 32);
+            C.m = DEFLATE_CHUNK;
+            C.prev = c ? (int)(stage[(c & 3u) ? w - 1 : w - 2] >> 24) : before;
+            const uint64_t at = start + (uint64_t)c * DEFLATE_CHUNK;
+            C.has_src = A.dist && at >= A.dist;
+            for (int q = 0; q < DEFLATE_NQ; ++q) C.src[q] = C.has_src ? deflate_source(A.text[mate], at + 8u * q, A.dist) : 0;
+            deflate_tokens(C, [&](uint32_t sym, int kind, uint32_t xbits, uint32_t) { bits += lens[sym] + xbits + kind_bits[kind]; });
         }
         const uint32_t *mine = stage + threadIdx.x * 33u;
         for (int i = 0; i < 32; ++i) {
@@ -492,13 +521,10 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_len(DeflateArgs A) 
             crc = tab[3][x & 0xffu] ^ tab[2][(x >> 8) & 0xffu] ^ tab[1][(x >> 16) & 0xffu] ^ tab[0][x >> 24];
         }
     } else {
-        for (uint32_t c = threadIdx.x; c * 8u < n; c += DEFLATE_THREADS) {
-            uint32_t m;
-            int prev;
-            uint64_t src;
-            bool has_src;
-            const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, start / 8u + c, A.dist, m, prev, src, has_src);
-            deflate_tokens(raw, m, prev, src, has_src, [&](uint32_t sym, int kind) { bits += lens[sym] + kind_bits[kind]; });
+        for (uint32_t c = threadIdx.x; c * DEFLATE_CHUNK < n; c += DEFLATE_THREADS) {
+            DeflateChunk C;
+            deflate_chunk(A.text[mate], A.n_bytes, start / DEFLATE_CHUNK + c, A.dist, C);
+            deflate_tokens(C, [&](uint32_t sym, int kind, uint32_t xbits, uint32_t) { bits += lens[sym] + xbits + kind_bits[kind]; });
         }
         const int64_t lo = (int64_t)n - (int64_t)(DEFLATE_THREADS - threadIdx.x) * 128;  // may be negative: zeros in front
         for (int64_t i = lo < 0 ? 0 : lo; i < lo + 128; ++i) crc = tab[0][(crc ^ t[i]) & 0xffu] ^ (crc >> 8);
@@ -541,11 +567,12 @@ __global__ __launch_bounds__(1024) void k_deflate_scan(DeflateArgs A) {
     if (threadIdx.x == 1023) A.block_off[mate][A.n_blocks] = part[1023];
 }
 
-// One workgroup per block.  Tiles of 256 lanes x 8 bytes: each lane concatenates the codes of its chunk (<= 120 bits), a
-// workgroup scan places them, the bits are ORed into an LDS window, whole words of the window go out and the
-// unfinished last word starts the next tile.  The block starts on a byte of `out`, not on a word: the window is
-// bit-shifted by the misalignment and the first / last word are merged with atomicOr (the buffer is zeroed).
-constexpr int DEFLATE_WIN_WORDS = DEFLATE_THREADS * 120 / 32 + 4;
+// One workgroup per block.  Tiles of 256 lanes x 32 bytes: each lane counts the bits of its chunk's tokens (<= 480), a
+// workgroup scan places them, then the lane walks its tokens again and ORs their bits into an LDS window, 32 at a
+// time; whole words of the window go out and the unfinished last word starts the next tile.  The block starts on a
+// byte of `out`, not on a word: the window is bit-shifted by the misalignment and the first / last word are merged
+// with atomicOr (the buffer is zeroed).
+constexpr int DEFLATE_WIN_WORDS = DEFLATE_THREADS * DEFLATE_CHUNK * 15 / 32 + 4;
 
 __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_encode(DeflateArgs A) {
     __shared__ uint32_t ent[DEFLATE_SYMS];
@@ -600,33 +627,16 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_encode(DeflateArgs 
     }
     fill += C->hdr_bits;
     flush(false);
-    // ---- literals
+    // ---- tokens
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < n; base += DEFLATE_THREADS * 8) {
-        const uint32_t at = base + threadIdx.x * 8u;
-        uint64_t lo = 0, hi = 0;
+    const uint32_t kind_bits[3] = {0u, 1u, 1u + A.dist_ebits};
+    for (uint32_t base = 0; base < n; base += DEFLATE_THREADS * DEFLATE_CHUNK) {
+        const uint32_t at = base + threadIdx.x * DEFLATE_CHUNK;
+        DeflateChunk K;
         uint32_t nb = 0;
         if (at < n) {
-            uint32_t m;
-            int prev;
-            uint64_t src;
-            bool has_src;
-            const uint64_t raw = deflate_chunk(A.text[mate], A.n_bytes, (start + at) / 8u, A.dist, m, prev, src, has_src);
-            deflate_tokens(raw, m, prev, src, has_src, [&](uint32_t sym, int kind) {
-                const uint32_t e = ent[sym];
-                uint64_t c = e & 0xffffu;
-                uint32_t l = e >> 16;
-                // after a length code: the distance code -- "0" for distance 1, "1" + extra bits for the record distance
-                if (kind == 1) l += 1u;
-                if (kind == 2) { c |= (uint64_t)(1u | (A.dist_eval << 1)) << l; l += 1u + A.dist_ebits; }
-                if (nb < 64u) {
-                    lo |= c << nb;
-                    if (nb + l > 64u) hi |= c >> (64u - nb);
-                } else {
-                    hi |= c << (nb - 64u);
-                }
-                nb += l;
-            });
+            deflate_chunk(A.text[mate], A.n_bytes, (start + at) / DEFLATE_CHUNK, A.dist, K);
+            deflate_tokens(K, [&](uint32_t sym, int kind, uint32_t xbits, uint32_t) { nb += (ent[sym] >> 16) + xbits + kind_bits[kind]; });
         }
         // exclusive scan of nb over the workgroup
         uint32_t x = nb;
@@ -641,8 +651,22 @@ __global__ __launch_bounds__(DEFLATE_THREADS) void k_deflate_encode(DeflateArgs 
             if (w < wave) pre += wsum[w];
             tile_bits += wsum[w];
         }
-        or_bits(fill + pre, lo);
-        if (nb > 64u) or_bits(fill + pre + 64u, hi);
+        if (at < n) {
+            uint32_t pos = fill + pre, have = 0;
+            uint64_t acc = 0;  // bits not yet in the window (< 32 of them between tokens)
+            deflate_tokens(K, [&](uint32_t sym, int kind, uint32_t xbits, uint32_t xval) {
+                const uint32_t e = ent[sym];
+                uint32_t v = e & 0xffffu, l = e >> 16;                     // <= 15 bits
+                v |= xval << l; l += xbits;                                // extra bits of the length code
+                // the distance code: "0" for distance 1, "1" + extra bits for the record distance (l <= 31)
+                if (kind == 1) l += 1u;
+                if (kind == 2) { v |= (1u | (A.dist_eval << 1)) << l; l += 1u + A.dist_ebits; }
+                acc |= (uint64_t)v << have;
+                have += l;
+                if (have >= 32u) { or_bits(pos, acc & 0xffffffffull); pos += 32u; acc >>= 32; have -= 32u; }
+            });
+            or_bits(pos, acc);
+        }
         fill += tile_bits;
         flush(false);
     }

@@ -189,36 +189,41 @@ def test_compress_file_is_one_gzip_stream(tmp_path):
             assert fh.read() == data
 
 
+def _length_code(n):
+    """RFC 1951 3.2.5 for match lengths 3..32: (symbol, extra bits, their value)"""
+    if n <= 10:
+        return 254 + n, 0, 0
+    k = n - 11
+    if k < 8:
+        return 265 + (k >> 1), 1, k & 1
+    return 269 + ((k - 8) >> 2), 2, (k - 8) & 3
+
+
 def _tokens(data, dist=0):
-    """The device's tokens (iss_deflate.hip.h, deflate_tokens): 8-byte chunks; at every position the run (the byte
+    """The device's tokens (iss_deflate.hip.h, deflate_tokens): 32-byte chunks; at every position the run (the byte
     repeats its predecessor) and the previous record (the same bytes `dist` earlier) are tried, the longer one wins
-    with >= 3 (run) / >= 4 (previous record) bytes inside the chunk (symbol 254 + length; kind 1 run, 2 previous
-    record), else a literal (kind 0)."""
+    with >= 3 (run) / >= 4 (previous record) bytes inside the chunk, else a literal.
+    -> (symbol, kind 0 literal / 1 run / 2 previous record, extra bits of the length code, their value)"""
     out = []
-    for at in range(0, len(data), 8):
-        chunk = data[at:at + 8]
-        prev = data[at - 1] if at else -1
+    for at in range(0, len(data), 32):
+        chunk = data[at:at + 32]
         has_src = bool(dist) and at >= dist
         i = 0
         while i < len(chunk):
             c = chunk[i]
             r1 = rd = 0
-            if c == prev:
-                r1 = 1
-                while i + r1 < len(chunk) and chunk[i + r1] == c:
-                    r1 += 1
+            while i + r1 < len(chunk) and at + i + r1 > 0 and data[at + i + r1] == data[at + i + r1 - 1]:
+                r1 += 1
             while has_src and i + rd < len(chunk) and chunk[i + rd] == data[at + i + rd - dist]:
                 rd += 1
             if r1 >= 3 and r1 >= rd:
-                out.append((254 + r1, 1))
+                out.append((*_length_code(r1)[:1], 1, *_length_code(r1)[1:]))
                 i += r1
             elif rd >= 4:
-                out.append((254 + rd, 2))
+                out.append((*_length_code(rd)[:1], 2, *_length_code(rd)[1:]))
                 i += rd
-                prev = chunk[i - 1]
             else:
-                out.append((c, 0))
-                prev = c
+                out.append((c, 0, 0, 0))
                 i += 1
     return out
 
@@ -230,10 +235,10 @@ def _deflate_block(native, data, hist=None, dist=0):
 
     toks = _tokens(data, dist)
     if hist is None:
-        hist = np.bincount(np.array([t[0] for t in toks] + [256], dtype=np.int64), minlength=263).astype(np.uint32)
+        hist = np.bincount(np.array([t[0] for t in toks] + [256], dtype=np.int64), minlength=273).astype(np.uint32)
     hist = np.ascontiguousarray(hist, dtype=np.uint32)
-    assert hist.size == 263
-    entry = np.zeros(263, dtype=np.uint32)
+    assert hist.size == 273
+    entry = np.zeros(273, dtype=np.uint32)
     hdr = np.zeros(64, dtype=np.uint32)
     dcode = np.zeros(3, dtype=np.uint32)
     nbits = C.c_uint32(0)
@@ -247,12 +252,14 @@ def _deflate_block(native, data, hist=None, dist=0):
         acc |= int(hdr[w]) << (32 * w)
     acc &= (1 << nbits.value) - 1
     n = nbits.value
-    for sym, kind in toks:
+    for sym, kind, xbits, xval in toks:
         acc |= (int(entry[sym]) & 0xffff) << n
         n += int(lens[sym])
-        if kind == 1:      # distance 1: the bit 0
+        acc |= xval << n           # extra bits of the length code
+        n += xbits
+        if kind == 1:              # distance 1: the bit 0
             n += 1
-        elif kind == 2:    # the record distance: the bit 1, then its extra bits
+        elif kind == 2:            # the record distance: the bit 1, then its extra bits
             acc |= (1 | (int(dcode[2]) << 1)) << n
             n += 1 + int(dcode[1])
     acc |= (int(entry[256]) & 0xffff) << n
@@ -285,12 +292,12 @@ def test_deflate_code_builder_makes_valid_streams(native):
     block, lens = _deflate_block(native, fastq, dist=rec)
     assert len(block) < 0.9 * len(runs_only) < 0.31 * len(fastq)
     # a code built from one histogram still encodes symbols the histogram never saw
-    hist = np.bincount(np.array([t[0] for t in _tokens(fastq)] + [256]), minlength=263).astype(np.uint32)
+    hist = np.bincount(np.array([t[0] for t in _tokens(fastq)] + [256]), minlength=273).astype(np.uint32)
     other = b"nnnnNNNN@@@\xff\x00" * 50
     block, _ = _deflate_block(native, other, hist=hist, dist=13)
     assert zlib.decompressobj(-15).decompress(block) == other
     # extreme counts (a long batch) keep the 15-bit limit
-    hist = np.ones(263, dtype=np.uint32)
+    hist = np.ones(273, dtype=np.uint32)
     hist[65], hist[67], hist[10] = 4_000_000_000, 200_000_000, 3
     block, lens = _deflate_block(native, b"ACCA\n", hist=hist)
     assert zlib.decompressobj(-15).decompress(block) == b"ACCA\n" and lens[65] == 1
@@ -326,7 +333,7 @@ def test_deflate_code_builder_randomized(native):
         dist = int(rng.choice([0, 0, 5, 37, 300, 4000, 32768]))
         scale = int(rng.choice([1, 1, 1000, 1_000_000]))  # the same statistics at a long batch's counts
         toks = _tokens(data, dist)
-        hist = np.bincount(np.array([t[0] for t in toks] + [256], dtype=np.int64), minlength=263) * scale
+        hist = np.bincount(np.array([t[0] for t in toks] + [256], dtype=np.int64), minlength=273) * scale
         hist = np.minimum(hist, 2**32 - 2).astype(np.uint32)
         block, lens = _deflate_block(native, data, hist=hist, dist=dist)
         assert zlib.decompressobj(-15).decompress(block) == data, case
