@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=READS_PER_STEP, help="reads per step per GPU")
     ap.add_argument("--model", default="novaseq")
+    ap.add_argument("--n-genomes", type=int, default=N_GENOMES, help="records of the synthetic community (BASELINE configs[3]: 50)")
     ap.add_argument("--indel", type=float, nargs=2, default=None, metavar=("P_INS", "P_DEL"),
                     help="override every insertion / deletion probability (BASELINE configs[4]-like indel-heavy model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,7 +101,7 @@ def main():
         if args.indel is not None:
             dense.ins[:] = args.indel[0]
             dense.dele[:] = args.indel[1]
-        genomes = synthetic_genomes(N_GENOMES, GENOME_LEN, 123)
+        genomes = synthetic_genomes(args.n_genomes, GENOME_LEN, 123)
     t_b = time.time()
     dense, genomes = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank))
     torch.cuda.synchronize()
@@ -123,12 +124,12 @@ def main():
     worker_seed = SEED + rank
     ordinal = [0]
 
-    def step():
-        row = 0
-        for rec, n in work:
-            eng.generate(gids[id(rec)], n, first_ordinal=ordinal[0], seed=worker_seed, out_first_pair=row)
-            ordinal[0] += n
-            row += n
+    item_ids = [gids[id(rec)] for rec, _ in work]
+    item_pairs = [n for _, n in work]
+
+    def step():  # the step's whole work list in one set of launches (iss_generate_batch)
+        eng.generate_batch(item_ids, item_pairs, first_ordinal=ordinal[0], seed=worker_seed, out_first_pair=0)
+        ordinal[0] += total_pairs_step
 
     def sync_all():
         eng.synchronize()
@@ -167,7 +168,7 @@ def main():
         value = pairs_total / elapsed
         b_pair = algorithmic_bytes_per_pair(RL)
         main_s = tm["main_ms"] / 1e3
-        n_main_launches = len(work) * args.steps
+        n_main_launches = args.steps  # one k_main launch per step (all work items)
         achieved = (total_pairs_step * args.steps * b_pair) / main_s / 1e9 if main_s > 0 else 0.0
         # the other kernels' milliseconds come from the warm-up steps (per step)
         other = {k: (tm_warm[k] / args.warmup if args.warmup else None) for k in ("setup_ms", "indel_scan_ms", "indel_fixup_ms")}
@@ -188,7 +189,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "k_main", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_pair * total_pairs_step / max(len(work), 1),
+                "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_pair * total_pairs_step,
                 "algorithmic_bytes_per_pair": b_pair, "avg_launch_ms": tm["main_ms"] / max(n_main_launches, 1),
                 "launches": n_main_launches,
                 # what actually bounds k_main: integer VALU issue.  Wavefront-level VALU instructions per launch from the
@@ -233,7 +234,8 @@ def committed_traffic():
     with open(files[-1]) as fh:
         t = json.load(fh)
     committed_traffic.valu_insts = t.get("valu_insts_per_launch")
-    return t["traffic_bytes_per_launch"], "bytes per launch (avg 1e6 pairs), from %s" % os.path.basename(files[-1])
+    return t["traffic_bytes_per_launch"], "bytes per launch (%d pairs), from %s" % (
+        t.get("pairs_per_launch_avg", 0), os.path.basename(files[-1]))
 
 
 def end_to_end(dense, records, abundance, n_pairs, compress=False):

@@ -117,6 +117,20 @@ int iss_output_device_ptrs(const iss_ctx *ctx, void **r1_base, void **r1_qual, v
 int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                  int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair);
 
+/*
+ * The same for a whole work list in ONE set of launches (reads_generator over several work items,
+ * iss/generator.py:69-95 + the loop of worker_iterator, :245-249): item k = (genome_ids[k], n_pairs[k]); its pairs take
+ * the ordinals and output rows that n_items consecutive iss_generate calls would give them (first_ordinal /
+ * out_first_pair onwards), so the rows are identical to those calls' -- without a kernel launch sequence per record.
+ * The records are laid side by side in one device arena (kept until a call names another list of records) and pair
+ * descriptors carry arena coordinates; iss_output_download_coords returns record coordinates as before.  Custom
+ * fragment lengths (iss_set_fragment) are not supported here: ISS_E_INVALID.  A record not longer than the read
+ * length: ISS_E_SHORT_RECORD, nothing generated (leave such records out, as reads_generator skips them).
+ */
+int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids, const int64_t *n_pairs,
+                       uint64_t first_ordinal, uint64_t seed, int32_t sequence_type, int32_t gc_bias,
+                       int64_t out_first_pair);
+
 /* Custom fragment length on the Philox path (--fragment-length / --fragment-length-sd, iss/generator.py:121-123):
  * fragment = int(mu + sd * gaussian), each pair running its own polar Box-Muller loop on its K_FRAG uniforms
  * (nothing is cached across pairs).  Negative inserts, templates cut by the genome end and Python's slice rules

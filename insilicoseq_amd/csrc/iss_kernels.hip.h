@@ -182,7 +182,34 @@ struct RunArgs {
     uint32_t *mut_count;          // slots reserved so far
     uint32_t mut_cap;
     int64_t pair_base;            // index of this launch's first pair within the iss_generate call
+    // iss_generate_batch: several records in one launch.  The genomes stand in ONE arena (DevGenome of the launch) at
+    // offsets `off` (bases, multiples of 32); pair i of the call belongs to the item k with item_first[k] <= i <
+    // item_first[k + 1]; pair descriptors carry ARENA coordinates, so k_main does not know about records at all.
+    const struct BatchItem *items;  // NULL: one record, the launch's DevGenome is that record
+    const int64_t *item_first;      // [n_items + 1]
+    int32_t n_items;
 };
+
+struct BatchItem {
+    int64_t off;             // arena coordinate of the record's first base
+    int64_t L;
+    int32_t has_exceptions;
+    int32_t pad;
+};
+
+// the item of pair `p` of a batch call (p counted from the call's first pair)
+__device__ __forceinline__ int batch_item_of(const RunArgs &A, int64_t p) {
+    int lo = 0, hi = A.n_items;  // largest k with item_first[k] <= p
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.item_first[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ DevGenome batch_genome(const DevGenome &arena, const BatchItem &it) {
+    return DevGenome{arena.packed + it.off / 16, arena.mask + it.off / 32, arena.ascii + it.off, it.L, it.has_exceptions};
+}
+
 
 // reserve n <= 64 record slots for the active lanes of this wavefront; returns the first slot (wave-uniform) or
 // 0xffffffff when the buffer is full (the host then reports the overflow)
@@ -375,7 +402,7 @@ __global__ __launch_bounds__(256) void k_pack_genome(const uint8_t *__restrict__
 // ================================================================== k_setup
 // `ov_frag` != NULL: second pass for the few pairs whose fragment length the host evaluated.
 __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g, const RunArgs &A, PairDesc *desc,
-                                           const uint64_t *s_isize, int64_t i, const int64_t *ov_frag) {
+                                           const uint64_t *s_isize, int64_t i, const int64_t *ov_frag, int64_t coord_off = 0) {
     const uint64_t ordinal = A.first_ordinal + (uint64_t)i;
     uint32_t attempt = 0;
     if (A.gc_bias) {  // generator.py:82-92 -- the 40<gc<60 window is dead, every candidate pair
@@ -465,8 +492,8 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
         A.fix_list[at + 1] = (uint32_t)i * 2u + 1u;
     }
     PairDesc d;
-    d.fs = (int32_t)fs;
-    d.re = (int32_t)re;
+    d.fs = (int32_t)(fs + coord_off);  // (batch calls: arena coordinates)
+    d.re = (int32_t)(re + coord_off);
     d.meta = (uint32_t)(M.bin_slot[bin_f] & 3) | ((uint32_t)(M.bin_slot[4 + bin_r] & 3) << 2) | exc | (irregular ? 64u : 0u) |
              (attempt << 16);
     d.isz = (int32_t)isz;
@@ -479,6 +506,11 @@ __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs 
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_pairs) return;
+    if (A.items) {  // the record of this pair, then as for a single record
+        const BatchItem it = A.items[batch_item_of(A, A.pair_base + i)];
+        setup_pair(M, batch_genome(g, it), A, desc, s_isize, i, nullptr, it.off);
+        return;
+    }
     setup_pair(M, g, A, desc, s_isize, i, nullptr);
 }
 
@@ -906,9 +938,16 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
         const uint32_t e = fix_list[i];
         const uint32_t pair = e >> 1;
         const int o = (int)(e & 1u);
-        const PairDesc d = desc[pair];
+        PairDesc d = desc[pair];
+        DevGenome gl = g;  // the record of the read: the launch's genome, or its slice of the arena (batch calls)
+        if (A.items) {
+            const BatchItem it = A.items[batch_item_of(A, A.pair_base + pair)];
+            gl = batch_genome(g, it);
+            d.fs -= (int32_t)it.off;
+            d.re -= (int32_t)it.off;
+        }
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
-        const MateGeom geo = mate_geom(o, d, RL, g.L);
+        const MateGeom geo = mate_geom(o, d, RL, gl.L);
         uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.pitch;
         const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.pitch;
         // ---- phase 0: the digits that several steps / positions share, one Philox block per LANE (a K_DEL block holds
@@ -960,7 +999,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
             if (n < RL) { ev[n] = (uint8_t)m8; map[n] = FIX_NONE; qual[n] = out_qual[n]; }
             { const uint64_t am = __ballot(m8 != 0); if (lane == 0) act[c] = am; }
         }
-        for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)geom_base(g, o, geo, k);
+        for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)geom_base(gl, o, geo, k);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 2: every lane runs the same walk (wave-uniform values); lane 0 does the LDS writes
@@ -1003,7 +1042,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
                             tok = sp > 0 ? -(int)stk[--sp] : k++;
                             if (A.mut && exists) {  // ref = mutable_seq[position] after the pop (__init__.py:211-221)
                                 row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
-                                row.ref = (uint8_t)(tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : geom_base(g, o, geo, tok)));
+                                row.ref = (uint8_t)(tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : geom_base(gl, o, geo, tok)));
                                 row.alt = '.';
                                 mut_emit(A, mchunk, lane == 0, row);
                             }
@@ -1032,7 +1071,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
                 while (rec_n0[r] > j) --r;
                 tok = rec_k0[r] + (j - rec_n0[r]);
             }
-            int base = tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : geom_base(g, o, geo, tok));
+            int base = tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : geom_base(gl, o, geo, tok));
             const uint32_t h = dqm[j];
             const int q = qual[j];
             const uint32_t t = mut16[q];

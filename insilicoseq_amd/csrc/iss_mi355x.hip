@@ -147,6 +147,17 @@ struct iss_ctx {
     bool overlap = false;  // ISS_OVERLAP=1: run the indel passes beside the next chunk (measured: no gain, k_main is VALU-bound)
     std::vector<PendingIndel> pending;
     GenomeArena arena;
+    // iss_generate_batch: the records of the last batch copied side by side into one arena (ids + items cached)
+    std::vector<int32_t> comm_ids;
+    std::vector<iss::BatchItem> comm_items;
+    uint32_t *comm_packed = nullptr, *comm_mask = nullptr;
+    uint8_t *comm_ascii = nullptr;
+    iss::BatchItem *d_items[2] = {nullptr, nullptr}, *h_items[2] = {nullptr, nullptr};  // device / pinned host, two sets:
+    int64_t *d_item_first[2] = {nullptr, nullptr}, *h_item_first[2] = {nullptr, nullptr};  // a call's launches may still read
+    hipEvent_t ev_items[2] = {nullptr, nullptr};                                          // its set while the next is filled
+    size_t d_items_cap = 0;
+    uint64_t batch_seq = 0;
+    bool comm_exceptions = false;
     uint64_t chunk_seq = 0;
     std::string last_error;
     // model
@@ -177,6 +188,8 @@ struct iss_ctx {
     uint32_t *d_pmut_count = nullptr;
     int64_t pmut_cap = 0;
     int64_t last_row0 = 0, last_n = 0;  // rows of the last iss_generate call (their flags tell which rows are stale)
+    std::vector<int64_t> last_first;     // the last call was a batch: its item_first (rows last_row0 + ...), else empty
+    std::vector<int64_t> last_off;       // ... and the arena offsets its descriptors carry
     unsigned max_main_grid = 0;
     uint64_t *stats = nullptr;
     // reference-compatible MT19937 mode (iss_mt_compat.hip.h)
@@ -1048,7 +1061,9 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
         G.mask_alloc = reinterpret_cast<uint32_t *>(blk + pk_bytes);
         G.ascii = blk + pk_bytes + mk_bytes;
         G.in_arena = true;
-        he = hipMemcpyAsync(G.ascii, ascii, (size_t)length, hipMemcpyHostToDevice, ctx->stream);
+        // a synchronous copy: the caller's buffer may go away as soon as this call returns, and nothing waits for the
+        // stream here any more (the slice is fresh memory, so no earlier launch can be using it)
+        he = hipMemcpy(G.ascii, ascii, (size_t)length, hipMemcpyHostToDevice);
         if (he == hipSuccess) he = hipMemsetAsync(blk, 0, pk_bytes + mk_bytes, ctx->stream);
         if (he != hipSuccess) return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he));
         hipLaunchKernelGGL(iss::k_pack_genome, dim3((unsigned)((n_mk + 255) / 256)), dim3(256), 0, ctx->stream, G.ascii, length,
@@ -1091,6 +1106,9 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     return 0;
 }
 
+static void free_community(iss_ctx *ctx);
+static void free_item_tables(iss_ctx *ctx);
+
 int iss_genome_clear(iss_ctx *ctx) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
     (void)sync_all(ctx);
@@ -1098,6 +1116,8 @@ int iss_genome_clear(iss_ctx *ctx) {
         if (!G.in_arena) { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); }
     ctx->genomes.clear();
     ctx->arena.clear();
+    free_community(ctx);
+    free_item_tables(ctx);
     return 0;
 }
 
@@ -1137,6 +1157,10 @@ int iss_output_device_ptrs(const iss_ctx *ctx, void **a, void **b, void **c, voi
     return 0;
 }
 
+static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_exceptions, const iss::BatchItem *items,
+                         const int64_t *item_first, int32_t n_items, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
+                         int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair);
+
 int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                  int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
     if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_generate: upload a model first");
@@ -1153,6 +1177,15 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
     if (n_pairs == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
+    return generate_core(ctx, dg, G.has_exceptions, nullptr, nullptr, 0, n_pairs, first_ordinal, seed, sequence_type, gc_bias,
+                         out_first_pair);
+}
+
+// The launches of one generate call: `dg` is the record, or (items != NULL) the arena holding the records of a batch.
+static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_exceptions, const iss::BatchItem *items,
+                         const int64_t *item_first, int32_t n_items, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
+                         int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
+    const iss::DevModel &M = ctx->M;
     // lane-item indices are packed with 3 more bits in the deferred queue: keep them below 2^28
     const int64_t max_chunk = std::max<int64_t>(1, ((int64_t)1 << 28) / std::max(M.G, std::max(M.n_scan, 1)));
     if (ctx->d_pmut) {  // rows of THIS call only
@@ -1162,6 +1195,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
     }
     ctx->last_row0 = out_first_pair;
     ctx->last_n = n_pairs;
+    if (!items) { ctx->last_first.clear(); ctx->last_off.clear(); }
     for (int64_t done = 0; done < n_pairs;) {
         const int64_t n = std::min(max_chunk, n_pairs - done);
         const int64_t row0 = out_first_pair + done;
@@ -1210,6 +1244,9 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         A.mut_count = ctx->d_pmut_count;
         A.mut_cap = (uint32_t)ctx->pmut_cap;
         A.pair_base = done;
+        A.items = items;
+        A.item_first = item_first;
+        A.n_items = n_items;
         A.flags = flags;
         A.fix_list = fix_list;
         A.fix_count = counter;
@@ -1279,7 +1316,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
             per_tile = (unsigned)std::min<uint64_t>(per_tile, (items + iss::MAIN_THREADS - 1) / iss::MAIN_THREADS);
             per_tile = std::max(1u, std::min(per_tile, ctx->max_main_grid / (unsigned)M.n_tiles));
             const dim3 grid(per_tile * (unsigned)M.n_tiles), block(iss::MAIN_THREADS);
-            const bool plain = !G.has_exceptions && !ctx->has_frag;
+            const bool plain = !any_exceptions && !ctx->has_frag;
 #define ISS_LAUNCH_MAIN(MUT, PLAIN) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN>), grid, block, lds_bytes, s_main, M, dg, A, desc)
             if (A.mut) { if (plain) ISS_LAUNCH_MAIN(true, true); else ISS_LAUNCH_MAIN(true, false); }
             else { if (plain) ISS_LAUNCH_MAIN(false, true); else ISS_LAUNCH_MAIN(false, false); }
@@ -1349,6 +1386,140 @@ int iss_output_download(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, uint8
     return 0;
 }
 
+static void free_item_tables(iss_ctx *ctx) {
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->d_items[k]) (void)hipFree(ctx->d_items[k]);
+        if (ctx->d_item_first[k]) (void)hipFree(ctx->d_item_first[k]);
+        if (ctx->h_items[k]) (void)hipHostFree(ctx->h_items[k]);
+        if (ctx->h_item_first[k]) (void)hipHostFree(ctx->h_item_first[k]);
+        if (ctx->ev_items[k]) (void)hipEventDestroy(ctx->ev_items[k]);
+        ctx->d_items[k] = ctx->h_items[k] = nullptr;
+        ctx->d_item_first[k] = ctx->h_item_first[k] = nullptr;
+        ctx->ev_items[k] = nullptr;
+    }
+    ctx->d_items_cap = 0;
+}
+
+// with ISS_OVERLAP the indel passes of a call run on their own stream: the main stream waits for them here
+static int sync_indel_into_main(iss_ctx *ctx) {
+    if (!ctx->overlap) return 0;
+    return sync_all(ctx);
+}
+
+static void free_community(iss_ctx *ctx) {
+    if (ctx->comm_packed) (void)hipFree(ctx->comm_packed);
+    if (ctx->comm_mask) (void)hipFree(ctx->comm_mask);
+    if (ctx->comm_ascii) (void)hipFree(ctx->comm_ascii);
+    ctx->comm_packed = ctx->comm_mask = nullptr;
+    ctx->comm_ascii = nullptr;
+    ctx->comm_ids.clear();
+    ctx->comm_items.clear();
+}
+
+int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids, const int64_t *n_pairs, uint64_t first_ordinal,
+                       uint64_t seed, int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
+    if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: upload a model first");
+    if (n_items < 0 || (n_items && (!genome_ids || !n_pairs))) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: bad argument");
+    if (sequence_type != ISS_SEQ_METAGENOMICS && sequence_type != ISS_SEQ_AMPLICON)
+        return fail(ctx, ISS_E_INVALID, "sequence type is not supported");
+    const iss::DevModel &M = ctx->M;
+    if (M.quality_mode == 1)
+        return fail(ctx, ISS_E_INVALID, "BasicErrorModel runs in the reference-compatible mode only (iss_generate_mt / rng=\"mt\")");
+    if (ctx->has_frag) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: custom fragment lengths go through iss_generate");
+    int64_t total = 0;
+    std::vector<int64_t> first((size_t)n_items + 1, 0);
+    for (int32_t k = 0; k < n_items; ++k) {
+        if (genome_ids[k] < 0 || genome_ids[k] >= (int32_t)ctx->genomes.size()) return fail(ctx, ISS_E_INVALID, "unknown genome id");
+        if (n_pairs[k] < 0) return fail(ctx, ISS_E_INVALID, "negative pair count");
+        if (!(M.RL < ctx->genomes[genome_ids[k]].L))
+            return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
+        total += n_pairs[k];
+        first[(size_t)k + 1] = total;
+    }
+    if (out_first_pair < 0 || out_first_pair + total > ctx->capacity)
+        return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
+    if (total == 0) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // ---- the records side by side in one arena (kept until another set of records is asked for)
+    const std::vector<int32_t> ids(genome_ids, genome_ids + n_items);
+    if (ids != ctx->comm_ids) {
+        { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+        free_community(ctx);
+        std::vector<iss::BatchItem> items((size_t)n_items);
+        std::vector<int64_t> place(ctx->genomes.size(), -1);  // a record used by several items stands once
+        int64_t coord = 64;
+        bool exceptions = false;
+        for (int32_t k = 0; k < n_items; ++k) {
+            const Genome &G = ctx->genomes[ids[k]];
+            if (place[ids[k]] < 0) {
+                place[ids[k]] = coord;
+                coord += ((G.L + 31) / 32) * 32 + 64;  // zero padding between records (k_main's windows overhang by a few bases)
+            }
+            items[(size_t)k] = iss::BatchItem{place[ids[k]], G.L, G.has_exceptions ? 1 : 0, 0};
+            exceptions |= G.has_exceptions;
+        }
+        if (coord >= ((int64_t)1 << 31) - 4096) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: the records of one call must stay below 2^31 bases");
+        void *p = nullptr;
+        const size_t n_pk = (size_t)coord / 16 + 8, n_mk = (size_t)coord / 32 + 8;
+        HIP_TRY(ctx, hipMalloc(&p, n_pk * 4));
+        ctx->comm_packed = static_cast<uint32_t *>(p);
+        HIP_TRY(ctx, hipMalloc(&p, n_mk * 4));
+        ctx->comm_mask = static_cast<uint32_t *>(p);
+        HIP_TRY(ctx, hipMalloc(&p, (size_t)coord + 64));
+        ctx->comm_ascii = static_cast<uint8_t *>(p);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->comm_packed, 0, n_pk * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->comm_mask, 0, n_mk * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->comm_ascii, 'A', (size_t)coord + 64, ctx->stream));
+        for (size_t g = 0; g < place.size(); ++g) {
+            if (place[g] < 0) continue;
+            const Genome &G = ctx->genomes[g];
+            const size_t w_mk = (size_t)(G.L + 31) / 32;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_packed + 2 + place[g] / 16, G.packed, 2 * w_mk * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_mask + 2 + place[g] / 32, G.mask, w_mk * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_ascii + place[g], G.ascii, (size_t)G.L, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        ctx->comm_ids = ids;
+        ctx->comm_items = items;
+        ctx->comm_exceptions = exceptions;
+    }
+    if ((size_t)n_items + 1 > ctx->d_items_cap) {
+        { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+        free_item_tables(ctx);
+        const size_t cap = (size_t)n_items + 1 + 64;
+        for (int k = 0; k < 2; ++k) {
+            void *p = nullptr;
+            HIP_TRY(ctx, hipMalloc(&p, cap * sizeof(iss::BatchItem)));
+            ctx->d_items[k] = static_cast<iss::BatchItem *>(p);
+            HIP_TRY(ctx, hipMalloc(&p, cap * sizeof(int64_t)));
+            ctx->d_item_first[k] = static_cast<int64_t *>(p);
+            HIP_TRY(ctx, hipHostMalloc(&p, cap * sizeof(iss::BatchItem), hipHostMallocDefault));
+            ctx->h_items[k] = static_cast<iss::BatchItem *>(p);
+            HIP_TRY(ctx, hipHostMalloc(&p, cap * sizeof(int64_t), hipHostMallocDefault));
+            ctx->h_item_first[k] = static_cast<int64_t *>(p);
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_items[k], hipEventDisableTiming));
+        }
+        ctx->d_items_cap = cap;
+        ctx->batch_seq = 0;
+    }
+    const int set = (int)(ctx->batch_seq & 1u);
+    if (ctx->batch_seq >= 2) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_items[set]));  // the call before last is done with this set
+    memcpy(ctx->h_items[set], ctx->comm_items.data(), (size_t)n_items * sizeof(iss::BatchItem));
+    memcpy(ctx->h_item_first[set], first.data(), ((size_t)n_items + 1) * sizeof(int64_t));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_items[set], ctx->h_items[set], (size_t)n_items * sizeof(iss::BatchItem), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_item_first[set], ctx->h_item_first[set], ((size_t)n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    const iss::DevGenome dg{ctx->comm_packed + 2, ctx->comm_mask + 2, ctx->comm_ascii, 0, ctx->comm_exceptions ? 1 : 0};
+    const int rc = generate_core(ctx, dg, ctx->comm_exceptions, ctx->d_items[set], ctx->d_item_first[set], n_items, total, first_ordinal,
+                                 seed, sequence_type, gc_bias, out_first_pair);
+    if (rc) return rc;
+    { int rc_ = sync_indel_into_main(ctx); if (rc_) return rc_; }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_items[set], ctx->stream));
+    ++ctx->batch_seq;
+    ctx->last_first.assign(first.begin(), first.end());
+    ctx->last_off.resize((size_t)n_items);
+    for (int32_t k = 0; k < n_items; ++k) ctx->last_off[(size_t)k] = ctx->comm_items[(size_t)k].off;
+    return 0;
+}
+
 int iss_output_download_coords(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, int64_t *coords) {
     if (!ctx || !coords || first_pair < 0 || n_pairs < 0 || first_pair + n_pairs > ctx->capacity)
         return fail(ctx, ISS_E_INVALID, "iss_output_download_coords: rows out of range");
@@ -1359,9 +1530,15 @@ int iss_output_download_coords(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs
                                     hipMemcpyDeviceToHost, ctx->stream));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     for (int64_t i = 0; i < n_pairs; ++i) {
-        coords[4 * i + 0] = tmp[i].fs;
-        coords[4 * i + 1] = (int64_t)tmp[i].re - ctx->M.RL;
-        coords[4 * i + 2] = tmp[i].re;
+        int64_t off = 0;  // rows of a batch call carry arena coordinates: back to the record's own
+        const int64_t r = first_pair + i - ctx->last_row0;
+        if (!ctx->last_first.empty() && r >= 0 && r < ctx->last_n) {
+            const size_t k = (size_t)(std::upper_bound(ctx->last_first.begin(), ctx->last_first.end(), r) - ctx->last_first.begin()) - 1;
+            off = ctx->last_off[k];
+        }
+        coords[4 * i + 0] = tmp[i].fs - off;
+        coords[4 * i + 1] = (int64_t)tmp[i].re - off - ctx->M.RL;
+        coords[4 * i + 2] = tmp[i].re - off;
         coords[4 * i + 3] = tmp[i].isz;
     }
     return 0;

@@ -121,6 +121,20 @@ class ReadEngine(object):
                                            int(seed) & (2**64 - 1), SEQ_TYPES[sequence_type], int(bool(gc_bias)),
                                            int(out_first_pair)))
 
+    def generate_batch(self, genome_ids, n_pairs, first_ordinal=0, seed=0, sequence_type="metagenomics", gc_bias=False,
+                       out_first_pair=0):
+        """A whole work list -- items (genome_ids[k], n_pairs[k]) -- in one set of launches; the rows equal those of
+        consecutive generate() calls with running ordinals and rows.  No custom fragment lengths here."""
+        if sequence_type not in SEQ_TYPES:
+            raise ValueError("Sequence type %s not known" % sequence_type)
+        ids = np.ascontiguousarray(genome_ids, dtype=np.int32)
+        cnt = np.ascontiguousarray(n_pairs, dtype=np.int64)
+        assert ids.ndim == 1 and ids.shape == cnt.shape
+        self.reserve(out_first_pair + int(cnt.sum()))
+        self._check(self._lib.iss_generate_batch(self._ctx, int(ids.size), ids.ctypes.data, cnt.ctypes.data,
+                                                 int(first_ordinal) & (2**64 - 1), int(seed) & (2**64 - 1),
+                                                 SEQ_TYPES[sequence_type], int(bool(gc_bias)), int(out_first_pair)))
+
     def set_fragment(self, fragment_length=None, fragment_sd=None):
         """Custom fragment length for generate() (None, None: the model's insert sizes)."""
         on = fragment_length is not None and fragment_sd is not None

@@ -918,3 +918,55 @@ def test_letters_outside_the_rev_comp_alphabet_are_rejected(length):
         eng.add_genome(bytes(g))
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("case", ["novaseq", "hiseq_gc", "miseq_mixed", "ecoli_amplicon", "indel", "novaseq_vcf"])
+def test_generate_batch_equals_consecutive_calls(case):
+    """iss_generate_batch (one set of launches for a work list) == consecutive iss_generate calls: bases, phreds,
+    record coordinates, mutation rows; records repeated in the list, records with IUPAC / lower-case letters, zero-pair
+    items, gc_bias, amplicon mode, an indel-heavy model (every other read through the fix-up kernel)."""
+    from insilicoseq_amd.engine import ReadEngine
+    from helpers import synthetic_model
+
+    model = {"novaseq": "novaseq", "hiseq_gc": "hiseq", "miseq_mixed": "miseq", "ecoli_amplicon": "ecoli", "novaseq_vcf": "novaseq"}.get(case)
+    dense = synthetic_model(151, 41, 1000, 4, indel=(1e-3, 3e-3)) if case == "indel" else dense_model(model)
+    genomes = [random_genome(300, 30000), mixed_genome(301, 9000) if "mixed" in case else random_genome(301, 9000),
+               random_genome(302, 700), mixed_genome(303, 52000) if "mixed" in case else random_genome(303, 52000)]
+    items = [(0, 1500), (1, 0), (1, 777), (2, 64), (3, 4000), (0, 9), (2, 1)]
+    kw = dict(gc_bias="gc" in case, sequence_type="amplicon" if "amplicon" in case else "metagenomics", seed=91)
+    n_total = sum(n for _, n in items)
+    out = []
+    for batch in (False, True):
+        eng = ReadEngine(0)
+        try:
+            eng.load_model(dense)
+            if "vcf" in case or case == "indel":
+                eng.mutations_reserve(1 << 23)  # (slots are handed out in chunks of 256 per wavefront)
+            gids = [eng.add_genome(g) for g in genomes]
+            eng.reserve(n_total)  # (growing the buffers between calls would drop the rows already there)
+            rows, coords, muts = [], [], []
+            if batch:
+                eng.generate_batch([gids[g] for g, _ in items], [n for _, n in items], first_ordinal=1000, **kw)
+                rows.append(eng.download(0, n_total))
+                coords.append(eng.coords(0, n_total))
+                if "vcf" in case or case == "indel":
+                    muts = [tuple(int(m[k]) for k in ("pair", "mate", "type", "position", "ref", "alt", "quality")) for m in eng.mutations()]
+            else:
+                ordinal, row = 1000, 0
+                for g, n in items:
+                    eng.generate(gids[g], n, first_ordinal=ordinal, out_first_pair=row, **kw)
+                    coords.append(eng.coords(row, n))
+                    if n and ("vcf" in case or case == "indel"):  # (a call without pairs leaves the previous call's rows)
+                        muts += [(int(m["pair"]) + row,) + tuple(int(m[k]) for k in ("mate", "type", "position", "ref", "alt", "quality"))
+                                 for m in eng.mutations()]
+                    ordinal += n
+                    row += n
+                rows.append(eng.download(0, n_total))
+            out.append((rows, np.concatenate([np.asarray(c) for c in coords]), muts))
+        finally:
+            eng.close()
+    (ra, ca, ma), (rb, cb, mb) = out
+    for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+        assert np.array_equal(ra[0][k], rb[0][k]), k
+    assert np.array_equal(ca, cb)
+    assert ma == mb

@@ -47,8 +47,8 @@ def main(src, tag):
     summary = {"kernel": "iss::k_main", "launches": n, "calibration": cal, "valu_insts_per_launch": valu,
                "fetch_bytes_per_launch": fetch,
                "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
-               "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline (5,000,000 pairs per step in 5 launches)",
-               "pairs_per_launch_avg": 1_000_000}
+               "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline (5,000,000 pairs per step in one k_main launch)",
+               "pairs_per_launch_avg": 5_000_000}
     json.dump(summary, open(os.path.join(out_dir, tag + "_traffic.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
