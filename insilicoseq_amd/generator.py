@@ -177,6 +177,11 @@ class Worker(object):
     def close(self):
         self.engine.close()
 
+    def needs_room_for(self, record):
+        """Would uploading this record drop the resident genomes (GENOME_BUDGET)?"""
+        hit = self._gids.get(id(record))
+        return (hit is None or hit[0] is not record) and bool(self._gids) and self._resident + len(record.seq) > self.GENOME_BUDGET
+
     def genome_id(self, record):
         key = id(record)
         hit = self._gids.get(key)
@@ -244,6 +249,55 @@ class Worker(object):
         return done
 
 
+def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_handle, sequence_type, gc_bias):
+    """The worker's loop over its work items (iss/generator.py:245-249) with the parallel path's batches cut across
+    items: up to BATCH_PAIRS pairs of consecutive items go through ONE set of launches (engine.generate_batch; the
+    rows are those of one call per item), then every item's rows are handed to the FASTQ pipeline under its own record
+    id.  Same files as simulate_reads item by item."""
+    logger = logging.getLogger(__name__)
+    eng = w.engine
+    pending, cur = [], 0  # (record id, genome id, pairs, id of the item's first pair in this piece)
+
+    def run():
+        nonlocal pending, cur
+        if not pending:
+            return
+        eng.generate_batch([p[1] for p in pending], [p[2] for p in pending], first_ordinal=w.ordinal, seed=w.seed,
+                           sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0)
+        rows = eng.mutations() if w.store_mutations else None
+        row = 0
+        for rid, _gid, n, first_i in pending:
+            if rows is not None:  # rows come back in (pair, mate, ...) order: this item's are contiguous
+                sel = rows[(rows["pair"] >= row) & (rows["pair"] < row + n)].copy()
+                sel["pair"] -= row
+                write_mutations(sel, mutations_handle, rid, first_i, w.cpu_number)
+            eng.fastq_emit(forward_handle.fileno(), reverse_handle.fileno(), rid, first_i, w.cpu_number, row, n, n_threads=1)
+            row += n
+        w.ordinal += row
+        pending, cur = [], 0
+
+    for fh in (forward_handle, reverse_handle):
+        fh.flush()
+    for record, n_pairs, _mode in work:
+        logger.debug("Cpu #%s: Generating %s read pairs" % (w.cpu_number, n_pairs))
+        if not (eng.read_length < len(record.seq)):  # AssertionError in simulate_read -> record skipped (generator.py:77-80)
+            logger.warning("%s shorter than read length for this ErrorModel" % record.id)
+            logger.warning("Skipping %s. You will have less reads than specified" % record.id)
+            continue
+        if w.needs_room_for(record):
+            run()  # (the genomes about to be dropped are still named by the pending items)
+        gid = w.genome_id(record)
+        done = 0
+        while done < n_pairs:
+            take = min(n_pairs - done, w.BATCH_PAIRS - cur)
+            pending.append((record.id, gid, take, done))
+            cur += take
+            done += take
+            if cur >= w.BATCH_PAIRS:
+                run()
+    run()
+
+
 def write_mutations(rows, mutations_handle, record_id, first_i, cpu_number):
     """iss/generator.py:598-620 for the device's mutation records."""
     for m in rows:
@@ -293,9 +347,13 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
             w.engine.mutations_reserve(Worker.BATCH_PAIRS * 16)
     try:
         with forward_handle, reverse_handle, mutation_handle:
-            for record, n_pairs, _mode in work:
-                w.simulate_reads(record, n_pairs, forward_handle, reverse_handle, mutation_handle, sequence_type,
-                                 gc_bias, flush=False)  # keep the text pipeline running across work items
+            fragment = getattr(error_model, "fragment_length", None) is not None and getattr(error_model, "fragment_sd", None) is not None
+            if rng == "philox" and w.device_fastq and not fragment and os.environ.get("ISS_ITEMWISE", "") != "1":
+                _simulate_work_batched(w, work, forward_handle, reverse_handle, mutation_handle, sequence_type, gc_bias)
+            else:
+                for record, n_pairs, _mode in work:
+                    w.simulate_reads(record, n_pairs, forward_handle, reverse_handle, mutation_handle, sequence_type,
+                                     gc_bias, flush=False)  # keep the text pipeline running across work items
             w.engine.fastq_flush()
     finally:
         w.close()
