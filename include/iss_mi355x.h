@@ -217,6 +217,11 @@ int iss_mt_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity,
  */
 int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, int64_t first_i, int32_t cpu_number,
                    int64_t first_pair, int64_t n_pairs, int32_t n_threads);
+/* The same for the rows of several work items in ONE text job (one format launch, one pair of copies, one write per
+ * file): item k = rows [first_pair[k], +n_pairs[k]) under record_ids[k] with pair ids from first_i[k].  The bytes
+ * appended are those of n_items iss_fastq_emit calls in item order (compressed mode: one gzip member for the call). */
+int iss_fastq_emit_batch(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, const char *const *record_ids,
+                         const int64_t *first_i, const int64_t *first_pair, const int64_t *n_pairs, int32_t cpu_number);
 int iss_fastq_flush(iss_ctx *ctx);
 
 /*

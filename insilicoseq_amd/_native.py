@@ -21,7 +21,7 @@ EXPORTS = (
     "iss_mt_seed", "iss_generate_mt", "iss_mt_peek", "iss_mt_mutations_reserve", "iss_mt_mutations_download",
     "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
     "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush", "iss_fastq_compress", "iss_deflate_code_build",
-    "iss_generate_batch",
+    "iss_generate_batch", "iss_fastq_emit_batch",
 )
 
 
@@ -94,6 +94,7 @@ def lib():
     L.iss_mutations_download.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.iss_mt_mutations_download.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.iss_fastq_emit.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i64, i32]
+    L.iss_fastq_emit_batch.argtypes = [vp, C.c_int, C.c_int, i32, vp, vp, vp, vp, i32]
     L.iss_fastq_flush.argtypes = [vp]
     L.iss_generate_batch.argtypes = [vp, i32, vp, vp, C.c_uint64, C.c_uint64, i32, i32, i64]
     L.iss_fastq_compress.argtypes = [vp, i32]

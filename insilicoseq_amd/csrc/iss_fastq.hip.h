@@ -24,38 +24,57 @@ __host__ __device__ inline uint64_t digits_before(uint64_t x) {
     return cum + (uint64_t)d * (x - (d == 1 ? 1 : p));
 }
 
+// One emit call formats the rows of several work items (records): item k = rows [first_pair, +n_pairs) with ids
+// "{id_k}_{first_i + j}_{cpu}" and its text at byte `text_off` of the call's text.
+struct FastqItem {
+    uint64_t first_i;        // pair id of the item's first row
+    uint64_t before_first;   // digits_before(first_i)
+    uint64_t text_off;       // byte offset of the item's first record in the text
+    int64_t first_pair;      // first output row
+    int64_t rec_first;       // records of the items before this one
+    uint32_t id_off;         // of the record id in `ids`
+    int32_t id_len;
+};
+
 struct FastqArgs {
-    const uint8_t *base[2], *qual[2];  // rows of the first pair: [mate]
+    const uint8_t *base[2], *qual[2];  // output rows (row 0): [mate]
     uint8_t *text[2];                  // [mate] output text
-    const char *id;                    // record id (device copy), id_len bytes
-    int32_t id_len, pitch, RL, cpu_len;
+    const FastqItem *items;            // [n_items]
+    const char *ids;                   // record ids, back to back
+    int32_t n_items, pitch, RL, cpu_len;
     char cpu[12];                      // decimal cpu_number
-    int64_t n_pairs;
-    uint64_t first_i;                  // pair id of row 0
-    uint64_t before_first;             // digits_before(first_i)
+    int64_t n_records;                 // of all items
 };
 
 constexpr int FASTQ_WAVES = 4;
 
-// grid = (ceil(n_pairs / FASTQ_WAVES), 2 mates), block = 64 * FASTQ_WAVES: one wavefront per record
+// grid = (ceil(n_records / FASTQ_WAVES), 2 mates), block = 64 * FASTQ_WAVES: one wavefront per record
 __global__ __launch_bounds__(64 * FASTQ_WAVES) void k_fastq_format(FastqArgs A) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * FASTQ_WAVES + (threadIdx.x >> 6);
-    if (i >= A.n_pairs) return;
+    const int64_t r = (int64_t)blockIdx.x * FASTQ_WAVES + (threadIdx.x >> 6);
+    if (r >= A.n_records) return;
+    int lo = 0, hi = A.n_items;  // the item of record r: largest k with rec_first[k] <= r
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.items[mid].rec_first <= r) lo = mid; else hi = mid;
+    }
+    const FastqItem it = A.items[lo];
+    const int64_t i = r - it.rec_first;
     const int mate = blockIdx.y;
-    const uint64_t g = A.first_i + (uint64_t)i;
+    const uint64_t g = it.first_i + (uint64_t)i;
     int dg = 1;
     for (uint64_t p = 10; dg < 20 && g >= p; p *= 10) ++dg;
-    const uint64_t C = (uint64_t)A.id_len + (uint64_t)A.cpu_len + 2ull * (uint64_t)A.RL + 10ull;
-    uint8_t *w = A.text[mate] + (uint64_t)i * C + (digits_before(g) - A.before_first);
+    const uint64_t C = (uint64_t)it.id_len + (uint64_t)A.cpu_len + 2ull * (uint64_t)A.RL + 10ull;
+    uint8_t *w = A.text[mate] + it.text_off + (uint64_t)i * C + (digits_before(g) - it.before_first);
+    const char *id = A.ids + it.id_off;
     // ---- "@id_i_cpu/m\n"
-    const int h1 = 1 + A.id_len;       // '@' id
+    const int h1 = 1 + it.id_len;      // '@' id
     const int h2 = h1 + 1 + dg;        // '_' digits
     const int hlen = h2 + 1 + A.cpu_len + 3;
     for (int k = lane; k < hlen; k += 64) {
         char c;
         if (k == 0) c = '@';
-        else if (k < h1) c = A.id[k - 1];
+        else if (k < h1) c = id[k - 1];
         else if (k == h1) c = '_';
         else if (k < h2) {
             uint64_t v = g;
@@ -69,8 +88,8 @@ __global__ __launch_bounds__(64 * FASTQ_WAVES) void k_fastq_format(FastqArgs A) 
         w[k] = (uint8_t)c;
     }
     w += hlen;
-    const uint8_t *b = A.base[mate] + (size_t)i * A.pitch;
-    const uint8_t *q = A.qual[mate] + (size_t)i * A.pitch;
+    const uint8_t *b = A.base[mate] + (size_t)(it.first_pair + i) * A.pitch;
+    const uint8_t *q = A.qual[mate] + (size_t)(it.first_pair + i) * A.pitch;
     for (int k = lane; k < A.RL; k += 64) w[k] = b[k];
     if (lane < 3) w[A.RL + lane] = lane == 1 ? '+' : '\n';
     uint8_t *wq = w + A.RL + 3;

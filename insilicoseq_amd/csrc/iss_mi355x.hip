@@ -106,8 +106,10 @@ struct FastqPipe {
     hipEvent_t ev_fmt[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
     uint8_t *d_text[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [slot][mate]
     uint8_t *h_text[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    char *d_id = nullptr;  // [2][ID_MAX]
-    std::string id_keep[2];
+    // per slot: the item table and the record ids of the emit call (pinned host copy + device copy)
+    iss::FastqItem *h_items[2] = {nullptr, nullptr}, *d_items[2] = {nullptr, nullptr};
+    char *h_ids[2] = {nullptr, nullptr}, *d_ids[2] = {nullptr, nullptr};
+    size_t items_cap[2] = {0, 0}, ids_cap[2] = {0, 0};
     size_t cap = 0;
     int next = 0;
     int fd[2] = {-1, -1};
@@ -634,7 +636,15 @@ void fastq_shutdown(iss_ctx *ctx) {
     for (auto &sl : q.d_code) for (auto &p : sl) { if (p) (void)hipFree(p); p = nullptr; }
     for (auto &sl : q.h_total) for (auto &p : sl) { if (p) (void)hipHostFree(p); p = nullptr; }
     if (q.data_stream) (void)hipStreamDestroy(q.data_stream);
-    if (q.d_id) (void)hipFree(q.d_id);
+    for (int sl = 0; sl < 2; ++sl) {
+        if (q.h_items[sl]) (void)hipHostFree(q.h_items[sl]);
+        if (q.d_items[sl]) (void)hipFree(q.d_items[sl]);
+        if (q.h_ids[sl]) (void)hipHostFree(q.h_ids[sl]);
+        if (q.d_ids[sl]) (void)hipFree(q.d_ids[sl]);
+        q.h_items[sl] = q.d_items[sl] = nullptr;
+        q.h_ids[sl] = q.d_ids[sl] = nullptr;
+        q.items_cap[sl] = q.ids_cap[sl] = 0;
+    }
     for (auto &e : q.ev_fmt) if (e) (void)hipEventDestroy(e);
     for (auto &e : q.ev_copy) if (e) (void)hipEventDestroy(e);
     if (q.copy_stream) (void)hipStreamDestroy(q.copy_stream);
@@ -1988,39 +1998,60 @@ int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n)
 }
 
 // ------------------------------------------------------------------ FASTQ formatting (host)
-int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, int64_t first_i, int32_t cpu_number,
-                   int64_t first_pair, int64_t n_pairs, int32_t n_threads) {
-    if (!ctx || !ctx->have_model || !record_id || first_i < 0 || cpu_number < 0 || first_pair < 0 || n_pairs < 0 ||
-        first_pair + n_pairs > ctx->capacity || fd_r1 < 0 || fd_r2 < 0)
+// The rows of n_items work items -> FASTQ text (or gzip members) on their way to the two files.
+static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, const char *const *record_ids, const int64_t *first_i,
+                           const int64_t *first_pair, const int64_t *n_pairs, int32_t cpu_number, int32_t n_threads) {
+    if (!ctx || !ctx->have_model || n_items < 0 || cpu_number < 0 || fd_r1 < 0 || fd_r2 < 0)
         return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: bad argument");
-    const size_t idlen = strlen(record_id);
-    if (idlen > FASTQ_ID_MAX) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: record id longer than 4096 bytes");
-    if (n_pairs == 0) return 0;
+    const iss::DevModel &M = ctx->M;
+    iss::FastqArgs A{};
+    A.cpu_len = (int32_t)snprintf(A.cpu, sizeof A.cpu, "%d", cpu_number);
+    A.pitch = M.pitch;
+    A.RL = M.RL;
+    std::vector<iss::FastqItem> items;
+    std::string ids;
+    size_t bytes = 0, rec_len = 0;  // rec_len: record length of the item with the most pairs (the distance of its "previous record")
+    int64_t n_records = 0, most = 0;
+    for (int32_t k = 0; k < n_items; ++k) {
+        if (!record_ids[k] || first_i[k] < 0 || first_pair[k] < 0 || n_pairs[k] < 0 || first_pair[k] + n_pairs[k] > ctx->capacity)
+            return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: bad argument");
+        const size_t idlen = strlen(record_ids[k]);
+        if (idlen > FASTQ_ID_MAX) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: record id longer than 4096 bytes");
+        if (n_pairs[k] == 0) continue;
+        iss::FastqItem it{};
+        it.first_i = (uint64_t)first_i[k];
+        it.before_first = iss::digits_before(it.first_i);
+        it.text_off = bytes;
+        it.first_pair = first_pair[k];
+        it.rec_first = n_records;
+        it.id_off = (uint32_t)ids.size();
+        it.id_len = (int32_t)idlen;
+        ids.append(record_ids[k], idlen);
+        const size_t C = idlen + (size_t)A.cpu_len + 2 * (size_t)M.RL + 10;
+        bytes += (size_t)n_pairs[k] * C + (size_t)(iss::digits_before(it.first_i + (uint64_t)n_pairs[k]) - it.before_first);
+        n_records += n_pairs[k];
+        if (n_pairs[k] > most) {
+            most = n_pairs[k];
+            int dg = 1;
+            for (uint64_t v = it.first_i + (uint64_t)n_pairs[k] - 1; v >= 10; v /= 10) ++dg;
+            rec_len = C + (size_t)dg;
+        }
+        items.push_back(it);
+    }
+    if (items.empty()) return 0;
+    A.n_items = (int32_t)items.size();
+    A.n_records = n_records;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     FastqPipe &q = ctx->fq;
-    const iss::DevModel &M = ctx->M;
     if (!q.ready) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&q.copy_stream, hipStreamNonBlocking));
         for (auto &e : q.ev_fmt) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : q.ev_copy) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        void *p = nullptr;
-        HIP_TRY(ctx, hipMalloc(&p, 2 * FASTQ_ID_MAX));
-        q.d_id = static_cast<char *>(p);
         q.stop = false;
         q.writer = std::thread(fastq_writer_loop, ctx);
         q.ready = true;
     }
     if (ctx->overlap) { int rc_ = sync_all(ctx); if (rc_) return rc_; }  // fix-ups may still run on the indel stream
-    iss::FastqArgs A{};
-    A.cpu_len = (int32_t)snprintf(A.cpu, sizeof A.cpu, "%d", cpu_number);
-    A.id_len = (int32_t)idlen;
-    A.pitch = M.pitch;
-    A.RL = M.RL;
-    A.n_pairs = n_pairs;
-    A.first_i = (uint64_t)first_i;
-    A.before_first = iss::digits_before(A.first_i);
-    const size_t C = idlen + (size_t)A.cpu_len + 2 * (size_t)M.RL + 10;
-    const size_t bytes = (size_t)n_pairs * C + (size_t)(iss::digits_before(A.first_i + (uint64_t)n_pairs) - A.before_first);
     if (q.fd[0] != fd_r1 || q.fd[1] != fd_r2) {
         { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
         q.fd[0] = fd_r1; q.fd[1] = fd_r2;
@@ -2078,30 +2109,48 @@ int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, in
         q.cv.wait(lk, [&] { return !q.busy[slot]; });
         if (!q.error.empty()) { const std::string e = q.error; q.error.clear(); return fail(ctx, ISS_E_IO, e); }
     }
-    q.id_keep[slot].assign(record_id, idlen);
-    char *d_id = q.d_id + (size_t)slot * FASTQ_ID_MAX;
-    if (idlen) HIP_TRY(ctx, hipMemcpyAsync(d_id, q.id_keep[slot].data(), idlen, hipMemcpyHostToDevice, ctx->stream));
-    A.id = d_id;
+    if (items.size() > q.items_cap[slot] || ids.size() + 1 > q.ids_cap[slot]) {  // (the slot is free: nothing reads its tables)
+        if (q.h_items[slot]) (void)hipHostFree(q.h_items[slot]);
+        if (q.d_items[slot]) (void)hipFree(q.d_items[slot]);
+        if (q.h_ids[slot]) (void)hipHostFree(q.h_ids[slot]);
+        if (q.d_ids[slot]) (void)hipFree(q.d_ids[slot]);
+        q.h_items[slot] = q.d_items[slot] = nullptr;
+        q.h_ids[slot] = q.d_ids[slot] = nullptr;
+        const size_t ic = std::max<size_t>(64, 2 * items.size()), dc = std::max<size_t>(8192, 2 * (ids.size() + 1));
+        void *v = nullptr;
+        HIP_TRY(ctx, hipHostMalloc(&v, ic * sizeof(iss::FastqItem), hipHostMallocDefault));
+        q.h_items[slot] = static_cast<iss::FastqItem *>(v);
+        HIP_TRY(ctx, hipMalloc(&v, ic * sizeof(iss::FastqItem)));
+        q.d_items[slot] = static_cast<iss::FastqItem *>(v);
+        HIP_TRY(ctx, hipHostMalloc(&v, dc, hipHostMallocDefault));
+        q.h_ids[slot] = static_cast<char *>(v);
+        HIP_TRY(ctx, hipMalloc(&v, dc));
+        q.d_ids[slot] = static_cast<char *>(v);
+        q.items_cap[slot] = ic;
+        q.ids_cap[slot] = dc;
+    }
+    memcpy(q.h_items[slot], items.data(), items.size() * sizeof(iss::FastqItem));
+    memcpy(q.h_ids[slot], ids.data(), ids.size());
+    HIP_TRY(ctx, hipMemcpyAsync(q.d_items[slot], q.h_items[slot], items.size() * sizeof(iss::FastqItem), hipMemcpyHostToDevice, ctx->stream));
+    if (!ids.empty()) HIP_TRY(ctx, hipMemcpyAsync(q.d_ids[slot], q.h_ids[slot], ids.size(), hipMemcpyHostToDevice, ctx->stream));
+    A.items = q.d_items[slot];
+    A.ids = q.d_ids[slot];
     for (int m = 0; m < 2; ++m) {
-        A.base[m] = ctx->out[2 * m] + (size_t)first_pair * M.pitch;
-        A.qual[m] = ctx->out[2 * m + 1] + (size_t)first_pair * M.pitch;
+        A.base[m] = ctx->out[2 * m];
+        A.qual[m] = ctx->out[2 * m + 1];
         A.text[m] = q.d_text[slot][m];
     }
-    hipLaunchKernelGGL(iss::k_fastq_format, dim3((unsigned)((n_pairs + iss::FASTQ_WAVES - 1) / iss::FASTQ_WAVES), 2),
+    hipLaunchKernelGGL(iss::k_fastq_format, dim3((unsigned)((n_records + iss::FASTQ_WAVES - 1) / iss::FASTQ_WAVES), 2),
                        dim3(64 * iss::FASTQ_WAVES), 0, ctx->stream, A);
     if (q.gzip) {  // the text stays on the device: histogram -> code -> block sizes + CRCs -> offsets -> bits (iss_deflate.hip.h)
         iss::DeflateArgs D{};
         D.n_bytes = bytes;
         D.n_blocks = n_blocks;
         D.out_cap = q.comp_cap;
-        {   // the record length most records of this batch have: the distance of the "previous record" matches
-            int dg = 1;
-            for (uint64_t v = A.first_i + (uint64_t)n_pairs - 1; v >= 10; v /= 10) ++dg;
-            const size_t rec = C + (size_t)dg;
-            if (rec >= 8 && rec <= 32768 && !getenv("ISS_DEFLATE_RUNS_ONLY")) {
-                D.dist = (uint32_t)rec;
-                iss::deflate_dist_code(D.dist, &D.dist_sym, &D.dist_ebits, &D.dist_eval);
-            }
+        // the record length most records of this call have: the distance of the "previous record" matches
+        if (rec_len >= 8 && rec_len <= 32768 && !getenv("ISS_DEFLATE_RUNS_ONLY")) {
+            D.dist = (uint32_t)rec_len;
+            iss::deflate_dist_code(D.dist, &D.dist_sym, &D.dist_ebits, &D.dist_eval);
         }
         for (int m = 0; m < 2; ++m) {
             D.text[m] = q.d_text[slot][m];
@@ -2147,6 +2196,18 @@ int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, in
     }
     q.next ^= 1;
     return 0;
+}
+
+int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, int64_t first_i, int32_t cpu_number,
+                   int64_t first_pair, int64_t n_pairs, int32_t n_threads) {
+    if (!record_id) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: bad argument");
+    return fastq_emit_core(ctx, fd_r1, fd_r2, 1, &record_id, &first_i, &first_pair, &n_pairs, cpu_number, n_threads);
+}
+
+int iss_fastq_emit_batch(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, const char *const *record_ids, const int64_t *first_i,
+                         const int64_t *first_pair, const int64_t *n_pairs, int32_t cpu_number) {
+    if (n_items && (!record_ids || !first_i || !first_pair || !n_pairs)) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit_batch: bad argument");
+    return fastq_emit_core(ctx, fd_r1, fd_r2, n_items, record_ids, first_i, first_pair, n_pairs, cpu_number, 1);
 }
 
 int iss_fastq_flush(iss_ctx *ctx) {

@@ -202,6 +202,16 @@ class ReadEngine(object):
         self._check(self._lib.iss_fastq_emit(self._ctx, int(fd_r1), int(fd_r2), str(record_id).encode(), int(first_i),
                                              int(cpu_number), int(first_pair), int(n_pairs), int(n_threads)))
 
+    def fastq_emit_batch(self, fd_r1, fd_r2, items, cpu_number):
+        """items: (record id, first pair id, first output row, pairs) per work item -- one text job for all of them."""
+        n = len(items)
+        ids = (C.c_char_p * n)(*[str(it[0]).encode() for it in items])
+        first_i = np.array([it[1] for it in items], dtype=np.int64)
+        first_pair = np.array([it[2] for it in items], dtype=np.int64)
+        n_pairs = np.array([it[3] for it in items], dtype=np.int64)
+        self._check(self._lib.iss_fastq_emit_batch(self._ctx, int(fd_r1), int(fd_r2), n, ids, first_i.ctypes.data,
+                                                   first_pair.ctypes.data, n_pairs.ctypes.data, int(cpu_number)))
+
     def fastq_compress(self, on=True):
         """`--compress` on the device: every fastq_emit appends one gzip member per file instead of text."""
         self._check(self._lib.iss_fastq_compress(self._ctx, 1 if on else 0))

@@ -265,14 +265,15 @@ def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_ha
         eng.generate_batch([p[1] for p in pending], [p[2] for p in pending], first_ordinal=w.ordinal, seed=w.seed,
                            sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0)
         rows = eng.mutations() if w.store_mutations else None
-        row = 0
+        row, emit = 0, []
         for rid, _gid, n, first_i in pending:
             if rows is not None:  # rows come back in (pair, mate, ...) order: this item's are contiguous
                 sel = rows[(rows["pair"] >= row) & (rows["pair"] < row + n)].copy()
                 sel["pair"] -= row
                 write_mutations(sel, mutations_handle, rid, first_i, w.cpu_number)
-            eng.fastq_emit(forward_handle.fileno(), reverse_handle.fileno(), rid, first_i, w.cpu_number, row, n, n_threads=1)
+            emit.append((rid, first_i, row, n))
             row += n
+        eng.fastq_emit_batch(forward_handle.fileno(), reverse_handle.fileno(), emit, w.cpu_number)  # one text job
         w.ordinal += row
         pending, cur = [], 0
 
