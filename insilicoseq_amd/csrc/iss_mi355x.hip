@@ -160,6 +160,7 @@ struct iss_ctx {
     size_t d_items_cap = 0;
     uint64_t batch_seq = 0;
     bool comm_exceptions = false;
+    int64_t comm_cap = 0;  // bases the arena buffers hold
     uint64_t chunk_seq = 0;
     std::string last_error;
     // model
@@ -1422,6 +1423,7 @@ static void free_community(iss_ctx *ctx) {
     if (ctx->comm_ascii) (void)hipFree(ctx->comm_ascii);
     ctx->comm_packed = ctx->comm_mask = nullptr;
     ctx->comm_ascii = nullptr;
+    ctx->comm_cap = 0;
     ctx->comm_ids.clear();
     ctx->comm_items.clear();
 }
@@ -1450,47 +1452,69 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
         return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
     if (total == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // ---- the records side by side in one arena (kept until another set of records is asked for)
     const std::vector<int32_t> ids(genome_ids, genome_ids + n_items);
-    if (ids != ctx->comm_ids) {
-        { int rc_ = sync_all(ctx); if (rc_) return rc_; }
-        free_community(ctx);
-        std::vector<iss::BatchItem> items((size_t)n_items);
-        std::vector<int64_t> place(ctx->genomes.size(), -1);  // a record used by several items stands once
-        int64_t coord = 64;
-        bool exceptions = false;
-        for (int32_t k = 0; k < n_items; ++k) {
-            const Genome &G = ctx->genomes[ids[k]];
-            if (place[ids[k]] < 0) {
-                place[ids[k]] = coord;
-                coord += ((G.L + 31) / 32) * 32 + 64;  // zero padding between records (k_main's windows overhang by a few bases)
+    bool single = true;
+    for (int32_t k = 1; k < n_items; ++k) single &= ids[(size_t)k] == ids[0];
+    std::vector<iss::BatchItem> call_items;
+    iss::DevGenome dg{};
+    bool any_exceptions = false;
+    if (single) {
+        // one record (a batch cut inside a long work item): its own buffers are the "arena", at offset 0
+        const Genome &G = ctx->genomes[ids[0]];
+        call_items.assign((size_t)n_items, iss::BatchItem{0, G.L, G.has_exceptions ? 1 : 0, 0});
+        dg = iss::DevGenome{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
+        any_exceptions = G.has_exceptions;
+    } else {
+        // ---- the records side by side in one arena (kept until another list of records is asked for; the buffers are
+        // kept as long as they are large enough -- refilling them is ordered on the stream behind their last readers)
+        if (ids != ctx->comm_ids) {
+            std::vector<iss::BatchItem> items((size_t)n_items);
+            std::vector<int64_t> place(ctx->genomes.size(), -1);  // a record used by several items stands once
+            int64_t coord = 64;
+            bool exceptions = false;
+            for (int32_t k = 0; k < n_items; ++k) {
+                const Genome &G = ctx->genomes[ids[k]];
+                if (place[ids[k]] < 0) {
+                    place[ids[k]] = coord;
+                    coord += ((G.L + 31) / 32) * 32 + 64;  // zero padding between records (k_main's windows overhang by a few bases)
+                }
+                items[(size_t)k] = iss::BatchItem{place[ids[k]], G.L, G.has_exceptions ? 1 : 0, 0};
+                exceptions |= G.has_exceptions;
             }
-            items[(size_t)k] = iss::BatchItem{place[ids[k]], G.L, G.has_exceptions ? 1 : 0, 0};
-            exceptions |= G.has_exceptions;
+            if (coord >= ((int64_t)1 << 31) - 4096) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: the records of one call must stay below 2^31 bases");
+            if (ctx->overlap) { int rc_ = sync_all(ctx); if (rc_) return rc_; }  // (readers on the indel stream)
+            if (coord > ctx->comm_cap) {
+                { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+                free_community(ctx);
+                const int64_t cap = coord + coord / 4;
+                void *p = nullptr;
+                HIP_TRY(ctx, hipMalloc(&p, ((size_t)cap / 16 + 8) * 4));
+                ctx->comm_packed = static_cast<uint32_t *>(p);
+                HIP_TRY(ctx, hipMalloc(&p, ((size_t)cap / 32 + 8) * 4));
+                ctx->comm_mask = static_cast<uint32_t *>(p);
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)cap + 64));
+                ctx->comm_ascii = static_cast<uint8_t *>(p);
+                ctx->comm_cap = cap;
+            }
+            ctx->comm_ids.clear();  // (not valid while it is being refilled)
+            HIP_TRY(ctx, hipMemsetAsync(ctx->comm_packed, 0, ((size_t)coord / 16 + 8) * 4, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->comm_mask, 0, ((size_t)coord / 32 + 8) * 4, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->comm_ascii, 'A', (size_t)coord + 64, ctx->stream));
+            for (size_t g = 0; g < place.size(); ++g) {
+                if (place[g] < 0) continue;
+                const Genome &G = ctx->genomes[g];
+                const size_t w_mk = (size_t)(G.L + 31) / 32;
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_packed + 2 + place[g] / 16, G.packed, 2 * w_mk * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_mask + 2 + place[g] / 32, G.mask, w_mk * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_ascii + place[g], G.ascii, (size_t)G.L, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            ctx->comm_ids = ids;
+            ctx->comm_items = items;
+            ctx->comm_exceptions = exceptions;
         }
-        if (coord >= ((int64_t)1 << 31) - 4096) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: the records of one call must stay below 2^31 bases");
-        void *p = nullptr;
-        const size_t n_pk = (size_t)coord / 16 + 8, n_mk = (size_t)coord / 32 + 8;
-        HIP_TRY(ctx, hipMalloc(&p, n_pk * 4));
-        ctx->comm_packed = static_cast<uint32_t *>(p);
-        HIP_TRY(ctx, hipMalloc(&p, n_mk * 4));
-        ctx->comm_mask = static_cast<uint32_t *>(p);
-        HIP_TRY(ctx, hipMalloc(&p, (size_t)coord + 64));
-        ctx->comm_ascii = static_cast<uint8_t *>(p);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->comm_packed, 0, n_pk * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->comm_mask, 0, n_mk * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->comm_ascii, 'A', (size_t)coord + 64, ctx->stream));
-        for (size_t g = 0; g < place.size(); ++g) {
-            if (place[g] < 0) continue;
-            const Genome &G = ctx->genomes[g];
-            const size_t w_mk = (size_t)(G.L + 31) / 32;
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_packed + 2 + place[g] / 16, G.packed, 2 * w_mk * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_mask + 2 + place[g] / 32, G.mask, w_mk * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_ascii + place[g], G.ascii, (size_t)G.L, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        ctx->comm_ids = ids;
-        ctx->comm_items = items;
-        ctx->comm_exceptions = exceptions;
+        call_items = ctx->comm_items;
+        dg = iss::DevGenome{ctx->comm_packed + 2, ctx->comm_mask + 2, ctx->comm_ascii, 0, ctx->comm_exceptions ? 1 : 0};
+        any_exceptions = ctx->comm_exceptions;
     }
     if ((size_t)n_items + 1 > ctx->d_items_cap) {
         { int rc_ = sync_all(ctx); if (rc_) return rc_; }
@@ -1513,12 +1537,11 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
     }
     const int set = (int)(ctx->batch_seq & 1u);
     if (ctx->batch_seq >= 2) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_items[set]));  // the call before last is done with this set
-    memcpy(ctx->h_items[set], ctx->comm_items.data(), (size_t)n_items * sizeof(iss::BatchItem));
+    memcpy(ctx->h_items[set], call_items.data(), (size_t)n_items * sizeof(iss::BatchItem));
     memcpy(ctx->h_item_first[set], first.data(), ((size_t)n_items + 1) * sizeof(int64_t));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_items[set], ctx->h_items[set], (size_t)n_items * sizeof(iss::BatchItem), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_item_first[set], ctx->h_item_first[set], ((size_t)n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    const iss::DevGenome dg{ctx->comm_packed + 2, ctx->comm_mask + 2, ctx->comm_ascii, 0, ctx->comm_exceptions ? 1 : 0};
-    const int rc = generate_core(ctx, dg, ctx->comm_exceptions, ctx->d_items[set], ctx->d_item_first[set], n_items, total, first_ordinal,
+    const int rc = generate_core(ctx, dg, any_exceptions, ctx->d_items[set], ctx->d_item_first[set], n_items, total, first_ordinal,
                                  seed, sequence_type, gc_bias, out_first_pair);
     if (rc) return rc;
     { int rc_ = sync_indel_into_main(ctx); if (rc_) return rc_; }
@@ -1526,7 +1549,7 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
     ++ctx->batch_seq;
     ctx->last_first.assign(first.begin(), first.end());
     ctx->last_off.resize((size_t)n_items);
-    for (int32_t k = 0; k < n_items; ++k) ctx->last_off[(size_t)k] = ctx->comm_items[(size_t)k].off;
+    for (int32_t k = 0; k < n_items; ++k) ctx->last_off[(size_t)k] = call_items[(size_t)k].off;
     return 0;
 }
 
