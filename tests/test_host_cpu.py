@@ -364,3 +364,54 @@ def test_abundance_distributions_match_reference(case, tmp_path):
         dic = app.coverage_scaling(int(flags[3]), app.ABUNDANCE[flags[1]](ids), records, dense_model("hiseq").read_length)
         app._write_distribution(dic, out, "coverage")
         assert open(out + "_coverage.txt", "rb").read() == z["coverage"].tobytes()
+
+
+def test_batched_worker_loop_cuts_batches_across_items(monkeypatch):
+    """_simulate_work_batched (the worker's loop on the parallel path) against a recording stand-in for the engine:
+    batches of BATCH_PAIRS pairs cut across work items, pair ids continuing inside an item, running ordinals, records
+    not longer than the read length skipped with the reference's two warnings, one emit job per batch."""
+    import io
+
+    from insilicoseq_amd import generator as G
+
+    class FakeEngine:
+        read_length = 100
+
+        def __init__(self):
+            self.calls = []
+
+        def generate_batch(self, gids, counts, first_ordinal, seed, sequence_type, gc_bias, out_first_pair):
+            self.calls.append(("gen", list(gids), list(counts), first_ordinal))
+
+        def fastq_emit_batch(self, fd1, fd2, items, cpu):
+            self.calls.append(("emit", list(items), cpu))
+
+    class FakeWorker:
+        BATCH_PAIRS = 100
+        GENOME_BUDGET = 10**9
+
+        def __init__(self):
+            self.engine = FakeEngine()
+            self.ordinal, self.seed, self.cpu_number, self.store_mutations = 7, 5, 3, False
+            self.ids = {}
+
+        def needs_room_for(self, record):
+            return False
+
+        def genome_id(self, record):
+            return self.ids.setdefault(record.id, len(self.ids))
+
+    recs = [G.Record("A" * 500, id="r0"), G.Record("C" * 100, id="short"), G.Record("G" * 300, id="r2"), G.Record("T" * 999, id="r3")]
+    work = [(recs[0], 30, "default"), (recs[1], 50, "default"), (recs[2], 0, "default"), (recs[2], 170, "default"),
+            (recs[3], 1, "default"), (recs[0], 99, "default")]
+    w = FakeWorker()
+    f1, f2 = open(os.devnull, "wb"), open(os.devnull, "wb")
+    G._simulate_work_batched(w, work, f1, f2, io.StringIO(), "metagenomics", False)
+    gens = [c for c in w.engine.calls if c[0] == "gen"]
+    emits = [c for c in w.engine.calls if c[0] == "emit"]
+    assert [c[2] for c in gens] == [[30, 70], [100], [1, 99]] and [c[3] for c in gens] == [7, 107, 207]
+    assert [c[1] for c in gens] == [[0, 1], [1], [2, 0]]
+    assert emits[0][1] == [("r0", 0, 0, 30), ("r2", 0, 30, 70)]
+    assert emits[1][1] == [("r2", 70, 0, 100)]          # pair ids continue inside the work item
+    assert emits[2][1] == [("r3", 0, 0, 1), ("r0", 0, 1, 99)]  # ... and restart for the next item of the same record
+    assert w.ordinal == 7 + 300 and all(e[2] == 3 for e in emits)
