@@ -415,3 +415,36 @@ def test_batched_worker_loop_cuts_batches_across_items(monkeypatch):
     assert emits[1][1] == [("r2", 70, 0, 100)]          # pair ids continue inside the work item
     assert emits[2][1] == [("r3", 0, 0, 1), ("r0", 0, 1, 99)]  # ... and restart for the next item of the same record
     assert w.ordinal == 7 + 300 and all(e[2] == 3 for e in emits)
+
+
+@pytest.mark.parametrize("case", ["halfnormal", "zero_inflated_lognormal", "coverage_lognormal", "coverage_halfnormal",
+                                  "abundance_file", "coverage_file", "readcount_file"])
+def test_work_divider_matches_reference_cli_inputs(case):
+    """The pair counts per (record, worker) that the reference's FASTQ ids imply, for every kind of abundance / coverage /
+    read-count input (`--cpus 2`), against generate_work_divider fed with what the reference run wrote or was given."""
+    from insilicoseq_amd.generator import generate_work_divider, parse_fasta
+
+    z = np.load(os.path.join(GOLDEN, "generate", "cli_%s.npz" % case))
+    flags = str(z["flags"]).split()
+    records = list(parse_fasta(os.path.join(GOLDEN, "genomes.fasta")))
+    dense = dense_model("hiseq")
+    text = (z["given"] if z["given"].size else (z["coverage"] if z["has_coverage"] else z["abundance"])).tobytes().decode()
+    table = {line.split()[0]: float(line.split()[1]) for line in text.splitlines() if line.strip()}
+    coverage = flags[1] if flags[0] == "--coverage" else None
+    coverage_file = "given" if flags[0] == "--coverage_file" else None
+    readcount = {k: int(v) for k, v in table.items()} if flags[0] == "--readcount_file" else None
+    n_reads = sum(readcount.values()) if readcount else int(flags[flags.index("-n") + 1])
+    chunk_size = -((n_reads // 2) // -2)
+    chunks = list(generate_work_divider(records, readcount, None if readcount else table, n_reads, coverage, coverage_file, dense,
+                                        "x", chunk_size))
+    expect = {}
+    for cpu, chunk in enumerate(chunks[:2]):
+        for rec, n, _ in chunk:
+            if len(rec.seq) > dense.read_length:
+                expect[(rec.id, cpu)] = expect.get((rec.id, cpu), 0) + n
+    seen = {}
+    for line in z["r1"].tobytes().decode().splitlines()[0::4]:
+        m = re.match(r"@(.+)_(\d+)_(\d+)/1$", line)
+        key = (m.group(1), int(m.group(3)))
+        seen[key] = seen.get(key, 0) + 1
+    assert seen == expect
