@@ -448,3 +448,29 @@ def test_work_divider_matches_reference_cli_inputs(case):
         key = (m.group(1), int(m.group(3)))
         seen[key] = seen.get(key, 0) + 1
     assert seen == expect
+
+
+def test_concatenate_rank_files(tmp_path):
+    """util.concatenate over the workers' temp files (iss/app.py:123-133, iss/util.py:213-234): rank order, the VCF
+    header line, renamed outputs for workers that wrote gzip members, temp files removed, a missing file is an error."""
+    from insilicoseq_amd.distributed import VCF_HEADER, concatenate_rank_files, temp_prefix
+
+    out = str(tmp_path / "run")
+
+    def make(world, suffixes):
+        for r in range(world):
+            for s in suffixes:
+                with open(temp_prefix(out, r) + s, "wb") as fh:
+                    fh.write(("%s of rank %d\n" % (s, r)).encode() * (r + 1))
+
+    make(3, ("_R1.fastq", "_R2.fastq", ".vcf"))
+    concatenate_rank_files(out, 3, suffixes=("_R1.fastq", "_R2.fastq", ".vcf"), headers={".vcf": VCF_HEADER})
+    assert open(out + "_R1.fastq").read() == "".join("_R1.fastq of rank %d\n" % r * (r + 1) for r in range(3))
+    assert open(out + ".vcf").read() == VCF_HEADER + "\n" + "".join(".vcf of rank %d\n" % r * (r + 1) for r in range(3))
+    assert sorted(os.listdir(str(tmp_path))) == ["run.vcf", "run_R1.fastq", "run_R2.fastq"]
+    make(2, ("_R1.fastq", "_R2.fastq"))
+    concatenate_rank_files(out, 2, out_suffixes={"_R1.fastq": "_R1.fastq.gz", "_R2.fastq": "_R2.fastq.gz"})
+    assert open(out + "_R2.fastq.gz").read() == "_R2.fastq of rank 0\n" + "_R2.fastq of rank 1\n" * 2
+    make(1, ("_R1.fastq", "_R2.fastq"))
+    with pytest.raises(FileNotFoundError):  # fewer chunks than workers (SURVEY.md Appendix A-9)
+        concatenate_rank_files(out, 2)
