@@ -474,3 +474,14 @@ def test_concatenate_rank_files(tmp_path):
     make(1, ("_R1.fastq", "_R2.fastq"))
     with pytest.raises(FileNotFoundError):  # fewer chunks than workers
         concatenate_rank_files(out, 2)
+
+
+def test_device_code_has_no_stale_scc_select():
+    """tools/scan_isa.py: hipcc 7.2 lowered a uniform 64-bit `min` in the deflate kernels to a v_cmp followed by an
+    s_cselect on a stale SCC (wrong block sizes); the source avoids the construct now and the build is scanned for it."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("scan_isa", os.path.join(ROOT, "tools", "scan_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0
