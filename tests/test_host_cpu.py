@@ -485,3 +485,36 @@ def test_device_code_has_no_stale_scc_select():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main() == 0
+
+
+def test_write_mutations_format():
+    """The VCF rows of write_mutations (iss/generator.py:598-620, __init__.py:98-108, 197-221) against a row-by-row
+    restatement: substitutions carry their quality, insertions alt = ref + letter, deletions alt '.'."""
+    import io
+
+    from insilicoseq_amd.engine import MUT_DTYPE
+    from insilicoseq_amd.generator import write_mutations
+
+    r = np.random.RandomState(1)
+    n = 5000
+    rows = np.zeros(n, dtype=MUT_DTYPE)
+    rows["pair"] = np.sort(r.randint(0, 3000, n))
+    rows["mate"] = r.randint(0, 2, n)
+    rows["type"] = r.choice([0, 0, 0, 1, 2], n)
+    rows["position"] = r.randint(0, 301, n)
+    rows["ref"] = r.choice(list(b"ACGTNacgt"), n)
+    rows["alt"] = r.choice(list(b"ACGT."), n)
+    rows["quality"] = r.randint(-1, 41, n)
+    expect = []
+    for m in rows:
+        ref, alt = chr(m["ref"]), chr(m["alt"])
+        alt = ref + alt if m["type"] == 1 else alt
+        qual = str(int(m["quality"])) if m["type"] == 0 else "."
+        expect.append("\t".join(["rec|1_%d_%d/%d" % (77 + int(m["pair"]), 12, 1 + int(m["mate"])), str(int(m["position"]) + 1), ".",
+                                 ref, alt, qual, "", ""]) + "\n")
+    got = io.StringIO()
+    write_mutations(rows, got, "rec|1", 77, 12)
+    assert got.getvalue() == "".join(expect)
+    got = io.StringIO()
+    write_mutations(rows[:0], got, "x", 0, 0)
+    assert got.getvalue() == ""
