@@ -148,10 +148,12 @@ class ReadEngine(object):
     def mutations(self):
         """Rows of the last generate() call, in the reference's order (structured array, see iss_mutation)."""
         cap = getattr(self, "_pmut_cap", 0)
-        out = np.zeros(cap, dtype=MUT_DTYPE)
+        buf = getattr(self, "_pmut_buf", None)
+        if buf is None or buf.size < cap:  # (one landing buffer per engine: tens of MB, not per call)
+            buf = self._pmut_buf = np.empty(cap, dtype=MUT_DTYPE)
         n = C.c_int64(0)
-        self._check(self._lib.iss_mutations_download(self._ctx, out.ctypes.data, cap, C.byref(n)))
-        return out[: n.value]
+        self._check(self._lib.iss_mutations_download(self._ctx, buf.ctypes.data, cap, C.byref(n)))
+        return buf[: n.value].copy()
 
     # ------------------------------------------------------------------ reference-compatible MT mode
     def seed_mt(self, seed):

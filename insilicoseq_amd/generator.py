@@ -265,10 +265,12 @@ def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_ha
         eng.generate_batch([p[1] for p in pending], [p[2] for p in pending], first_ordinal=w.ordinal, seed=w.seed,
                            sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0)
         rows = eng.mutations() if w.store_mutations else None
+        pairs = rows["pair"] if rows is not None else None  # ascending: the rows come back in (pair, mate, ...) order
         row, emit = 0, []
         for rid, _gid, n, first_i in pending:
-            if rows is not None:  # rows come back in (pair, mate, ...) order: this item's are contiguous
-                sel = rows[(rows["pair"] >= row) & (rows["pair"] < row + n)].copy()
+            if rows is not None:  # this item's rows are contiguous
+                lo, hi = np.searchsorted(pairs, row, "left"), np.searchsorted(pairs, row + n, "left")
+                sel = rows[lo:hi].copy()
                 sel["pair"] -= row
                 write_mutations(sel, mutations_handle, rid, first_i, w.cpu_number)
             emit.append((rid, first_i, row, n))
