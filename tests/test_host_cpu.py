@@ -518,3 +518,20 @@ def test_write_mutations_format():
     got = io.StringIO()
     write_mutations(rows[:0], got, "x", 0, 0)
     assert got.getvalue() == ""
+
+
+def test_parse_fasta_fast_path_equals_line_parser(tmp_path):
+    """parse_fasta on a path (records cut at header lines, line ends removed in one pass) == the line-by-line parser:
+    CRLF, blank lines, text before the first header, empty ids, white space inside sequence lines, no final newline."""
+    import io
+
+    from insilicoseq_amd.generator import _parse_fasta_lines, parse_fasta
+
+    cases = [b"", b"\n\n", b">a\nACGT\n", b">a desc here\r\nAC\r\nGT\r\n>b\r\n\r\nTT", b"junk\nmore\n>x\nAA\n\n>y z\nCC\n>\nGG\n>empty\n",
+             b">s\nA C\n G\tT \n>t\nAAA", b">only", b"ACGT\n", b">a\nAC>GT\n>b\nT", b"\n>a\nAC\n", b">a\n" + b"ACGTacgtNN\n" * 5000 + b">b\nT"]
+    for k, data in enumerate(cases):
+        path = tmp_path / ("c%d.fasta" % k)
+        path.write_bytes(data)
+        fast = [(r.id, r.description, r.seq) for r in parse_fasta(str(path))]
+        slow = [(r.id, r.description, r.seq) for r in _parse_fasta_lines(io.StringIO(data.decode()))]
+        assert fast == slow, k
