@@ -210,6 +210,11 @@ def main():
             out["end_to_end_gzip"] = end_to_end(dense, records, abundance, args.e2e_pairs, compress=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dense, work, args.cpu_sample_pairs)
+            try:  # informational: every host core at once
+                if args.indel is None:
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(model_path, args.n_genomes, work, args.cpu_sample_pairs // 3)
+            except Exception as e:
+                out["cpu_baseline_all_cores"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
@@ -301,5 +306,64 @@ def cpu_baseline(dense, work, sample_pairs):
     }
 
 
+def _cpu_worker_main(argv):
+    """`python bench.py --cpu-worker <model> <n_genomes> <cpu> <pairs per genome ...>`: one process of the all-cores CPU
+    leg -- the oracle on its share of the sample with its own pair of MT19937 streams (seed + cpu_number, like a reference
+    worker).  Prints `pairs seconds`."""
+    from insilicoseq_amd.model import DenseModel
+    from oracle import oracle as O
+
+    model_path, n_genomes, cpu = argv[0], int(argv[1]), int(argv[2])
+    shares = [int(x) for x in argv[3:]]
+    dense = DenseModel.load(model_path)
+    genomes = synthetic_genomes(n_genomes, GENOME_LEN, 123)
+    orc = O.Oracle(dense)
+    rng = O.Rng().seed_mt(SEED + cpu)
+    t0 = time.perf_counter()
+    done = 0
+    for g, k in zip(genomes, shares):
+        if k > 0:
+            res = orc.simulate(rng, g, k)
+            assert res["status"] == 0
+            done += res["n_done"]
+    print("%d %.6f" % (done, time.perf_counter() - t0), flush=True)
+
+
+def cpu_baseline_all_cores(model_path, n_genomes, work, pairs_per_core, limit_s=90.0):
+    """The same CPU oracle on every host core at once (one process per core, each a reference-style worker with its own
+    streams): the box-level CPU rate the GPU number stands beside.  Bounded: pairs_per_core pairs per process, and the
+    whole leg is abandoned (its processes killed by pid) after limit_s seconds."""
+    import subprocess
+
+    cores = max(1, min(os.cpu_count() or 1, 256))
+    total = sum(n for _, n in work)
+    shares = [str(max(1, int(round(pairs_per_core * n / total)))) for _, n in work]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", model_path, str(n_genomes), str(c)] + shares,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT) for c in range(cores)]
+    res = []
+    try:
+        for p in procs:
+            left = max(1.0, limit_s - (time.perf_counter() - t0))
+            out, _ = p.communicate(timeout=left)
+            if p.returncode != 0:
+                raise RuntimeError("a CPU worker failed")
+            a, b = out.decode().split()
+            res.append((int(a), float(b)))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    wall = time.perf_counter() - t0
+    done = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    return {"value": done / busy, "unit": "read-pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d pairs on %d processes (%d each), slowest process %.1f s, %.1f s with start-up" % (
+                done, cores, sum(int(x) for x in shares), busy, wall)}
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        _cpu_worker_main(sys.argv[2:])
+        sys.exit(0)
     main()
