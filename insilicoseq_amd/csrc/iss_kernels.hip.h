@@ -6,9 +6,10 @@
 //   gen_phred_scores/random_insert_size iss/error_models/kde.py:52-98
 //   mut_sequence                       iss/error_models/__init__.py:69-112
 //
-// Kernel plan (one iss_generate call = up to four launches on one stream):
+// Kernel plan (one iss_generate / iss_generate_batch call = up to four launches on one stream; in a batch call the
+// records stand side by side in one arena and the pair descriptors carry arena coordinates):
 //   k_setup  : 1 lane / pair   -> PairDesc {forward_start, reverse_end, bin slots, attempt, insert}
-//   k_main   : persistent workgroups (1024 lanes, one per CU); the compressed per-position quality
+//   k_main   : persistent workgroups (1024 lanes, two per CU); the compressed per-position quality
 //              CDF rows of a position tile are staged ONCE per workgroup in LDS; 1 lane /
 //              (pair, 4 consecutive positions, both mates): two Philox calls give the sixteen
 //              16-bit leading digits of its 16 uniforms; CDF inversion = LDS guide byte + packed

@@ -1,6 +1,9 @@
 // iss_mi355x.hip -- C-ABI shared library of the MI355X read-generation engine (see include/iss_mi355x.h).
-// Host side: context, HBM uploads (model tables, genomes), launch sequencing on one HIP stream,
-// HIP-event timing, downloads, FASTQ formatting.  Device side: iss_kernels.hip.h.
+// Host side: context, HBM uploads (model tables, genomes; small records from an arena), launch sequencing on one HIP
+// stream for one record (iss_generate) or a whole work list (iss_generate_batch: records side by side in one arena),
+// HIP-event timing, downloads, the FASTQ pipeline (text or gzip members built on the device, copy stream, writer thread).
+// Device side: iss_kernels.hip.h (the Philox path), iss_mt_compat.hip.h (the reference's Mersenne-Twister streams),
+// iss_fastq.hip.h, iss_deflate.hip.h.
 #include "iss_mi355x.h"
 
 #include <hip/hip_runtime.h>
