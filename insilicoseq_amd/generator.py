@@ -287,9 +287,29 @@ def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_ha
         nonlocal pending, cur
         if not pending:
             return
-        eng.generate_batch([p[1] for p in pending], [p[2] for p in pending], first_ordinal=w.ordinal, seed=w.seed,
-                           sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0)
-        rows = eng.mutations() if w.store_mutations else None
+        rows = None
+        try:
+            eng.generate_batch([p[1] for p in pending], [p[2] for p in pending], first_ordinal=w.ordinal, seed=w.seed,
+                               sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0)
+            if w.store_mutations:
+                rows = eng.mutations()
+        except _native.EngineError as e:
+            if e.code != _native.E_INVALID or "2^31" not in str(e):
+                raise
+            # records too long to stand side by side in one arena: the same rows from one call per item
+            eng.reserve(sum(p[2] for p in pending))
+            parts, row, ordinal = [], 0, w.ordinal
+            for _rid, gid, n, _first_i in pending:
+                eng.generate(gid, n, first_ordinal=ordinal, seed=w.seed, sequence_type=sequence_type, gc_bias=gc_bias,
+                             out_first_pair=row)
+                if w.store_mutations:
+                    part = eng.mutations()
+                    part["pair"] += row
+                    parts.append(part)
+                row += n
+                ordinal += n
+            if w.store_mutations:
+                rows = np.concatenate(parts) if parts else None
         pairs = rows["pair"] if rows is not None else None  # ascending: the rows come back in (pair, mate, ...) order
         row, emit = 0, []
         for rid, _gid, n, first_i in pending:

@@ -535,3 +535,60 @@ def test_parse_fasta_fast_path_equals_line_parser(tmp_path):
         fast = [(r.id, r.description, r.seq) for r in parse_fasta(str(path))]
         slow = [(r.id, r.description, r.seq) for r in _parse_fasta_lines(io.StringIO(data.decode()))]
         assert fast == slow, k
+
+
+def test_batched_worker_loop_falls_back_to_single_calls():
+    """Records too long for one arena (iss_generate_batch: ISS_E_INVALID, "... 2^31 bases"): the batch is generated item
+    by item into the same rows (running ordinals), mutation rows renumbered to the batch, one emit job as before."""
+    import io
+
+    from insilicoseq_amd import _native
+    from insilicoseq_amd import generator as G
+    from insilicoseq_amd.engine import MUT_DTYPE
+
+    class FakeEngine:
+        read_length = 100
+
+        def __init__(self):
+            self.calls, self.last = [], None
+
+        def generate_batch(self, *a, **k):
+            raise _native.EngineError(_native.E_INVALID, "iss_generate_batch: the records of one call must stay below 2^31 bases")
+
+        def reserve(self, n):
+            self.calls.append(("reserve", n))
+
+        def generate(self, gid, n, first_ordinal, seed, sequence_type, gc_bias, out_first_pair):
+            self.calls.append(("gen1", gid, n, first_ordinal, out_first_pair))
+            self.last = n
+
+        def mutations(self):
+            rows = np.zeros(2, dtype=MUT_DTYPE)
+            rows["pair"] = [0, self.last - 1]
+            rows["ref"], rows["alt"] = ord("A"), ord("C")
+            return rows
+
+        def fastq_emit_batch(self, fd1, fd2, items, cpu):
+            self.calls.append(("emit", list(items)))
+
+    class FakeWorker:
+        BATCH_PAIRS = 1000
+
+        def __init__(self):
+            self.engine = FakeEngine()
+            self.ordinal, self.seed, self.cpu_number, self.store_mutations = 0, 1, 4, True
+
+        def needs_room_for(self, record):
+            return False
+
+        def genome_id(self, record):
+            return {"a": 0, "b": 1}[record.id]
+
+    w = FakeWorker()
+    vcf = io.StringIO()
+    work = [(G.Record("A" * 500, id="a"), 40, "default"), (G.Record("C" * 500, id="b"), 25, "default")]
+    G._simulate_work_batched(w, work, open(os.devnull, "wb"), open(os.devnull, "wb"), vcf, "metagenomics", False)
+    assert [c for c in w.engine.calls if c[0] == "gen1"] == [("gen1", 0, 40, 0, 0), ("gen1", 1, 25, 40, 40)]
+    assert [c for c in w.engine.calls if c[0] == "emit"] == [("emit", [("a", 0, 0, 40), ("b", 0, 40, 25)])]
+    ids = [line.split("\t")[0] for line in vcf.getvalue().splitlines()]
+    assert ids == ["a_0_4/1", "a_39_4/1", "b_0_4/1", "b_24_4/1"] and w.ordinal == 65
