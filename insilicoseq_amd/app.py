@@ -182,11 +182,11 @@ def compress_file(path, block_bytes=32 << 20, threads=None):
 
 
 def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_type, gc_bias, rng, store_mutations,
-            fragment, compress=False):
+            fragment, compress=False, records=None):
     """One pool process == one GPU.  Records are re-read from the concatenated FASTA (the reference
-    pickles them; same content)."""
+    pickles them; same content) unless the caller runs in this process and hands its own over."""
     logging.basicConfig(level=logging.WARNING)
-    records = {r.id: r for r in parse_fasta(genome_file)}
+    records = {r.id: r for r in (records if records is not None else parse_fasta(genome_file))}
     if npz is None:  # --mode basic
         model = BasicErrorModel(fragment[0], fragment[1], store_mutations)
     else:
@@ -255,7 +255,7 @@ def generate_reads(args):
                      (args.fragment_length, args.fragment_length_sd), device_gzip))
     if workers == 1:
         for j in jobs:
-            _worker(*j)
+            _worker(*j, records=records)
     else:
         with mp.get_context("spawn").Pool(workers) as pool:
             pool.starmap(_worker, jobs)
