@@ -28,6 +28,8 @@
 extern "C" {
 #endif
 
+/* 3: iss_fastq_compress / iss_deflate_code_build (gzip members built on the device), iss_generate_batch,
+ *    iss_fastq_emit_batch (a whole work list per call).  2: iss_fastq_emit / iss_fastq_flush, MT-mode path counters. */
 #define ISS_ABI_VERSION 3
 
 #define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
