@@ -28,9 +28,11 @@
 extern "C" {
 #endif
 
-/* 3: iss_fastq_compress / iss_deflate_code_build (gzip members built on the device), iss_generate_batch,
+/* 4: device rows interleaved per pair (whole 128-byte lines per store, see iss_output_reserve), iss_output_row;
+ *    Philox address map of the hot draws: three blocks per 16 bases.
+ * 3: iss_fastq_compress / iss_deflate_code_build (gzip members built on the device), iss_generate_batch,
  *    iss_fastq_emit_batch (a whole work list per call).  2: iss_fastq_emit / iss_fastq_flush, MT-mode path counters. */
-#define ISS_ABI_VERSION 3
+#define ISS_ABI_VERSION 4
 
 #define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
 #define ISS_E_HIP (-2)         /* HIP runtime failure (message has the hip error)  */
@@ -98,12 +100,19 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *tables);
 int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_t *genome_id);
 int iss_genome_clear(iss_ctx *ctx);
 
-/* Device output buffers: four arrays [capacity_pairs][pitch] (R1 bases, R1 phred, R2 bases,
- * R2 phred), pitch = 4*ceil(read_length/4).  Reserve before generating. */
+/* Device output rows (R1 bases, R1 phred, R2 bases, R2 phred).  Reserve before generating.
+ * On the HOST (iss_output_download, iss_fastq_write) they are four arrays [pairs][pitch],
+ * pitch = 8*ceil(read_length/8) (ask iss_output_pitch).  On the DEVICE a pair owns one row of
+ * row = 128*ceil(pitch/32) bytes; the 32 positions 32l..32l+31 are line l (128 bytes) of the row: bytes 0-63
+ * mate 1, 64-127 mate 2, each four 16-byte pieces [8 bases][8 phreds], i.e. position p of array k
+ * (0 R1 bases, 1 R1 phred, 2 R2 bases, 3 R2 phred) of pair i is byte
+ * i*row + 128*(p/32) + 64*(k/2) + 16*((p/8)%4) + 8*(k%2) + p%8 (the kernel writes whole lines this way). */
 int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs);
 int iss_output_pitch(const iss_ctx *ctx);
-/* raw device pointers (for a caller that consumes the reads on the GPU / benchmarks) */
+/* raw device pointers (for a caller that consumes the reads on the GPU / benchmarks): byte 0 of
+ * each array's part of row 0 (layout above); iss_output_row = row */
 int iss_output_device_ptrs(const iss_ctx *ctx, void **r1_base, void **r1_qual, void **r2_base, void **r2_qual);
+int iss_output_row(const iss_ctx *ctx);
 
 /*
  * The hot path: n_pairs read pairs from one record, replaces

@@ -16,7 +16,7 @@ SEQ_TYPES = {"metagenomics": 0, "amplicon": 1}
 EXPORTS = (
     "iss_abi_version", "iss_ctx_create", "iss_ctx_destroy", "iss_last_error", "iss_ctx_set_stream",
     "iss_model_upload", "iss_genome_upload", "iss_genome_clear", "iss_output_reserve", "iss_output_pitch",
-    "iss_output_device_ptrs", "iss_generate", "iss_synchronize", "iss_output_download",
+    "iss_output_device_ptrs", "iss_output_row", "iss_generate", "iss_synchronize", "iss_output_download",
     "iss_output_download_coords", "iss_timing_enable", "iss_timing_read", "iss_stats_read", "iss_fastq_write",
     "iss_mt_seed", "iss_generate_mt", "iss_mt_peek", "iss_mt_mutations_reserve", "iss_mt_mutations_download",
     "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
@@ -75,6 +75,7 @@ def lib():
     L.iss_genome_clear.argtypes = [vp]
     L.iss_output_reserve.argtypes = [vp, i64]
     L.iss_output_pitch.argtypes = [vp]
+    L.iss_output_row.argtypes = [vp]
     L.iss_output_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.iss_generate.argtypes = [vp, i32, i64, u64, u64, i32, i32, i64]
     L.iss_synchronize.argtypes = [vp]

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "iss_kernels.hip.h"  // xp(): layout of the output rows
 
 namespace iss {
 
@@ -37,11 +38,11 @@ struct FastqItem {
 };
 
 struct FastqArgs {
-    const uint8_t *base[2], *qual[2];  // output rows (row 0): [mate]
+    const uint8_t *base[2], *qual[2];  // output rows (row 0): [mate]; position p of row i at [i * row + xp(p)]
     uint8_t *text[2];                  // [mate] output text
     const FastqItem *items;            // [n_items]
     const char *ids;                   // record ids, back to back
-    int32_t n_items, pitch, RL, cpu_len;
+    int32_t n_items, row, RL, cpu_len;
     char cpu[12];                      // decimal cpu_number
     int64_t n_records;                 // of all items
 };
@@ -88,12 +89,12 @@ __global__ __launch_bounds__(64 * FASTQ_WAVES) void k_fastq_format(FastqArgs A) 
         w[k] = (uint8_t)c;
     }
     w += hlen;
-    const uint8_t *b = A.base[mate] + (size_t)(it.first_pair + i) * A.pitch;
-    const uint8_t *q = A.qual[mate] + (size_t)(it.first_pair + i) * A.pitch;
-    for (int k = lane; k < A.RL; k += 64) w[k] = b[k];
+    const uint8_t *b = A.base[mate] + (size_t)(it.first_pair + i) * A.row;
+    const uint8_t *q = A.qual[mate] + (size_t)(it.first_pair + i) * A.row;
+    for (int k = lane; k < A.RL; k += 64) w[k] = b[xp(k)];
     if (lane < 3) w[A.RL + lane] = lane == 1 ? '+' : '\n';
     uint8_t *wq = w + A.RL + 3;
-    for (int k = lane; k < A.RL; k += 64) wq[k] = (uint8_t)(33 + q[k]);
+    for (int k = lane; k < A.RL; k += 64) wq[k] = (uint8_t)(33 + q[xp(k)]);
     if (lane == 0) wq[A.RL] = '\n';
 }
 

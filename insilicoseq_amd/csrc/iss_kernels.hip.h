@@ -80,26 +80,36 @@ __device__ __forceinline__ uint64_t lo37(const u32x4 &v, int pair) {
 }
 __device__ __forceinline__ uint64_t mk_digit(uint32_t h16, uint64_t l37) { return ((uint64_t)h16 << 37) | l37; }
 
+// Output rows.  A pair owns ONE row of M.row bytes (a multiple of 128).  The 32 read positions 32 l .. 32 l + 31 are the
+// 128-byte line l of the row: bytes 0-63 the forward mate, 64-127 the reverse mate, each four 16-byte pieces
+// [bases 8][phreds 8] of 8 positions -- the four lanes that work on a pair write 64 contiguous bytes per store.
+// RunArgs::out[k] points at array k's first byte of the launch's first row (ROW_ARRAY_OFF): position p of array k of
+// pair i is out[k][i * M.row + xp(p)].
+__host__ __device__ __forceinline__ int xp(int p) { return ((p >> 5) << 7) + (((p >> 3) & 3) << 4) + (p & 7); }
+__host__ __device__ __forceinline__ int row_array_off(int k) { return (k >> 1) * 64 + (k & 1) * 8; }
+
 // ---------------------------------------------------------------- device-side tables
 struct DevModel {
-    int32_t RL, n_isize, n_q, G, pitch;  // G = pitch/4 = position groups per read
+    int32_t RL, n_isize, n_q, G, pitch;  // pitch = 8 * ceil(RL / 8); G = pitch/4 = position groups per read
+    int32_t row;         // bytes of a pair's output row: 128 * ceil(S / 4) (see xp())
     // compressed quality rows for k_main (built at upload, see iss_mi355x.hip: build_qrows)
     int32_t NB;          // bin slots per orientation (non-empty bins, compacted)
     int32_t GB;          // guide bits: a row starts with 1 << GB guide bytes (top GB bits of the digit)
     int32_t stride_w;    // u32 words per row: guide words + (S_max + 2) entries
     int32_t GS;          // words per position group = 4 * stride_w + 1 (odd: consecutive lanes hit distinct LDS banks)
-    int32_t TG, TP;      // position groups / positions per tile
+    int32_t TG, TP;      // position groups / positions per tile (TG even)
+    int32_t S, TS;       // superitems (8 positions) per read (pitch / 8) / per tile (TG / 2)
     int32_t n_tiles;
     int32_t tile_words;  // 2 * NB * TG * GS rounded up to a multiple of 4
     int8_t bin_slot[8];  // [o][bin] -> slot (or -1)
     int8_t slot_bin[8];  // [o][slot] -> bin
     const uint32_t *qrows;      // [n_tiles][2][NB][TG] groups of GS words (4 rows of stride_w + 1 pad)
-    const uint32_t *mut16;      // [n_q+1]  mut_thr >> 37
-    const uint32_t *subst16;    // [n_tiles][2][TP][4] x {t0_16 | t1_16 << 16, alt0 | alt1 << 8 | alt2 << 16}
-    int32_t subst_words;        // per tile: 2 * TP * 4 * 2
     const uint64_t *isize_thr;  // [n_isize]
     const uint64_t *bin_thr;    // [2][4]
     const uint64_t *q_thr;      // [2][4][RL][n_q]   (exact tie resolution)
+    const uint32_t *subst13;    // [n_tiles][2][TP][4]: t0_13 | t1_13 << 13 | (alt0 | alt1 << 2 | alt2 << 4) << 26: leading 13 bits of
+                                // subst_thr, alternatives as indices into alt_letters
+    uint32_t alt_letters;       // the (<= 4) distinct letters of subst_alt
     const uint64_t *subst_thr;  // [2][RL][4][3]
     const uint8_t *subst_alt;   // [2][RL][4][3]
     const uint64_t *ins_thr;    // [2][RL][4]
@@ -168,7 +178,7 @@ struct RunArgs {
     int32_t sequence_type;
     int32_t gc_bias;
     uint64_t gc_thr;  // ceil(0.90 * 2^53): accept iff m < gc_thr (generator.py:88)
-    uint8_t *out[4];  // rows of this launch: R1 base, R1 qual, R2 base, R2 qual
+    uint8_t *out[4];  // rows of this launch: R1 base, R1 qual, R2 base, R2 qual (out[k] = out[0] + row_array_off(k), see xp())
     int32_t scan_every;  // k_indel_scan: flush period (iterations), chosen from the model's indel probabilities
     // custom fragment length (generator.py:121-123): fragment = int(mu + sd * gaussian), per-pair polar Box-Muller
     int32_t has_frag;
@@ -345,17 +355,12 @@ __device__ __forceinline__ int quality_exact(const DevModel &M, const Addr &a, i
     const int bin = M.slot_bin[o * 4 + slot];
     return count_lt(M.q_thr + ((size_t)(o * 4 + bin) * M.RL + p) * M.n_q, M.n_q, m);
 }
-// exact "is it an error" for a tied leading digit
-__device__ __forceinline__ bool mut_exact(const DevModel &M, const Addr &a, int o, int p, uint32_t h, int q) {
-    const u32x4 lo = draw_block(a, K_QM_LO, (uint32_t)p, (uint32_t)o);
-    return mk_digit(h, lo37(lo, 1)) > M.mut_thr[q];
-}
+// the K_SUB block of base (p, mate o): its substitution choice (x, y) and the trailing bits of its error-test draw (z, w)
 // np.random.choice(alternatives, p=...) for an erroneous, non-ambiguous base (__init__.py:95-97)
-__device__ __forceinline__ int substitute(const DevModel &M, const Addr &a, int o, int p, int base) {
+__device__ __forceinline__ int substitute(const DevModel &M, const u32x4 &sb, int o, int p, int base) {
     const int bi = base_index(base);
     if (bi < 0) return base;  // nucl.upper() in "RYWSMKHBVDN": left alone
-    const u32x4 s = draw_block(a, K_SUB, (uint32_t)p, 0);
-    const uint64_t m = o ? mk53(s.z, s.w) : mk53(s.x, s.y);
+    const uint64_t m = mk53(sb.x, sb.y);
     const size_t row = ((size_t)(o * M.RL + p) * 4 + bi) * 3;
     const int k = (m >= M.subst_thr[row]) + (m >= M.subst_thr[row + 1]);
     return M.subst_alt[row + k];
@@ -397,6 +402,20 @@ __global__ __launch_bounds__(256) void k_pack_genome(const uint8_t *__restrict__
     if (bad) {
         atomicAdd(&status[0], (unsigned long long)bad);
         atomicMin(&status[1], (unsigned long long)first_bad);
+    }
+}
+
+// ================================================================== k_rows_to_arrays
+// iss_output_download: interleaved rows (xp) -> four plain arrays [n_pairs][8 * S]; one wavefront per pair, one lane per
+// 8-byte piece (block = 64 x 4)
+__global__ __launch_bounds__(256) void k_rows_to_arrays(const uint8_t *__restrict__ rows, uint8_t *__restrict__ arrays,
+                                                        int64_t n_pairs, int32_t S, int32_t row) {
+    const int64_t pair = (int64_t)blockIdx.x * 4 + threadIdx.y;
+    if (pair >= n_pairs) return;
+    for (uint32_t r = threadIdx.x; r < (uint32_t)S * 4u; r += 64u) {  // piece r: superitem r >> 2, array r & 3
+        const uint32_t s = r >> 2, k = r & 3u;
+        const uint2 v = *reinterpret_cast<const uint2 *>(rows + (size_t)pair * (size_t)row + (size_t)(row_array_off((int)k) + xp((int)s * 8)));
+        *reinterpret_cast<uint2 *>(arrays + (((size_t)k * (size_t)n_pairs + (size_t)pair) * (size_t)S + s) * 8u) = v;
     }
 }
 
@@ -532,74 +551,103 @@ __device__ __forceinline__ uint32_t codes_to_ascii4(uint32_t b) {
     return __builtin_amdgcn_perm(0u, 0x47435441u, sel);  // selector values 0..3 pick bytes of "ATCG"
 }
 
+// The hot digits of superitem s (8 read positions, both mates) are three Philox blocks (K_QM, s, sub 0..2):
+//   sub 0 / 2: quality digits (16 bits) of positions 0-3 / 4-7: word mate * 2 + (cc >> 1), half cc & 1
+//   sub 1    : error-test digits (8 bits): word half * 2 + mate, byte cc            (c = p & 7, half = c >> 2, cc = c & 3)
+// The quality draw is m = h16 << 37 | l37 (l37 from K_QM_LO), the error-test draw m = e8 << 45 | l45 (l45 from the
+// K_SUB block of the base, which also holds its substitution choice): trailing bits are drawn on a tie only.
+__device__ __forceinline__ uint32_t hot_h16(const u32x4 &blk, int o, int cc) {
+    return (word_of(blk, o * 2 + (cc >> 1)) >> (16 * (cc & 1))) & 0xffffu;
+}
+__device__ __forceinline__ uint32_t hot_e8(const u32x4 &blk1, int half, int o, int cc) {
+    return (word_of(blk1, half * 2 + o) >> (8 * cc)) & 0xffu;
+}
+__device__ __forceinline__ uint64_t error_test_draw(uint32_t e8, const u32x4 &sub_blk) {
+    return ((uint64_t)e8 << 45) | ((uint64_t)(sub_blk.z & 0x1fffu) << 32) | sub_blk.w;
+}
+
 constexpr int MAIN_THREADS = 1024;
-constexpr int SLOW_RING = 128;  // entries of a wavefront's private ring of deferred lane-items (LDS): a wavefront pushes
-                                // <= 64 per iteration and drains a round of 64 as soon as it has one
+constexpr int MAIN_PAIRS = MAIN_THREADS / 4;  // pairs of one workgroup pass: four lanes per pair
+constexpr int MAIN_MUT_WORDS = 128;  // LDS words of the substitution-test thresholds (n_q <= 60)
+constexpr int SLOW_RING = 128;  // entries (two words) of a wavefront's private ring of deferred lane-items (LDS): a
+                                // wavefront pushes <= 64 per half iteration and drains a round of 64 as soon as it has one
 // Dynamic LDS of k_main (32-bit words):
-//   [0, mut_words)            error-test table: mut16[q] - 1 (signed), q = 0..n_q
-//   [rows, +tile_words)       compressed quality rows of the position tile: per (mate, bin slot, group)
+//   [0, tile_words)           compressed quality rows of the position tile: per (mate, bin slot, group)
 //                             GS words = 4 rows of stride_w words + 1 pad word; a row = guide bytes
-//                             (1 << GB of them, each the BYTE offset 4 * j of an entry) then packed entries (t16 << 15 | phred << 8 | phred << 2), ascending,
-//                             closed by two sentinels
-//   [subst, +subst_words)     substitution table (leading digits + alternatives)
-//   [rings]                   MAIN_THREADS / 64 private rings of SLOW_RING deferred lane-items
-struct MainTile {  // per-workgroup constants of k_main (word offsets into the dynamic LDS array)
-    uint32_t rows;
-    uint32_t subst16;
-    int g0;        // first position group of the tile
-    uint32_t tg;   // groups in the tile
+//                             (1 << GB of them, each the BYTE offset 4 * j of an entry) then packed entries
+//                             (t16 << 16 | phred << 8 | te8), ascending, closed by two sentinels; te8 = leading
+//                             8 bits of the phred's substitution-test threshold
+//   [mut, +128)               the substitution-test thresholds (u64) of phreds 0 .. n_q (exact path)
+//   [subst, +2 * TP * 4)      per (mate, position of the tile, template base): leading 13 bits of the two substitution
+//                             thresholds | alternatives (2 bits each, indices into DevModel::alt_letters) << 26
+//   [rings]                   MAIN_THREADS / 64 private rings of SLOW_RING deferred lane-items, two words each
+struct MainTile {  // per-workgroup constants of k_main
+    int s0;        // first superitem (8 positions) of the tile
+    uint32_t ts;   // superitems in the tile
 };
 
-// The rare work of ONE base, done exactly (one lane per flagged base, so the pass is dense): base s =
-// mate*4 + c of lane-item `it` hit a rare condition in the hot loop (leading-digit tie, more than two
-// thresholds in its guide bucket, or the substitution test fired / tied).  Everything about the base is
-// recomputed from its uniforms; its phred / base BYTES are patched in place (two lanes may patch
-// different bytes of one dword, hence byte stores).
+// The rare work of ONE base, done exactly (one lane per flagged base, so the pass is dense): base s = mate*4 + cc of
+// half `half` of superitem `sl` of the tile hit a rare condition in the hot loop (leading-digit tie, more than two
+// thresholds in its guide bucket, or the substitution test fired / tied).  Everything about the base is recomputed
+// from its uniforms; its phred / base BYTES are patched in place (two lanes may patch different bytes of one dword,
+// hence byte stores).  A round is bound by latency, not by instructions, and a global load behind this kernel's write
+// stream takes microseconds: so the common case touches NO global memory except for the two byte stores -- the queue
+// entry carries the lane-item's two 8-base genome windows and the pair's bin slots, the thresholds sit in LDS.
+// (Records with IUPAC / lower-case letters, gc_bias and digit ties do load: descriptor, ASCII genome, full thresholds.)
 // Returns true and fills `rec` when the base was substituted by a different letter (a --store_mutations row).
-__device__ __forceinline__ bool main_slow_base(const DevModel &M, const RunArgs &A, const PairDesc *__restrict__ desc,
-                                               const uint32_t *lds, const MainTile &T, uint32_t it, int s, MutRecord &rec) {
-    const uint32_t pair = it / T.tg, grp = it - pair * T.tg;
-    const int o = s >> 2, c = s & 3;
-    const int p = (T.g0 + (int)grp) * 4 + c;
+template <bool PLAIN>
+__device__ __forceinline__ bool main_slow_base(const DevModel &M, const DevGenome &g, const RunArgs &A,
+                                               const PairDesc *__restrict__ desc, const uint32_t *lds, const MainTile &T,
+                                               uint32_t pair, uint32_t sl, int half, int s, uint32_t slots, uint32_t windows,
+                                               MutRecord &rec) {
+    const int o = s >> 2, cc = s & 3, c = half * 4 + cc;
+    const uint32_t s_abs = (uint32_t)T.s0 + sl;
+    const int p = (int)s_abs * 8 + c;
     if (p >= M.RL) return false;
-    const PairDesc d = desc[pair];
-    const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
-    const size_t byte_off = (size_t)pair * M.pitch + (size_t)p;
-    const uint32_t slot = (d.meta >> (2 * o)) & 3u;
-    const u32x4 w = draw_block(a, K_QM, (uint32_t)(p >> 1), 0);
-    const uint32_t wd = word_of(w, (p & 1) * 2 + o);  // low half: quality digit, high half: error-test digit
-    const uint32_t h = wd & 0xffffu, hm = wd >> 16;
+    uint32_t attempt = 0;
+    if (A.gc_bias) attempt = desc[pair].meta >> 16;  // (the only use of the attempt number)
+    const Addr a = make_addr(A.seed, A.first_ordinal + pair, attempt);
+    const uint32_t h = hot_h16(draw_block(a, K_QM, s_abs, half ? 2u : 0u), o, cc);
+    const uint32_t e8 = hot_e8(draw_block(a, K_QM, s_abs, 1u), half, o, cc);
+    const size_t byte_off = (size_t)pair * M.row + (size_t)xp(p);
+    const uint32_t slot = (slots >> (2 * o)) & 3u;
     // quality: full search of the LDS row, exact thresholds on a tie
     const uint32_t gwords = (1u << M.GB) / 4;
-    const uint32_t row = T.rows + (((uint32_t)(o * M.NB) + slot) * (uint32_t)M.TG + grp) * (uint32_t)M.GS +
-                         (uint32_t)c * (uint32_t)M.stride_w;
+    const uint32_t row = (((uint32_t)(o * M.NB) + slot) * (uint32_t)M.TG + 2u * sl + (uint32_t)half) * (uint32_t)M.GS +
+                         (uint32_t)cc * (uint32_t)M.stride_w;
     uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))] >> 2;  // guide bytes hold 4 * index
     uint32_t e = lds[row + gwords + j];
-    while ((e >> 15) < h) e = lds[row + gwords + (++j)];
-    uint32_t q = (e >> 2) & 0x3fu;
-    if ((e >> 15) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
+    while ((e >> 16) < h) e = lds[row + gwords + (++j)];
+    uint32_t q = (e >> 8) & 0xffu;
+    if ((e >> 16) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
     A.out[2 * o + 1][byte_off] = (uint8_t)q;
     // substitution test (__init__.py:94)
-    const uint32_t t = (uint32_t)((int32_t)lds[q] + 1);
-    bool err = hm > t;
-    if (hm == t) err = mut_exact(M, a, o, p, hm, (int)q);
-    if (!err) return false;
-    const int base = A.out[2 * o][byte_off];
-    const int bi = base_index(base);
-    if (bi < 0) return false;  // nucl.upper() in "RYWSMKHBVDN": left alone
-    const u32x4 sb = draw_block(a, K_SUB, (uint32_t)p, 0);
-    const uint64_t m = o ? mk53(sb.z, sb.w) : mk53(sb.x, sb.y);
-    const uint32_t hs = (uint32_t)(m >> 37);
-    const uint32_t *se = lds + T.subst16 + ((uint32_t)(o * M.TP + (p - T.g0 * 4)) * 4 + bi) * 2;
-    const uint32_t t0 = se[0] & 0xffffu, t1 = se[0] >> 16;
-    int k;
+    const uint64_t thr = reinterpret_cast<const uint64_t *>(lds + M.tile_words)[q];
+    const uint32_t t8 = (uint32_t)(thr >> 45);
+    if (e8 < t8) return false;
+    const u32x4 sb = draw_block(a, K_SUB, (uint32_t)p, (uint32_t)o);
+    if (e8 == t8 && !(error_test_draw(e8, sb) > thr)) return false;
+    // the template base: forward window bit pair c; reverse window (already complemented) bit pair 7 - c
+    const uint32_t code = o ? ((windows >> (16 + 2 * (7 - c))) & 3u) : ((windows >> (2 * c)) & 3u);
+    int base = code_to_ascii(code), bi = (int)code;
+    if (!PLAIN) {  // the letter may be IUPAC / lower case, the pair irregular (custom fragment lengths)
+        const PairDesc d = desc[pair];
+        if (A.has_frag && (d.meta & 64u)) return false;  // irregular pair: the fix-up kernel builds its bases
+        base = fetch_ascii(g, o ? (int64_t)d.re - 1 - p : (int64_t)d.fs + p);
+        if (o) base = complement_ascii(base);
+        bi = base_index(base);
+        if (bi < 0) return false;  // nucl.upper() in "RYWSMKHBVDN": left alone
+    }
+    const uint64_t m = mk53(sb.x, sb.y);
+    // leading 13 bits of the two thresholds + the three alternatives (two bits each; model_alt: their letters)
+    const uint32_t sd = lds[M.tile_words + MAIN_MUT_WORDS + ((uint32_t)(o * M.TP) + 8u * sl + (uint32_t)c) * 4u + (uint32_t)bi];
+    const uint32_t hs = (uint32_t)(m >> 40), t0 = sd & 0x1fffu, t1 = (sd >> 13) & 0x1fffu;
+    int k = (hs > t0) + (hs > t1);
     if (hs == t0 || hs == t1) {  // tie of a leading digit: exact thresholds
         const size_t srow = ((size_t)(o * M.RL + p) * 4 + bi) * 3;
         k = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
-    } else {
-        k = (hs > t0) + (hs > t1);
     }
-    const uint32_t nb = (se[1] >> (8 * k)) & 0xffu;
+    const uint32_t nb = (M.alt_letters >> (8 * ((sd >> (26 + 2 * k)) & 3u))) & 0xffu;
     A.out[2 * o][byte_off] = (uint8_t)nb;
     // without indels the original read equals the template, i.e. the base just replaced (__init__.py:98)
     rec.pair = (int32_t)(A.pair_base + pair); rec.mate = (int8_t)o; rec.type = 0; rec.position = (int16_t)p;
@@ -607,192 +655,247 @@ __device__ __forceinline__ bool main_slow_base(const DevModel &M, const RunArgs 
     return (int)nb != base;
 }
 
-// One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive
-// entries -> select.  Entry = (t16 << 15) | (phred << 8) | (phred << 2): < 2^31, so differences carry their sign;
-// the low byte is the byte offset of the phred's error-test threshold, bits 8-13 the phred (< 64) for the output.  Returns the selected entry and
-// ORs into `x` a word whose SIGN BIT is set when the base needs the exact path (tie, > 2 thresholds
-// in the guide bucket, substitution test fires or ties).
-__device__ __forceinline__ uint32_t hot_lookup(const uint32_t *lds, uint32_t row_b, uint32_t wd, int gshift,
-                                               uint32_t gbytes, uint32_t &x) {
-    const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds);
-    const uint32_t h = wd & 0xffffu;
-    const uint32_t j = ldsb[row_b + (h >> gshift)];
-    const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + row_b + gbytes + j);  // guide bytes hold 4 * index
+// One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive entries -> select.
+// Entry = t16 << 16 | phred << 8 | te8.  `wq` holds the base's quality digit in its low (HI = 0) or high half, `we`
+// its error-test digit in byte BYTE; row_g / row_e = byte offsets of the row's guide / entries.  Returns the selected
+// entry; `flag`: lane mask of the bases that need the exact path (digit tie, > 2 thresholds of the guide bucket below the digit,
+// substitution test fires or ties).
+template <int HI, int BYTE>
+__device__ __forceinline__ uint32_t hot_lookup(const uint8_t *ldsb, uint32_t row_g, uint32_t row_e, uint32_t off, uint32_t wq,
+                                               uint32_t we, uint32_t gsh, uint32_t gb, unsigned long long &flag) {
+    const uint32_t h = HI ? (wq >> 16) : (wq & 0xffffu);
+    const uint32_t gi = HI ? (wq >> (gsh + 16u)) : __builtin_amdgcn_ubfe(wq, gsh, gb);
+#ifdef ISS_EXP_NOLDS
+    const uint32_t j = row_g + off + gi;
+    const uint32_t e0 = row_e + off + j, e1 = e0 * 3u;
+#else
+    const uint32_t j = ldsb[row_g + off + gi];
+    const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + row_e + off + j);  // guide bytes hold 4 * index
     const uint32_t e0 = ent[0], e1 = ent[1];
-    const uint32_t hs = h << 15;
-    const uint32_t sel = e0 >= hs ? e0 : e1;           // first entry with t16 >= h (if among the two)
-    const int32_t mt1 = *reinterpret_cast<const int32_t *>(ldsb + (sel & 0xffu));  // mut16[phred] - 1
-    x = (e1 - hs)                  // < 0: a third threshold of the bucket is below h
-        | ((sel ^ hs) - 32768u)    // < 0: tie of the leading digit
-        | (uint32_t)(mt1 - (int32_t)(wd >> 16));  // < 0: substitution test fires or ties
+#endif
+    const uint32_t sel = (e0 >> 16) < h ? e1 : e0;   // first entry with t16 >= h (if among the two)
+    const uint32_t e8 = (we >> (8 * BYTE)) & 0xffu;
+    // (one ballot per compare: each folds into its v_cmp, the masks are combined by the scalar unit)
+    flag = __builtin_amdgcn_ballot_w64((sel >> 16) <= h) | __builtin_amdgcn_ballot_w64((sel & 0xffu) <= e8);
     return sel;
+}
+
+// r = r << 1 | flag in one instruction: the flag's lane mask is the carry-in of v_addc
+__device__ __forceinline__ uint32_t shift_in(uint32_t r, unsigned long long flag_mask) {
+    asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(r) : "s"(flag_mask) : "vcc");
+    return r;
 }
 
 // STORE_MUT: --store_mutations variant (keeps the row bookkeeping out of the common kernel's register budget)
 // PLAIN: the record holds nothing but A/C/G/T and there is no custom fragment length (no irregular pairs) -- the
 // common case runs without the tests, masks and zero-initialisations of the other two.
+//
+// Work layout: a wavefront holds 16 pairs, four lanes each; per iteration lane j of a pair takes superitem 4 * i + j
+// (8 read positions of both mates = 16 bases: three Philox blocks, two 8-base genome windows, 16 table lookups,
+// four 8-byte stores -- the four lanes of a pair write 32 contiguous bytes of each output row).  Everything that
+// belongs to the pair (descriptor, Philox address, row offsets of its bin slots) is loaded once and stays in registers
+// for the pair's iterations.
 template <bool STORE_MUT, bool PLAIN>
 __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tile = blockIdx.x % M.n_tiles;
     const uint32_t wg = blockIdx.x / M.n_tiles, n_wg = gridDim.x / M.n_tiles;
-    const int mut_words = (M.n_q + 1 + 3) & ~3;
     MainTile T;
-    T.rows = (uint32_t)mut_words;
-    T.subst16 = (uint32_t)(mut_words + M.tile_words);
-    T.g0 = tile * M.TG;
-    T.tg = (uint32_t)min(M.TG, M.G - T.g0);
+    T.s0 = tile * M.TS;
+    T.ts = (uint32_t)min(M.TS, M.S - T.s0);
     // Deferred lane-items (a base needs the exact path): a private ring per wavefront -- no atomics, no barriers.
-    // Entry = iteration << 14 | lane << 8 | base mask; head / tail are wave-uniform.
-    uint32_t *ring = lds + T.subst16 + M.subst_words + (threadIdx.x >> 6) * SLOW_RING;
+    // Entry = {pass << 24 | iteration << 19 | lane << 13 | half << 12 | bin slots << 8 | base mask,
+    //          forward window | complemented reverse window << 16 (2-bit codes of the lane-item's 8 + 8 template bases)};
+    // head / tail are wave-uniform.
+    uint2 *ring = reinterpret_cast<uint2 *>(lds + M.tile_words + MAIN_MUT_WORDS + 2 * M.TP * 4) + (threadIdx.x >> 6) * SLOW_RING;
     uint32_t q_head = 0, q_tail = 0;
     const uint32_t lane = threadIdx.x & 63u;
     {   // stage this tile's tables in LDS (once per workgroup)
-        for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) lds[i] = M.mut16[i] - 1u;
         const uint4 *src = reinterpret_cast<const uint4 *>(M.qrows + (size_t)tile * M.tile_words);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds + T.rows);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
         for (int i = threadIdx.x; i < M.tile_words / 4; i += blockDim.x) dst[i] = src[i];
-        const uint32_t *ssrc = M.subst16 + (size_t)tile * M.subst_words;
-        for (int i = threadIdx.x; i < M.subst_words; i += blockDim.x) lds[T.subst16 + i] = ssrc[i];
+        for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) reinterpret_cast<uint64_t *>(lds + M.tile_words)[i] = M.mut_thr[i];
+        const uint32_t *ssrc = M.subst13 + (size_t)tile * 2 * M.TP * 4;
+        for (int i = threadIdx.x; i < 2 * M.TP * 4; i += blockDim.x) lds[M.tile_words + MAIN_MUT_WORDS + i] = ssrc[i];
     }
     __syncthreads();
-    const uint32_t tg = T.tg;
-    const int g0 = T.g0;
-    const uint32_t n_items = (uint32_t)A.n_pairs * tg;
-    const uint32_t step = n_wg * blockDim.x;
-    // (uniform values that come out of a division live in vector registers unless told otherwise: the kernel has none to spare)
+    const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds);
     auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    const uint32_t step_pair = sgpr(step / tg), step_grp = sgpr(step - step_pair * tg);
-    const uint32_t first = wg * blockDim.x;
-    const uint32_t n_iter = sgpr(n_items > first ? (n_items - first + step - 1) / step : 0);  // uniform in the workgroup
-    uint32_t it = first + threadIdx.x;
-    uint32_t pair = it / tg, grp = it - pair * tg;
-    const int RL = M.RL;
-    const int gshift = 16 - M.GB;
+    const uint32_t n_iter = sgpr((T.ts + 3u) >> 2);
+    const uint32_t n_pass = sgpr(((uint32_t)A.n_pairs + MAIN_PAIRS - 1) / MAIN_PAIRS);
+    const uint32_t gsh = 16u - (uint32_t)M.GB, gb = (uint32_t)M.GB;
     const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
-    const uint32_t slot_b = (uint32_t)M.TG * (uint32_t)M.GS * 4u;  // bytes per (mate, bin slot)
-    // 32-bit byte offsets, advanced by addition (a chunk is < 2^28 lane-items, so nothing here overflows):
-    // row_g = LDS byte offset of the item's position group; out_b = byte offset of its dword in the four outputs
     const uint32_t gs_b = (uint32_t)M.GS * 4u;
-    uint32_t row_g = T.rows * 4u + grp * gs_b;
-    uint32_t out_b = (pair * (uint32_t)M.G + (uint32_t)g0 + grp) * 4u;
-    const uint32_t row_step = sgpr(step_grp * gs_b), row_wrap = sgpr(tg * gs_b);
-    const uint32_t out_step = sgpr((step_pair * (uint32_t)M.G + step_grp) * 4u), out_wrap = sgpr(((uint32_t)M.G - tg) * 4u);
+    const uint32_t slot_b = (uint32_t)M.TG * gs_b;  // bytes per (mate, bin slot)
+    // byte offsets of the rows of the 8 positions of a superitem (two position groups)
+    uint32_t off_g[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) off_g[c] = sgpr((uint32_t)(c >> 2) * gs_b + (uint32_t)(c & 3) * stride_b);
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // the leading padding word: offsets >= 0
     MutChunk mchunk = {0u, MUT_CHUNK};  // --store_mutations: forces a reservation at first use
+    const uint32_t wave_pair0 = (threadIdx.x >> 6) * 16u;
     // one round of the exact path: lane k takes ONE base of the k-th pending entry of this wavefront (n <= 64 of them);
     // an entry with more bases (noisy models: NextSeq, MiSeq) goes back into the ring, so every round runs full
     // instead of looping until the lane with the most bases is done (at most 64 come back for the 64 taken out)
     auto drain_round = [&](uint32_t n) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's output dwords have reached the L2
-        uint32_t rest = 0;
+        // (the byte patches below follow this wavefront's own stores of the same lines: vector memory instructions of
+        //  one wavefront reach a given address in issue order, no wait is needed)
+        uint2 rest = {0u, 0u};
         if (lane < n) {
-            const uint32_t ent = ring[(q_head + lane) & (SLOW_RING - 1)];
-            const uint32_t it_e = first + (threadIdx.x & ~63u) + ((ent >> 8) & 63u) + (ent >> 14) * step;
-            const uint32_t mask = ent & 0xffu;  // never empty
+            const uint2 ent = ring[(q_head + lane) & (SLOW_RING - 1)];
+            const uint32_t e_pass = ent.x >> 24, e_it = (ent.x >> 19) & 31u, e_lane = (ent.x >> 13) & 63u;
+            const uint32_t e_pair = (wg + e_pass * n_wg) * MAIN_PAIRS + wave_pair0 + (e_lane >> 2);
+            const uint32_t mask = ent.x & 0xffu;  // never empty
             const int bit = 31 - __clz(mask);
-            if (mask & (mask - 1u)) rest = ent & ~(1u << bit);
+            if (mask & (mask - 1u)) rest = make_uint2(ent.x & ~(1u << bit), ent.y);
             MutRecord rec;
-            const bool have = main_slow_base(M, A, desc, lds, T, it_e, 7 - bit, rec);
+            const bool have = main_slow_base<PLAIN>(M, g, A, desc, lds, T, e_pair, 4u * e_it + (e_lane & 3u), (int)((ent.x >> 12) & 1u),
+                                                    7 - bit, (ent.x >> 8) & 15u, ent.y, rec);
             if (STORE_MUT) mut_emit(A, mchunk, have, rec);
         }
         q_head += n;
-        const unsigned long long again = __ballot(rest != 0u);
+        const unsigned long long again = __ballot(rest.x != 0u);
         if (again) {
-            if (rest) {
+            if (rest.x) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
                 ring[(q_tail + rank) & (SLOW_RING - 1)] = rest;
             }
             q_tail += (uint32_t)__popcll(again);
         }
     };
-    for (uint32_t iter = 0; iter < n_iter; ++iter) {
-        uint32_t rare = 0;
-        if (it < n_items) {
-            const int p0 = (g0 + (int)grp) * 4;
-            const PairDesc d = *reinterpret_cast<const PairDesc *>(reinterpret_cast<const char *>(desc) + (size_t)(pair * 16u));
-            const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
-            // ---- sixteen 16-bit leading digits: (quality, error test) x (fwd, rev) x 4 positions
-            const u32x4 wq0 = draw_block(a, K_QM, (uint32_t)(p0 >> 1), 0);
-            const u32x4 wq1 = draw_block(a, K_QM, (uint32_t)(p0 >> 1) + 1, 0);
-            // ---- template bases: forward g[fs+p0 .. +3]; reverse comp(g[re-1-p0 .. -3])
-            uint32_t fb = 0, rb = 0, fm = 0, rm = 0;
-            if (PLAIN || !(A.has_frag && (d.meta & 64u))) {  // irregular pairs are built by the fix-up kernel
-                const int32_t pf = d.fs + p0;
-                const uint32_t *pw = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(uint32_t)(((pf >> 4) + 1) << 2));
-                fb = funnel_r(pw[0], pw[1], (uint32_t)(pf & 15) * 2) & 0xffu;
-                const int32_t pr = d.re - 4 - p0;  // lowest genome position of the 4 reverse bases
-                const uint32_t *qw = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(uint32_t)(((pr >> 4) + 1) << 2));
-                rb = funnel_r(qw[0], qw[1], (uint32_t)(pr & 15) * 2) & 0xffu;
-                if (!PLAIN && (d.meta & 0x30u)) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
-                    const uint32_t *mw = g.mask + (pf >> 5);
-                    fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xfu;
-                    const uint32_t *nw = g.mask + (pr >> 5);
-                    rm = funnel_r(nw[0], nw[1], (uint32_t)(pr & 31)) & 0xfu;
-                }
-            }
-            // ---- phred scores + substitution test, loop-free (hot_lookup); 8 independent lookups
-            const uint32_t rowf_b = row_g + __umul24(d.meta & 3u, slot_b);  // (slot_b < 160 KB: 24-bit operands)
-            const uint32_t rowr_b = row_g + __umul24((uint32_t)M.NB + ((d.meta >> 2) & 3u), slot_b);
-            uint32_t sel[8];  // (the rows of the last group's padding positions repeat the last position's row)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t pc_b = (uint32_t)c * stride_b;
-                const u32x4 &w = (c >> 1) ? wq1 : wq0;
-                uint32_t x;
-                sel[c] = hot_lookup(lds, rowf_b + pc_b, (c & 1) ? w.z : w.x, gshift, gbytes, x);
-                rare = __builtin_amdgcn_alignbit(rare, x, 31);  // rare = rare << 1 | sign(x)
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t pc_b = (uint32_t)c * stride_b;
-                const u32x4 &w = (c >> 1) ? wq1 : wq0;
-                uint32_t x;
-                sel[4 + c] = hot_lookup(lds, rowr_b + pc_b, (c & 1) ? w.w : w.y, gshift, gbytes, x);
-                rare = __builtin_amdgcn_alignbit(rare, x, 31);
-            }
-            // phred bytes: bits 8-13 of each selected entry
-            const uint32_t qual_f = (__builtin_amdgcn_perm(sel[1], sel[0], 0x0c0c0501u) |
-                                     __builtin_amdgcn_perm(sel[3], sel[2], 0x05010c0cu)) & 0x3f3f3f3fu;
-            const uint32_t qual_r = (__builtin_amdgcn_perm(sel[5], sel[4], 0x0c0c0501u) |
-                                     __builtin_amdgcn_perm(sel[7], sel[6], 0x05010c0cu)) & 0x3f3f3f3fu;
-            uint32_t base_f = codes_to_ascii4(fb);
-            uint32_t base_r = __builtin_amdgcn_perm(0u, codes_to_ascii4(rb ^ 0x55u), 0x00010203u);  // complement, reversed
-            if (!PLAIN && (fm | rm)) {  // IUPAC / lower-case letters: patch from the ASCII copy
-                for (int c = 0; c < 4; ++c) {
-                    if ((fm >> c) & 1u) {
-                        const uint32_t ch = g.ascii[(int64_t)d.fs + p0 + c];
-                        base_f = (base_f & ~(0xffu << (8 * c))) | (ch << (8 * c));
-                    }
-                    if ((rm >> (3 - c)) & 1u) {
-                        const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)d.re - 1 - p0 - c]);
-                        base_r = (base_r & ~(0xffu << (8 * c))) | (ch << (8 * c));
-                    }
-                }
-            }
-            // (the <= 3 padding bytes of the last group hold the clamped last row's values; nothing reads them)
-            *reinterpret_cast<uint32_t *>(A.out[0] + (size_t)out_b) = base_f;
-            *reinterpret_cast<uint32_t *>(A.out[1] + (size_t)out_b) = qual_f;
-            *reinterpret_cast<uint32_t *>(A.out[2] + (size_t)out_b) = base_r;
-            *reinterpret_cast<uint32_t *>(A.out[3] + (size_t)out_b) = qual_r;
-            rare &= 0xffu;  // bit (7 - s) <=> base s needs the exact path (~1 % of bases: mostly substitution events)
-        }
+    // tag: pass << 24 | iteration << 19 | lane << 13 | half << 12 | bin slots << 8
+    auto push = [&](uint32_t rare, uint32_t tag, uint32_t windows) {
         const unsigned long long rm = __ballot(rare != 0u);
         if (rm) {
             if (rare) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
-                ring[(q_tail + rank) & (SLOW_RING - 1)] = (iter << 14) | (lane << 8) | rare;
+                ring[(q_tail + rank) & (SLOW_RING - 1)] = make_uint2(tag | rare, windows);
             }
             q_tail += (uint32_t)__popcll(rm);
             while (q_tail - q_head >= 64u) drain_round(64u);
         }
-        it += step;
-        pair += step_pair;
-        grp += step_grp;
-        row_g += row_step;
-        out_b += out_step;
-        if (grp >= tg) { grp -= tg; ++pair; row_g -= row_wrap; out_b += out_wrap; }
+    };
+    const uint32_t j4 = lane & 3u;
+    for (uint32_t pass = 0, blk = wg; blk < n_pass; ++pass, blk += n_wg) {
+        const uint32_t pair = blk * MAIN_PAIRS + wave_pair0 + (lane >> 2);
+        const bool valid = pair < (uint32_t)A.n_pairs;
+        PairDesc d = {0, 0, 0u, 0};
+        if (valid) d = desc[pair];
+        const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
+        // LDS byte offsets of the pair's rows (its bin slots) at this lane's first superitem; one iteration = 8 groups on
+        const uint32_t lane_row = j4 * 2u * gs_b;
+        uint32_t rowf = __umul24(d.meta & 3u, slot_b) + lane_row, rowf_e = rowf + gbytes;
+        uint32_t rowr = __umul24((uint32_t)M.NB + ((d.meta >> 2) & 3u), slot_b) + lane_row, rowr_e = rowr + gbytes;
+        const uint32_t s_lane = (uint32_t)T.s0 + j4;
+        int32_t pf = d.fs + (int32_t)(s_lane * 8u);           // genome position of the lane's first forward base
+        int32_t pr = d.re - 8 - (int32_t)(s_lane * 8u);       // lowest genome position of its 8 reverse bases
+        uint32_t out_b = pair * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u;  // (tiles start at multiples of 4 superitems: whole lines)
+        const bool regular = PLAIN || !(A.has_frag && (d.meta & 64u));  // irregular pairs are built by the fix-up kernel
+        const uint32_t tag0 = (pass << 24) | (lane << 13) | ((d.meta & 15u) << 8);
+        for (uint32_t it = 0; it < n_iter; ++it) {
+            uint32_t rare0 = 0, rare1 = 0, windows = 0;
+            if (valid && 4u * it + j4 < T.ts) {
+                const uint32_t s_abs = s_lane + 4u * it;
+                // ---- the two 8-base windows of the 2-bit genome: forward g[pf .. pf+7]; reverse comp(g[pr+7 .. pr]); loaded
+                //      first, used last (the wait for them would otherwise also be a wait for the previous stores)
+                uint2 gf = {0u, 0u}, gr = {0u, 0u};
+#ifdef ISS_EXP_NOGENOME
+                if (false) {
+#else
+                if (regular) {
+#endif
+                    gf = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pf >> 4) + 1) << 2));
+                    gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pr >> 4) + 1) << 2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- hot digits: 16 quality digits (16 bits) + 16 error-test digits (8 bits)
+                const u32x4 q0 = draw_block(a, K_QM, s_abs, 0);
+                const u32x4 ee = draw_block(a, K_QM, s_abs, 1);
+                const u32x4 q1 = draw_block(a, K_QM, s_abs, 2);
+                // ---- phred scores + substitution test, loop-free (hot_lookup); 16 independent lookups
+                uint32_t sel[16];
+                unsigned long long fl;
+#define ISS_LOOKUP(K, ROW, C, HI, BYTE, WQ, WE, RARE)                                                                \
+                sel[K] = hot_lookup<HI, BYTE>(ldsb, ROW, ROW##_e, off_g[C], WQ, WE, gsh, gb, fl);                      \
+                RARE = shift_in(RARE, fl);
+                // half 0: positions 0-3; bit (7 - s) of rare0 <=> base s = mate * 4 + cc
+                ISS_LOOKUP(0, rowf, 0, 0, 0, q0.x, ee.x, rare0)
+                ISS_LOOKUP(1, rowf, 1, 1, 1, q0.x, ee.x, rare0)
+                ISS_LOOKUP(2, rowf, 2, 0, 2, q0.y, ee.x, rare0)
+                ISS_LOOKUP(3, rowf, 3, 1, 3, q0.y, ee.x, rare0)
+                ISS_LOOKUP(4, rowr, 0, 0, 0, q0.z, ee.y, rare0)
+                ISS_LOOKUP(5, rowr, 1, 1, 1, q0.z, ee.y, rare0)
+                ISS_LOOKUP(6, rowr, 2, 0, 2, q0.w, ee.y, rare0)
+                ISS_LOOKUP(7, rowr, 3, 1, 3, q0.w, ee.y, rare0)
+                // half 1: positions 4-7
+                ISS_LOOKUP(8, rowf, 4, 0, 0, q1.x, ee.z, rare1)
+                ISS_LOOKUP(9, rowf, 5, 1, 1, q1.x, ee.z, rare1)
+                ISS_LOOKUP(10, rowf, 6, 0, 2, q1.y, ee.z, rare1)
+                ISS_LOOKUP(11, rowf, 7, 1, 3, q1.y, ee.z, rare1)
+                ISS_LOOKUP(12, rowr, 4, 0, 0, q1.z, ee.w, rare1)
+                ISS_LOOKUP(13, rowr, 5, 1, 1, q1.z, ee.w, rare1)
+                ISS_LOOKUP(14, rowr, 6, 0, 2, q1.w, ee.w, rare1)
+                ISS_LOOKUP(15, rowr, 7, 1, 3, q1.w, ee.w, rare1)
+#undef ISS_LOOKUP
+                // phred bytes: byte 1 of each selected entry
+                auto quals = [&](int k) {
+                    return __builtin_amdgcn_perm(sel[k + 1], sel[k], 0x0c0c0501u) | __builtin_amdgcn_perm(sel[k + 3], sel[k + 2], 0x05010c0cu);
+                };
+                uint2 qual_f = {quals(0), quals(8)}, qual_r = {quals(4), quals(12)};
+                // ---- template bases
+                uint32_t fm = 0, rm = 0;
+                const uint32_t fb = funnel_r(gf.x, gf.y, (uint32_t)(pf & 15) * 2);
+                const uint32_t rb = funnel_r(gr.x, gr.y, (uint32_t)(pr & 15) * 2) ^ 0x5555u;  // complement: code ^ 1
+                windows = __builtin_amdgcn_perm(rb, fb, 0x05040100u);  // fb[15:0] | rb[15:0] << 16
+                if (!PLAIN && regular && (d.meta & 0x30u)) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
+                    const uint32_t *mw = g.mask + (pf >> 5);
+                    fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xffu;
+                    const uint32_t *nw = g.mask + (pr >> 5);
+                    rm = funnel_r(nw[0], nw[1], (uint32_t)(pr & 31)) & 0xffu;
+                }
+                uint2 base_f = {codes_to_ascii4(fb & 0xffu), codes_to_ascii4((fb >> 8) & 0xffu)};
+                // reverse mate: read position c <-> genome position pr + 7 - c
+                uint2 base_r = {__builtin_amdgcn_perm(0u, codes_to_ascii4((rb >> 8) & 0xffu), 0x00010203u),
+                                __builtin_amdgcn_perm(0u, codes_to_ascii4(rb & 0xffu), 0x00010203u)};
+                if (!PLAIN && (fm | rm)) {  // IUPAC / lower-case letters: patch from the ASCII copy
+                    for (int c = 0; c < 8; ++c) {
+                        if ((fm >> c) & 1u) {
+                            const uint32_t ch = g.ascii[(int64_t)pf + c];
+                            uint32_t &w = c < 4 ? base_f.x : base_f.y;
+                            w = (w & ~(0xffu << (8 * (c & 3)))) | (ch << (8 * (c & 3)));
+                        }
+                        if ((rm >> (7 - c)) & 1u) {
+                            const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)pr + 7 - c]);
+                            uint32_t &w = c < 4 ? base_r.x : base_r.y;
+                            w = (w & ~(0xffu << (8 * (c & 3)))) | (ch << (8 * (c & 3)));
+                        }
+                    }
+                }
+                // (the padding bytes of the last superitem hold the clamped last row's values; nothing reads them)
+                uint4 *dst = reinterpret_cast<uint4 *>(A.out[0] + (size_t)out_b);  // two 16-byte pieces of the pair's 128-byte line
+#ifdef ISS_EXP_NOSTORE
+                if ((base_f.x ^ base_f.y ^ qual_f.x ^ qual_f.y ^ base_r.x ^ base_r.y ^ qual_r.x ^ qual_r.y) == 0x12345u)
+#endif
+                {
+                dst[0] = make_uint4(base_f.x, base_f.y, qual_f.x, qual_f.y);
+                dst[4] = make_uint4(base_r.x, base_r.y, qual_r.x, qual_r.y);
+                }
+            }
+            // bit (7 - s) <=> base s of the half needs the exact path (~1.7 % of bases: mostly substitution events)
+#ifdef ISS_EXP_NODRAIN
+            if (rare0 == 0x12345u && rare1 == 0x54321u)
+#endif
+            {
+            push(rare0, tag0 | (it << 19), windows);
+            push(rare1, tag0 | (it << 19) | 4096u, windows);
+            }
+            rowf += 8u * gs_b; rowf_e += 8u * gs_b;
+            rowr += 8u * gs_b; rowr_e += 8u * gs_b;
+            pf += 32;
+            pr -= 32;
+            out_b += 128u;
+        }
     }
     while (q_tail != q_head) drain_round(min(64u, q_tail - q_head));
 }
@@ -892,7 +995,7 @@ constexpr int FIX_MAX_RL = 1024;  // read_length limit (checked at model upload)
 constexpr int FIX_WAVES = 4;      // wavefronts (reads) per workgroup
 constexpr int16_t FIX_NONE = 0x7fff;
 
-// dynamic LDS of k_indel_fixup, in bytes: [fix table 2*RL*8 u32][mut16 64 u32][per wave: see below]
+// dynamic LDS of k_indel_fixup, in bytes: [fix table 2*RL*8 u32][mut8 64 u32][per wave: see below]
 __host__ __device__ inline int fix_rlp(int RL) { return (RL + 63) & ~63; }
 __host__ __device__ inline size_t fix_wave_bytes(int RL) {
     const size_t rlp = (size_t)fix_rlp(RL);
@@ -913,15 +1016,15 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
     const int RL = M.RL;
     const int rlp = fix_rlp(RL);
     uint32_t *tab = reinterpret_cast<uint32_t *>(fix_lds);            // [2][RL][8]: digit limits of ins x4, del x4
-    uint32_t *mut16 = tab + (size_t)2 * RL * 8;                        // [64]
+    uint32_t *mut8 = tab + (size_t)2 * RL * 8;                         // [64] leading 8 bits of the substitution-test thresholds
     const uint32_t n_fix = *fix_count;
     if (blockIdx.x * FIX_WAVES >= n_fix) return;                       // whole workgroup idle (uniform)
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)stats, (unsigned long long)n_fix);
     for (int i = threadIdx.x; i < 2 * RL * 8; i += blockDim.x) tab[i] = M.fix_tab[i];
-    for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut16[i] = M.mut16[i];
+    for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut8[i] = (uint32_t)(M.mut_thr[i] >> 45);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint8_t *wbase = reinterpret_cast<uint8_t *>(mut16 + 64) + (size_t)wv * fix_wave_bytes(RL);
+    uint8_t *wbase = reinterpret_cast<uint8_t *>(mut8 + 64) + (size_t)wv * fix_wave_bytes(RL);
     uint8_t *ev = wbase;
     uint8_t *stk = ev + rlp;
     uint8_t *qual = stk + rlp;
@@ -930,7 +1033,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
     int16_t *rec_n0 = map + (rlp + 64);
     int16_t *rec_k0 = rec_n0 + (rlp + 64);
     uint16_t *ddel = reinterpret_cast<uint16_t *>(rec_k0 + (rlp + 64));  // [rlp] deletion digit of step n (K_DEL)
-    uint16_t *dqm = ddel + rlp;                                           // [rlp] error-test digit of position j (K_QM)
+    uint16_t *dqm = ddel + rlp;                                           // [rlp] error-test digit (8 bits) of position j (K_QM)
     uint64_t *act = reinterpret_cast<uint64_t *>(dqm + rlp);              // [FIX_MAX_RL / 64] steps with an event
     const int n_pre = RL + 64;
     const int n_chunks = rlp / 64;  // 64-step chunks covering indices 0 .. RL-1
@@ -949,8 +1052,8 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
         }
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
         const MateGeom geo = mate_geom(o, d, RL, gl.L);
-        uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.pitch;
-        const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.pitch;
+        uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.row;
+        const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.row;
         // ---- phase 0: the digits that several steps / positions share, one Philox block per LANE (a K_DEL block holds
         //      the deletion digits of 4 steps, a K_QM block the error-test digits of 2 positions)
         for (int b = lane; b * 4 < RL - 1; b += 64) {
@@ -958,10 +1061,10 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
 #pragma unroll
             for (int c = 0; c < 4; ++c) ddel[b * 4 + c] = (uint16_t)digit16(w, c * 2 + o);
         }
-        for (int b = lane; b * 2 < RL; b += 64) {
-            const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 0);
-            dqm[b * 2] = (uint16_t)digit16(w, 2 * o + 1);
-            dqm[b * 2 + 1] = (uint16_t)digit16(w, 4 + 2 * o + 1);
+        for (int b = lane; b * 8 < RL; b += 64) {
+            const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dqm[b * 8 + c] = (uint16_t)((word_of(w, (c >> 2) * 2 + o) >> (8 * (c & 3))) & 0xffu);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -997,7 +1100,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
                     }
                 }
             }
-            if (n < RL) { ev[n] = (uint8_t)m8; map[n] = FIX_NONE; qual[n] = out_qual[n]; }
+            if (n < RL) { ev[n] = (uint8_t)m8; map[n] = FIX_NONE; qual[n] = out_qual[xp(n)]; }
             { const uint64_t am = __ballot(m8 != 0); if (lane == 0) act[c] = am; }
         }
         for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)geom_base(gl, o, geo, k);
@@ -1073,14 +1176,17 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
                 tok = rec_k0[r] + (j - rec_n0[r]);
             }
             int base = tok < 0 ? -tok : (tok < n_pre ? (int)tmpl[tok] : geom_base(gl, o, geo, tok));
-            const uint32_t h = dqm[j];
+            const uint32_t e8 = dqm[j];
             const int q = qual[j];
-            const uint32_t t = mut16[q];
-            bool err = h > t;
-            if (h == t) err = mut_exact(M, a, o, j, h, q);
+            const uint32_t t8 = mut8[q];
+            bool err = e8 > t8;
             const int before = base;
-            if (err) base = substitute(M, a, o, j, base);
-            out_base[j] = (uint8_t)base;
+            if (e8 >= t8) {
+                const u32x4 sb = draw_block(a, K_SUB, (uint32_t)j, (uint32_t)o);
+                if (e8 == t8) err = error_test_draw(e8, sb) > M.mut_thr[q];
+                if (err) base = substitute(M, sb, o, j, base);
+            }
+            out_base[xp(j)] = (uint8_t)base;
             if (A.mut) {  // only if the new letter differs from the ORIGINAL read at this index (__init__.py:98)
                 MutRecord sub;
                 sub.pair = (int32_t)(A.pair_base + pair); sub.mate = (int8_t)o; sub.type = (int8_t)32; sub.position = (int16_t)j;

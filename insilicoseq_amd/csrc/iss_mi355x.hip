@@ -23,9 +23,9 @@
 #include <thread>
 #include <vector>
 
+#include "iss_kernels.hip.h"
 #include "iss_fastq.hip.h"
 #include "iss_deflate.hip.h"
-#include "iss_kernels.hip.h"
 #include "iss_mt_compat.hip.h"
 
 namespace {
@@ -174,7 +174,9 @@ struct iss_ctx {
     std::vector<Genome> genomes;
     // outputs
     int64_t capacity = 0;
-    uint8_t *out[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t *out[4] = {nullptr, nullptr, nullptr, nullptr};  // ONE allocation of interleaved rows (iss::xp): out[k] = out[0] + iss::row_array_off(k)
+    uint8_t *d_stage = nullptr;  // iss_output_download: the four plain arrays of the rows being copied
+    size_t stage_cap = 0;
     iss::PairDesc *desc = nullptr;
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
@@ -259,7 +261,10 @@ void free_model(iss_ctx *ctx) {
 }
 
 void free_outputs(iss_ctx *ctx) {
-    for (auto &p : ctx->out) { if (p) (void)hipFree(p); p = nullptr; }
+    if (ctx->out[0]) (void)hipFree(ctx->out[0]);
+    for (auto &p : ctx->out) p = nullptr;
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    ctx->d_stage = nullptr; ctx->stage_cap = 0;
     if (ctx->desc) (void)hipFree(ctx->desc);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->fix_list) (void)hipFree(ctx->fix_list);
@@ -431,10 +436,9 @@ int mt_prefetch_commit(iss_ctx *ctx, const MtPrefetch &pf) {
     return 0;
 }
 
-// dynamic LDS of k_main: quality rows + error-test thresholds + substitution table + deferred-work queue
+// dynamic LDS of k_main: quality rows + deferred-work queues
 size_t main_lds_bytes(const iss::DevModel &M) {
-    const size_t mut_words = ((size_t)M.n_q + 1 + 3) & ~(size_t)3;
-    return ((size_t)M.tile_words + mut_words + (size_t)M.subst_words + (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING) * 4;
+    return ((size_t)M.tile_words + iss::MAIN_MUT_WORDS + (size_t)2 * M.TP * 4 + (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 2) * 4;
 }
 
 int settle_timing(iss_ctx *ctx) {
@@ -774,10 +778,11 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     M.quality_mode = t->quality_mode;
     M.basic_insert_size = t->basic_insert_size;
     M.basic_mean = t->basic_mean; M.basic_sd = t->basic_sd; M.basic_cap = t->basic_cap;
-    M.G = (RL + 3) / 4; M.pitch = M.G * 4;
+    M.S = (RL + 7) / 8; M.pitch = M.S * 8; M.G = M.S * 2;
+    M.row = 128 * ((M.S + 3) / 4);
     // ---- compressed quality rows for k_main: per (orientation, bin slot, position) the distinct
-    // 16-bit leading digits of the thresholds, packed (t16 << 8 | #thresholds below), + a 64-byte
-    // guide (first entry for each value of the top 6 bits) + a sentinel.
+    // 16-bit leading digits of the thresholds, packed t16 << 16 | phred << 8 | te8 (te8 = leading 8 bits of the
+    // phred's substitution-test threshold), + a guide (first entry for each value of the top GB bits) + sentinels.
     int n_slots[2] = {0, 0};
     for (int o = 0; o < 2; ++o)
         for (int b = 0; b < 4; ++b) {
@@ -795,16 +800,18 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     M.NB = std::max(n_slots[0], n_slots[1]);
     for (int o = 0; o < 2; ++o)
         for (int sl = n_slots[o]; sl < M.NB; ++sl) M.slot_bin[o * 4 + sl] = M.slot_bin[o * 4];
+    // (a threshold of 2^53 -- never an error -- clamps to 255: the digit 255 then ties and is resolved exactly)
+    auto te8 = [&](int q) { return (uint32_t)std::min<uint64_t>(t->mut_thr[q] >> 45, 255u); };
     auto build_row = [&](int o, int bin, int p, std::vector<uint32_t> &entries) {
         const uint64_t *row = t->q_thr + ((size_t)(o * 4 + bin) * RL + p) * nq;
         entries.clear();
         for (int i = 0; i < nq; ++i) {
             const uint32_t v = (uint32_t)std::min<uint64_t>(row[i] >> 37, 0xffffu);  // 2^53 (cdf == 1.0) clamps: a tie
-            if (entries.empty() || (entries.back() >> 15) != v) entries.push_back((v << 15) | ((uint32_t)i << 8) | ((uint32_t)i << 2));
+            if (entries.empty() || (entries.back() >> 16) != v) entries.push_back((v << 16) | ((uint32_t)i << 8) | te8(i));
         }
         // two closing sentinels (the hot loop reads entries j and j + 1 unconditionally); digit 0xffff
         // "ties" with them and is resolved exactly
-        if ((entries.back() >> 15) != 0xffffu) entries.push_back((0xffffu << 15) | ((uint32_t)nq << 8) | ((uint32_t)nq << 2));
+        if ((entries.back() >> 16) != 0xffffu) entries.push_back((0xffffu << 16) | ((uint32_t)nq << 8) | te8(nq));
         entries.push_back(entries.back());
         entries.push_back(entries.back());
     };
@@ -830,11 +837,11 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     size_t j = 0;
                     for (uint32_t b = 0; b < (1u << gb); ++b) {
                         const uint32_t lo = b * width, hi = lo + width;
-                        while (j < entries.size() && (entries[j] >> 15) < lo) ++j;
+                        while (j < entries.size() && (entries[j] >> 16) < lo) ++j;
                         size_t k = j;
                         int inside = 0;
                         uint32_t second = 0;
-                        while (k < entries.size() && (entries[k] >> 15) < hi) { if (++inside == 2) second = entries[k] >> 15; ++k; }
+                        while (k < entries.size() && (entries[k] >> 16) < hi) { if (++inside == 2) second = entries[k] >> 16; ++k; }
                         if (inside >= 2 && hi - 1 > second) acc += (double)(hi - 1 - second);
                     }
                     ++rows;
@@ -850,11 +857,11 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         // (guide 8 bits, one workgroup / CU: 7.7 ms per 5 M pairs; 6 bits, two: 7.0 ms).
         auto two_fit = [&](int gb) {
             const size_t gs = 4 * ((size_t)(1 << gb) / 4 + s_max) + 1;
-            for (int nt = 1; nt <= (RL + 3) / 4; ++nt) {
-                const size_t tg = ((size_t)(RL + 3) / 4 + nt - 1) / nt;
-                if (tg < (size_t)std::min(12, (RL + 3) / 4)) break;
-                const size_t words = (2 * (size_t)M.NB * tg * gs + 3) / 4 * 4 + (((size_t)nq + 1 + 3) & ~(size_t)3) + 2 * tg * 4 * 4 * 2 +
-                                     (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING;
+            for (int nt = 1; nt <= M.S; ++nt) {
+                const size_t tg = 2 * (nt > 1 ? (((size_t)M.S + nt - 1) / nt + 3) / 4 * 4 : (size_t)M.S);
+                if (tg < (size_t)std::min(12, M.G)) break;
+                const size_t words = (2 * (size_t)M.NB * tg * gs + 3) / 4 * 4 + iss::MAIN_MUT_WORDS + 2 * tg * 4 * 4 +
+                                     (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 2;
                 if (words * 4 <= 79 * 1024) return true;
             }
             return false;
@@ -887,25 +894,26 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     // Position tiling: prefer tiles small enough for TWO resident workgroups per CU (8 waves / SIMD) as long
     // as a tile keeps >= 12 groups (48-byte output segments); otherwise the largest tile one workgroup can hold.
     auto fits = [&](int n_tiles, size_t budget) {
-        M.TG = (M.G + n_tiles - 1) / n_tiles;
+        M.TS = (M.S + n_tiles - 1) / n_tiles;
+        if (n_tiles > 1) M.TS = (M.TS + 3) / 4 * 4;  // tiles start at whole 128-byte lines of the output rows (4 superitems)
+        M.TG = M.TS * 2;
         M.TP = M.TG * 4;
         M.tile_words = (2 * M.NB * M.TG * M.GS + 3) / 4 * 4;
-        M.subst_words = 2 * M.TP * 4 * 2;
         return main_lds_bytes(M) <= budget;
     };
     const size_t two_per_cu = 79 * 1024, one_per_cu = 158 * 1024;
     const int env_tiles = getenv("ISS_TILES") ? atoi(getenv("ISS_TILES")) : 0;  // tuning aid
     M.n_tiles = 0;
     if (env_tiles > 0 && fits(env_tiles, one_per_cu)) M.n_tiles = env_tiles;
-    for (int nt = 1; !M.n_tiles && nt <= M.G; ++nt) {
-        if ((M.G + nt - 1) / nt < std::min(12, M.G)) break;
-        if (fits(nt, two_per_cu)) M.n_tiles = nt;
+    for (int nt = 1; !M.n_tiles && nt <= M.S; ++nt) {
+        if (2 * ((M.S + nt - 1) / nt) < std::min(12, M.G)) break;
+        if (fits(nt, two_per_cu) && (M.S + M.TS - 1) / M.TS == nt) M.n_tiles = nt;
     }
-    for (int nt = 1; !M.n_tiles && nt <= M.G; ++nt)
+    for (int nt = 1; !M.n_tiles && nt <= M.S; ++nt)
         if (fits(nt, one_per_cu)) M.n_tiles = nt;
-    if (!M.n_tiles) return fail(ctx, ISS_E_INVALID, "quality tables do not fit the LDS even for one position group");
+    if (!M.n_tiles) return fail(ctx, ISS_E_INVALID, "quality tables do not fit the LDS even for one superitem (8 positions)");
     (void)fits(M.n_tiles, one_per_cu);
-    M.n_tiles = (M.G + M.TG - 1) / M.TG;
+    M.n_tiles = (M.S + M.TS - 1) / M.TS;
     if (getenv("ISS_DEBUG_MODEL"))
         fprintf(stderr, "[model] RL %d G %d NB %d GB %d stride_w %d GS %d TG %d n_tiles %d tile %.1f KB (k_main LDS %.1f KB)\n",
                 M.RL, M.G, M.NB, M.GB, M.stride_w, M.GS, M.TG, M.n_tiles, M.tile_words * 4 / 1024.0,
@@ -922,27 +930,42 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     uint8_t *guide = reinterpret_cast<uint8_t *>(dst);
                     size_t j = 0;
                     for (uint32_t b = 0; b < (1u << M.GB); ++b) {
-                        while ((entries[j] >> 15) < (b << (16 - M.GB))) ++j;
+                        while ((entries[j] >> 16) < (b << (16 - M.GB))) ++j;
                         guide[b] = (uint8_t)(4 * j);  // byte offset of the entry (<= 4 * 63)
                     }
                     std::copy(entries.begin(), entries.end(), dst + gwords);
                     for (size_t k = gwords + entries.size(); k < (size_t)M.stride_w; ++k) dst[k] = entries.back();
                 }
-    std::vector<uint32_t> subst16((size_t)M.n_tiles * M.subst_words, 0);
-    for (int tl = 0; tl < M.n_tiles; ++tl)
-        for (int o = 0; o < 2; ++o)
-            for (int pp = 0; pp < M.TP; ++pp)
-                for (int bi = 0; bi < 4; ++bi) {
-                    const int p = std::min(tl * M.TP + pp, RL - 1);
-                    const size_t row = ((size_t)(o * RL + p) * 4 + bi) * 3;
-                    auto d16 = [](uint64_t T) { return (uint32_t)std::min<uint64_t>(T >> 37, 0xffffu); };
-                    uint32_t *dst = subst16.data() + (size_t)tl * M.subst_words + ((size_t)(o * M.TP + pp) * 4 + bi) * 2;
-                    dst[0] = d16(t->subst_thr[row]) | (d16(t->subst_thr[row + 1]) << 16);
-                    dst[1] = (uint32_t)t->subst_alt[row] | ((uint32_t)t->subst_alt[row + 1] << 8) |
-                             ((uint32_t)t->subst_alt[row + 2] << 16);
-                }
-    std::vector<uint32_t> mut16(nq + 1);
-    for (int i = 0; i <= nq; ++i) mut16[i] = (uint32_t)(t->mut_thr[i] >> 37);
+    // substitution table of k_main's exact path (LDS): leading 13 bits of the two thresholds + the alternatives as indices
+    // into the (<= 4) distinct letters the model uses
+    std::vector<uint32_t> subst13((size_t)M.n_tiles * 2 * M.TP * 4, 0);
+    {
+        uint8_t letters[4] = {0, 0, 0, 0};
+        int n_letters = 0;
+        auto letter_index = [&](uint8_t c) {
+            for (int i = 0; i < n_letters; ++i) if (letters[i] == c) return i;
+            if (n_letters == 4) return -1;
+            letters[n_letters] = c;
+            return n_letters++;
+        };
+        for (int tl = 0; tl < M.n_tiles; ++tl)
+            for (int o = 0; o < 2; ++o)
+                for (int pp = 0; pp < M.TP; ++pp)
+                    for (int bi = 0; bi < 4; ++bi) {
+                        const int p = std::min(tl * M.TP + pp, RL - 1);
+                        const size_t row = ((size_t)(o * RL + p) * 4 + bi) * 3;
+                        auto d13 = [](uint64_t T) { return (uint32_t)std::min<uint64_t>(T >> 40, 0x1fffu); };
+                        uint32_t alts = 0;
+                        for (int k = 0; k < 3; ++k) {
+                            const int li = letter_index(t->subst_alt[row + k]);
+                            if (li < 0) return fail(ctx, ISS_E_INVALID, "substitution alternatives use more than four distinct letters");
+                            alts |= (uint32_t)li << (2 * k);
+                        }
+                        subst13[(size_t)tl * 2 * M.TP * 4 + ((size_t)(o * M.TP + pp) * 4 + bi)] =
+                            d13(t->subst_thr[row]) | (d13(t->subst_thr[row + 1]) << 13) | (alts << 26);
+                    }
+        M.alt_letters = (uint32_t)letters[0] | ((uint32_t)letters[1] << 8) | ((uint32_t)letters[2] << 16) | ((uint32_t)letters[3] << 24);
+    }
     std::vector<uint64_t> del_max((size_t)2 * RL);
     std::vector<uint8_t> ins_any((size_t)2 * RL);
     for (int o = 0; o < 2; ++o)
@@ -1022,8 +1045,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(bin_thr, t->bin_thr, 8, uint64_t);
     UP(q_thr, t->q_thr, n_qthr, uint64_t);
     UP(qrows, qrows.data(), qrows.size(), uint32_t);
-    UP(mut16, mut16.data(), mut16.size(), uint32_t);
-    UP(subst16, subst16.data(), subst16.size(), uint32_t);
+    UP(subst13, subst13.data(), subst13.size(), uint32_t);
     UP(subst_thr, t->subst_thr, (size_t)2 * RL * 12, uint64_t);
     UP(subst_alt, t->subst_alt, (size_t)2 * RL * 12, uint8_t);
     UP(ins_thr, t->ins_thr, (size_t)2 * RL * 4, uint64_t);
@@ -1143,13 +1165,9 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     free_outputs(ctx);
-    const size_t row = (size_t)ctx->M.pitch;
-    for (auto &p : ctx->out) {
-        void *q = nullptr;
-        HIP_TRY(ctx, hipMalloc(&q, row * (size_t)capacity_pairs));
-        p = static_cast<uint8_t *>(q);
-    }
     void *q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.row * (size_t)capacity_pairs));
+    for (int k = 0; k < 4; ++k) ctx->out[k] = static_cast<uint8_t *>(q) + iss::row_array_off(k);
     HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));
     ctx->desc = static_cast<iss::PairDesc *>(q);
     HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * (size_t)capacity_pairs));
@@ -1161,6 +1179,7 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
 }
 
 int iss_output_pitch(const iss_ctx *ctx) { return (ctx && ctx->have_model) ? ctx->M.pitch : ISS_E_INVALID; }
+int iss_output_row(const iss_ctx *ctx) { return (ctx && ctx->have_model) ? ctx->M.row : ISS_E_INVALID; }
 
 int iss_output_device_ptrs(const iss_ctx *ctx, void **a, void **b, void **c, void **d) {
     if (!ctx || !ctx->capacity) return ISS_E_INVALID;
@@ -1200,8 +1219,13 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                          const int64_t *item_first, int32_t n_items, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                          int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
     const iss::DevModel &M = ctx->M;
-    // lane-item indices are packed with 3 more bits in the deferred queue: keep them below 2^28
-    const int64_t max_chunk = std::max<int64_t>(1, ((int64_t)1 << 28) / std::max(M.G, std::max(M.n_scan, 1)));
+    // k_indel_scan packs lane-item indices into 32 bits (keep them below 2^28); k_main's deferred queue has 8 bits for
+    // the pass number of a workgroup (>= 1 workgroup per tile, 256 pairs per pass)
+    const size_t lds_bytes = main_lds_bytes(M);
+    const unsigned per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;  // 1024-lane workgroups, two per CU when the LDS tables allow it
+    const unsigned wg_per_tile = std::max(1u, std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid) / (unsigned)M.n_tiles);
+    const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(((int64_t)1 << 28) / std::max(M.G, std::max(M.n_scan, 1)),
+                                                                    (int64_t)255 * iss::MAIN_PAIRS * wg_per_tile));
     if (ctx->d_pmut) {  // rows of THIS call only
         ctx->d_pmut_count = reinterpret_cast<uint32_t *>(ctx->fix_count) + 60;  // +240 B of the scratch block
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_pmut, 0xff, (size_t)ctx->pmut_cap * sizeof(iss::MutRecord), ctx->stream));
@@ -1220,7 +1244,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.sequence_type = sequence_type;
         A.gc_bias = gc_bias ? 1 : 0;
         A.gc_thr = 8106479329266893ull;  // ceil(0.90 * 2^53), 0.90 being the f64 nearest to 0.9
-        for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
+        for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.row;
         A.scan_every = ctx->scan_every;
         iss::PairDesc *desc = ctx->desc + row0;
         uint32_t *flags = ctx->flags + row0;
@@ -1321,14 +1345,9 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         }
         HIP_TRY(ctx, mark(1, s_main));
         {
-            const size_t lds_bytes = main_lds_bytes(M);
-            const uint64_t items = (uint64_t)n * M.TG;
-            // persistent grid: 1024-lane workgroups, two per CU when the LDS tables allow it (8 waves / SIMD),
-            // split evenly over the position tiles
-            const unsigned per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;
-            unsigned per_tile = std::max(1u, per_cu * (unsigned)ctx->n_cu / (unsigned)M.n_tiles);
-            per_tile = (unsigned)std::min<uint64_t>(per_tile, (items + iss::MAIN_THREADS - 1) / iss::MAIN_THREADS);
-            per_tile = std::max(1u, std::min(per_tile, ctx->max_main_grid / (unsigned)M.n_tiles));
+            const uint64_t passes = ((uint64_t)n + iss::MAIN_PAIRS - 1) / iss::MAIN_PAIRS;  // a workgroup pass = 256 pairs
+            // persistent grid (8 waves / SIMD when two workgroups share a CU), split evenly over the position tiles
+            const unsigned per_tile = (unsigned)std::min<uint64_t>(wg_per_tile, passes);
             const dim3 grid(per_tile * (unsigned)M.n_tiles), block(iss::MAIN_THREADS);
             const bool plain = !any_exceptions && !ctx->has_frag;
 #define ISS_LAUNCH_MAIN(MUT, PLAIN) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN>), grid, block, lds_bytes, s_main, M, dg, A, desc)
@@ -1392,9 +1411,25 @@ int iss_output_download(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs, uint8
     const size_t pitch = (size_t)ctx->M.pitch;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    if (!n_pairs) return 0;
+    // the device rows are interleaved (iss::xp): four plain [n_pairs][pitch] arrays are formed on the device, then copied
+    const size_t need = 4 * pitch * (size_t)n_pairs;
+    if (ctx->stage_cap < need) {
+        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr; ctx->stage_cap = 0;
+        void *q = nullptr;
+        HIP_TRY(ctx, hipMalloc(&q, need));
+        ctx->d_stage = static_cast<uint8_t *>(q);
+        ctx->stage_cap = need;
+    }
+    {
+        hipLaunchKernelGGL(iss::k_rows_to_arrays, dim3((unsigned)((n_pairs + 3) / 4)), dim3(64, 4), 0, ctx->stream,
+                           ctx->out[0] + (size_t)first_pair * ctx->M.row, ctx->d_stage, n_pairs, ctx->M.S, ctx->M.row);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     for (int k = 0; k < 4; ++k)
-        if (host[k] && n_pairs)
-            HIP_TRY(ctx, hipMemcpyAsync(host[k], ctx->out[k] + (size_t)first_pair * pitch, pitch * (size_t)n_pairs,
+        if (host[k])
+            HIP_TRY(ctx, hipMemcpyAsync(host[k], ctx->d_stage + (size_t)k * pitch * (size_t)n_pairs, pitch * (size_t)n_pairs,
                                         hipMemcpyDeviceToHost, ctx->stream));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     return 0;
@@ -1787,8 +1822,8 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
                 auto emit = [&](const iss::MtEmitMut &E) {
                     hipLaunchKernelGGL(iss::k_mt_emit, dim3((unsigned)((2 * res.n_done + 3) / 4)), dim3(256), 0, ctx->stream, M, dg,
                                        R.py_base, R.np_base, res.n_done, ctx->desc + row0, m.d_rec,
-                                       ctx->out[0] + (size_t)row0 * M.pitch, ctx->out[1] + (size_t)row0 * M.pitch,
-                                       ctx->out[2] + (size_t)row0 * M.pitch, ctx->out[3] + (size_t)row0 * M.pitch, E);
+                                       ctx->out[0] + (size_t)row0 * M.row, ctx->out[1] + (size_t)row0 * M.row,
+                                       ctx->out[2] + (size_t)row0 * M.row, ctx->out[3] + (size_t)row0 * M.row, E);
                 };
                 iss::MtEmitMut E{};
                 if (!m.d_mut) {
@@ -1835,7 +1870,7 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         A.sequence_type = sequence_type;
         A.gc_bias = gc_bias ? 1 : 0;
         A.gc_thr = 8106479329266893ull;
-        for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.pitch;
+        for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.row;
         A.res = m.d_res;
         A.use_rows = use_rows && n > 64 ? 1 : 0;  // staging the rows (one wavefront, tens of KB) only pays for a real batch
         A.mut = m.d_mut;
@@ -2032,7 +2067,7 @@ static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, 
     const iss::DevModel &M = ctx->M;
     iss::FastqArgs A{};
     A.cpu_len = (int32_t)snprintf(A.cpu, sizeof A.cpu, "%d", cpu_number);
-    A.pitch = M.pitch;
+    A.row = M.row;
     A.RL = M.RL;
     std::vector<iss::FastqItem> items;
     std::string ids;

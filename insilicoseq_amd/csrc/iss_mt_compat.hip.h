@@ -489,8 +489,8 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
             __syncthreads();
             }
             // ---- mut_sequence: one py double per position, one np double per substitution event, in order
-            uint8_t *ob = A.out[2 * o] + (size_t)i * M.pitch;
-            uint8_t *oq = A.out[2 * o + 1] + (size_t)i * M.pitch;
+            uint8_t *ob = A.out[2 * o] + (size_t)i * M.row;
+            uint8_t *oq = A.out[2 * o + 1] + (size_t)i * M.row;
             uint32_t nev = 0;
             for (int p0 = 0; p0 < RL; p0 += 64) {
                 const int p = p0 + lane;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
                 if (rec) put_mut(o, 0, p, ref_ch, ch, q, n_mut + (int64_t)__popcll(recm & ((1ull << lane) - 1ull)));
                 n_mut += (int64_t)__popcll(recm);
                 nev += (uint32_t)__popcll(evm);
-                if (p < RL) { ob[p] = (uint8_t)ch; oq[p] = (uint8_t)q; }
+                if (p < RL) { ob[xp(p)] = (uint8_t)ch; oq[xp(p)] = (uint8_t)q; }
             }
             opy += 2u * (uint32_t)RL;
             onp += 2u * nev;
@@ -936,8 +936,8 @@ __global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const 
     const uint32_t onp_q = r.onp_bin[o] + 2u, onp_s = onp_q + 2u * (uint32_t)RL, opy_e = r.opy_err[o];
     int bin = count_le(M.bin_thr + 4 * o, 4, mk53(np[r.onp_bin[o]], np[r.onp_bin[o] + 1]));
     bin = bin > 3 ? 3 : bin;
-    uint8_t *ob = (o ? out2 : out0) + (size_t)i * M.pitch;
-    uint8_t *oq = (o ? out3 : out1) + (size_t)i * M.pitch;
+    uint8_t *ob = (o ? out2 : out0) + (size_t)i * M.row;
+    uint8_t *oq = (o ? out3 : out1) + (size_t)i * M.row;
     uint32_t nev = 0, n_rows = 0;
     const int64_t row0 = E.mut ? E.mut_off[item] : 0;
     for (int p0 = 0; p0 < RL; p0 += 64) {
@@ -975,10 +975,10 @@ __global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const 
             }
         }
         n_rows += (uint32_t)__popcll(rm);
-        if (p < RL) { ob[p] = (uint8_t)ch; oq[p] = (uint8_t)q; }
+        if (p < RL) { ob[xp(p)] = (uint8_t)ch; oq[xp(p)] = (uint8_t)q; }
     }
     if (E.mut_cnt && lane == 0) E.mut_cnt[item] = (int32_t)n_rows;
-    for (int p = RL + lane; p < M.pitch; p += 64) { ob[p] = 0; oq[p] = 0; }
+    for (int p = RL + lane; p < M.pitch; p += 64) { ob[xp(p)] = 0; oq[xp(p)] = 0; }
 }
 
 }  // namespace iss

@@ -140,19 +140,24 @@ void iss_oracle_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t
 }
 
 /* Draw kinds of the Philox address map (DESIGN.md "RNG address map").
- * A "digit draw" builds its 53-bit numerator as m = (h16 << 37) | l37: the 16-bit leading digit
- * comes from a PRIMARY block shared by 8 draws (so the device needs one Philox call per 8 draws
- * and compares 16-bit prefixes), the trailing 37 bits from a SECONDARY block that the device only
- * evaluates when the prefix ties with a threshold.  u = m / 2^53 exactly. */
+ * A "digit draw" builds its 53-bit numerator as m = (digit << (53 - w)) | trailing bits: the w-bit leading
+ * digit comes from a PRIMARY block shared by many draws (the device compares digits and needs three Philox
+ * calls per 16 bases), the trailing bits from a SECONDARY block that the device only evaluates when the
+ * digit ties with a threshold's.  w = 16 for the quality, insertion and deletion draws, 8 for the
+ * substitution test (kde.py:84, __init__.py:94, :194, :209).  u = m / 2^53 exactly. */
 enum {
     K_PAIR = 0,   /* index 0; full draws mk53(sub0.word[s], sub1.word[s]), s = isize, bin_fwd, bin_rev, gc */
     K_FS = 1,     /* forward-start randbelow words: word t -> index t/4, word t%4        */
     K_RS = 2,     /* reverse-end fallback randbelow words, same addressing               */
-    K_QM = 3,     /* primary digits; index = p>>1; digit (p&1)*4 + {0 qual_fwd,1 mut_fwd,2 qual_rev,3 mut_rev} */
-    K_SUB = 4,    /* index = p; full draws mk53(w0,w1) fwd, mk53(w2,w3) rev              */
+    K_QM = 3,     /* hot digits of the 8 positions of superitem s = p>>3 (both mates): index = s, sub = 0, 1, 2.
+                   * c = p&7, half = c>>2, cc = c&3.  Quality digit h16 (16 bits): block sub = 2*half, word
+                   * mate*2 + (cc>>1), 16-bit half cc&1.  Error-test digit e8 (8 bits): block sub = 1, word
+                   * half*2 + mate, byte cc.                                                        */
+    K_SUB = 4,    /* index = p, sub = mate: (w0,w1) substitution choice (full draw); the 45 trailing bits of the
+                   * error-test draw = (w2 & 0x1fff) << 32 | w3                                      */
     K_INS = 5,    /* primary digits; index = n; digit mate*4 + letter slot               */
     K_DEL = 6,    /* primary digits; index = n>>2; digit (n&3)*2 + mate                   */
-    K_QM_LO = 7,  /* secondary; index = p; sub = mate; (w0,w1) qual, (w2,w3) mut          */
+    K_QM_LO = 7,  /* trailing 37 bits of the quality draw; index = p; sub = mate; (w0,w1)  */
     K_INS_LO = 8, /* secondary; index = n; sub = mate*2 + (slot>>1); pair slot&1          */
     K_DEL_LO = 9, /* secondary; index = n; sub 0; (w0,w1) fwd, (w2,w3) rev                */
     K_FRAG = 10   /* custom fragment length: polar candidate t -> index t; x1 from mk53(w0,w1), x2 from mk53(w2,w3) */
@@ -253,6 +258,28 @@ static double draw_digit(iss_rng *r, int stream, int kind_p, uint32_t index_p, i
     uint64_t l37 = ((uint64_t)wl[2 * pair_l] << 5) | (wl[2 * pair_l + 1] >> 27);
     uint64_t m = (h16 << 37) | l37;
     return (double)m * (1.0 / 9007199254740992.0);
+}
+
+/* The two hot draws of read position p of mate o (see K_QM / K_SUB / K_QM_LO in the enum). */
+static double draw_quality(iss_rng *r, int p, int o) { /* kde.py:84 */
+    if (r->mode == ISS_RNG_MT) return iss_oracle_np_random(r);
+    const int c = p & 7, half = c >> 2, cc = c & 3;
+    uint32_t wp[4], wl[4];
+    philox_at(r, K_QM, (uint32_t)p >> 3, (uint32_t)(2 * half), wp);
+    philox_at(r, K_QM_LO, (uint32_t)p, (uint32_t)o, wl);
+    uint64_t h16 = (wp[o * 2 + (cc >> 1)] >> (16 * (cc & 1))) & 0xffffu;
+    uint64_t l37 = ((uint64_t)wl[0] << 5) | (wl[1] >> 27);
+    return (double)((h16 << 37) | l37) * (1.0 / 9007199254740992.0);
+}
+static double draw_error_test(iss_rng *r, int p, int o) { /* __init__.py:94 */
+    if (r->mode == ISS_RNG_MT) return iss_oracle_py_random(r);
+    const int c = p & 7, half = c >> 2, cc = c & 3;
+    uint32_t wp[4], wl[4];
+    philox_at(r, K_QM, (uint32_t)p >> 3, 1u, wp);
+    philox_at(r, K_SUB, (uint32_t)p, (uint32_t)o, wl);
+    uint64_t e8 = (wp[half * 2 + o] >> (8 * cc)) & 0xffu;
+    uint64_t l45 = ((uint64_t)(wl[2] & 0x1fffu) << 32) | wl[3];
+    return (double)((e8 << 45) | l45) * (1.0 / 9007199254740992.0);
 }
 
 static int bit_length64(uint64_t n) { int k = 0; while (n) { k++; n >>= 1; } return k; }
@@ -478,8 +505,7 @@ static void gen_phred_scores(const iss_model *m, iss_rng *r, int o, uint8_t *qua
     if (bin >= 4) bin = 3; /* unreachable (cdf[-1] == 1.0 > u), mirrors kde.py:77-78 */
     const double *rows = m->qcdf + (((size_t)o * 4 + bin) * RL) * m->n_q;
     for (int p = 0; p < RL; p++) { /* kde.py:83-85 */
-        double u = draw_digit(r, STREAM_NP, K_QM, (uint32_t)p >> 1, (p & 1) * 4 + 2 * o, K_QM_LO, (uint32_t)p,
-                              (uint32_t)o, 0);
+        double u = draw_quality(r, p, o);
         qual[p] = (uint8_t)searchsorted_left(rows + (size_t)p * m->n_q, m->n_q, u);
     }
 }
@@ -490,14 +516,13 @@ static int mut_sequence(const iss_model *m, iss_rng *r, int o, uint8_t *seq, con
                         const uint8_t *original, mut_sink *sink) {
     const int RL = m->read_length;
     for (int p = 0; p < RL; p++) {
-        double u = draw_digit(r, STREAM_PY, K_QM, (uint32_t)p >> 1, (p & 1) * 4 + 2 * o + 1, K_QM_LO, (uint32_t)p,
-                              (uint32_t)o, 1); /* always drawn, :94 */
+        double u = draw_error_test(r, p, o); /* always drawn, :94 */
         int cu = upper_c(seq[p]);
         if (u > m->phred_thr[qual[p]] && !is_ambiguous_upper(cu)) {
             int bi = base_index(cu);
             if (bi < 0) return ISS_ERR_KEY;
             const size_t row = (((size_t)o * RL + p) * 4 + bi) * 3;
-            double us = draw_double(r, STREAM_NP, K_SUB, (uint32_t)p, 0, o, 0);
+            double us = draw_double(r, STREAM_NP, K_SUB, (uint32_t)p, (uint32_t)o, 0, 0);
             int k = (int)searchsorted_right(m->subst_cdf + row, 3, us);
             if (k > 2) k = 2; /* unreachable: cdf[-1] == 1.0 */
             uint8_t alt = m->subst_alt[row + k];
