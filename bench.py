@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- read-pairs/s of the MI355X read-generation path on BASELINE.json's headline config.
 
-A "step" = one pass of the hot path over one batch of synthetic input: 10 M reads (5 M pairs) of
+A "step" = one pass of the hot path over one batch of synthetic input: 10 M reads (5 M pairs) per GPU of
 the NovaSeq KDE model (read_length 151) over 5 synthetic 5 Mbp genomes with log-normal abundances
 (BASELINE.json configs[2]; SURVEY.md 8d "cfg 3").  Genomes, model tables and work list are resident
-in HBM before the timed region; outputs stay in HBM (R1/R2 base + phred buffers).
+in HBM before the timed region; outputs stay in HBM (R1/R2 base + phred rows).
 
-N > 1 (one process per GPU, launched by torch.distributed.run): weak scaling -- every rank is one
-reference worker (cpu_number = rank, worker seed = seed + rank) generating its own 5 M pairs;
-the only collective is ONE RCCL broadcast of the model tables + packed genomes from rank 0 before
-the timed region (the path itself has no exchange step).
+N > 1 (one process per GPU, launched by torch.distributed.run): the community run of 10 M x N reads is sharded the
+reference's way -- the flattened (record, pairs) list cut into N contiguous chunks of ceil(pairs / N) (iss/app.py:81-83),
+rank r = worker cpu_number r (worker seed = seed + r, read ids ..._r) -- so the per-GPU work is fixed (weak scaling)
+and N = 1 is the same code path.  The only collective is ONE RCCL broadcast of the model tables + 2-bit packed genomes
+from rank 0 before the timed region (the path itself has no exchange step); the ranks upload their genomes straight
+from the received device buffer.  `--workload configs3`: BASELINE configs[3] instead -- 100 M HiSeq reads per step over
+50 x 5 Mbp genomes, the TOTAL fixed and sharded over the N ranks (strong scaling).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline` and `parity_window`
+(windows of the last timed step recomputed by the CPU oracle after the timed region).
 """
 import argparse
 import json
@@ -37,6 +41,16 @@ def synthetic_genomes(n, length, seed):
     return [letters[rng.randint(0, 4, size=length)] for _ in range(n)]
 
 
+class _SeqLen(object):
+    """What the work divider needs of a record's letters: how many there are."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __len__(self):
+        return self.n
+
+
 def algorithmic_bytes_per_pair(read_length):
     # SURVEY.md 8d: 4*RL output bytes (R1+R2 bases and phreds) + two RL-base windows of the 2-bit genome
     return 4 * read_length + 2 * ((read_length + 3) // 4)
@@ -47,9 +61,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reads", type=int, default=READS_PER_STEP, help="reads per step per GPU")
-    ap.add_argument("--model", default="novaseq")
-    ap.add_argument("--n-genomes", type=int, default=N_GENOMES, help="records of the synthetic community (BASELINE configs[3]: 50)")
+    ap.add_argument("--workload", default="configs2", choices=["configs2", "configs3"],
+                    help="configs2: BASELINE configs[2], 10 M NovaSeq reads per step PER GPU over 5 genomes (weak scaling); "
+                         "configs3: BASELINE configs[3], 100 M HiSeq reads per step IN TOTAL over 50 genomes (strong scaling)")
+    ap.add_argument("--reads", type=int, default=None, help="reads per step (configs2: per GPU; configs3: in total)")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--n-genomes", type=int, default=None, help="records of the synthetic community")
     ap.add_argument("--indel", type=float, nargs=2, default=None, metavar=("P_INS", "P_DEL"),
                     help="override every insertion / deletion probability (BASELINE configs[4]-like indel-heavy model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -58,9 +75,15 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo: a dry run of "
                     "the multi-rank logic, e.g. with ISS_BENCH_SHARE_GPU=1 on a single-GPU box)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_500_000)
-    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU oracle as one process per host core "
-                    "(<= 64; off by default: on a box with hundreds of cores the start-up alone takes a minute)")
+    ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the all-cores CPU leg (default: min(host cores, 64))")
     args = ap.parse_args()
+    strong = args.workload == "configs3"
+    if args.reads is None:
+        args.reads = 100_000_000 if strong else READS_PER_STEP
+    if args.model is None:
+        args.model = "hiseq" if strong else "novaseq"
+    if args.n_genomes is None:
+        args.n_genomes = 50 if strong else N_GENOMES
 
     import torch
 
@@ -105,28 +128,29 @@ def main():
             dense.dele[:] = args.indel[1]
         genomes = synthetic_genomes(args.n_genomes, GENOME_LEN, 123)
     t_b = time.time()
-    dense, genomes = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank))
+    dense, grefs = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank), as_refs=True)
     torch.cuda.synchronize()
     bcast_s = time.time() - t_b if dist is not None else 0.0
 
-    records = [Record(g, id="genome_%d" % i) for i, g in enumerate(genomes)]
-    abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(123))
-    n_pairs_step = args.reads // 2
-    work = []
-    for chunk in generate_work_divider(records, None, abundance, args.reads, None, None, dense, "bench",
-                                       chunk_size=n_pairs_step):
-        work.extend(chunk)
-    work = [(r, n) for r, n, _ in work]
-    total_pairs_step = sum(n for _, n in work)
-
     eng = ReadEngine(local_rank)
     eng.load_model(dense)
-    gids = {id(r): eng.add_genome(r.seq) for r in records}
-    eng.reserve(total_pairs_step)
+    # records: id + length for the work divider, letters only where the CPU legs need them (rank 0)
+    records = [Record(_SeqLen(g.length), id="genome_%d" % i) for i, g in enumerate(grefs)]
+    letters = {id(r): g for r, g in zip(records, genomes)} if rank == 0 else {}
+    gid_of = {id(r): g.upload(eng) for r, g in zip(records, grefs)}  # (N > 1: straight from the broadcast buffer in HBM)
+    abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(123))
+    # the reference's sharding: chunk `rank` of the divider with cpus = world (iss/app.py:81-83, 99-106)
+    from insilicoseq_amd.distributed import rank_work
+
+    total_reads = args.reads if strong else args.reads * world
+    chunk, chunk_size, n_chunks = rank_work(records, None, abundance, total_reads, None, None, dense, "bench", world, rank)
+    work = [(r, n) for r, n, _ in (chunk or [])]
+    total_pairs_step = sum(n for _, n in work)
+    eng.reserve(max(total_pairs_step, 1))
     worker_seed = SEED + rank
     ordinal = [0]
 
-    item_ids = [gids[id(rec)] for rec, _ in work]
+    item_ids = [gid_of[id(rec)] for rec, _ in work]
     item_pairs = [n for _, n in work]
 
     def step():  # the step's whole work list in one set of launches (iss_generate_batch)
@@ -159,14 +183,22 @@ def main():
     tm = eng.timing_read()
     eng.timing_enable(0)
     stats = eng.stats_read()
+    per_rank = [(total_pairs_step, elapsed)]
     if dist is not None:
-        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+        mine = torch.tensor([float(total_pairs_step), elapsed], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [(int(x[0].item()), float(x[1].item())) for x in allr]
+        elapsed = max(e for _, e in per_rank)  # the slowest rank's time
+
+    # ---- after the timed region: windows of the LAST timed step recomputed by the CPU oracle (rank 0's rows)
+    parity = None
+    if rank == 0 and total_pairs_step:
+        parity = parity_window(eng, dense, work, letters, ordinal[0] - total_pairs_step, worker_seed)
 
     if rank == 0:
         RL = dense.read_length
-        pairs_total = total_pairs_step * args.steps * world
+        pairs_total = sum(n for n, _ in per_rank) * args.steps
         value = pairs_total / elapsed
         b_pair = algorithmic_bytes_per_pair(RL)
         main_s = tm["main_ms"] / 1e3
@@ -175,48 +207,57 @@ def main():
         # the other kernels' milliseconds come from the warm-up steps (per step)
         other = {k: (tm_warm[k] / args.warmup if args.warmup else None) for k in ("setup_ms", "indel_scan_ms", "indel_fixup_ms")}
         all_kernels_s = (tm["main_ms"] + sum(v or 0.0 for v in other.values()) * args.steps) / 1e3
-        traffic, traffic_note = committed_traffic()
+        traffic = committed_traffic()
+        label = ("BASELINE configs[3]: %d reads/step in total" % args.reads) if strong else (
+            "BASELINE configs[2]: %d reads/step/GPU" % args.reads)
         out = {
             "metric": "read_pairs_per_sec", "value": value, "unit": "read-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: %d reads/step/GPU, %s KDE model (read_length %d), %d x %d bp "
-                            "uniform ACGT genomes, log-normal abundance, seed %d; outputs left in HBM" % (
-                                args.reads, args.model, RL, N_GENOMES, GENOME_LEN, SEED),
-                "pairs_per_step_per_gpu": total_pairs_step, "read_length": RL, "work_items": len(work),
-                "rng": "philox4x32-10", "parallelism": "1 worker/GPU, no data-path collective",
+                "workload": "%s, %s KDE model (read_length %d), %d x %d bp uniform ACGT genomes, log-normal abundance, "
+                            "seed %d; sharded by the reference's chunk rule (rank = cpu_number); outputs left in HBM" % (
+                                label, args.model, RL, args.n_genomes, GENOME_LEN, SEED),
+                "pairs_per_step_per_gpu": [n for n, _ in per_rank] if world > 1 else total_pairs_step, "read_length": RL,
+                "work_items": len(work), "rng": "philox4x32-10",
+                "parallelism": "1 worker/GPU, chunk r of ceil(pairs/N) per rank (iss/app.py:81-83), no data-path collective",
                 "indel_override": args.indel,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_main", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_pair * total_pairs_step,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic.get("traffic_bytes_per_launch"),
+                "traffic_note": traffic.get("note"), "traffic_fresh": traffic.get("fresh"),
+                "algorithmic_bytes_per_launch": b_pair * total_pairs_step,
                 "algorithmic_bytes_per_pair": b_pair, "avg_launch_ms": tm["main_ms"] / max(n_main_launches, 1),
                 "launches": n_main_launches,
                 # what actually bounds k_main: integer VALU issue.  Wavefront-level VALU instructions per launch from the
-                # committed PMC pass; 4 cycles each on one of 1024 SIMDs (256 CUs x 4) at 2.4 GHz
-                "valu": {"insts_per_launch": getattr(committed_traffic, "valu_insts", None),
-                         "issue_busy_frac_est": (getattr(committed_traffic, "valu_insts", None) or 0) * 4.0 / (
-                             1024 * 2.4e9 * (tm["main_ms"] / max(n_main_launches, 1)) / 1e3) if main_s > 0 else None,
-                         "note": "excludes the second issue cycle pair of v_mad_u64_u32 (Philox), ~12 % more"},
+                # committed PMC pass; measured issue cost 1.8 ns per wavefront instruction and SIMD (tools/instr_rate.hip:
+                # 4 cycles), 1024 SIMDs
+                "valu": {"insts_per_launch": traffic.get("valu_insts_per_launch"),
+                         "issue_busy_frac_est": (traffic.get("valu_insts_per_launch") or 0) * 1.8e-9 / 1024 / (
+                             main_s / max(n_main_launches, 1)) if main_s > 0 else None},
             },
             "kernel_ms_per_step": dict(other, main_ms=tm["main_ms"] / args.steps,
                                        note="main_ms: HIP events over the timed region; the others: over the warm-up steps"),
             "all_kernels_GBps": (total_pairs_step * args.steps * b_pair) / all_kernels_s / 1e9 if all_kernels_s else 0,
             "indel_fixup_reads_per_step": stats["fixup_reads"] / max(args.steps, 1),
             "model_broadcast_s": bcast_s,
+            "parity_window": parity,
         }
+        if world > 1:
+            out["per_rank_pairs_per_sec"] = [n * args.steps / e if e > 0 else None for n, e in per_rank]
         if world == 1 and not args.no_end_to_end:
-            out["end_to_end"] = end_to_end(dense, records, abundance, args.e2e_pairs)
-            out["end_to_end_gzip"] = end_to_end(dense, records, abundance, args.e2e_pairs, compress=True)
+            e2e_records = [Record(letters[id(r)], id=r.id) for r in records]
+            out["end_to_end"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs)
+            out["end_to_end_gzip"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs, compress=True)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dense, work, args.cpu_sample_pairs)
-            if args.cpu_all_cores and args.indel is None:  # opt-in: one oracle process per host core
-                try:
-                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(model_path, args.n_genomes, work, args.cpu_sample_pairs // 6)
-                except Exception as e:
-                    out["cpu_baseline_all_cores"] = {"value": None, "error": repr(e)}
+            cpu_work = [(letters[id(r)], n) for r, n in work]
+            out["cpu_baseline"] = cpu_baseline(dense, cpu_work, args.cpu_sample_pairs)
+            try:  # the same oracle on all host cores (threads: the C call releases the GIL), ~5 s
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(dense, cpu_work, args.cpu_threads, out["cpu_baseline"]["value"])
+            except Exception as e:
+                out["cpu_baseline_all_cores"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
@@ -224,10 +265,55 @@ def main():
     eng.close()
 
 
+def parity_window(eng, dense, work, letters, step_first_ordinal, worker_seed, n=64):
+    """Rows of the last timed step against the CPU oracle (Philox provider; every pair is a pure function of seed,
+    ordinal and genome): the first n pairs of the step, n pairs straddling each of (up to) two work-item boundaries, and
+    the last n pairs.  "ok" or a description of the first mismatch."""
+    from oracle import oracle as O
+
+    orc = O.Oracle(dense)
+    firsts = np.concatenate(([0], np.cumsum([k for _, k in work]))).astype(np.int64)
+    total = int(firsts[-1])
+    starts = {0, max(0, total - n)}
+    for b in firsts[1:-1][:2]:
+        starts.add(int(max(0, b - n // 2)))
+    checked = 0
+    for s0 in sorted(starts):
+        m = int(min(n, total - s0))
+        got = eng.download(s0, m)
+        i = s0
+        while i < s0 + m:  # one oracle call per (window, work item)
+            k = int(np.searchsorted(firsts, i, side="right") - 1)
+            cnt = int(min(s0 + m, firsts[k + 1]) - i)
+            res = orc.simulate(O.Rng().seed_philox(worker_seed), letters[id(work[k][0])], cnt,
+                               first_ordinal=step_first_ordinal + i)
+            if res["status"] != 0:
+                return "oracle status %d at pair %d" % (res["status"], i)
+            for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                if not np.array_equal(got[key][i - s0:i - s0 + cnt], res[key]):
+                    return "mismatch: pairs %d..%d of the step (item %d), %s" % (i, i + cnt - 1, k, key)
+            checked += cnt
+            i += cnt
+    return "ok (%d pairs of the last timed step, item boundaries included, bit-identical to the CPU oracle)" % checked
+
+
+def kernel_source_hash():
+    """Hash of the HIP sources: a committed PMC summary says which sources it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "insilicoseq_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic():
     """HBM-side bytes per k_main launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
     runs of this same command, corrected with the calibration kernels as MI355X_MICROARCH.md prescribes).  PMC
-    collection cannot run inside the timed region, so the latest committed measurement is reported."""
+    collection cannot run inside the timed region, so the latest committed measurement is reported, with `fresh` =
+    whether it was taken on the kernel sources this run was built from."""
     import glob
 
     import re
@@ -237,12 +323,14 @@ def committed_traffic():
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=natural)
     if not files:
-        return None, "no PMC pass committed"
+        return {"note": "no PMC pass committed"}
     with open(files[-1]) as fh:
         t = json.load(fh)
-    committed_traffic.valu_insts = t.get("valu_insts_per_launch")
-    return t["traffic_bytes_per_launch"], "bytes per launch (%d pairs), from %s" % (
-        t.get("pairs_per_launch_avg", 0), os.path.basename(files[-1]))
+    t["fresh"] = t.get("kernel_source_hash") == kernel_source_hash()
+    t["note"] = "bytes per launch (%d pairs), from %s%s" % (
+        t.get("pairs_per_launch_avg", 0), os.path.basename(files[-1]),
+        "" if t["fresh"] else " -- STALE: measured on other kernel sources than this run's")
+    return t
 
 
 def end_to_end(dense, records, abundance, n_pairs, compress=False):
@@ -291,11 +379,11 @@ def cpu_baseline(dense, work, sample_pairs):
     todo = sample_pairs
     t0 = time.perf_counter()
     done = 0
-    for rec, n in work:
+    for seq, n in work:
         k = min(n, max(1, int(round(sample_pairs * n / sum(x for _, x in work)))), todo)
         if k <= 0:
             continue
-        res = orc.simulate(rng, rec.seq, k)
+        res = orc.simulate(rng, seq, k)
         assert res["status"] == 0
         done += res["n_done"]
         todo -= k
@@ -308,64 +396,51 @@ def cpu_baseline(dense, work, sample_pairs):
     }
 
 
-def _cpu_worker_main(argv):
-    """`python bench.py --cpu-worker <model> <n_genomes> <cpu> <pairs per genome ...>`: one process of the all-cores CPU
-    leg -- the oracle on its share of the sample with its own pair of MT19937 streams (seed + cpu_number, like a reference
-    worker).  Prints `pairs seconds`."""
-    from insilicoseq_amd.model import DenseModel
+def cpu_baseline_all_cores(dense, work, threads, one_core_rate, budget_s=5.0):
+    """The same CPU oracle on every host core at once: one THREAD per core (the ctypes call into the C oracle releases
+    the GIL), each a reference-style worker with its own pair of MT19937 streams (seed + cpu_number) on its share of the
+    work list -- the box-level CPU rate the GPU number stands beside (the reference's pool: iss/app.py:99-106).  Sized
+    from the one-core rate to take about budget_s seconds."""
+    import threading
+
     from oracle import oracle as O
 
-    model_path, n_genomes, cpu = argv[0], int(argv[1]), int(argv[2])
-    shares = [int(x) for x in argv[3:]]
-    dense = DenseModel.load(model_path)
-    genomes = synthetic_genomes(n_genomes, GENOME_LEN, 123)
-    orc = O.Oracle(dense)
-    rng = O.Rng().seed_mt(SEED + cpu)
-    t0 = time.perf_counter()
-    done = 0
-    for g, k in zip(genomes, shares):
-        if k > 0:
-            res = orc.simulate(rng, g, k)
-            assert res["status"] == 0
-            done += res["n_done"]
-    print("%d %.6f" % (done, time.perf_counter() - t0), flush=True)
-
-
-def cpu_baseline_all_cores(model_path, n_genomes, work, pairs_per_core, limit_s=60.0):
-    """The same CPU oracle on every host core at once (one process per core, each a reference-style worker with its own
-    streams): the box-level CPU rate the GPU number stands beside.  Bounded: pairs_per_core pairs per process, and the
-    whole leg is abandoned (its processes killed by pid) after limit_s seconds."""
-    import subprocess
-
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = max(1, min(os.cpu_count() or 1, 64)) if not threads else int(threads)
+    per_thread = max(1000, int(one_core_rate * budget_s / 4))  # (a thread of a full box runs at about a quarter of the lone core's rate)
     total = sum(n for _, n in work)
-    shares = [str(max(1, int(round(pairs_per_core * n / total)))) for _, n in work]
+    shares = [max(1, int(round(per_thread * n / total))) for _, n in work]
+    done = [0] * cores
+    secs = [0.0] * cores
+    errors = []
+
+    def run(c):
+        try:
+            orc = O.Oracle(dense)
+            rng = O.Rng().seed_mt(SEED + c)
+            t0 = time.perf_counter()
+            for (seq, _), k in zip(work, shares):
+                res = orc.simulate(rng, seq, k)
+                assert res["status"] == 0
+                done[c] += res["n_done"]
+            secs[c] = time.perf_counter() - t0
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", model_path, str(n_genomes), str(c)] + shares,
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT) for c in range(cores)]
-    res = []
-    try:
-        for p in procs:
-            left = max(1.0, limit_s - (time.perf_counter() - t0))
-            out, _ = p.communicate(timeout=left)
-            if p.returncode != 0:
-                raise RuntimeError("a CPU worker failed")
-            a, b = out.decode().split()
-            res.append((int(a), float(b)))
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    ts = [threading.Thread(target=run, args=(c,)) for c in range(cores)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
     wall = time.perf_counter() - t0
-    done = sum(r[0] for r in res)
-    busy = max(r[1] for r in res)
-    return {"value": done / busy, "unit": "read-pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d pairs on %d processes (%d each), slowest process %.1f s, %.1f s with start-up" % (
-                done, cores, sum(int(x) for x in shares), busy, wall)}
+    if errors:
+        raise RuntimeError(errors[0])
+    return {"value": sum(done) / wall, "unit": "read-pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d pairs on %d threads (%d each), %.1f s wall (slowest thread %.1f s)" % (
+                sum(done), cores, sum(shares), wall, max(secs)),
+            "note": "reference-vs-port ratio measured in the build container: the Python reference 873 pairs/s per process, "
+                    "this port ~9e4 per core"}
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
-        _cpu_worker_main(sys.argv[2:])
-        sys.exit(0)
     main()

@@ -98,6 +98,10 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *tables);
  * 1-bit "exception" mask (IUPAC / lower case) + the ASCII copy the exceptions are read from.
  */
 int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_t *genome_id);
+/* The same for a record of plain A/C/G/T handed over as 2-bit codes (16 bases per little-endian 32-bit word, base i in
+ * bits 2*(i%16).., A,T,C,G = 0..3), from host memory or -- codes_on_device != 0 -- from device memory of this GPU: what a
+ * rank of a multi-GPU run receives in the one RCCL broadcast of the packed genomes (no ASCII, no host bounce). */
+int iss_genome_upload_packed(iss_ctx *ctx, const uint32_t *codes, int64_t length, int32_t codes_on_device, int32_t *genome_id);
 int iss_genome_clear(iss_ctx *ctx);
 
 /* Device output rows (R1 bases, R1 phred, R2 bases, R2 phred).  Reserve before generating.

@@ -15,7 +15,7 @@ SEQ_TYPES = {"metagenomics": 0, "amplicon": 1}
 # every symbol include/iss_mi355x.h declares (tests check the library exports all of them)
 EXPORTS = (
     "iss_abi_version", "iss_ctx_create", "iss_ctx_destroy", "iss_last_error", "iss_ctx_set_stream",
-    "iss_model_upload", "iss_genome_upload", "iss_genome_clear", "iss_output_reserve", "iss_output_pitch",
+    "iss_model_upload", "iss_genome_upload", "iss_genome_upload_packed", "iss_genome_clear", "iss_output_reserve", "iss_output_pitch",
     "iss_output_device_ptrs", "iss_output_row", "iss_generate", "iss_synchronize", "iss_output_download",
     "iss_output_download_coords", "iss_timing_enable", "iss_timing_read", "iss_stats_read", "iss_fastq_write",
     "iss_mt_seed", "iss_generate_mt", "iss_mt_peek", "iss_mt_mutations_reserve", "iss_mt_mutations_download",
@@ -72,6 +72,7 @@ def lib():
     L.iss_ctx_set_stream.argtypes = [vp, vp]
     L.iss_model_upload.argtypes = [vp, C.POINTER(ModelTables)]
     L.iss_genome_upload.argtypes = [vp, vp, i64, C.POINTER(i32)]
+    L.iss_genome_upload_packed.argtypes = [vp, vp, i64, i32, C.POINTER(i32)]
     L.iss_genome_clear.argtypes = [vp]
     L.iss_output_reserve.argtypes = [vp, i64]
     L.iss_output_pitch.argtypes = [vp]

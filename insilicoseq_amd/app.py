@@ -186,12 +186,13 @@ def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_ty
     """One pool process == one GPU.  Records are re-read from the concatenated FASTA (the reference
     pickles them; same content) unless the caller runs in this process and hands its own over."""
     logging.basicConfig(level=logging.WARNING)
-    records = {r.id: r for r in (records if records is not None else parse_fasta(genome_file))}
+    # (records are identified by their ordinal in the concatenated FASTA, not by id: draft assemblies repeat ids)
+    records = list(records if records is not None else parse_fasta(genome_file))
     if npz is None:  # --mode basic
         model = BasicErrorModel(fragment[0], fragment[1], store_mutations)
     else:
         model = KDErrorModel(npz, fragment[0], fragment[1], store_mutations)
-    work = [(records[rid], n, "default") for rid, n in work_spec]
+    work = [(records[idx], n, "default") for idx, n in work_spec]
     worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device, rng=rng, compress=compress)
 
 
@@ -248,8 +249,9 @@ def generate_reads(args):
     chunks = list(generate_work_divider(records, readcount_dic, abundance_dic, n_reads, args.coverage, args.coverage_file,
                                         error_model, args.output, chunk_size))
     jobs = []
+    ordinal_of = {id(r): i for i, r in enumerate(records)}
     for rank, chunk in enumerate(chunks[:workers]):  # zip(work_chunks, temp_file_list), app.py:104
-        spec = [(rec.id, n) for rec, n, _ in chunk]
+        spec = [(ordinal_of[id(rec)], n) for rec, n, _ in chunk]
         jobs.append((rank, rank % max(args.devices, 1), genome_file, spec, error_model.npz_path, args.seed,
                      temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng, args.store_mutations,
                      (args.fragment_length, args.fragment_length_sd), device_gzip))

@@ -405,6 +405,19 @@ __global__ __launch_bounds__(256) void k_pack_genome(const uint8_t *__restrict__
     }
 }
 
+// ================================================================== k_unpack_genome
+// iss_genome_upload_packed: 2-bit codes (16 bases / word, A,T,C,G = 0..3) -> the ASCII copy; one lane per word.  The
+// codes of positions >= L in the last word are cleared.
+__global__ __launch_bounds__(256) void k_unpack_genome(uint32_t *__restrict__ packed, int64_t L, uint8_t *__restrict__ ascii) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t base = w * 16;
+    if (base >= L) return;
+    uint32_t v = packed[w];
+    const int n = (int)min((int64_t)16, L - base);
+    if (n < 16) { v &= (1u << (2 * n)) - 1u; packed[w] = v; }
+    for (int i = 0; i < n; ++i) ascii[base + i] = code_to_ascii((v >> (2 * i)) & 3u);
+}
+
 // ================================================================== k_rows_to_arrays
 // iss_output_download: interleaved rows (xp) -> four plain arrays [n_pairs][8 * S]; one wavefront per pair, one lane per
 // 8-byte piece (block = 64 x 4)

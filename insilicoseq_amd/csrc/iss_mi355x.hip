@@ -1142,6 +1142,40 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     return 0;
 }
 
+int iss_genome_upload_packed(iss_ctx *ctx, const uint32_t *codes, int64_t length, int32_t codes_on_device, int32_t *genome_id) {
+    if (!ctx || !codes || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload_packed: NULL argument");
+    if (length < 1 || length >= (int64_t)0x7fffffff) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^31-2]");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n_mk = (size_t)(length + 31) / 32, n_pk = 2 * n_mk, n_in = (size_t)(length + 15) / 16;
+    Genome G;
+    G.L = length;
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, (n_pk + 4) * sizeof(uint32_t)));
+    G.packed_alloc = static_cast<uint32_t *>(p);
+    HIP_TRY(ctx, hipMalloc(&p, (n_mk + 4) * sizeof(uint32_t)));
+    G.mask_alloc = static_cast<uint32_t *>(p);
+    HIP_TRY(ctx, hipMalloc(&p, (size_t)length));
+    G.ascii = static_cast<uint8_t *>(p);
+    auto release = [&]() { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); };
+    hipError_t he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + 4) * sizeof(uint32_t), ctx->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(G.mask_alloc, 0, (n_mk + 4) * sizeof(uint32_t), ctx->stream);
+    if (he == hipSuccess)
+        he = hipMemcpyAsync(G.packed_alloc + 1, codes, n_in * sizeof(uint32_t), codes_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                            ctx->stream);
+    if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he)); }
+    // the ASCII copy (exact path, FASTA-free consumers) from the codes; codes past the end are cleared
+    hipLaunchKernelGGL(iss::k_unpack_genome, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, ctx->stream, G.packed_alloc + 1, length,
+                       G.ascii);
+    he = hipStreamSynchronize(ctx->stream);  // the caller's buffer may go away once this call returns
+    if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome unpack: ") + hipGetErrorString(he)); }
+    G.has_exceptions = false;
+    G.packed = G.packed_alloc + 1;
+    G.mask = G.mask_alloc + 1;
+    ctx->genomes.push_back(G);
+    *genome_id = (int32_t)ctx->genomes.size() - 1;
+    return 0;
+}
+
 static void free_community(iss_ctx *ctx);
 static void free_item_tables(iss_ctx *ctx);
 

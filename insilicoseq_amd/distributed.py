@@ -1,8 +1,8 @@
 """Multi-GPU plumbing: one process per GPU, rank r == the reference's worker ``cpu_number`` r.
 
 The path shards with NO data-path collective (pairs are independent given genome, tables and the
-RNG address): the only collective is one broadcast of the dense model tables and the genomes from
-rank 0 before generation (RCCL over xGMI with backend "nccl"; "gloo" on CPU in the tests), issued
+RNG address): the only collective is ONE broadcast of the dense model tables and the 2-bit packed genomes
+from rank 0 before generation (RCCL over xGMI with backend "nccl"; "gloo" on CPU in the tests), issued
 only when world_size > 1.  Work division and output assembly mirror the reference:
 
 * chunk size ``ceil((n_reads // 2) / world)`` and ``zip(work_chunks, temp_file_list)`` -- a surplus
@@ -19,49 +19,128 @@ from .generator import generate_work_divider
 from .model import DenseModel
 
 _U8_FIELDS = ("bin_nonempty", "subst_alt", "ins_letter")
+_CODE_OF = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate(b"ATCG"):  # the engine's 2-bit alphabet: A,T,C,G = 0..3 (complement = code ^ 1)
+    _CODE_OF[_c] = _i
 
 
-def _bcast_bytes(dist, arr_or_none, nbytes, device, src=0):
+def pack_2bit(ascii_u8):
+    """uint8 letters -> uint32 words of 2-bit codes (16 bases per word, base i in bits 2*(i % 16)...), or None when the
+    record holds anything but plain A/C/G/T (it is shipped as ASCII then)."""
+    codes = _CODE_OF[np.asarray(ascii_u8, dtype=np.uint8)]
+    if codes.size == 0 or int(codes.max()) > 3:
+        return None
+    n = (codes.size + 15) // 16
+    buf = np.zeros(n * 16, dtype=np.uint32)
+    buf[:codes.size] = codes
+    return (buf.reshape(n, 16) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+
+
+def unpack_2bit(words, length):
+    """Inverse of pack_2bit (host side: tests, CPU consumers)."""
+    w = np.asarray(words, dtype=np.uint32)
+    codes = ((w[:, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(-1)[:length]
+    return np.frombuffer(b"ATCG", dtype=np.uint8)[codes]
+
+
+class BroadcastGenome(object):
+    """One record as a rank holds it after the broadcast: ``length`` letters, either 2-bit codes (``packed`` True) or
+    ASCII, as a uint8 view ``raw`` on the host and -- when the payload lives on a GPU -- the device address ``dev_ptr``."""
+
+    def __init__(self, length, packed, raw, dev_ptr=None):
+        self.length, self.packed, self.raw, self.dev_ptr = int(length), bool(packed), raw, dev_ptr
+
+    def ascii(self):
+        if not self.packed:
+            return np.asarray(self.raw, dtype=np.uint8)[:self.length]
+        return unpack_2bit(np.asarray(self.raw).view(np.uint32), self.length)
+
+    def upload(self, engine):
+        """To the engine's HBM: straight from the broadcast buffer on the device when there is one."""
+        if self.packed:
+            return engine.add_genome_packed(None if self.dev_ptr is not None else np.asarray(self.raw).view(np.uint32),
+                                            self.length, device_ptr=self.dev_ptr)
+        return engine.add_genome(np.asarray(self.raw, dtype=np.uint8)[:self.length])
+
+
+def _align16(n):
+    return (n + 15) & ~15
+
+
+def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, as_refs=False):
+    """Rank ``src`` passes (DenseModel, list of uint8 arrays / bytes); other ranks pass (None, None).
+    Returns (DenseModel, genomes) on every rank; no-op when ``dist`` is None / world == 1.
+
+    ONE payload: [header][model tables][genomes], the genomes as 2-bit codes (plain A/C/G/T records: a quarter of the
+    letters -- 62.5 MB for BASELINE configs[3]'s 250 Mbp) or ASCII (records with IUPAC / lower-case letters), sent by one
+    broadcast (RCCL over xGMI with backend "nccl") after an 8-byte size announcement.  ``as_refs``: return
+    BroadcastGenome objects -- on a GPU they point INTO the received device buffer, which ``upload`` hands to
+    iss_genome_upload_packed without a detour through the host; otherwise uint8 ASCII arrays (host consumers)."""
+    def as_u8(g):
+        return np.frombuffer(g, dtype=np.uint8) if isinstance(g, (bytes, bytearray)) else np.ascontiguousarray(g, dtype=np.uint8)
+
+    if dist is None or dist.get_world_size() == 1:
+        glist = [as_u8(g) for g in genomes]
+        return dense, ([BroadcastGenome(g.size, False, g) for g in glist] if as_refs else glist)
+    import json
+
     import torch
 
-    t = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    if arr_or_none is not None:
-        t.copy_(torch.from_numpy(np.ascontiguousarray(arr_or_none).view(np.uint8).reshape(-1)))
-    dist.broadcast(t, src=src)
-    return t.cpu().numpy()
-
-
-def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0):
-    """Rank ``src`` passes (DenseModel, list of uint8 arrays / bytes); other ranks pass (None, None).
-    Returns (DenseModel, [uint8 arrays]) on every rank.  No-op when ``dist`` is None / world == 1."""
-    if dist is None or dist.get_world_size() == 1:
-        return dense, [np.frombuffer(g, dtype=np.uint8) if isinstance(g, (bytes, bytearray)) else np.asarray(
-            g, dtype=np.uint8) for g in genomes]
     rank = dist.get_rank()
     if rank == src:
         fields = [np.ascontiguousarray(getattr(dense, k)) for k in DenseModel.FIELDS]
-        glist = [np.frombuffer(g, dtype=np.uint8) if isinstance(g, (bytes, bytearray)) else np.ascontiguousarray(
-            g, dtype=np.uint8) for g in genomes]
-        meta = {"read_length": dense.read_length, "shapes": [list(f.shape) for f in fields],
-                "genome_lengths": [int(g.size) for g in glist]}
+        parts, gmeta = [], []
+        for g in (as_u8(x) for x in genomes):
+            words = pack_2bit(g)
+            raw = words.view(np.uint8) if words is not None else g
+            gmeta.append([int(g.size), 1 if words is not None else 0, int(raw.size)])
+            parts.append(raw)
+        header = json.dumps({"read_length": dense.read_length, "shapes": [list(f.shape) for f in fields],
+                             "genomes": gmeta}).encode()
+        segs = [np.frombuffer(header, dtype=np.uint8)] + [f.view(np.uint8).reshape(-1) for f in fields] + parts
+        total = 16 + sum(_align16(x.size) for x in segs)
+        flat = np.zeros(total, dtype=np.uint8)
+        flat[:8] = np.frombuffer(np.int64(len(header)).tobytes(), dtype=np.uint8)
+        off = 16
+        for x in segs:
+            flat[off:off + x.size] = x
+            off += _align16(x.size)
+        size = torch.tensor([total], dtype=torch.int64, device=device)
     else:
-        fields, glist, meta = None, None, None
-    box = [meta]
-    dist.broadcast_object_list(box, src=src)
-    meta = box[0]
+        flat, size = None, torch.zeros(1, dtype=torch.int64, device=device)
+    dist.broadcast(size, src=src)
+    total = int(size.item())
+    t = torch.empty(total, dtype=torch.uint8, device=device)
+    if rank == src:
+        t.copy_(torch.from_numpy(flat))
+    dist.broadcast(t, src=src)  # the one collective of a multi-GPU run
+    on_gpu = t.is_cuda
+    # header + model tables: to the host (iss_model_upload takes host tables; < 1 MB); genomes stay where they are
+    hlen = int(np.frombuffer(t[:8].cpu().numpy().tobytes(), dtype=np.int64)[0])
+    meta = json.loads(t[16:16 + hlen].cpu().numpy().tobytes().decode())
+    off = 16 + _align16(hlen)
     out_fields = []
-    for i, (k, shape) in enumerate(zip(DenseModel.FIELDS, meta["shapes"])):
+    for k, shape in zip(DenseModel.FIELDS, meta["shapes"]):
         dt = np.uint8 if k in _U8_FIELDS else np.float64
         nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
-        raw = _bcast_bytes(dist, fields[i] if rank == src else None, nbytes, device, src)
-        out_fields.append(raw.view(dt).reshape(shape))
-    total = int(sum(meta["genome_lengths"]))
-    flat = _bcast_bytes(dist, np.concatenate(glist) if rank == src else None, total, device, src)
-    offs = np.concatenate(([0], np.cumsum(meta["genome_lengths"]))).astype(np.int64)
-    out_genomes = [flat[offs[i]:offs[i + 1]] for i in range(len(meta["genome_lengths"]))]
+        out_fields.append(t[off:off + nbytes].cpu().numpy().view(dt).reshape(shape).copy())
+        off += _align16(nbytes)
+    host = None if on_gpu and as_refs else t.cpu().numpy()
+    refs = []
+    for length, packed, nbytes in meta["genomes"]:
+        if host is not None:
+            raw = host[off:off + nbytes]
+        else:  # on a GPU only the ASCII records (IUPAC / lower-case letters: validated and packed by iss_genome_upload) come back
+            raw = None if packed else t[off:off + nbytes].cpu().numpy()
+        refs.append(BroadcastGenome(length, packed, raw, dev_ptr=(t.data_ptr() + off) if on_gpu else None))
+        off += _align16(nbytes)
     if rank != src:
         dense = DenseModel(meta["read_length"], *out_fields)
-    return dense, out_genomes
+    if as_refs:
+        for r in refs:
+            r._keep = t  # the device buffer must outlive the uploads
+        return dense, refs
+    return dense, [r.ascii() for r in refs]
 
 
 def rank_work(records, readcount_dic, abundance_dic, n_reads, coverage, coverage_file, error_model, output, world,

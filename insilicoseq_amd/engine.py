@@ -96,6 +96,19 @@ class ReadEngine(object):
         self._genome_lengths.append(int(a.size))
         return gid.value
 
+    def add_genome_packed(self, codes, length, device_ptr=None):
+        """Upload a record of plain A/C/G/T given as 2-bit codes (see distributed.pack_2bit): ``codes`` a uint32 array
+        on the host, or ``device_ptr`` the address of the words in this GPU's memory (a slice of the broadcast buffer)."""
+        gid = C.c_int32(-1)
+        if device_ptr is not None:
+            self._check(self._lib.iss_genome_upload_packed(self._ctx, C.c_void_p(int(device_ptr)), int(length), 1, C.byref(gid)))
+        else:
+            a = np.ascontiguousarray(codes, dtype=np.uint32)
+            assert a.size >= (int(length) + 15) // 16
+            self._check(self._lib.iss_genome_upload_packed(self._ctx, a.ctypes.data, int(length), 0, C.byref(gid)))
+        self._genome_lengths.append(int(length))
+        return gid.value
+
     def clear_genomes(self):
         self._check(self._lib.iss_genome_clear(self._ctx))
         self._genome_lengths = []

@@ -1,0 +1,95 @@
+"""The world_size > 1 path THROUGH THE DEVICE on a single-GPU box: two ranks (gloo; both on GPU 0) receive the one flat
+broadcast of model tables + 2-bit packed genomes into device memory, upload their genomes straight from that buffer
+(iss_genome_upload_packed), take chunk `rank` of the reference's divider (iss/app.py:81-83), generate their work list with
+iss_generate_batch, and every rank's rows are compared with the CPU oracle (worker seed = seed + rank, ordinals running
+across its work items); the per-rank FASTQ files concatenated in rank order equal the oracle's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, tmpdir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    from helpers import dense_model, mixed_genome, random_genome
+    from insilicoseq_amd import distributed as D
+    from insilicoseq_amd.engine import ReadEngine, fastq_write
+    from insilicoseq_amd.generator import Record, lognormal_abundance
+    from oracle import oracle as O
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        seed, n_reads = 77, 60000
+        # rank 0 owns the inputs; the other rank builds the same letters only to CHECK what it received
+        letters = [random_genome(300 + i, 20000 + 3000 * i) for i in range(6)] + [mixed_genome(5, 9000)]
+        dense0 = dense_model("hiseq")
+        dense, refs = D.broadcast_model_and_genomes(dense0 if rank == 0 else None,
+                                                    [g.encode() for g in letters] if rank == 0 else None, dist,
+                                                    device=torch.device("cuda", 0), as_refs=True)
+        assert [r.packed for r in refs] == [True] * 6 + [False]  # the mixed-case record travels as ASCII
+        assert all(r.dev_ptr for r in refs)
+        for k in type(dense).FIELDS:
+            assert np.array_equal(getattr(dense, k), getattr(dense0, k)), k
+        records = [Record(g, id="g%d" % i) for i, g in enumerate(letters)]
+        abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(seed))
+        output = os.path.join(tmpdir, "out")
+        work, chunk_size, n_chunks = D.rank_work(records, None, abundance, n_reads, None, None, dense, output, world, rank)
+        assert n_chunks >= world and work
+        prefix = D.temp_prefix(output, rank)
+        with ReadEngine(0) as eng:
+            eng.load_model(dense)
+            gid = {id(r): g.upload(eng) for r, g in zip(records, refs)}  # from the broadcast buffer in HBM
+            pairs = [n for _, n, _ in work]
+            eng.reserve(sum(pairs))
+            eng.generate_batch([gid[id(r)] for r, _, _ in work], pairs, first_ordinal=0, seed=seed + rank, out_first_pair=0)
+            eng.synchronize()
+            got = eng.download(0, sum(pairs))
+        orc = O.Oracle(dense)
+        first = 0
+        with open(prefix + "_R1.fastq", "wb") as f1, open(prefix + "_R2.fastq", "wb") as f2, \
+                open(prefix + "_exp_R1.fastq", "wb") as e1, open(prefix + "_exp_R2.fastq", "wb") as e2:
+            for (rec, n, _) in work:
+                res = orc.simulate(O.Rng().seed_philox(seed + rank), rec.seq, n, first_ordinal=first)
+                assert res["status"] == 0
+                for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                    assert np.array_equal(got[key][first:first + n], res[key]), (rank, rec.id, key)
+                rows = [np.ascontiguousarray(got[key][first:first + n]) for key in ("r1_base", "r1_qual", "r2_base", "r2_qual")]
+                fastq_write(f1.fileno(), f2.fileno(), rec.id, 0, rank, n, dense.read_length, dense.read_length, *rows, 1)
+                fastq_write(e1.fileno(), e2.fileno(), rec.id, 0, rank, n, dense.read_length, dense.read_length,
+                            res["r1_base"], res["r1_qual"], res["r2_base"], res["r2_qual"], 1)
+                first += n
+        dist.barrier()
+        if rank == 0:
+            exp = [b"".join(open(D.temp_prefix(output, r) + "_exp" + sfx, "rb").read() for r in range(world))
+                   for sfx in ("_R1.fastq", "_R2.fastq")]
+            D.concatenate_rank_files(output, world)
+            assert open(output + "_R1.fastq", "rb").read() == exp[0]
+            assert open(output + "_R2.fastq", "rb").read() == exp[1]
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_through_the_device(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

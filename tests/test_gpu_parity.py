@@ -524,12 +524,15 @@ def test_device_fastq_equals_host_formatter(model, rid, cpu, first_i, counts, tm
     assert os.path.getsize(paths[0]) > 100 * sum(counts) // 4
 
 
-@pytest.mark.parametrize("model,n_genomes,pairs_total", [("novaseq", 5, 5_000_000), ("hiseq", 7, 6_250_000)])
-def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total):
+@pytest.mark.parametrize("model,n_genomes,pairs_total,batch", [("novaseq", 5, 5_000_000, True), ("hiseq", 50, 6_250_000, True),
+                                                               ("novaseq", 5, 5_000_000, False)])
+def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total, batch):
     """BASELINE.json's full sizes (configs[2]: 10 M NovaSeq reads over 5 x 5 Mbp; one rank's 6.25 M-pair share of
-    configs[3]: HiSeq, 5 Mbp genomes): the whole work list is generated on the GPU as bench.py does it, and --
-    every pair being a pure function of (seed, ordinal, genome) -- windows of consecutive ordinals spread over
-    every work item are recomputed by the CPU oracle and compared byte for byte, coordinates included."""
+    configs[3]: HiSeq, 50 x 5 Mbp genomes): the whole work list is generated on the GPU exactly as bench.py times it
+    (ONE iss_generate_batch call; `batch` False: one iss_generate call per record), and -- every pair being a pure
+    function of (seed, ordinal, genome) -- windows of consecutive ordinals are recomputed by the CPU oracle and compared
+    byte for byte, coordinates included: the first and last pairs of every work item (the item boundaries of the batch),
+    random windows inside, and the pairs either side of the engine's launch-chunk edges."""
     from insilicoseq_amd.engine import ReadEngine
     from insilicoseq_amd.generator import lognormal_abundance
     from oracle import oracle as O
@@ -539,7 +542,7 @@ def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total):
     letters = np.frombuffer(b"ACGT", dtype=np.uint8)
     genomes = [letters[rng.randint(0, 4, size=5_000_000)].tobytes().decode() for _ in range(n_genomes)]
     ab = lognormal_abundance(list(range(n_genomes)), np.random.RandomState(123))
-    counts = [int(pairs_total * ab[k]) for k in range(n_genomes)]
+    counts = [max(1, int(pairs_total * ab[k])) for k in range(n_genomes)]
     orc = O.Oracle(dense)
     with ReadEngine(0) as eng:
         eng.load_model(dense)
@@ -547,14 +550,23 @@ def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total):
         eng.reserve(sum(counts))
         row, ordinal, items = 0, 0, []
         for gid, n in zip(gids, counts):
-            eng.generate(gid, n, first_ordinal=ordinal, seed=42, out_first_pair=row)
+            if not batch:
+                eng.generate(gid, n, first_ordinal=ordinal, seed=42, out_first_pair=row)
             items.append((gid, n, row, ordinal))
             row += n
             ordinal += n
+        if batch:
+            eng.generate_batch(gids, counts, first_ordinal=0, seed=42, out_first_pair=0)
         eng.synchronize()
         pick = np.random.RandomState(7)
+        total = sum(counts)
+        # pairs around multiples of 2^20 (any launch-chunk edge of the engine is one) fall into some item's window list
+        edges = [e for e in range(1 << 20, total, 1 << 20)][:: max(1, (total >> 20) // 6)]
         for k, (gid, n, row0, ord0) in enumerate(items):
-            for start in sorted(set([0, max(n - 64, 0)] + list(pick.randint(0, max(n - 64, 1), size=6)))):
+            inner = 6 if n_genomes <= 8 else 1
+            starts = set([0, max(n - 64, 0)] + list(pick.randint(0, max(n - 64, 1), size=inner)))
+            starts.update(min(max(e - row0 - 32, 0), max(n - 64, 0)) for e in edges if row0 <= e < row0 + n)
+            for start in sorted(starts):
                 w = min(64, n - start)
                 got = eng.download(row0 + start, w)
                 cg = eng.coords(row0 + start, w)

@@ -592,3 +592,23 @@ def test_batched_worker_loop_falls_back_to_single_calls():
     assert [c for c in w.engine.calls if c[0] == "emit"] == [("emit", [("a", 0, 0, 40), ("b", 0, 40, 25)])]
     ids = [line.split("\t")[0] for line in vcf.getvalue().splitlines()]
     assert ids == ["a_0_4/1", "a_39_4/1", "b_0_4/1", "b_24_4/1"] and w.ordinal == 65
+
+
+def test_worker_resolves_records_by_ordinal_not_by_id(tmp_path, monkeypatch):
+    """Draft assemblies repeat contig ids: a worker must simulate every work item from ITS record (the reference hands
+    the record objects to the pool, iss/app.py:99-106), not from the last record carrying the same id."""
+    from insilicoseq_amd import app
+
+    fasta = tmp_path / "g.fasta"
+    fasta.write_text(">contig_1 first\n" + "ACGT" * 100 + "\n>contig_1 second\n" + "TTGGCCAA" * 60 + "\n>other\n" + "GATTACA" * 70 + "\n")
+    seen = []
+
+    def fake_worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, **kw):
+        seen.extend((str(rec.seq), n) for rec, n, _ in work)
+
+    monkeypatch.setattr(app, "worker_iterator", fake_worker_iterator)
+    monkeypatch.setattr(app, "BasicErrorModel", lambda *a, **k: object())
+    app._worker(0, 0, str(fasta), [(0, 5), (1, 7), (2, 9)], None, 1, str(tmp_path / "w"), "metagenomics", False, "mt", False,
+                (None, None))
+    assert [n for _, n in seen] == [5, 7, 9]
+    assert seen[0][0].startswith("ACGTACGT") and seen[1][0].startswith("TTGGCCAA") and seen[2][0].startswith("GATTACA")

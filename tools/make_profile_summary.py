@@ -44,7 +44,10 @@ def main(src, tag):
     fetch = m["FETCH_SIZE"] / n * 1024 * cal.get("fetch_factor", 2.0)
     write = m["WRITE_SIZE"] / calls[key]["WRITE_SIZE"] * 1024 * cal.get("write_factor", 1.0)
     valu = m.get("SQ_INSTS_VALU", 0.0) / max(calls[key].get("SQ_INSTS_VALU", 1), 1)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
     summary = {"kernel": "iss::k_main", "launches": n, "calibration": cal, "valu_insts_per_launch": valu,
+               "kernel_source_hash": kernel_source_hash(),
                "fetch_bytes_per_launch": fetch,
                "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
                "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline (5,000,000 pairs per step in one k_main launch)",
