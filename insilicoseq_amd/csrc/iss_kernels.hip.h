@@ -189,6 +189,9 @@ struct RunArgs {
     const int64_t *ov_frags;      // ... with these host-evaluated fragment lengths
     uint32_t n_ov;
     uint32_t *flags, *fix_list, *fix_count;  // irregular pairs (template shorter than the read, ...) go straight to the fix-up
+    // indel events (k_indel_scan -> k_indel_apply): per read a counter and EV_K event words (step << 8 | event mask); pairs
+    // with an event are listed once in pair_list
+    uint32_t *ev_count, *ev_list, *pair_list, *pair_count;
     MutRecord *mut;               // --store_mutations rows (NULL: off)
     uint32_t *mut_count;          // slots reserved so far
     uint32_t mut_cap;
@@ -242,6 +245,12 @@ __device__ __forceinline__ void mut_emit(const RunArgs &A, MutChunk &c, bool hav
     if (!m) return;
     const uint32_t at = mut_alloc(A, c, (uint32_t)__popcll(m));
     if (have && at != 0xffffffffu) A.mut[at + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = r;
+}
+
+// one row from one lane (the two halves of a k_indel_apply wavefront walk different mates: no wave-uniform chunk there)
+__device__ __forceinline__ void mut_emit1(const RunArgs &A, const MutRecord &r) {
+    const uint32_t at = atomicAdd(A.mut_count, 1u);
+    if (at < A.mut_cap) A.mut[at] = r;
 }
 
 // ---------------------------------------------------------------- small helpers
@@ -517,7 +526,10 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
         for (int64_t w = (rs - 3) >> 5; w <= (re - 1) >> 5; ++w) any |= g.mask[w];
         exc |= any ? 32u : 0u;
     }
-    if (!ov_frag) A.flags[i] = 0u;  // first pass: the pair's indel / irregular flags start clean (no separate memset)
+    if (!ov_frag) {  // first pass: the pair's indel / irregular flags and event counters start clean (no separate memset)
+        A.flags[i] = 0u;
+        if (A.ev_count) *reinterpret_cast<uint2 *>(A.ev_count + 2 * i) = make_uint2(0u, 0u);
+    }
     if (irregular && !(A.flags[i] & 3u)) {
         A.flags[i] = 3u;
         const uint32_t at = atomicAdd(A.fix_count, 2u);
@@ -914,29 +926,35 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
 }
 
 // ================================================================== k_indel_scan
-// Conservative: flags mate o of a pair when some indel uniform's leading digit is <= the leading
-// digit of a non-zero threshold (max over bases for deletions).  No flag  =>  provably no indel
-// event (the first event in loop order would have been flagged), so k_main's output stands.
-// One lane per (pair, Philox block holding a digit that can matter): exactly one block and eight
-// compares per lane-item, no divergence between the lanes of a wavefront whatever mix of table
-// entries they hold.  The limits (digit < lim  <=>  candidate; lim = (thr >> 37) + 1, 0 = never) sit in
-// LDS.  Flagged reads go to a workgroup-local LDS list that is flushed to the global fix list with ONE
-// atomic per flush.
+// One lane per (pair, Philox block holding an indel digit with a non-zero probability): exactly one block and eight
+// compares per lane-item, no divergence between the lanes of a wavefront whatever mix of table entries they hold.  The
+// limits (digit < lim  <=>  candidate; lim = (thr >> 37) + 1, 0 = never; max over bases for deletions) sit in LDS.
+// A candidate is then decided exactly (rare): per (mate, loop step) the 8-bit EVENT MASK of the reference's loop --
+// bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b (__init__.py:193-196,
+// :209) -- and a non-empty mask is appended to the read's event list (EV_K words, step << 8 | mask).  k_indel_apply
+// replays the lists; no event => provably no indel, k_main's output stands.  A read with more than EV_K events goes to
+// the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  Pairs with an event are collected in a
+// workgroup-local LDS list that is appended to the global pair list with ONE atomic per flush.
 constexpr int SCAN_W = 9;         // words per table entry (odd: bank-conflict free): [0] kind << 24 | index,
                                   // [1..8] limits of the block's 8 digits
 constexpr int SCAN_THREADS = 512;
-constexpr int SCAN_LIST = 8192;   // LDS list entries; flushed every RunArgs::scan_every iterations, chosen on the
-                                  // host so that a period cannot overflow it (2 * scan_every * SCAN_THREADS <= SCAN_LIST
-                                  // in the worst case, longer periods when the model's indel probabilities are small)
+constexpr int SCAN_CAND = 2048;   // candidate lane-items of the LDS buffer; flushed every RunArgs::scan_every iterations,
+                                  // chosen on the host from the model's indel probabilities (a candidate that finds
+                                  // the buffer full is settled on the spot)
+constexpr int EV_K = 8;           // events kept per read
+constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
+                                       // bit 4 pair is in pair_list
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc,
-                                                             uint32_t *flags, uint32_t *fix_list, uint32_t *fix_count) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *l_count = lds;      // [0] entries in the list, [1] global base of the current flush
-    uint32_t *l_list = lds + 4;   // SCAN_LIST entries
-    uint32_t *tab0 = l_list + SCAN_LIST;
+    uint32_t *l_count = lds;      // [0] candidates in the buffer, [1] newly listed pairs, [2] global base of the current flush
+    uint2 *l_cand = reinterpret_cast<uint2 *>(lds + 4);  // SCAN_CAND x {pair, table entry << 8 | digits below their limits}
+    uint32_t *l_pairs = lds + 4 + 2 * SCAN_CAND;         // newly listed pairs of a flush (<= 8 per candidate ... 2 really)
+    uint32_t *tab0 = l_pairs + 2 * SCAN_CAND;
+    uint32_t *fix0 = tab0 + M.n_scan * SCAN_W;  // [2][RL][8]: digit limits of the 4 insertion slots and the 4 bases' deletions
     for (int i = threadIdx.x; i < M.n_scan * SCAN_W; i += blockDim.x) tab0[i] = M.scan_tab[i];
-    if (threadIdx.x == 0) l_count[0] = 0;
+    for (int i = threadIdx.x; i < 2 * M.RL * 8; i += blockDim.x) fix0[i] = M.fix_tab[i];
+    if (threadIdx.x < 2) l_count[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t ns = (uint32_t)M.n_scan;
     const uint32_t n_items = (uint32_t)A.n_pairs * ns;
@@ -947,6 +965,58 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     uint32_t it = first + threadIdx.x;
     uint32_t pair = it / ns, e = it - pair * ns;
     uint32_t since_flush = 0;
+    // One candidate lane-item, exactly (dense at flush time: one lane per candidate): the event masks of its (mate, step)s
+    // -- bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b -- go to their
+    // reads' lists; returns nothing, lists pairs in l_pairs.
+    auto settle = [&](uint32_t c_pair, uint32_t c_e, uint32_t hit) {
+        const uint32_t c2 = tab0[c_e * SCAN_W];
+        const Addr a = make_addr(A.seed, A.first_ordinal + c_pair, A.gc_bias ? desc[c_pair].meta >> 16 : 0u);
+        const u32x4 w = philox4x32_10(a.c0, a.c1, c2, 0u, a.k0, a.k1);
+        const bool is_del = (c2 >> 24) == K_DEL;
+        const int idx = (int)(c2 & 0xffffffu);
+        while (hit) {
+            const int dg = __ffs(hit) - 1;
+            hit &= hit - 1u;
+            // digit -> (mate, step): K_DEL (n & 3) * 2 + mate, K_INS mate * 4 + slot
+            const int o = is_del ? dg & 1 : dg >> 2;
+            const int n = is_del ? idx * 4 + (dg >> 1) : idx;
+            const uint32_t h = digit16(w, dg);
+            const uint32_t *t8 = fix0 + ((uint32_t)o * (uint32_t)M.RL + (uint32_t)n) * 8u;
+            const size_t en = (size_t)o * M.RL + n;
+            uint32_t m8 = 0;
+            if (is_del) {  // (:209)
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t lim = t8[4 + b];  // (thr >> 37) + 1, 0 = zero probability
+                    bool fire = h + 1u < lim;
+                    if (lim && h + 1u == lim)  // tie of the leading digit: exact
+                        fire = mk_digit(h, lo37(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < M.del_thr[en * 4 + b];
+                    if (fire) m8 |= 16u << b;
+                }
+            } else {  // (:193-196)
+                const int x = dg & 3;
+                const uint32_t lim = t8[x];
+                bool fire = h + 1u < lim;
+                if (lim && h + 1u == lim) {
+                    const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)n, (uint32_t)(o * 2 + (x >> 1)));
+                    fire = mk_digit(h, lo37(l, x & 1)) < M.ins_thr[en * 4 + x];
+                }
+                if (fire) m8 = 1u << x;
+            }
+            if (!m8) continue;
+            const uint32_t rd = 2u * c_pair + (uint32_t)o;
+            const uint32_t at = atomicAdd(&A.ev_count[rd], 1u);
+            if (at < (uint32_t)EV_K) {
+                A.ev_list[(size_t)rd * EV_K + at] = ((uint32_t)n << 8) | m8;
+                if (!(atomicOr(&A.flags[c_pair], FLAG_LISTED) & FLAG_LISTED)) {
+                    const uint32_t lp = atomicAdd(&l_count[1], 1u);
+                    if (lp < 2u * (uint32_t)SCAN_CAND) l_pairs[lp] = c_pair;
+                    else A.pair_list[atomicAdd(A.pair_count, 1u)] = c_pair;
+                }
+            } else if (at == (uint32_t)EV_K) {  // too many events for the list: the wavefront-per-read kernel takes the read
+                if (!(atomicOr(&A.flags[c_pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
+            }
+        }
+    };
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
         if (it < n_items) {
             const uint32_t *tab = tab0 + e * SCAN_W;
@@ -957,33 +1027,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
             uint32_t hit = 0;  // bit d: digit d is below its limit
 #pragma unroll
             for (int dgt = 0; dgt < 8; ++dgt) hit |= (digit16(w, dgt) < tab[1 + dgt] ? 1u : 0u) << dgt;
-            // digit -> mate: K_DEL (n & 3) * 2 + mate, K_INS mate * 4 + slot
-            const uint32_t cand = (c2 >> 24) == K_DEL ? (((hit & 0x55u) ? 1u : 0u) | ((hit & 0xaau) ? 2u : 0u))
-                                                      : (((hit & 0x0fu) ? 1u : 0u) | ((hit & 0xf0u) ? 2u : 0u));
-            if (cand) {
-                const uint32_t old = atomicOr(&flags[pair], cand);
-                uint32_t fresh = cand & ~old;
-                while (fresh) {
-                    const int o = __ffs(fresh) - 1;
-                    fresh &= fresh - 1;
-                    const uint32_t at = atomicAdd(&l_count[0], 1u);
-                    if (at < (uint32_t)SCAN_LIST) l_list[at] = pair * 2u + (uint32_t)o;
-                    else fix_list[atomicAdd(fix_count, 1u)] = pair * 2u + (uint32_t)o;  // list full (rates above the estimate)
-                }
+            if (hit) {  // rare: remembered, settled when the buffer is flushed (one lane per candidate then)
+                const uint32_t at = atomicAdd(&l_count[0], 1u);
+                if (at < (uint32_t)SCAN_CAND) l_cand[at] = make_uint2(pair, (e << 8) | hit);
+                else settle(pair, e, hit);  // buffer full (rates far above the host's estimate)
             }
         }
         if (++since_flush == (uint32_t)A.scan_every || iter == n_iter - 1) {
             since_flush = 0;
             __syncthreads();
-            const uint32_t n = min(l_count[0], (uint32_t)SCAN_LIST);
-            if (n) {
-                if (threadIdx.x == 0) l_count[1] = atomicAdd(fix_count, n);
-                __syncthreads();
-                const uint32_t base = l_count[1];
-                for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) fix_list[base + i] = l_list[i];
-                __syncthreads();
-                if (threadIdx.x == 0) l_count[0] = 0;
+            const uint32_t n_c = min(l_count[0], (uint32_t)SCAN_CAND);
+            for (uint32_t i = threadIdx.x; i < n_c; i += blockDim.x) {
+                const uint2 c = l_cand[i];
+                settle(c.x, c.y >> 8, c.y & 0xffu);
             }
+            __syncthreads();
+            const uint32_t n_new = min(l_count[1], 2u * (uint32_t)SCAN_CAND);
+            if (n_new) {  // the pairs listed for the first time: ONE global atomic
+                if (threadIdx.x == 0) l_count[2] = atomicAdd(A.pair_count, n_new);
+                __syncthreads();
+                const uint32_t base = l_count[2];
+                for (uint32_t i = threadIdx.x; i < n_new; i += blockDim.x) A.pair_list[base + i] = l_pairs[i];
+            }
+            __syncthreads();
+            if (threadIdx.x < 2) l_count[threadIdx.x] = 0;
             __syncthreads();
         }
         it += step;
@@ -991,6 +1058,320 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
         e += step_e;
         if (e >= ns) { e -= ns; ++pair; }
     }
+}
+
+// ================================================================== k_indel_apply
+// One wavefront per listed pair, lanes 0-31 on the forward mate, 32-63 on the reverse mate.  introduce_indels +
+// adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
+// prefix [0, n) is final when step n starts; the not-yet-visited suffix is (stack of freshly inserted letters, LIFO)
+// ++ E(k), E(k+1), ...
+//   1. the read's events: sorted by step, masks of one step merged (both halves at once)
+//   2. (all lanes) the template E(0 .. RL+63) of both mates into LDS, 8 bases per lane from the 2-bit genome; the
+//      error-test digits of both mates (one Philox block per 8 positions)
+//   3. the walk over the steps with an event (the two mates side by side, one per half): explicit map[] entries for
+//      those steps and for the steps that drain the insertion stack, "from step n0 on, source index = k0 + (n - n0)"
+//      records for everything in between
+//   4. (all lanes, 8 positions each) token -> base -> mut_sequence -> one 8-byte store
+// A pair is a chain of dependent loads (list entry -> descriptor, events, phreds -> genome windows) behind a write
+// stream, i.e. microseconds of latency: the list entry is requested two pairs ahead, everything its address needs only
+// the pair for one pair ahead, and the tables the walk and the substitutions read sit in LDS.
+constexpr int APPLY_WAVES = 4;    // pairs per workgroup
+#ifndef ISS_APPLY_OCC
+#define ISS_APPLY_OCC 4           // wavefronts per SIMD the register budget is cut for (measured: 3 -> 4: -20 % time)
+#endif
+constexpr int APPLY_ITEMS = 512;  // batch calls: item_first of up to this many work items is cached in LDS
+constexpr int16_t FIX_NONE = 0x7fff;
+
+__host__ __device__ inline int apply_tl(int pitch) { return pitch + 8; }  // staged template positions: a read of <= EV_K events reaches <= EV_K past its end
+__host__ __device__ inline size_t apply_wave_bytes(int pitch) {
+    // per mate: tmpl (tl) + dqm (pitch) + stk (pitch + 4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + map (2 * pitch)
+    //           + events (4 * EV_K * 2)
+    return 2 * ((size_t)apply_tl(pitch) + 3 * (size_t)pitch + 4 * EV_K + 2 * (size_t)pitch + 8 * EV_K);
+}
+// [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+1 i64][per wave]
+__host__ __device__ inline size_t apply_tab_bytes(int RL) {
+    return 256 + (size_t)2 * RL * 4 * 4 + (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + (APPLY_ITEMS + 2) * 8;
+}
+__host__ __device__ inline size_t apply_lds_bytes(int RL, int pitch) { return apply_tab_bytes(RL) + APPLY_WAVES * apply_wave_bytes(pitch); }
+
+template <bool STORE_MUT>
+__global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply(DevModel M, DevGenome g, RunArgs A,
+                                                                  const PairDesc *__restrict__ desc, uint64_t *stats) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t apply_lds[];
+    const int RL = M.RL, pitch = M.pitch, TL = apply_tl(pitch);
+    uint32_t *mut8 = reinterpret_cast<uint32_t *>(apply_lds);  // [64] leading 8 bits of the substitution-test thresholds
+    uint32_t *sub13 = mut8 + 64;                                // [2][RL][4] (see DevModel::subst13, position-major here)
+    uint8_t *insl = reinterpret_cast<uint8_t *>(sub13 + 2 * RL * 4);  // [2][RL][4]
+    int64_t *ifirst = reinterpret_cast<int64_t *>(apply_lds + apply_tab_bytes(RL) - (APPLY_ITEMS + 2) * 8);
+    const uint32_t n_list = *A.pair_count;
+    if (blockIdx.x * APPLY_WAVES >= n_list) return;  // whole workgroup idle (uniform)
+    for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut8[i] = (uint32_t)(M.mut_thr[i] >> 45);
+    for (int i = threadIdx.x; i < 2 * RL * 4; i += blockDim.x) {
+        const int o = i / (RL * 4), r = i - o * RL * 4, p = r >> 2, bi = r & 3;
+        const int tl = p / M.TP, pp = p - tl * M.TP;
+        sub13[i] = M.subst13[(size_t)tl * 2 * M.TP * 4 + ((size_t)(o * M.TP + pp) * 4 + bi)];
+        insl[i] = M.ins_letter[i];
+    }
+    const bool items_cached = A.items && A.n_items <= APPLY_ITEMS;
+    if (items_cached) for (int i = threadIdx.x; i <= A.n_items; i += blockDim.x) ifirst[i] = A.item_first[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int o = lane >> 5, hl = lane & 31;  // mate, lane within the half
+    uint8_t *wave0 = apply_lds + apply_tab_bytes(RL) + (size_t)wv * apply_wave_bytes(pitch);
+    uint8_t *wbase = wave0 + (size_t)o * (apply_wave_bytes(pitch) / 2);
+    uint8_t *tmpl = wbase;                                  // [TL]
+    uint8_t *dqm = tmpl + TL;                               // [pitch] error-test digit (8 bits) of position j
+    uint8_t *stk = dqm + pitch;                             // [pitch + 4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
+    int8_t *dsh = reinterpret_cast<int8_t *>(stk + pitch + 4 * EV_K);   // [pitch] change of (token - step) at the steps where a new run starts
+    int16_t *map = reinterpret_cast<int16_t *>(dsh + pitch);  // [pitch] explicit tokens (steps with an event, stack drains)
+    uint32_t *ev_raw = reinterpret_cast<uint32_t *>(map + pitch);  // [EV_K]
+    uint32_t *ev_srt = ev_raw + EV_K;                       // [EV_K]
+    const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);
+    uint64_t n_reads = 0;
+    const uint32_t stride = gridDim.x * APPLY_WAVES;
+    const uint32_t li0 = blockIdx.x * APPLY_WAVES + wv;
+    // software pipeline: the list entry two pairs ahead, what hangs on the pair number one pair ahead
+    uint32_t pair_a = li0 < n_list ? A.pair_list[li0] : 0u;                     // pair of iteration `li`
+    uint32_t pair_b = li0 + stride < n_list ? A.pair_list[li0 + stride] : 0u;   // ... of `li + stride`
+    PairDesc d_a = desc[pair_a];
+    uint32_t fl_a = A.flags[pair_a], cnt_a = A.ev_count[2 * pair_a + o];
+    uint32_t evw_a = hl < EV_K ? A.ev_list[(size_t)(2 * pair_a + o) * EV_K + hl] : 0u;
+    for (uint32_t li = li0; li < n_list; li += stride) {
+        const uint32_t pair = pair_a;
+        PairDesc d = d_a;
+        const uint32_t fl = fl_a, cnt_raw = cnt_a, evw = evw_a;
+        {   // requests for the next two iterations
+            pair_a = pair_b;
+            const bool more = li + stride < n_list;
+            const uint32_t pn = more ? pair_a : pair;
+            d_a = desc[pn];
+            fl_a = A.flags[pn];
+            cnt_a = A.ev_count[2 * pn + o];
+            evw_a = hl < EV_K ? A.ev_list[(size_t)(2 * pn + o) * EV_K + hl] : 0u;
+            pair_b = li + 2 * stride < n_list ? A.pair_list[li + 2 * stride] : 0u;
+        }
+        DevGenome gl = g;  // the record of the pair: the launch's genome, or its slice of the arena (batch calls)
+        int64_t arena_off = 0;
+        if (A.items) {
+            int k;
+            if (items_cached) {
+                int lo = 0, hi = A.n_items;  // largest k with item_first[k] <= p
+                const int64_t p = A.pair_base + pair;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ifirst[mid] <= p) lo = mid; else hi = mid; }
+                k = lo;
+            } else {
+                k = batch_item_of(A, A.pair_base + pair);
+            }
+            const BatchItem it = A.items[k];
+            gl = batch_genome(g, it);
+            arena_off = it.off;
+            d.fs -= (int32_t)it.off;
+            d.re -= (int32_t)it.off;
+        }
+        const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
+        uint32_t cnt = min(cnt_raw, (uint32_t)EV_K);
+        if ((fl >> o) & 1u) cnt = 0;  // this mate is k_indel_fixup's (too many events / irregular pair)
+        const MateGeom geo = mate_geom(o, d, RL, gl.L);
+        uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.row;
+        const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.row;
+        // ---- requests of this pair: its phreds and its genome windows (used after the event sort and the Philox blocks)
+        uint2 q8 = {0u, 0u};
+        if (cnt && hl * 8 < pitch) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(hl * 8));
+        uint2 gw = {0u, 0u};
+        bool fast = false;
+        {
+            // E(k) = g[fs + k] / comp(g[re - 1 - k]) for template and padding alike as long as the position is inside the
+            // record (regular geometry: the mates of irregular pairs are k_indel_fixup's)
+            const int k0 = hl * 8;
+            const int64_t g0 = o == 0 ? geo.lo + k0 : geo.hi - 8 - k0;  // lowest genome position of the lane's 8 bases
+            fast = cnt && k0 < TL && geo.t_len == RL && g0 >= 0 && g0 + 8 <= gl.L && !gl.has_exceptions;
+            if (fast) gw = *reinterpret_cast<const uint2 *>(packed_b + (size_t)((((g0 + arena_off) >> 4) + 1) << 2));
+        }
+        // ---- 1. events: sorted by step, one word per step
+        if (hl < EV_K) ev_raw[hl] = evw;
+        for (int j = hl * 4; j < pitch; j += 128) *reinterpret_cast<uint2 *>(map + j) = make_uint2(0x7fff7fffu, 0x7fff7fffu);  // FIX_NONE
+        for (int j = hl * 8; j < pitch; j += 256) *reinterpret_cast<uint2 *>(dsh + j) = make_uint2(0u, 0u);
+        for (int b = lane; b * 8 < pitch; b += 64) {  // one Philox block holds the digits of 8 positions of both mates
+            const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 1);
+            *reinterpret_cast<uint2 *>(wave0 + TL + b * 8) = make_uint2(w.x, w.z);                                  // mate 0
+            *reinterpret_cast<uint2 *>(wave0 + apply_wave_bytes(pitch) / 2 + TL + b * 8) = make_uint2(w.y, w.w);   // mate 1
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n_act = cnt;
+        {   // rank = events with a smaller step, or the same step and a smaller index (the walk merges equal steps)
+            uint32_t rank = 0;
+            for (uint32_t i = 0; i < (uint32_t)EV_K; ++i) {
+                const uint32_t other = ev_raw[i];
+                rank += (i < cnt && ((other >> 8) < (evw >> 8) || ((other >> 8) == (evw >> 8) && (int)i < hl))) ? 1u : 0u;
+            }
+            if (hl < (int)cnt) ev_srt[rank] = evw;
+        }
+        // ---- 2. templates: 8 read-direction positions per lane
+        for (int b = hl; cnt && b * 8 < TL; b += 32) {
+            const int k0 = b * 8;
+            if (b == hl && fast) {  // the 8 positions are template bases inside the record, plain A/C/G/T: from the window
+                const int64_t ga = (o == 0 ? geo.lo + k0 : geo.hi - 8 - k0) + arena_off;
+                uint32_t w16 = funnel_r(gw.x, gw.y, (uint32_t)(ga & 15) * 2);
+                uint2 v;
+                if (o == 0) {
+                    v = make_uint2(codes_to_ascii4(w16 & 0xffu), codes_to_ascii4((w16 >> 8) & 0xffu));
+                } else {  // read position k0 + c <-> genome position g0 + 7 - c, complemented
+                    w16 ^= 0x5555u;
+                    v = make_uint2(__builtin_amdgcn_perm(0u, codes_to_ascii4((w16 >> 8) & 0xffu), 0x00010203u),
+                                   __builtin_amdgcn_perm(0u, codes_to_ascii4(w16 & 0xffu), 0x00010203u));
+                }
+                *reinterpret_cast<uint2 *>(tmpl + k0) = v;
+            } else {
+                for (int c = 0; c < 8; ++c) tmpl[k0 + c] = (uint8_t)geom_base(gl, o, geo, k0 + c);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- 3. the walk: every lane of a half runs the same walk (half-uniform values); lane 0 of the half does the LDS writes
+        MutRecord row;  // --store_mutations row being built
+        row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
+        int sp = 0, k = 0, last = -1, cur_shift = 0;  // `last`: last step whose map entry / run is settled
+#ifdef ISS_EXP_NOWALK
+        for (uint32_t ei = 0; ei < 0u; ++ei) {
+#else
+        for (uint32_t ei = 0; ei < (uint32_t)EV_K; ++ei) {
+#endif
+            if (ei >= n_act) break;
+            const uint32_t evs = ev_srt[ei];
+            const int n = (int)(evs >> 8);
+            uint32_t m8 = evs & 0xffu;
+            while (ei + 1 < n_act && (int)(ev_srt[ei + 1] >> 8) == n) m8 |= ev_srt[++ei] & 0xffu;  // the step's other digits
+            const int next_n = ei + 1 < n_act ? (int)(ev_srt[ei + 1] >> 8) : RL;
+            k += n - (last + 1);  // the settled record covers steps last+1 .. n-1 from the source
+            int tok = sp > 0 ? -(int)stk[--sp] : k++;
+            if (tok < geo.t_len) {  // tok >= len(template): n >= len(seq), IndexError swallowed (:223): emitted unvisited
+                const int ch = tok < 0 ? -tok : (int)tmpl[tok];
+                const int bi = base_index(ch);
+                if (bi >= 0) {  // else ambiguous: skipped (:190-192)
+                    for (int x = 0; x < 4; ++x)
+                        if ((m8 >> x) & 1u) {
+                            const int letter = insl[((size_t)o * RL + n) * 4 + x];
+                            if (hl == 0) stk[sp] = (uint8_t)letter;
+                            ++sp;
+                            if (STORE_MUT) {  // ref = mutable_seq[position], alt = ref + letter (__init__.py:197-207)
+                                row.type = (int8_t)(1 | (x << 2) | 32); row.position = (int16_t)n;
+                                row.ref = (uint8_t)ch; row.alt = (uint8_t)letter;
+                                if (hl == 0) mut_emit1(A, row);
+                            }
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    if ((m8 >> (4 + bi)) & 1u) {  // deleted: next token slides in
+                        const bool exists = sp > 0 || k < geo.t_len;  // else mutable_seq[position] raises IndexError: no row
+                        tok = sp > 0 ? -(int)stk[--sp] : k++;
+                        if (STORE_MUT && exists) {  // ref = mutable_seq[position] after the pop (__init__.py:211-221)
+                            row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
+                            row.ref = (uint8_t)(tok < 0 ? -tok : (int)tmpl[min(tok, TL - 1)]);
+                            row.alt = '.';
+                            if (hl == 0) mut_emit1(A, row);
+                        }
+                    }
+                }
+            }
+            if (hl == 0) map[n] = (int16_t)tok;
+            last = n;
+            // steps after n drain the insertion stack until it is empty or the next step with an event
+            while (sp > 0 && last + 1 < RL && last + 1 != next_n) {
+                ++last;
+                --sp;
+                if (hl == 0) map[last] = (int16_t)(-(int)stk[sp]);
+            }
+            // from step last + 1 on: token = step + (k - (last + 1)) until the next step with an event
+            if (hl == 0 && last + 1 < pitch) dsh[last + 1] = (int8_t)(k - (last + 1) - cur_shift);
+            cur_shift = k - (last + 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- 4. the read: 8 positions per lane
+#ifdef ISS_EXP_NOGATHER
+        if (n_act > 100) {
+#else
+        if (n_act) {
+#endif
+            if (hl == 0) { ++n_reads; atomicOr(&A.flags[pair], 4u << o); }  // (bits 2-3: this kernel rebuilt the mate)
+            int carry = 0;  // (token - step) at the end of the previous pass (read_length > 256)
+            for (int b = hl; (b - hl) * 8 < pitch; b += 32) {  // (every lane of the half takes part in the prefix sums)
+                const int j0 = b * 8;
+                const bool in = j0 < pitch;
+                if (b != hl && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (read_length > 256)
+                uint2 e8w = {0u, 0u}, dw = {0u, 0u};
+                uint4 mw = {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+                if (in) {
+                    e8w = *reinterpret_cast<const uint2 *>(dqm + j0);
+                    dw = *reinterpret_cast<const uint2 *>(dsh + j0);
+                    mw = *reinterpret_cast<const uint4 *>(map + j0);
+                }
+                // (token - step) in front of the lane's first position: prefix sum of the changes over the half's lanes
+                const int lane_sum = __builtin_amdgcn_sdot4((int)dw.x, 0x01010101, __builtin_amdgcn_sdot4((int)dw.y, 0x01010101, 0, false), false);
+                int incl = lane_sum;
+                for (int dd = 1; dd < 32; dd <<= 1) {
+                    const int t = __shfl_up(incl, dd, 32);
+                    if (hl >= dd) incl += t;
+                }
+                int shift = carry + incl - lane_sum;
+                carry += __shfl(incl, 31, 32);
+                if (!in) continue;
+                uint32_t ob0 = 0u, ob1 = 0u, cand = 0u;  // cand: positions whose substitution test fires or ties
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int j = j0 + c;
+                    shift += (int)(int8_t)(((c < 4 ? dw.x : dw.y) >> (8 * (c & 3))) & 0xffu);
+                    const uint32_t mword = c < 2 ? mw.x : (c < 4 ? mw.y : (c < 6 ? mw.z : mw.w));
+                    const int mtok = (int)(int16_t)((mword >> (16 * (c & 1))) & 0xffffu);
+                    int tok = mtok != (int)FIX_NONE ? mtok : j + shift;
+                    int base = -tok;
+                    if (tok >= 0) base = (int)tmpl[tok];  // (tok <= j + EV_K < TL: a step deletes at most one base)
+                    const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
+                    const uint32_t q = ((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu;
+                    if (j < RL && e8 >= mut8[q]) cand |= 1u << c;
+                    if (c < 4) ob0 |= (uint32_t)base << (8 * c); else ob1 |= (uint32_t)base << (8 * (c - 4));
+                }
+                while (cand) {  // rare per lane: the substitution test fires or ties (__init__.py:94)
+                    const int c = __ffs(cand) - 1;
+                    cand &= cand - 1u;
+                    const int j = j0 + c;
+                    const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
+                    const int q = (int)(((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu);
+                    const uint32_t t8 = mut8[q];
+                    const int before = (int)(((c < 4 ? ob0 : ob1) >> (8 * (c & 3))) & 0xffu);
+                    const u32x4 sb = draw_block(a, K_SUB, (uint32_t)j, (uint32_t)o);
+                    bool err = e8 > t8;
+                    if (e8 == t8) err = error_test_draw(e8, sb) > M.mut_thr[q];
+                    const int bi = base_index(before);
+                    if (err && bi >= 0) {  // (else nucl.upper() in "RYWSMKHBVDN": left alone)
+                        const uint64_t m = mk53(sb.x, sb.y);
+                        const uint32_t sd = sub13[((uint32_t)(o * RL + j)) * 4u + (uint32_t)bi];
+                        const uint32_t hs = (uint32_t)(m >> 40), t0 = sd & 0x1fffu, t1 = (sd >> 13) & 0x1fffu;
+                        int kk = (hs > t0) + (hs > t1);
+                        if (hs == t0 || hs == t1) {  // tie of a leading digit: exact thresholds
+                            const size_t srow = ((size_t)(o * RL + j) * 4 + bi) * 3;
+                            kk = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
+                        }
+                        const int base = (int)((M.alt_letters >> (8 * ((sd >> (26 + 2 * kk)) & 3u))) & 0xffu);
+                        if (c < 4) ob0 = (ob0 & ~(0xffu << (8 * c))) | ((uint32_t)base << (8 * c));
+                        else ob1 = (ob1 & ~(0xffu << (8 * (c - 4)))) | ((uint32_t)base << (8 * (c - 4)));
+                        if (STORE_MUT) {  // only if the new letter differs from the ORIGINAL read at this index (__init__.py:98)
+                            MutRecord sub;
+                            sub.pair = (int32_t)(A.pair_base + pair); sub.mate = (int8_t)o; sub.type = (int8_t)32; sub.position = (int16_t)j;
+                            sub.ref = (uint8_t)before; sub.alt = (uint8_t)base; sub.quality = (int16_t)q;
+                            // (a read position past a template the genome end cut short has no "original" letter: the
+                            //  reference raises IndexError there; the row is kept)
+                            if (j >= geo.t_len || base != (int)tmpl[j]) mut_emit1(A, sub);
+                        }
+                    }
+                }
+                *reinterpret_cast<uint2 *>(out_base + xp(j0)) = make_uint2(ob0, ob1);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (hl == 0 && n_reads) atomicAdd((unsigned long long *)stats, (unsigned long long)n_reads);
 }
 
 // ================================================================== k_indel_fixup
@@ -1006,7 +1387,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
 //   phase 3 (all lanes): token -> base -> mut_sequence -> store.
 constexpr int FIX_MAX_RL = 1024;  // read_length limit (checked at model upload)
 constexpr int FIX_WAVES = 4;      // wavefronts (reads) per workgroup
-constexpr int16_t FIX_NONE = 0x7fff;
 
 // dynamic LDS of k_indel_fixup, in bytes: [fix table 2*RL*8 u32][mut8 64 u32][per wave: see below]
 __host__ __device__ inline int fix_rlp(int RL) { return (RL + 63) & ~63; }

@@ -181,6 +181,8 @@ struct iss_ctx {
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
+    uint32_t *ev_count = nullptr, *ev_list = nullptr, *pair_list = nullptr;  // indel events (k_indel_scan -> k_indel_apply), per row
+    uint32_t *pair_count = nullptr;  // FIX_SLOTS counters of the pair lists, like fix_count
     int scan_every = 8;
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
     // custom fragment length on the Philox path
@@ -268,6 +270,10 @@ void free_outputs(iss_ctx *ctx) {
     if (ctx->desc) (void)hipFree(ctx->desc);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->fix_list) (void)hipFree(ctx->fix_list);
+    if (ctx->ev_count) (void)hipFree(ctx->ev_count);
+    if (ctx->ev_list) (void)hipFree(ctx->ev_list);
+    if (ctx->pair_list) (void)hipFree(ctx->pair_list);
+    ctx->ev_count = ctx->ev_list = ctx->pair_list = nullptr;
     ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
     ctx->capacity = 0;
 }
@@ -691,6 +697,10 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_apply<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_apply<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
@@ -701,6 +711,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->fix_count = static_cast<uint32_t *>(p);  // FIX_SLOTS counters; +128 B stats; +192 B genome-pack status
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
+    HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * FIX_SLOTS));
+    ctx->pair_count = static_cast<uint32_t *>(p);
+    HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * FIX_SLOTS));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
     *out = ctx;
     return 0;
@@ -718,6 +731,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     free_outputs(ctx);
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
+    if (ctx->pair_count) (void)hipFree(ctx->pair_count);
     if (ctx->d_amb) (void)hipFree(ctx->d_amb);
     if (ctx->d_pmut) (void)hipFree(ctx->d_pmut);
     if (ctx->d_ov_pairs) (void)hipFree(ctx->d_ov_pairs);
@@ -1007,7 +1021,9 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             for (int k = 1; k <= 8; ++k) rate += (double)scan_tab[e + k] / 65536.0;
         rate = M.n_scan ? rate / M.n_scan : 0.0;
         const double per_iter = std::max(rate, 1e-6) * iss::SCAN_THREADS;
-        ctx->scan_every = (int)std::max(8.0, std::min(512.0, 0.5 * iss::SCAN_LIST / per_iter));
+        // (`rate` = expected events per lane-item; the period keeps the LDS buffer about half full on average, and an
+        //  event that finds it full goes to its list directly)
+        ctx->scan_every = (int)std::max(1.0, std::min(512.0, 0.5 * iss::SCAN_CAND / per_iter));
     }
     std::vector<uint32_t> fix_tab((size_t)2 * RL * 8);
     for (size_t e = 0; e < (size_t)2 * RL; ++e)
@@ -1208,6 +1224,12 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     ctx->flags = static_cast<uint32_t *>(q);
     HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
     ctx->fix_list = static_cast<uint32_t *>(q);
+    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
+    ctx->ev_count = static_cast<uint32_t *>(q);
+    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * iss::EV_K * (size_t)capacity_pairs));
+    ctx->ev_list = static_cast<uint32_t *>(q);
+    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * (size_t)capacity_pairs));
+    ctx->pair_list = static_cast<uint32_t *>(q);
     ctx->capacity = capacity_pairs;
     return 0;
 }
@@ -1253,12 +1275,13 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                          const int64_t *item_first, int32_t n_items, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                          int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
     const iss::DevModel &M = ctx->M;
-    // k_indel_scan packs lane-item indices into 32 bits (keep them below 2^28); k_main's deferred queue has 8 bits for
-    // the pass number of a workgroup (>= 1 workgroup per tile, 256 pairs per pass)
+    // k_indel_scan counts lane-items in 32 bits (keep them below 2^31); k_main's deferred queue has 8 bits for
     const size_t lds_bytes = main_lds_bytes(M);
     const unsigned per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;  // 1024-lane workgroups, two per CU when the LDS tables allow it
     const unsigned wg_per_tile = std::max(1u, std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid) / (unsigned)M.n_tiles);
-    const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(((int64_t)1 << 28) / std::max(M.G, std::max(M.n_scan, 1)),
+    // the pass number of a workgroup (>= 1 workgroup per tile, 256 pairs per pass), and 32 bits for a row's byte offset
+    const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)1 << 31) / std::max(M.n_scan, 1),
+                                                                                      (((int64_t)1 << 32) - 1) / M.row),
                                                                     (int64_t)255 * iss::MAIN_PAIRS * wg_per_tile));
     if (ctx->d_pmut) {  // rows of THIS call only
         ctx->d_pmut_count = reinterpret_cast<uint32_t *>(ctx->fix_count) + 60;  // +240 B of the scratch block
@@ -1310,8 +1333,14 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         // are cleared by k_setup itself.)
         const unsigned slot_i = (unsigned)(ctx->chunk_seq++ % FIX_SLOTS);
         uint32_t *counter = ctx->fix_count + slot_i;
-        if (ctx->overlap) HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
-        else if (slot_i == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
+        uint32_t *pair_counter = ctx->pair_count + slot_i;
+        if (ctx->overlap) {
+            HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
+            HIP_TRY(ctx, hipMemsetAsync(pair_counter, 0, sizeof(uint32_t), s_main));
+        } else if (slot_i == 0) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->pair_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
+        }
         A.mut = ctx->d_pmut;
         A.mut_count = ctx->d_pmut_count;
         A.mut_cap = (uint32_t)ctx->pmut_cap;
@@ -1322,6 +1351,10 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.flags = flags;
         A.fix_list = fix_list;
         A.fix_count = counter;
+        A.ev_count = M.n_scan > 0 ? ctx->ev_count + 2 * row0 : nullptr;
+        A.ev_list = ctx->ev_list + 2 * (size_t)iss::EV_K * row0;
+        A.pair_list = ctx->pair_list + row0;
+        A.pair_count = pair_counter;
         A.has_frag = ctx->has_frag ? 1 : 0;
         A.frag_mu = ctx->frag_mu;
         A.frag_sd = ctx->frag_sd;
@@ -1402,14 +1435,22 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                 const uint64_t items = (uint64_t)n * M.n_scan;
                 const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4,
                                                                      (items + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
-                const size_t lds = (4 + (size_t)iss::SCAN_LIST + (size_t)M.n_scan * iss::SCAN_W) * 4;
-                hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), lds, s_indel, M, A, desc, flags,
-                                   fix_list, counter);
+                const size_t lds = (4 + (size_t)4 * iss::SCAN_CAND + (size_t)M.n_scan * iss::SCAN_W + (size_t)2 * M.RL * 8) * 4;
+                hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), lds, s_indel, M, A, desc);
             }
             HIP_TRY(ctx, mark(4, s_indel));
             if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
             HIP_TRY(ctx, mark(5, s_indel));
-            {
+            if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, one wavefront per pair
+                const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (n + iss::APPLY_WAVES - 1) / iss::APPLY_WAVES);
+                if (A.mut)
+                    hipLaunchKernelGGL(iss::k_indel_apply<true>, dim3(blocks), dim3(64 * iss::APPLY_WAVES), iss::apply_lds_bytes(M.RL, M.pitch),
+                                       s_indel, M, dg, A, desc, ctx->stats);
+                else
+                    hipLaunchKernelGGL(iss::k_indel_apply<false>, dim3(blocks), dim3(64 * iss::APPLY_WAVES), iss::apply_lds_bytes(M.RL, M.pitch),
+                                       s_indel, M, dg, A, desc, ctx->stats);
+            }
+            {   // the rest (irregular pairs, reads with more events than a list holds): one wavefront per read
                 const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
                 hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), iss::fix_lds_bytes(M.RL), s_indel, M, dg, A, desc,
                                    fix_list, counter, ctx->stats);
@@ -2020,7 +2061,7 @@ int iss_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, in
         if (r.pair < 0) continue;
         const int t = (uint8_t)r.type;
         const bool from_fixup = (t & 32) != 0;
-        if (!from_fixup && (flags[(size_t)r.pair] >> r.mate) & 1u) continue;
+        if (!from_fixup && (((flags[(size_t)r.pair] >> r.mate) | (flags[(size_t)r.pair] >> (2 + r.mate))) & 1u)) continue;
         const uint64_t phase = (t & 3) == 0 ? 1 : 0;
         const uint64_t key = ((uint64_t)(uint32_t)r.pair << 32) | ((uint64_t)(r.mate & 1) << 31) | (phase << 30) |
                              ((uint64_t)(uint16_t)r.position << 8) | (uint64_t)((t >> 2) & 7);

@@ -250,10 +250,10 @@ def test_device_genome_packing_roundtrip(engine):
 
 
 def test_chunked_launches_compose(engine):
-    """One call larger than the library's per-launch chunk (2^28 lane-items) == two smaller calls with
+    """One call larger than the library's per-launch chunk (row byte offsets are 32 bits wide) == two smaller calls with
     consecutive ordinals; spot-checked around the chunk boundary and at both ends."""
-    dense = dense_model("hiseq")  # G = 32 groups -> chunk = 2^28 / 32 = 8,388,608 pairs
-    chunk = (1 << 28) // 32
+    dense = dense_model("hiseq")  # rows of 512 bytes -> chunk = (2^32 - 1) / 512 = 8,388,607 pairs
+    chunk = ((1 << 32) - 1) // 512
     n = chunk + 300_000
     genome = random_genome(123, 2_000_000)
     engine.load_model(dense)
