@@ -171,6 +171,8 @@ struct FragAmb {
     double x1, x2;  // the accepted polar candidate
 };
 
+constexpr int MAX_TILES = 64;  // position tiles of k_main (a model whose tables need more is rejected at upload)
+
 struct RunArgs {
     int64_t n_pairs;
     uint64_t first_ordinal;
@@ -192,6 +194,7 @@ struct RunArgs {
     // indel events (k_indel_scan -> k_indel_apply): per read a counter and EV_K event words (step << 8 | event mask); pairs
     // with an event are listed once in pair_list
     uint32_t *ev_count, *ev_list, *pair_list, *pair_count;
+    uint16_t tile_wg0[MAX_TILES + 2];  // k_main: workgroups [tile_wg0[t], tile_wg0[t + 1]) work on position tile t
     MutRecord *mut;               // --store_mutations rows (NULL: off)
     uint32_t *mut_count;          // slots reserved so far
     uint32_t mut_cap;
@@ -724,13 +727,15 @@ template <bool STORE_MUT, bool PLAIN>
 __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int tile = blockIdx.x % M.n_tiles;
-    const uint32_t wg = blockIdx.x / M.n_tiles, n_wg = gridDim.x / M.n_tiles;
+    // workgroups are dealt to the position tiles in proportion to the tiles' sizes (the last tile may be short)
+    int tile = 0;
+    while (tile + 1 < M.n_tiles && blockIdx.x >= A.tile_wg0[tile + 1]) ++tile;
+    const uint32_t wg = blockIdx.x - A.tile_wg0[tile], n_wg = (uint32_t)A.tile_wg0[tile + 1] - A.tile_wg0[tile];
     MainTile T;
     T.s0 = tile * M.TS;
     T.ts = (uint32_t)min(M.TS, M.S - T.s0);
     // Deferred lane-items (a base needs the exact path): a private ring per wavefront -- no atomics, no barriers.
-    // Entry = {pass << 24 | iteration << 19 | lane << 13 | half << 12 | bin slots << 8 | base mask,
+    // Entry = {(pass << it_bits | iteration) << 19 | lane << 13 | half << 12 | bin slots << 8 | base mask,
     //          forward window | complemented reverse window << 16 (2-bit codes of the lane-item's 8 + 8 template bases)};
     // head / tail are wave-uniform.
     uint2 *ring = reinterpret_cast<uint2 *>(lds + M.tile_words + MAIN_MUT_WORDS + 2 * M.TP * 4) + (threadIdx.x >> 6) * SLOW_RING;
@@ -748,6 +753,8 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
     const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds);
     auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     const uint32_t n_iter = sgpr((T.ts + 3u) >> 2);
+    const uint32_t it_max = ((uint32_t)M.TS + 3u) / 4u - 1u;  // largest iteration number of a pass
+    const uint32_t it_bits = sgpr(it_max ? 32u - (uint32_t)__clz(it_max) : 0u);  // (13 bits hold pass and iteration)
     const uint32_t n_pass = sgpr(((uint32_t)A.n_pairs + MAIN_PAIRS - 1) / MAIN_PAIRS);
     const uint32_t gsh = 16u - (uint32_t)M.GB, gb = (uint32_t)M.GB;
     const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
         uint2 rest = {0u, 0u};
         if (lane < n) {
             const uint2 ent = ring[(q_head + lane) & (SLOW_RING - 1)];
-            const uint32_t e_pass = ent.x >> 24, e_it = (ent.x >> 19) & 31u, e_lane = (ent.x >> 13) & 63u;
+            const uint32_t e_pass = ent.x >> (19u + it_bits), e_it = (ent.x >> 19) & ((1u << it_bits) - 1u), e_lane = (ent.x >> 13) & 63u;
             const uint32_t e_pair = (wg + e_pass * n_wg) * MAIN_PAIRS + wave_pair0 + (e_lane >> 2);
             const uint32_t mask = ent.x & 0xffu;  // never empty
             const int bit = 31 - __clz(mask);
@@ -789,7 +796,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
             q_tail += (uint32_t)__popcll(again);
         }
     };
-    // tag: pass << 24 | iteration << 19 | lane << 13 | half << 12 | bin slots << 8
+    // tag: (pass << it_bits | iteration) << 19 | lane << 13 | half << 12 | bin slots << 8
     auto push = [&](uint32_t rare, uint32_t tag, uint32_t windows) {
         const unsigned long long rm = __ballot(rare != 0u);
         if (rm) {
@@ -817,7 +824,7 @@ __global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome 
         int32_t pr = d.re - 8 - (int32_t)(s_lane * 8u);       // lowest genome position of its 8 reverse bases
         uint32_t out_b = pair * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u;  // (tiles start at multiples of 4 superitems: whole lines)
         const bool regular = PLAIN || !(A.has_frag && (d.meta & 64u));  // irregular pairs are built by the fix-up kernel
-        const uint32_t tag0 = (pass << 24) | (lane << 13) | ((d.meta & 15u) << 8);
+        const uint32_t tag0 = (pass << (19u + it_bits)) | (lane << 13) | ((d.meta & 15u) << 8);
         for (uint32_t it = 0; it < n_iter; ++it) {
             uint32_t rare0 = 0, rare1 = 0, windows = 0;
             if (valid && 4u * it + j4 < T.ts) {

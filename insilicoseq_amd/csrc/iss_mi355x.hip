@@ -862,27 +862,32 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                 }
         return acc / 65536.0 / (double)std::max<size_t>(rows, 1);
     };
+    // Guide bits and position tiles, chosen together by a small cost model fitted to measurements (DESIGN.md section 7:
+    // NovaSeq / HiSeq / NextSeq / MiSeq sweeps): a workgroup keeps ONE tile of tables in LDS (<= 158 KB: one workgroup per
+    // CU is as fast as two, bigger tiles are what pays), the work of a pass has a fixed part next to its ceil(TS / 4)
+    // iterations, and every base the two-probe lookup cannot decide costs about eight hot bases.
+    auto tiles_needed = [&](int gb, int *ts_out) {  // fewest tiles whose tables fit one workgroup per CU
+        const size_t gs = 4 * ((size_t)(1 << gb) / 4 + s_max) + 1;
+        for (int nt = 1; nt <= M.S; ++nt) {
+            const int ts = nt > 1 ? ((M.S + nt - 1) / nt + 3) / 4 * 4 : M.S;
+            const size_t tg = 2 * (size_t)ts;
+            const size_t words = (2 * (size_t)M.NB * tg * gs + 3) / 4 * 4 + iss::MAIN_MUT_WORDS + 2 * tg * 4 * 4 +
+                                 (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 2;
+            if (words * 4 <= 158 * 1024) { *ts_out = ts; return (M.S + ts - 1) / ts; }
+        }
+        *ts_out = 0;
+        return 0;
+    };
     M.GB = 6;
     if (const char *e = getenv("ISS_GUIDE_BITS")) M.GB = std::min(8, std::max(6, atoi(e)));
     else {
-        while (M.GB < 8 && more_rate(M.GB) > 0.004) ++M.GB;
-        // ... unless a smaller guide is what lets TWO workgroups share a CU with tiles of >= 12 position groups:
-        // measured (MiSeq, 301 x 3 bins), 8 wavefronts / SIMD are worth more than the extra deferred bases
-        // (guide 8 bits, one workgroup / CU: 7.7 ms per 5 M pairs; 6 bits, two: 7.0 ms).
-        auto two_fit = [&](int gb) {
-            const size_t gs = 4 * ((size_t)(1 << gb) / 4 + s_max) + 1;
-            for (int nt = 1; nt <= M.S; ++nt) {
-                const size_t tg = 2 * (nt > 1 ? (((size_t)M.S + nt - 1) / nt + 3) / 4 * 4 : (size_t)M.S);
-                if (tg < (size_t)std::min(12, M.G)) break;
-                const size_t words = (2 * (size_t)M.NB * tg * gs + 3) / 4 * 4 + iss::MAIN_MUT_WORDS + 2 * tg * 4 * 4 +
-                                     (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 2;
-                if (words * 4 <= 79 * 1024) return true;
-            }
-            return false;
-        };
-        if (!two_fit(M.GB))
-            for (int gb = M.GB - 1; gb >= 6; --gb)
-                if (two_fit(gb)) { M.GB = gb; break; }
+        double best = 1e30;
+        for (int gb = 6; gb <= 8; ++gb) {
+            int ts = 0;
+            if (!tiles_needed(gb, &ts)) continue;
+            const double cost = (1.0 + 8.0 * more_rate(gb)) * (1.0 + 0.3 / (double)((ts + 3) / 4));
+            if (cost < best - 1e-9) { best = cost; M.GB = gb; }
+        }
     }
     if (getenv("ISS_DEBUG_MODEL")) {  // expected share of bases that leave the hot loop
         double err = 0;
@@ -905,8 +910,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     const int gwords = (1 << M.GB) / 4;
     M.stride_w = (int32_t)(gwords + s_max);
     M.GS = 4 * M.stride_w + 1;
-    // Position tiling: prefer tiles small enough for TWO resident workgroups per CU (8 waves / SIMD) as long
-    // as a tile keeps >= 12 groups (48-byte output segments); otherwise the largest tile one workgroup can hold.
+    // Position tiling: the fewest tiles one workgroup per CU can hold (two workgroups share a CU when the tile is small
+    // enough anyway).
     auto fits = [&](int n_tiles, size_t budget) {
         M.TS = (M.S + n_tiles - 1) / n_tiles;
         if (n_tiles > 1) M.TS = (M.TS + 3) / 4 * 4;  // tiles start at whole 128-byte lines of the output rows (4 superitems)
@@ -919,13 +924,11 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     const int env_tiles = getenv("ISS_TILES") ? atoi(getenv("ISS_TILES")) : 0;  // tuning aid
     M.n_tiles = 0;
     if (env_tiles > 0 && fits(env_tiles, one_per_cu)) M.n_tiles = env_tiles;
-    for (int nt = 1; !M.n_tiles && nt <= M.S; ++nt) {
-        if (2 * ((M.S + nt - 1) / nt) < std::min(12, M.G)) break;
-        if (fits(nt, two_per_cu) && (M.S + M.TS - 1) / M.TS == nt) M.n_tiles = nt;
-    }
+    (void)two_per_cu;
     for (int nt = 1; !M.n_tiles && nt <= M.S; ++nt)
         if (fits(nt, one_per_cu)) M.n_tiles = nt;
     if (!M.n_tiles) return fail(ctx, ISS_E_INVALID, "quality tables do not fit the LDS even for one superitem (8 positions)");
+    if ((M.S + M.TS - 1) / M.TS > iss::MAX_TILES) return fail(ctx, ISS_E_INVALID, "quality tables need more position tiles than the engine supports");
     (void)fits(M.n_tiles, one_per_cu);
     M.n_tiles = (M.S + M.TS - 1) / M.TS;
     if (getenv("ISS_DEBUG_MODEL"))
@@ -1275,14 +1278,27 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                          const int64_t *item_first, int32_t n_items, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                          int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
     const iss::DevModel &M = ctx->M;
-    // k_indel_scan counts lane-items in 32 bits (keep them below 2^31); k_main's deferred queue has 8 bits for
+    // k_indel_scan counts lane-items in 32 bits (keep them below 2^31)
     const size_t lds_bytes = main_lds_bytes(M);
-    const unsigned per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;  // 1024-lane workgroups, two per CU when the LDS tables allow it
+    unsigned per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;  // 1024-lane workgroups, two per CU when the LDS tables allow it
+    if (const char *e = getenv("ISS_MAIN_PER_CU")) per_cu = std::min(per_cu, (unsigned)std::max(1, atoi(e)));  // tuning aid
     const unsigned wg_per_tile = std::max(1u, std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid) / (unsigned)M.n_tiles);
+    const unsigned wg_per_tile_cap = 8192;  // (tile_wg0 is 16 bits wide)
+    // k_main's deferred queue: 13 bits for (pass of a workgroup, iteration of the pass); the tile with the fewest
+    // workgroups (a short last tile) makes the most passes
+    const unsigned it_max = ((unsigned)M.TS + 3u) / 4u - 1u;
+    unsigned it_bits = 0;
+    while ((1u << it_bits) <= it_max && it_max) ++it_bits;
+    const int64_t max_passes = ((int64_t)1 << (13 - it_bits)) - 1;
+    const unsigned budget_all = std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid);
+    unsigned weight_all = 0;
+    for (int t = 0; t < M.n_tiles; ++t) weight_all += 1u + (unsigned)(std::min(M.TS, M.S - t * M.TS) + 3) / 4u;
+    const unsigned last_weight = 1u + (unsigned)(M.S - (M.n_tiles - 1) * M.TS + 3) / 4u;
+    const unsigned min_tile_wg = std::max(1u, (unsigned)((uint64_t)budget_all * last_weight / weight_all));
     // the pass number of a workgroup (>= 1 workgroup per tile, 256 pairs per pass), and 32 bits for a row's byte offset
     const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)1 << 31) / std::max(M.n_scan, 1),
                                                                                       (((int64_t)1 << 32) - 1) / M.row),
-                                                                    (int64_t)255 * iss::MAIN_PAIRS * wg_per_tile));
+                                                                    max_passes * iss::MAIN_PAIRS * min_tile_wg));
     if (ctx->d_pmut) {  // rows of THIS call only
         ctx->d_pmut_count = reinterpret_cast<uint32_t *>(ctx->fix_count) + 60;  // +240 B of the scratch block
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_pmut, 0xff, (size_t)ctx->pmut_cap * sizeof(iss::MutRecord), ctx->stream));
@@ -1414,8 +1430,21 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         {
             const uint64_t passes = ((uint64_t)n + iss::MAIN_PAIRS - 1) / iss::MAIN_PAIRS;  // a workgroup pass = 256 pairs
             // persistent grid (8 waves / SIMD when two workgroups share a CU), split evenly over the position tiles
-            const unsigned per_tile = (unsigned)std::min<uint64_t>(wg_per_tile, passes);
-            const dim3 grid(per_tile * (unsigned)M.n_tiles), block(iss::MAIN_THREADS);
+            // ... in proportion to the tiles' work per pass -- a fixed part (descriptor, addresses) + one part per iteration
+            // of 4 superitems, whether or not all four lanes of a pair have one (the last tile may be short) -- at most one
+            // workgroup per pass of a tile
+            const unsigned budget = std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid);
+            unsigned total = 0, weight_sum = 0;
+            for (int t = 0; t < M.n_tiles; ++t) weight_sum += 1u + (unsigned)(std::min(M.TS, M.S - t * M.TS) + 3) / 4u;
+            for (int t = 0; t < M.n_tiles; ++t) {
+                const unsigned weight = 1u + (unsigned)(std::min(M.TS, M.S - t * M.TS) + 3) / 4u;
+                unsigned w = std::max(1u, (unsigned)((uint64_t)budget * weight / weight_sum));
+                w = (unsigned)std::min<uint64_t>(std::min<uint64_t>(w, wg_per_tile_cap), passes);
+                A.tile_wg0[t] = (uint16_t)total;
+                total += w;
+            }
+            A.tile_wg0[M.n_tiles] = (uint16_t)total;
+            const dim3 grid(total), block(iss::MAIN_THREADS);
             const bool plain = !any_exceptions && !ctx->has_frag;
 #define ISS_LAUNCH_MAIN(MUT, PLAIN) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN>), grid, block, lds_bytes, s_main, M, dg, A, desc)
             if (A.mut) { if (plain) ISS_LAUNCH_MAIN(true, true); else ISS_LAUNCH_MAIN(true, false); }
