@@ -154,6 +154,30 @@ int iss_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, doub
 
 int iss_synchronize(iss_ctx *ctx);
 
+/*
+ * The inner plugin surface: the per-read methods of the reference's ErrorModel duck type, batched (n reads per call, read i
+ * drawing at Philox ordinal first_ordinal + i of the worker stream `seed`, attempt 0; same address map as iss_generate, so a
+ * read generated by iss_generate at that ordinal saw exactly these draws).  Host arrays in and out, rows of read_length bytes.
+ *   iss_gen_phred_scores   KDErrorModel.gen_phred_scores(cdfs, orientation)      iss/error_models/kde.py:52-86
+ *                          (through ErrorModel.introduce_error_scores, iss/error_models/__init__.py:52-67)
+ *   iss_mut_sequence       ErrorModel.mut_sequence(record, orientation)           iss/error_models/__init__.py:69-112
+ *                          seq in place (ASCII), quality = its phred scores; status[i] = 2: a letter the substitution table
+ *                          does not hold (the reference's KeyError)
+ *   iss_random_insert_size KDErrorModel.random_insert_size()                      iss/error_models/kde.py:88-98
+ *   iss_introduce_indels   ErrorModel.introduce_indels(record, orientation, full_seq, bounds) incl. adjust_seq_length
+ *                          iss/error_models/__init__.py:158-228, 114-156.  seq: n rows of read_length bytes holding seq_len[i]
+ *                          letters in read direction; bounds: n x (read_start, read_end) in full_seq; status[i]: 0, 2 KeyError,
+ *                          3 IndexError
+ * orientation: 0 "forward", 1 "reverse".  Kept out of the hot path: one lane per read, exact 53-bit comparisons.
+ */
+int iss_gen_phred_scores(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t first_ordinal, uint64_t seed, uint8_t *quality);
+int iss_mut_sequence(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t first_ordinal, uint64_t seed, uint8_t *seq,
+                     const uint8_t *quality, int32_t *status);
+int iss_random_insert_size(iss_ctx *ctx, int64_t n, uint64_t first_ordinal, uint64_t seed, int64_t *insert_size);
+int iss_introduce_indels(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t first_ordinal, uint64_t seed, const uint8_t *seq,
+                         const int32_t *seq_len, const uint8_t *full_seq, int64_t full_len, const int64_t *bounds, uint8_t *out,
+                         int32_t *status);
+
 /* --store_mutations: one VCF row of the reference (iss/error_models/__init__.py:98-108, 197-221, written by
  * write_mutations, iss/generator.py:598-620). */
 typedef struct {

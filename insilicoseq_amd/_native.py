@@ -21,7 +21,8 @@ EXPORTS = (
     "iss_mt_seed", "iss_generate_mt", "iss_mt_peek", "iss_mt_mutations_reserve", "iss_mt_mutations_download",
     "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
     "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush", "iss_fastq_compress", "iss_deflate_code_build",
-    "iss_generate_batch", "iss_fastq_emit_batch",
+    "iss_generate_batch", "iss_fastq_emit_batch", "iss_gen_phred_scores", "iss_mut_sequence", "iss_random_insert_size",
+    "iss_introduce_indels",
 )
 
 
@@ -101,6 +102,10 @@ def lib():
     L.iss_generate_batch.argtypes = [vp, i32, vp, vp, C.c_uint64, C.c_uint64, i32, i32, i64]
     L.iss_fastq_compress.argtypes = [vp, i32]
     L.iss_deflate_code_build.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
+    L.iss_gen_phred_scores.argtypes = [vp, i32, i64, u64, u64, vp]
+    L.iss_mut_sequence.argtypes = [vp, i32, i64, u64, u64, vp, vp, vp]
+    L.iss_random_insert_size.argtypes = [vp, i64, u64, u64, vp]
+    L.iss_introduce_indels.argtypes = [vp, i32, i64, u64, u64, vp, vp, vp, i64, vp, vp, vp]
     L.iss_fastq_write.argtypes = [C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i32, i32, vp, vp, vp, vp, i32]
     for name in EXPORTS:
         if name not in ("iss_ctx_destroy", "iss_last_error"):

@@ -27,6 +27,7 @@
 #include "iss_fastq.hip.h"
 #include "iss_deflate.hip.h"
 #include "iss_mt_compat.hip.h"
+#include "iss_units.hip.h"
 
 namespace {
 
@@ -1692,6 +1693,110 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
     ctx->last_first.assign(first.begin(), first.end());
     ctx->last_off.resize((size_t)n_items);
     for (int32_t k = 0; k < n_items; ++k) ctx->last_off[(size_t)k] = call_items[(size_t)k].off;
+    return 0;
+}
+
+// ---- the inner plugin surface (ErrorModel methods), batched: see iss_units.hip.h and include/iss_mi355x.h
+namespace {
+struct DevBuf {  // a device allocation freed at scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+int unit_prologue(iss_ctx *ctx, int32_t orientation, int64_t n, const char *what) {
+    if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, std::string(what) + ": upload a model first");
+    if (ctx->M.quality_mode != 0) return fail(ctx, ISS_E_INVALID, std::string(what) + ": KDErrorModel tables only");
+    if ((orientation != 0 && orientation != 1) || n < 0 || n > (int64_t)0x7fffffff) return fail(ctx, ISS_E_INVALID, std::string(what) + ": bad argument");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, ISS_E_HIP, hipGetErrorString(e));
+    return 0;
+}
+}  // namespace
+
+int iss_gen_phred_scores(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t first_ordinal, uint64_t seed, uint8_t *quality) {
+    if (int rc = unit_prologue(ctx, orientation, n, "iss_gen_phred_scores")) return rc;
+    if (!n) return 0;
+    if (!quality) return fail(ctx, ISS_E_INVALID, "iss_gen_phred_scores: NULL output");
+    const size_t bytes = (size_t)n * ctx->M.RL;
+    DevBuf d;
+    HIP_TRY(ctx, hipMalloc(&d.p, bytes));
+    const iss::UnitArgs U{seed, first_ordinal, orientation, (int32_t)n};
+    hipLaunchKernelGGL(iss::k_unit_phred, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->M, U, static_cast<uint8_t *>(d.p));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(quality, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int iss_mut_sequence(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t first_ordinal, uint64_t seed, uint8_t *seq,
+                     const uint8_t *quality, int32_t *status) {
+    if (int rc = unit_prologue(ctx, orientation, n, "iss_mut_sequence")) return rc;
+    if (!n) return 0;
+    if (!seq || !quality || !status) return fail(ctx, ISS_E_INVALID, "iss_mut_sequence: NULL argument");
+    const size_t bytes = (size_t)n * ctx->M.RL;
+    for (size_t k = 0; k < bytes; ++k)
+        if (quality[k] > (uint8_t)ctx->M.n_q) return fail(ctx, ISS_E_INVALID, "iss_mut_sequence: phred score outside the model's table");
+    DevBuf ds, dq, dst;
+    HIP_TRY(ctx, hipMalloc(&ds.p, bytes));
+    HIP_TRY(ctx, hipMalloc(&dq.p, bytes));
+    HIP_TRY(ctx, hipMalloc(&dst.p, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemcpyAsync(ds.p, seq, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dq.p, quality, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const iss::UnitArgs U{seed, first_ordinal, orientation, (int32_t)n};
+    hipLaunchKernelGGL(iss::k_unit_mut, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->M, U, static_cast<uint8_t *>(ds.p),
+                       static_cast<const uint8_t *>(dq.p), static_cast<int32_t *>(dst.p));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(seq, ds.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(status, dst.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int iss_random_insert_size(iss_ctx *ctx, int64_t n, uint64_t first_ordinal, uint64_t seed, int64_t *insert_size) {
+    if (int rc = unit_prologue(ctx, 0, n, "iss_random_insert_size")) return rc;
+    if (!n) return 0;
+    if (!insert_size) return fail(ctx, ISS_E_INVALID, "iss_random_insert_size: NULL output");
+    DevBuf d;
+    HIP_TRY(ctx, hipMalloc(&d.p, (size_t)n * sizeof(int64_t)));
+    const iss::UnitArgs U{seed, first_ordinal, 0, (int32_t)n};
+    hipLaunchKernelGGL(iss::k_unit_isize, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->M, U, static_cast<int64_t *>(d.p));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(insert_size, d.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int iss_introduce_indels(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t first_ordinal, uint64_t seed, const uint8_t *seq,
+                         const int32_t *seq_len, const uint8_t *full_seq, int64_t full_len, const int64_t *bounds, uint8_t *out,
+                         int32_t *status) {
+    if (int rc = unit_prologue(ctx, orientation, n, "iss_introduce_indels")) return rc;
+    if (!n) return 0;
+    if (!seq || !seq_len || !full_seq || !bounds || !out || !status || full_len < 1)
+        return fail(ctx, ISS_E_INVALID, "iss_introduce_indels: NULL argument");
+    const int RL = ctx->M.RL;
+    for (int64_t i = 0; i < n; ++i)
+        if (seq_len[i] < 0 || seq_len[i] > RL) return fail(ctx, ISS_E_INVALID, "iss_introduce_indels: a read longer than read_length");
+    const int32_t cap = 5 * RL + 8;
+    const size_t bytes = (size_t)n * RL;
+    DevBuf ds, dl, dg, db, dw, dout, dst;
+    HIP_TRY(ctx, hipMalloc(&ds.p, bytes));
+    HIP_TRY(ctx, hipMalloc(&dl.p, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(&dg.p, (size_t)full_len));
+    HIP_TRY(ctx, hipMalloc(&db.p, (size_t)n * 2 * sizeof(int64_t)));
+    HIP_TRY(ctx, hipMalloc(&dw.p, (size_t)n * cap));
+    HIP_TRY(ctx, hipMalloc(&dout.p, bytes));
+    HIP_TRY(ctx, hipMalloc(&dst.p, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemcpyAsync(ds.p, seq, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dl.p, seq_len, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dg.p, full_seq, (size_t)full_len, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(db.p, bounds, (size_t)n * 2 * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    const iss::UnitArgs U{seed, first_ordinal, orientation, (int32_t)n};
+    hipLaunchKernelGGL(iss::k_unit_indels, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->M, U, static_cast<const uint8_t *>(ds.p),
+                       static_cast<const int32_t *>(dl.p), static_cast<const uint8_t *>(dg.p), full_len, static_cast<const int64_t *>(db.p),
+                       static_cast<uint8_t *>(dw.p), cap, static_cast<uint8_t *>(dout.p), static_cast<int32_t *>(dst.p));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(status, dst.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

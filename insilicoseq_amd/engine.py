@@ -148,6 +148,49 @@ class ReadEngine(object):
                                                  int(first_ordinal) & (2**64 - 1), int(seed) & (2**64 - 1),
                                                  SEQ_TYPES[sequence_type], int(bool(gc_bias)), int(out_first_pair)))
 
+    # ------------------------------------------------------------------ the ErrorModel methods, batched (inner plugin surface)
+    def gen_phred_scores(self, orientation, n, first_ordinal=0, seed=0):
+        """KDErrorModel.gen_phred_scores for n reads (iss/error_models/kde.py:52-86): uint8 [n, read_length]; read i draws
+        at ordinal first_ordinal + i of the worker stream `seed` -- the phreds iss_generate gives that pair's mate."""
+        out = np.empty((int(n), self.read_length), dtype=np.uint8)
+        self._check(self._lib.iss_gen_phred_scores(self._ctx, int(orientation), int(n), int(first_ordinal) & (2**64 - 1),
+                                                   int(seed) & (2**64 - 1), out.ctypes.data))
+        return out
+
+    def mut_sequence(self, orientation, seqs, quals, first_ordinal=0, seed=0):
+        """ErrorModel.mut_sequence (iss/error_models/__init__.py:69-112) for uint8 [n, read_length] letters and phreds:
+        (mutated letters, status per read -- 2: the reference's KeyError)."""
+        s = np.array(seqs, dtype=np.uint8, order="C", copy=True).reshape(-1, self.read_length)
+        q = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1, self.read_length)
+        assert s.shape == q.shape
+        st = np.zeros(s.shape[0], dtype=np.int32)
+        self._check(self._lib.iss_mut_sequence(self._ctx, int(orientation), s.shape[0], int(first_ordinal) & (2**64 - 1),
+                                               int(seed) & (2**64 - 1), s.ctypes.data, q.ctypes.data, st.ctypes.data))
+        return s, st
+
+    def random_insert_size(self, n, first_ordinal=0, seed=0):
+        """KDErrorModel.random_insert_size (iss/error_models/kde.py:88-98) for n pairs: int64 [n]."""
+        out = np.empty(int(n), dtype=np.int64)
+        self._check(self._lib.iss_random_insert_size(self._ctx, int(n), int(first_ordinal) & (2**64 - 1), int(seed) & (2**64 - 1),
+                                                     out.ctypes.data))
+        return out
+
+    def introduce_indels(self, orientation, seqs, lengths, full_seq, bounds, first_ordinal=0, seed=0):
+        """ErrorModel.introduce_indels incl. adjust_seq_length (iss/error_models/__init__.py:158-228, 114-156): seqs uint8
+        [n, read_length] holding lengths[i] letters each (read direction), bounds int64 [n, 2] = (read_start, read_end) in
+        full_seq.  Returns (uint8 [n, read_length], status per read: 0, 2 KeyError, 3 IndexError)."""
+        s = np.ascontiguousarray(seqs, dtype=np.uint8).reshape(-1, self.read_length)
+        ln = np.ascontiguousarray(lengths, dtype=np.int32)
+        b = np.ascontiguousarray(bounds, dtype=np.int64).reshape(-1, 2)
+        g = np.frombuffer(full_seq.encode("ascii") if isinstance(full_seq, str) else bytes(full_seq), dtype=np.uint8)
+        assert s.shape[0] == ln.size == b.shape[0]
+        out = np.zeros_like(s)
+        st = np.zeros(s.shape[0], dtype=np.int32)
+        self._check(self._lib.iss_introduce_indels(self._ctx, int(orientation), s.shape[0], int(first_ordinal) & (2**64 - 1),
+                                                   int(seed) & (2**64 - 1), s.ctypes.data, ln.ctypes.data, g.ctypes.data, g.size,
+                                                   b.ctypes.data, out.ctypes.data, st.ctypes.data))
+        return out, st
+
     def set_fragment(self, fragment_length=None, fragment_sd=None):
         """Custom fragment length for generate() (None, None: the model's insert sizes)."""
         on = fragment_length is not None and fragment_sd is not None

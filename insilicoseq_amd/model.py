@@ -391,6 +391,70 @@ class KDErrorModel(object):
         )
 
 
+    # ---- the reference's per-read methods, on the GPU (inner plugin surface) -----------------------
+    # ``bind(engine, seed)`` attaches an engine holding this model's tables; every method then makes one (batch of 1) call
+    # of the batched C-ABI entry of the same name.  ``self.ordinal`` is the Philox address of the read being built -- the
+    # methods of one read share it (as they share the reference's stream position), ``next_read()`` advances it.
+    _ORIENT = {"forward": 0, "reverse": 1}
+
+    def bind(self, engine, seed=0, ordinal=0):
+        engine.load_model(self.dense())
+        self._engine, self._seed, self.ordinal = engine, int(seed), int(ordinal)
+        return self
+
+    def next_read(self):
+        self.ordinal += 1
+
+    def _orientation(self, orientation):
+        if orientation not in self._ORIENT:
+            raise ValueError("orientation must be 'forward' or 'reverse'")
+        return self._ORIENT[orientation]
+
+    def gen_phred_scores(self, cdfs, orientation):
+        """kde.py:52-86.  ``cdfs`` is accepted for signature parity: the engine reads the uploaded tables."""
+        return [int(q) for q in self._engine.gen_phred_scores(self._orientation(orientation), 1, self.ordinal, self._seed)[0]]
+
+    def introduce_error_scores(self, record, orientation):
+        """__init__.py:52-67: phred scores into record.letter_annotations["phred_quality"]."""
+        cdfs = self.quality_forward if orientation == "forward" else self.quality_reverse
+        record.letter_annotations = dict(getattr(record, "letter_annotations", None) or {})
+        record.letter_annotations["phred_quality"] = self.gen_phred_scores(cdfs, orientation)
+        return record
+
+    def mut_sequence(self, record, orientation):
+        """__init__.py:69-112: substitutions according to record.letter_annotations["phred_quality"]; returns the sequence."""
+        RL = int(self.read_length)
+        seq = np.frombuffer(str(record.seq).encode("ascii"), dtype=np.uint8)
+        qual = np.asarray(record.letter_annotations["phred_quality"], dtype=np.uint8)
+        if seq.size != RL or qual.size != RL:
+            raise ValueError("mut_sequence needs a read of read_length letters and phreds")
+        out, st = self._engine.mut_sequence(self._orientation(orientation), seq[None, :], qual[None, :], self.ordinal, self._seed)
+        if st[0] == 2:
+            raise KeyError("letter outside the substitution table")
+        return out[0].tobytes().decode("ascii")
+
+    def introduce_indels(self, record, orientation, full_seq, bounds):
+        """__init__.py:158-228 (+ adjust_seq_length :114-156): record.seq replaced by the read with indels."""
+        RL = int(self.read_length)
+        seq = np.frombuffer(str(record.seq).encode("ascii"), dtype=np.uint8)
+        if seq.size > RL:
+            raise ValueError("a read longer than read_length")
+        row = np.zeros((1, RL), dtype=np.uint8)
+        row[0, :seq.size] = seq
+        out, st = self._engine.introduce_indels(self._orientation(orientation), row, [seq.size], str(full_seq), [list(bounds)],
+                                                self.ordinal, self._seed)
+        if st[0] == 2:
+            raise KeyError("letter outside the deletion table")
+        if st[0] == 3:
+            raise IndexError("padding index outside the reference sequence")
+        record.seq = out[0].tobytes().decode("ascii")
+        return record
+
+    def random_insert_size(self):
+        """kde.py:88-98."""
+        return int(self._engine.random_insert_size(1, self.ordinal, self._seed)[0])
+
+
 class BasicErrorModel(object):
     """Host-side mirror of ``iss.error_models.basic.BasicErrorModel`` (basic.py:10-63): same constructor and
     attributes; ``dense()`` gives the tables the engine uploads.  On the device it runs in the
