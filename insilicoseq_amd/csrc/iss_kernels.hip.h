@@ -723,8 +723,11 @@ __device__ __forceinline__ uint32_t shift_in(uint32_t r, unsigned long long flag
 // four 8-byte stores -- the four lanes of a pair write 32 contiguous bytes of each output row).  Everything that
 // belongs to the pair (descriptor, Philox address, row offsets of its bin slots) is loaded once and stays in registers
 // for the pair's iterations.
+#ifndef ISS_MAIN_OCC
+#define ISS_MAIN_OCC 4   // wavefronts per SIMD the register budget is cut for: one 1024-lane workgroup per CU, 128 VGPRs (measured against 8 / 64: -12 % time)
+#endif
 template <bool STORE_MUT, bool PLAIN>
-__global__ __launch_bounds__(MAIN_THREADS, 8) void k_main(DevModel M, DevGenome g, RunArgs A,
+__global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // workgroups are dealt to the position tiles in proportion to the tiles' sizes (the last tile may be short)

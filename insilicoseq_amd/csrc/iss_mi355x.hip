@@ -1281,7 +1281,8 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
     const iss::DevModel &M = ctx->M;
     // k_indel_scan counts lane-items in 32 bits (keep them below 2^31)
     const size_t lds_bytes = main_lds_bytes(M);
-    unsigned per_cu = lds_bytes <= 80 * 1024 ? 2u : 1u;  // 1024-lane workgroups, two per CU when the LDS tables allow it
+    (void)lds_bytes;
+    unsigned per_cu = 1u;  // ONE 1024-lane workgroup per CU: k_main is compiled for 128 VGPRs (4 wavefronts / SIMD)
     if (const char *e = getenv("ISS_MAIN_PER_CU")) per_cu = std::min(per_cu, (unsigned)std::max(1, atoi(e)));  // tuning aid
     const unsigned wg_per_tile = std::max(1u, std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid) / (unsigned)M.n_tiles);
     const unsigned wg_per_tile_cap = 8192;  // (tile_wg0 is 16 bits wide)
