@@ -812,11 +812,20 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         }
     };
     const uint32_t j4 = lane & 3u;
+    // (the descriptor of the NEXT pass is requested at the start of a pass: its latency hides behind the pass)
+    PairDesc d_next = {0, 0, 0u, 0};
+    {
+        const uint32_t pair0 = wg * MAIN_PAIRS + wave_pair0 + (lane >> 2);
+        if (wg < n_pass && pair0 < (uint32_t)A.n_pairs) d_next = desc[pair0];
+    }
     for (uint32_t pass = 0, blk = wg; blk < n_pass; ++pass, blk += n_wg) {
         const uint32_t pair = blk * MAIN_PAIRS + wave_pair0 + (lane >> 2);
         const bool valid = pair < (uint32_t)A.n_pairs;
-        PairDesc d = {0, 0, 0u, 0};
-        if (valid) d = desc[pair];
+        const PairDesc d = d_next;
+        {
+            const uint32_t pair_n = pair + n_wg * MAIN_PAIRS;
+            if (blk + n_wg < n_pass && pair_n < (uint32_t)A.n_pairs) d_next = desc[pair_n];
+        }
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
         // LDS byte offsets of the pair's rows (its bin slots) at this lane's first superitem; one iteration = 8 groups on
         const uint32_t lane_row = j4 * 2u * gs_b;
