@@ -693,14 +693,9 @@ __device__ __forceinline__ uint32_t hot_lookup(const uint8_t *ldsb, uint32_t row
                                                uint32_t we, uint32_t gsh, uint32_t gb, unsigned long long &flag) {
     const uint32_t h = HI ? (wq >> 16) : (wq & 0xffffu);
     const uint32_t gi = HI ? (wq >> (gsh + 16u)) : __builtin_amdgcn_ubfe(wq, gsh, gb);
-#ifdef ISS_EXP_NOLDS
-    const uint32_t j = row_g + off + gi;
-    const uint32_t e0 = row_e + off + j, e1 = e0 * 3u;
-#else
     const uint32_t j = ldsb[row_g + off + gi];
     const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + row_e + off + j);  // guide bytes hold 4 * index
     const uint32_t e0 = ent[0], e1 = ent[1];
-#endif
     const uint32_t sel = (e0 >> 16) < h ? e1 : e0;   // first entry with t16 >= h (if among the two)
     const uint32_t e8 = (we >> (8 * BYTE)) & 0xffu;
     // (one ballot per compare: each folds into its v_cmp, the masks are combined by the scalar unit)
@@ -844,11 +839,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 // ---- the two 8-base windows of the 2-bit genome: forward g[pf .. pf+7]; reverse comp(g[pr+7 .. pr]); loaded
                 //      first, used last (the wait for them would otherwise also be a wait for the previous stores)
                 uint2 gf = {0u, 0u}, gr = {0u, 0u};
-#ifdef ISS_EXP_NOGENOME
-                if (false) {
-#else
                 if (regular) {
-#endif
                     gf = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pf >> 4) + 1) << 2));
                     gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pr >> 4) + 1) << 2));
                 }
@@ -918,22 +909,12 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 }
                 // (the padding bytes of the last superitem hold the clamped last row's values; nothing reads them)
                 uint4 *dst = reinterpret_cast<uint4 *>(A.out[0] + (size_t)out_b);  // two 16-byte pieces of the pair's 128-byte line
-#ifdef ISS_EXP_NOSTORE
-                if ((base_f.x ^ base_f.y ^ qual_f.x ^ qual_f.y ^ base_r.x ^ base_r.y ^ qual_r.x ^ qual_r.y) == 0x12345u)
-#endif
-                {
                 dst[0] = make_uint4(base_f.x, base_f.y, qual_f.x, qual_f.y);
                 dst[4] = make_uint4(base_r.x, base_r.y, qual_r.x, qual_r.y);
-                }
             }
             // bit (7 - s) <=> base s of the half needs the exact path (~1.7 % of bases: mostly substitution events)
-#ifdef ISS_EXP_NODRAIN
-            if (rare0 == 0x12345u && rare1 == 0x54321u)
-#endif
-            {
             push(rare0, tag0 | (it << 19), windows);
             push(rare1, tag0 | (it << 19) | 4096u, windows);
-            }
             rowf += 8u * gs_b; rowf_e += 8u * gs_b;
             rowr += 8u * gs_b; rowr_e += 8u * gs_b;
             pf += 32;
@@ -1251,11 +1232,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         MutRecord row;  // --store_mutations row being built
         row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
         int sp = 0, k = 0, last = -1, cur_shift = 0;  // `last`: last step whose map entry / run is settled
-#ifdef ISS_EXP_NOWALK
-        for (uint32_t ei = 0; ei < 0u; ++ei) {
-#else
         for (uint32_t ei = 0; ei < (uint32_t)EV_K; ++ei) {
-#endif
             if (ei >= n_act) break;
             const uint32_t evs = ev_srt[ei];
             const int n = (int)(evs >> 8);
@@ -1307,11 +1284,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- 4. the read: 8 positions per lane
-#ifdef ISS_EXP_NOGATHER
-        if (n_act > 100) {
-#else
         if (n_act) {
-#endif
             if (hl == 0) { ++n_reads; atomicOr(&A.flags[pair], 4u << o); }  // (bits 2-3: this kernel rebuilt the mate)
             int carry = 0;  // (token - step) at the end of the previous pass (read_length > 256)
             for (int b = hl; (b - hl) * 8 < pitch; b += 32) {  // (every lane of the half takes part in the prefix sums)

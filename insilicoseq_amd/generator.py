@@ -195,6 +195,8 @@ class Worker(object):
         else:
             self.engine.set_fragment(getattr(error_model, "fragment_length", None),
                                      getattr(error_model, "fragment_sd", None))
+        self.has_fragment = (getattr(error_model, "fragment_length", None) is not None and
+                             getattr(error_model, "fragment_sd", None) is not None)
         self.ordinal = 0
         self._gids = {}  # id(record) -> (record, genome id on the device)
         self._resident = 0
@@ -239,7 +241,13 @@ class Worker(object):
                 try:
                     eng.generate_mt(self.genome_id(record), 1)
                 except _native.EngineError as e:
-                    if e.code != _native.E_SHORT_RECORD:
+                    if e.code == _native.E_INVALID and getattr(self, "has_fragment", False):
+                        # --fragment-length: the reference would consume one legacy-gauss draw (and cache the second) here;
+                        # the device cannot replay that for a record it refuses, so the streams are no longer the
+                        # reference's from this point on (documented in INTEGRATION.md)
+                        logger.warning("%s: skipped; with --fragment-length the MT streams are no longer aligned with the "
+                                       "reference's after a record shorter than the read length" % record.id)
+                    elif e.code != _native.E_SHORT_RECORD:
                         raise
             return 0
         gid = self.genome_id(record)
@@ -398,10 +406,13 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
     w = Worker(error_model, cpu_number, seed, device=device, rng=rng, compress=compress)
     if store_mutations:
         w.store_mutations = True
+        # row buffers of a batch, from the model's own error rates (twice the expectation + slack; the Philox kernels
+        # reserve 256-row chunks per wavefront on top)
+        per_pair = 2.0 * _dense_of(error_model).expected_mutation_rows_per_pair() + 4.0
         if rng == "mt":
-            w.engine.mt_mutations_reserve(Worker.BATCH_PAIRS * 8)
+            w.engine.mt_mutations_reserve(int(Worker.BATCH_PAIRS * per_pair))
         else:
-            w.engine.mutations_reserve(Worker.BATCH_PAIRS * 16)
+            w.engine.mutations_reserve(int(Worker.BATCH_PAIRS * per_pair) + (1 << 21))
     try:
         with forward_handle, reverse_handle, mutation_handle:
             fragment = getattr(error_model, "fragment_length", None) is not None and getattr(error_model, "fragment_sd", None) is not None

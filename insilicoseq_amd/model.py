@@ -251,6 +251,31 @@ class DenseModel(object):
         return cls.from_reference_npz(path)
 
     # -------------------------------------------------------- integer thresholds
+    def expected_mutation_rows_per_pair(self):
+        """Expected --store_mutations rows of one read pair: substitutions (sum over positions of
+        P(phred) * 10**(-phred/10), bins weighted by their probability) + insertions + deletions (an upper estimate: the
+        largest deletion probability of a position).  Sizes the device's row buffers (generator.py:worker_iterator)."""
+        total = 0.0
+        if int(getattr(self, "quality_mode", 0)) == 1:  # BasicErrorModel: phreds around basic_mean_quality, floor 20 (basic.py:52)
+            total = 2.0 * self.read_length * 10.0 ** (-(int(getattr(self, "basic_mean_quality", 30)) - 10) / 10.0)
+        for o in range(2):
+            if int(getattr(self, "quality_mode", 0)) == 1:
+                ins = np.nan_to_num(np.clip(self.ins[o], 0.0, 1.0))
+                dele = np.nan_to_num(np.clip(self.dele[o], 0.0, 1.0))
+                total += float(ins.sum() + dele.max(axis=1).sum())
+                continue
+            w = np.diff(np.concatenate(([0.0], self.bin_cdf[o])))
+            for b in range(4):
+                if not self.bin_nonempty[o][b] or w[b] <= 0:
+                    continue
+                pm = np.diff(np.concatenate((np.zeros((self.read_length, 1)), self.qcdf[o, b]), axis=1), axis=1)
+                rest = 1.0 - self.qcdf[o, b][:, -1]  # phred n_q
+                total += w[b] * float((pm * (1.0 - self.phred_thr[:self.n_q])[None, :]).sum() + (rest * (1.0 - self.phred_thr[self.n_q])).sum())
+            ins = np.nan_to_num(np.clip(self.ins[o], 0.0, 1.0))
+            dele = np.nan_to_num(np.clip(self.dele[o], 0.0, 1.0))
+            total += float(ins.sum() + dele.max(axis=1).sum())
+        return total
+
     def device_tables(self):
         """Integer restatement of every f64 comparison on the path ("integer thresholds").
 
@@ -372,10 +397,29 @@ class KDErrorModel(object):
         self.ins_rev = [{chr(d.ins_letter[1, p, x]): d.ins[1, p, x] for x in range(4)} for p in range(RL)]
         self.del_for = [{b: d.dele[0, p, i] for i, b in enumerate(BASES)} for p in range(RL)]
         self.del_rev = [{b: d.dele[1, p, i] for i, b in enumerate(BASES)} for p in range(RL)]
+        self._pristine = self._fingerprint()
+
+    def _fingerprint(self):
+        """What dense() may hand back from the stored dense file as long as nobody edited it: the attributes rebuilt from
+        the file (substitution choices, bin means, identity of the insert-size / histogram arrays) + the stored tables."""
+        import hashlib
+
+        h = hashlib.sha1()
+        d = self._dense_file
+        for a in (self.mean_forward, self.mean_reverse, self.i_size_cdf, d.qcdf, d.bin_cdf, d.subst_cdf, d.subst_alt, d.isize_cdf):
+            h.update(np.ascontiguousarray(a).tobytes())
+        for t in (self.subst_choices_for, self.subst_choices_rev):
+            h.update(repr(t).encode())
+        for t in (self.quality_forward, self.quality_reverse):
+            h.update(repr([[id(x) for x in b] for b in t]).encode())
+        return h.hexdigest()
 
     def dense(self):
-        """Flatten the CURRENT attribute values (so in-place edits are honoured)."""
-        if self._dense_file is not None and not getattr(self, "_edited", False):
+        """Flatten the CURRENT attribute values (so in-place edits are honoured: a model loaded from a dense file hands its
+        stored tables back only while every attribute still is what the file gave -- histogram rows are views on the
+        stored arrays, indel tables are re-read below, anything else that changed sends the model through
+        from_attributes)."""
+        if self._dense_file is not None and not getattr(self, "_edited", False) and self._fingerprint() == self._pristine:
             # a dense file stores post-normalisation CDFs; re-deriving them from differences
             # would not be bit-exact, so hand the stored tables back unless the caller edited
             d = self._dense_file

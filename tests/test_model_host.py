@@ -84,3 +84,26 @@ def test_model_validation_rejects_what_the_engine_cannot_reproduce():
     with pytest.raises(ModelError):
         DenseModel(d.read_length, d.isize_cdf, d.bin_cdf, d.bin_nonempty, bad, d.subst_cdf, d.subst_alt, d.ins,
                    d.ins_letter, d.dele, d.phred_thr)
+
+
+def test_dense_loaded_model_honours_in_place_edits():
+    """A KDErrorModel loaded from a dense profile (every bundled --model name) must not hand back stale tables after its
+    reference-shaped attributes were edited in place (the reference's tests edit models this way)."""
+    import os
+
+    from insilicoseq_amd.model import KDErrorModel
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    em = KDErrorModel(os.path.join(root, "insilicoseq_amd", "profiles", "ecoli.dense.npz"))
+    base = em.dense()
+    assert np.array_equal(em.dense().subst_cdf, base.subst_cdf)
+    em.subst_choices_for[3]["A"] = (["T", "C", "G"], [1.0, 0.0, 0.0])
+    edited = em.dense()
+    assert np.allclose(edited.subst_cdf[0, 3, 0], [1.0, 1.0, 1.0])
+    assert not np.array_equal(edited.subst_cdf, base.subst_cdf)
+    em2 = KDErrorModel(os.path.join(root, "insilicoseq_amd", "profiles", "ecoli.dense.npz"))
+    em2.quality_forward[3][2][:] = 1.0  # histogram rows are views on the stored tables
+    assert np.all(em2.dense().qcdf[0, 3, 2] == 1.0)
+    em3 = KDErrorModel(os.path.join(root, "insilicoseq_amd", "profiles", "ecoli.dense.npz"))
+    em3.del_for[0]["A"] = 1.0
+    assert em3.dense().dele[0, 0, 0] == 1.0
