@@ -584,11 +584,16 @@ __device__ __forceinline__ uint32_t codes_to_ascii4(uint32_t b) {
 //   sub 1    : error-test digits (8 bits): word half * 2 + mate, byte cc            (c = p & 7, half = c >> 2, cc = c & 3)
 // The quality draw is m = h16 << 37 | l37 (l37 from K_QM_LO), the error-test draw m = e8 << 45 | l45 (l45 from the
 // K_SUB block of the base, which also holds its substitution choice): trailing bits are drawn on a tie only.
+// word i of a block, i a per-lane value: two levels of selects (no branches around the block's last round)
+__device__ __forceinline__ uint32_t word_sel(const u32x4 &v, int i) {
+    const uint32_t lo = (i & 1) ? v.y : v.x, hi = (i & 1) ? v.w : v.z;
+    return (i & 2) ? hi : lo;
+}
 __device__ __forceinline__ uint32_t hot_h16(const u32x4 &blk, int o, int cc) {
-    return (word_of(blk, o * 2 + (cc >> 1)) >> (16 * (cc & 1))) & 0xffffu;
+    return (word_sel(blk, o * 2 + (cc >> 1)) >> (16 * (cc & 1))) & 0xffffu;
 }
 __device__ __forceinline__ uint32_t hot_e8(const u32x4 &blk1, int half, int o, int cc) {
-    return (word_of(blk1, half * 2 + o) >> (8 * cc)) & 0xffu;
+    return (word_sel(blk1, half * 2 + o) >> (8 * cc)) & 0xffu;
 }
 __device__ __forceinline__ uint64_t error_test_draw(uint32_t e8, const u32x4 &sub_blk) {
     return ((uint64_t)e8 << 45) | ((uint64_t)(sub_blk.z & 0x1fffu) << 32) | sub_blk.w;
@@ -637,12 +642,12 @@ __device__ __forceinline__ bool main_slow_base(const DevModel &M, const DevGenom
     const Addr a = make_addr(A.seed, A.first_ordinal + pair, attempt);
     const uint32_t h = hot_h16(draw_block(a, K_QM, s_abs, half ? 2u : 0u), o, cc);
     const uint32_t e8 = hot_e8(draw_block(a, K_QM, s_abs, 1u), half, o, cc);
-    const size_t byte_off = (size_t)pair * M.row + (size_t)xp(p);
+    const uint32_t byte_off = pair * (uint32_t)M.row + (uint32_t)xp(p);  // (a launch's rows span < 2^32 bytes)
     const uint32_t slot = (slots >> (2 * o)) & 3u;
     // quality: full search of the LDS row, exact thresholds on a tie
     const uint32_t gwords = (1u << M.GB) / 4;
-    const uint32_t row = (((uint32_t)(o * M.NB) + slot) * (uint32_t)M.TG + 2u * sl + (uint32_t)half) * (uint32_t)M.GS +
-                         (uint32_t)cc * (uint32_t)M.stride_w;
+    const uint32_t row = __umul24(__umul24((uint32_t)(o * M.NB) + slot, (uint32_t)M.TG) + 2u * sl + (uint32_t)half, (uint32_t)M.GS) +
+                         __umul24((uint32_t)cc, (uint32_t)M.stride_w);
     uint32_t j = reinterpret_cast<const uint8_t *>(lds)[row * 4 + (h >> (16 - M.GB))] >> 2;  // guide bytes hold 4 * index
     uint32_t e = lds[row + gwords + j];
     while ((e >> 16) < h) e = lds[row + gwords + (++j)];
@@ -775,7 +780,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         if (lane < n) {
             const uint2 ent = ring[(q_head + lane) & (SLOW_RING - 1)];
             const uint32_t e_pass = ent.x >> (19u + it_bits), e_it = (ent.x >> 19) & ((1u << it_bits) - 1u), e_lane = (ent.x >> 13) & 63u;
-            const uint32_t e_pair = (wg + e_pass * n_wg) * MAIN_PAIRS + wave_pair0 + (e_lane >> 2);
+            const uint32_t e_pair = __umul24(wg + __umul24(e_pass, n_wg), (uint32_t)MAIN_PAIRS) + wave_pair0 + (e_lane >> 2);
             const uint32_t mask = ent.x & 0xffu;  // never empty
             const int bit = 31 - __clz(mask);
             if (mask & (mask - 1u)) rest = make_uint2(ent.x & ~(1u << bit), ent.y);

@@ -115,6 +115,8 @@ def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, 
         t.copy_(torch.from_numpy(flat))
     dist.broadcast(t, src=src)  # the one collective of a multi-GPU run
     on_gpu = t.is_cuda
+    if on_gpu:
+        torch.cuda.synchronize(t.device)  # the engine reads the buffer on its own HIP stream
     # header + model tables: to the host (iss_model_upload takes host tables; < 1 MB); genomes stay where they are
     hlen = int(np.frombuffer(t[:8].cpu().numpy().tobytes(), dtype=np.int64)[0])
     meta = json.loads(t[16:16 + hlen].cpu().numpy().tobytes().decode())
