@@ -943,7 +943,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
 constexpr int SCAN_W = 9;         // words per table entry (odd: bank-conflict free): [0] kind << 24 | index,
                                   // [1..8] limits of the block's 8 digits
 constexpr int SCAN_THREADS = 512;
-constexpr int SCAN_CAND = 2048;   // candidate lane-items of the LDS buffer; flushed every RunArgs::scan_every iterations,
+constexpr int SCAN_CAND = 1024;   // candidate lane-items of the LDS buffer; flushed every RunArgs::scan_every iterations,
                                   // chosen on the host from the model's indel probabilities (a candidate that finds
                                   // the buffer full is settled on the spot)
 constexpr int EV_K = 8;           // events kept per read
@@ -1029,10 +1029,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
             // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
             const Addr a = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
             const u32x4 w = philox4x32_10(a.c0, a.c1, c2, 0u, a.k0, a.k1);
-            uint32_t hit = 0;  // bit d: digit d is below its limit
+            // any digit below its limit?  Eight half-word compares whose lane masks the scalar unit ORs; the bit mask of
+            // the digits is only formed for a candidate
+            const unsigned long long any =
+                __builtin_amdgcn_ballot_w64((w.x & 0xffffu) < tab[1]) | __builtin_amdgcn_ballot_w64((w.x >> 16) < tab[2]) |
+                __builtin_amdgcn_ballot_w64((w.y & 0xffffu) < tab[3]) | __builtin_amdgcn_ballot_w64((w.y >> 16) < tab[4]) |
+                __builtin_amdgcn_ballot_w64((w.z & 0xffffu) < tab[5]) | __builtin_amdgcn_ballot_w64((w.z >> 16) < tab[6]) |
+                __builtin_amdgcn_ballot_w64((w.w & 0xffffu) < tab[7]) | __builtin_amdgcn_ballot_w64((w.w >> 16) < tab[8]);
+            if ((any >> (threadIdx.x & 63u)) & 1ull) {  // rare: remembered, settled when the buffer is flushed (one lane per candidate then)
+                uint32_t hit = 0;  // bit d: digit d is below its limit
 #pragma unroll
-            for (int dgt = 0; dgt < 8; ++dgt) hit |= (digit16(w, dgt) < tab[1 + dgt] ? 1u : 0u) << dgt;
-            if (hit) {  // rare: remembered, settled when the buffer is flushed (one lane per candidate then)
+                for (int dgt = 0; dgt < 8; ++dgt) hit |= (digit16(w, dgt) < tab[1 + dgt] ? 1u : 0u) << dgt;
                 const uint32_t at = atomicAdd(&l_count[0], 1u);
                 if (at < (uint32_t)SCAN_CAND) l_cand[at] = make_uint2(pair, (e << 8) | hit);
                 else settle(pair, e, hit);  // buffer full (rates far above the host's estimate)
