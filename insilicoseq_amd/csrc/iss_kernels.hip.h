@@ -9,18 +9,22 @@
 // Kernel plan (one iss_generate / iss_generate_batch call = up to four launches on one stream; in a batch call the
 // records stand side by side in one arena and the pair descriptors carry arena coordinates):
 //   k_setup  : 1 lane / pair   -> PairDesc {forward_start, reverse_end, bin slots, attempt, insert}
-//   k_main   : persistent workgroups (1024 lanes, two per CU); the compressed per-position quality
-//              CDF rows of a position tile are staged ONCE per workgroup in LDS; 1 lane /
-//              (pair, 4 consecutive positions, both mates): two Philox calls give the sixteen
-//              16-bit leading digits of its 16 uniforms; CDF inversion = LDS guide byte + packed
-//              (threshold, phred) entries; bases come from the 2-bit genome with funnel shifts
-//              and one v_perm; four packed dword stores per lane, contiguous across lanes.
-//              Assumes "no indel in this read" (true for all but ~1e-4 of reads of shipped models).
-//   k_indel_scan : 1 lane / (pair, group of 4 loop steps with a non-zero indel probability): draws the
-//              indel digits and flags reads in which an indel MAY fire (conservative).
-//   k_indel_fixup: 1 wavefront / flagged read: exact sequential indel semantics (lane 0 walks the
-//              token transducer over an event mask computed by all lanes) + re-mutation by all
-//              lanes, rewrites that read's base row.
+//   k_main   : persistent workgroups (1024 lanes, one per CU); the compressed per-position quality
+//              CDF rows of a position tile are staged ONCE per workgroup in LDS; 4 lanes / pair, a lane
+//              takes 8 consecutive positions of both mates at a time: three Philox calls give its
+//              quality digits (16 bits) and error-test digits (8 bits); CDF inversion = LDS guide byte +
+//              packed (threshold, phred, error threshold) entries; bases come from the 2-bit genome with
+//              funnel shifts and one v_perm; two 16-byte stores per lane, 64 contiguous bytes per pair.
+//              Digits that tie with a table entry, and positions whose error test fires, are queued in a
+//              per-wave LDS ring and settled exactly (no global loads) every few iterations.
+//              Assumes "no indel in this read".
+//   k_indel_scan : 1 lane / (pair, Philox block of indel digits with a non-zero probability): lists every
+//              read in which an indel fires, with its events (step, event mask), exactly.
+//   k_indel_apply: half a wavefront / listed read: replays the read's event list through the token
+//              transducer, re-derives the read (template, substitutions) and rewrites its base row.
+//   k_indel_fixup: 1 wavefront / flagged read (irregular pairs, reads with more events than a list
+//              holds): exact sequential indel semantics (lane 0 walks the token transducer over an
+//              event mask computed by all lanes) + re-mutation by all lanes, rewrites that read's base row.
 // No MFMA anywhere: this is sampling/indexing.  All f64 comparisons of the reference are exact
 // integer comparisons here (thresholds prepared on the host, see iss_mi355x.h / DESIGN.md).
 #pragma once
@@ -191,9 +195,9 @@ struct RunArgs {
     const int64_t *ov_frags;      // ... with these host-evaluated fragment lengths
     uint32_t n_ov;
     uint32_t *flags, *fix_list, *fix_count;  // irregular pairs (template shorter than the read, ...) go straight to the fix-up
-    // indel events (k_indel_scan -> k_indel_apply): per read a counter and EV_K event words (step << 8 | event mask); pairs
-    // with an event are listed once in pair_list
-    uint32_t *ev_count, *ev_list, *pair_list, *pair_count;
+    // indel events (k_indel_scan -> k_indel_apply): per read a counter and EV_K event words (step << 8 | event mask); reads
+    // (2 * pair + mate) with an event are listed once in read_list
+    uint32_t *ev_count, *ev_list, *read_list, *read_count;
     uint16_t tile_wg0[MAX_TILES + 2];  // k_main: workgroups [tile_wg0[t], tile_wg0[t + 1]) work on position tile t
     MutRecord *mut;               // --store_mutations rows (NULL: off)
     uint32_t *mut_count;          // slots reserved so far
@@ -938,8 +942,8 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
 // bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b (__init__.py:193-196,
 // :209) -- and a non-empty mask is appended to the read's event list (EV_K words, step << 8 | mask).  k_indel_apply
 // replays the lists; no event => provably no indel, k_main's output stands.  A read with more than EV_K events goes to
-// the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  Pairs with an event are collected in a
-// workgroup-local LDS list that is appended to the global pair list with ONE atomic per flush.
+// the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  Reads with an event are collected in a
+// workgroup-local LDS list that is appended to the global read list with ONE atomic per flush.
 constexpr int SCAN_W = 9;         // words per table entry (odd: bank-conflict free): [0] kind << 24 | index,
                                   // [1..8] limits of the block's 8 digits
 constexpr int SCAN_THREADS = 512;
@@ -948,14 +952,14 @@ constexpr int SCAN_CAND = 1024;   // candidate lane-items of the LDS buffer; flu
                                   // the buffer full is settled on the spot)
 constexpr int EV_K = 8;           // events kept per read
 constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
-                                       // bit 4 pair is in pair_list
+                                       // bits 4-5 mate is in read_list
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *l_count = lds;      // [0] candidates in the buffer, [1] newly listed pairs, [2] global base of the current flush
+    uint32_t *l_count = lds;      // [0] candidates in the buffer, [1] newly listed reads, [2] global base of the current flush
     uint2 *l_cand = reinterpret_cast<uint2 *>(lds + 4);  // SCAN_CAND x {pair, table entry << 8 | digits below their limits}
-    uint32_t *l_pairs = lds + 4 + 2 * SCAN_CAND;         // newly listed pairs of a flush (<= 8 per candidate ... 2 really)
-    uint32_t *tab0 = l_pairs + 2 * SCAN_CAND;
+    uint32_t *l_reads = lds + 4 + 2 * SCAN_CAND;         // newly listed reads (2 * pair + mate) of a flush: <= 2 per candidate
+    uint32_t *tab0 = l_reads + 2 * SCAN_CAND;
     uint32_t *fix0 = tab0 + M.n_scan * SCAN_W;  // [2][RL][8]: digit limits of the 4 insertion slots and the 4 bases' deletions
     for (int i = threadIdx.x; i < M.n_scan * SCAN_W; i += blockDim.x) tab0[i] = M.scan_tab[i];
     for (int i = threadIdx.x; i < 2 * M.RL * 8; i += blockDim.x) fix0[i] = M.fix_tab[i];
@@ -972,7 +976,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     uint32_t since_flush = 0;
     // One candidate lane-item, exactly (dense at flush time: one lane per candidate): the event masks of its (mate, step)s
     // -- bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b -- go to their
-    // reads' lists; returns nothing, lists pairs in l_pairs.
+    // reads' lists; a read's first event lists it in l_reads.
     auto settle = [&](uint32_t c_pair, uint32_t c_e, uint32_t hit) {
         const uint32_t c2 = tab0[c_e * SCAN_W];
         const Addr a = make_addr(A.seed, A.first_ordinal + c_pair, A.gc_bias ? desc[c_pair].meta >> 16 : 0u);
@@ -1012,10 +1016,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
             const uint32_t at = atomicAdd(&A.ev_count[rd], 1u);
             if (at < (uint32_t)EV_K) {
                 A.ev_list[(size_t)rd * EV_K + at] = ((uint32_t)n << 8) | m8;
-                if (!(atomicOr(&A.flags[c_pair], FLAG_LISTED) & FLAG_LISTED)) {
+                if (!(atomicOr(&A.flags[c_pair], FLAG_LISTED << o) & (FLAG_LISTED << o))) {
                     const uint32_t lp = atomicAdd(&l_count[1], 1u);
-                    if (lp < 2u * (uint32_t)SCAN_CAND) l_pairs[lp] = c_pair;
-                    else A.pair_list[atomicAdd(A.pair_count, 1u)] = c_pair;
+                    if (lp < 2u * (uint32_t)SCAN_CAND) l_reads[lp] = rd;
+                    else A.read_list[atomicAdd(A.read_count, 1u)] = rd;
                 }
             } else if (at == (uint32_t)EV_K) {  // too many events for the list: the wavefront-per-read kernel takes the read
                 if (!(atomicOr(&A.flags[c_pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
@@ -1055,11 +1059,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
             }
             __syncthreads();
             const uint32_t n_new = min(l_count[1], 2u * (uint32_t)SCAN_CAND);
-            if (n_new) {  // the pairs listed for the first time: ONE global atomic
-                if (threadIdx.x == 0) l_count[2] = atomicAdd(A.pair_count, n_new);
+            if (n_new) {  // the reads listed for the first time: ONE global atomic
+                if (threadIdx.x == 0) l_count[2] = atomicAdd(A.read_count, n_new);
                 __syncthreads();
                 const uint32_t base = l_count[2];
-                for (uint32_t i = threadIdx.x; i < n_new; i += blockDim.x) A.pair_list[base + i] = l_pairs[i];
+                for (uint32_t i = threadIdx.x; i < n_new; i += blockDim.x) A.read_list[base + i] = l_reads[i];
             }
             __syncthreads();
             if (threadIdx.x < 2) l_count[threadIdx.x] = 0;
@@ -1073,21 +1077,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
 }
 
 // ================================================================== k_indel_apply
-// One wavefront per listed pair, lanes 0-31 on the forward mate, 32-63 on the reverse mate.  introduce_indels +
-// adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
+// One half-wavefront (32 lanes) per listed READ -- a mate with at least one event; the two halves of a wavefront take
+// neighbouring list entries, whatever pairs and mates those are, so no lane idles on an event-free mate.  introduce_indels
+// + adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
 // prefix [0, n) is final when step n starts; the not-yet-visited suffix is (stack of freshly inserted letters, LIFO)
 // ++ E(k), E(k+1), ...
-//   1. the read's events: sorted by step, masks of one step merged (both halves at once)
-//   2. (all lanes) the template E(0 .. RL+63) of both mates into LDS, 8 bases per lane from the 2-bit genome; the
-//      error-test digits of both mates (one Philox block per 8 positions)
-//   3. the walk over the steps with an event (the two mates side by side, one per half): explicit map[] entries for
+//   1. the read's events: sorted by step, masks of one step merged
+//   2. (all lanes) the template E(0 .. pitch+7) into LDS, 8 bases per lane from the 2-bit genome; the error-test digits
+//      (one Philox block per 8 positions)
+//   3. the walk over the steps with an event (the two reads side by side, one per half): explicit map[] entries for
 //      those steps and for the steps that drain the insertion stack, "from step n0 on, source index = k0 + (n - n0)"
 //      records for everything in between
 //   4. (all lanes, 8 positions each) token -> base -> mut_sequence -> one 8-byte store
 // A pair is a chain of dependent loads (list entry -> descriptor, events, phreds -> genome windows) behind a write
-// stream, i.e. microseconds of latency: the list entry is requested two pairs ahead, everything its address needs only
-// the pair for one pair ahead, and the tables the walk and the substitutions read sit in LDS.
-constexpr int APPLY_WAVES = 4;    // pairs per workgroup
+// stream, i.e. microseconds of latency: the list entry is requested two reads ahead, everything its address needs only
+// the read number for one read ahead, and the tables the walk and the substitutions read sit in LDS.
+constexpr int APPLY_WAVES = 4;    // wavefronts (2 reads each) per workgroup
 #ifndef ISS_APPLY_OCC
 #define ISS_APPLY_OCC 4           // wavefronts per SIMD the register budget is cut for (measured: 3 -> 4: -20 % time)
 #endif
@@ -1115,8 +1120,8 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     uint32_t *sub13 = mut8 + 64;                                // [2][RL][4] (see DevModel::subst13, position-major here)
     uint8_t *insl = reinterpret_cast<uint8_t *>(sub13 + 2 * RL * 4);  // [2][RL][4]
     int64_t *ifirst = reinterpret_cast<int64_t *>(apply_lds + apply_tab_bytes(RL) - (APPLY_ITEMS + 2) * 8);
-    const uint32_t n_list = *A.pair_count;
-    if (blockIdx.x * APPLY_WAVES >= n_list) return;  // whole workgroup idle (uniform)
+    const uint32_t n_list = *A.read_count;
+    if (blockIdx.x * APPLY_WAVES * 2 >= n_list) return;  // whole workgroup idle (uniform)
     for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut8[i] = (uint32_t)(M.mut_thr[i] >> 45);
     for (int i = threadIdx.x; i < 2 * RL * 4; i += blockDim.x) {
         const int o = i / (RL * 4), r = i - o * RL * 4, p = r >> 2, bi = r & 3;
@@ -1128,9 +1133,9 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     if (items_cached) for (int i = threadIdx.x; i <= A.n_items; i += blockDim.x) ifirst[i] = A.item_first[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int o = lane >> 5, hl = lane & 31;  // mate, lane within the half
+    const int hf = lane >> 5, hl = lane & 31;  // half of the wavefront, lane within the half
     uint8_t *wave0 = apply_lds + apply_tab_bytes(RL) + (size_t)wv * apply_wave_bytes(pitch);
-    uint8_t *wbase = wave0 + (size_t)o * (apply_wave_bytes(pitch) / 2);
+    uint8_t *wbase = wave0 + (size_t)hf * (apply_wave_bytes(pitch) / 2);
     uint8_t *tmpl = wbase;                                  // [TL]
     uint8_t *dqm = tmpl + TL;                               // [pitch] error-test digit (8 bits) of position j
     uint8_t *stk = dqm + pitch;                             // [pitch + 4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
@@ -1140,27 +1145,30 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     uint32_t *ev_srt = ev_raw + EV_K;                       // [EV_K]
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);
     uint64_t n_reads = 0;
-    const uint32_t stride = gridDim.x * APPLY_WAVES;
-    const uint32_t li0 = blockIdx.x * APPLY_WAVES + wv;
-    // software pipeline: the list entry two pairs ahead, what hangs on the pair number one pair ahead
-    uint32_t pair_a = li0 < n_list ? A.pair_list[li0] : 0u;                     // pair of iteration `li`
-    uint32_t pair_b = li0 + stride < n_list ? A.pair_list[li0 + stride] : 0u;   // ... of `li + stride`
-    PairDesc d_a = desc[pair_a];
-    uint32_t fl_a = A.flags[pair_a], cnt_a = A.ev_count[2 * pair_a + o];
-    uint32_t evw_a = hl < EV_K ? A.ev_list[(size_t)(2 * pair_a + o) * EV_K + hl] : 0u;
+    const uint32_t stride = gridDim.x * APPLY_WAVES * 2;
+    const uint32_t li0 = (blockIdx.x * APPLY_WAVES + wv) * 2;  // the wavefront's first two list entries (one per half)
+    // software pipeline: the list entry two reads ahead, what hangs on the read number one read ahead.  (A half past the end
+    // of the list repeats the last entry with no events.)
+    const uint32_t NO_READ = 0xffffffffu;
+    uint32_t rd_a = li0 + hf < n_list ? A.read_list[li0 + hf] : NO_READ;                      // read of iteration `li`
+    uint32_t rd_b = li0 + stride + hf < n_list ? A.read_list[li0 + stride + hf] : NO_READ;   // ... of `li + stride`
+    uint32_t ra = rd_a == NO_READ ? 0u : rd_a;
+    PairDesc d_a = desc[ra >> 1];
+    uint32_t fl_a = A.flags[ra >> 1], cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
+    uint32_t evw_a = hl < EV_K ? A.ev_list[(size_t)ra * EV_K + hl] : 0u;
     for (uint32_t li = li0; li < n_list; li += stride) {
-        const uint32_t pair = pair_a;
+        const uint32_t pair = ra >> 1;
+        const int o = (int)(ra & 1u);  // mate
         PairDesc d = d_a;
         const uint32_t fl = fl_a, cnt_raw = cnt_a, evw = evw_a;
         {   // requests for the next two iterations
-            pair_a = pair_b;
-            const bool more = li + stride < n_list;
-            const uint32_t pn = more ? pair_a : pair;
-            d_a = desc[pn];
-            fl_a = A.flags[pn];
-            cnt_a = A.ev_count[2 * pn + o];
-            evw_a = hl < EV_K ? A.ev_list[(size_t)(2 * pn + o) * EV_K + hl] : 0u;
-            pair_b = li + 2 * stride < n_list ? A.pair_list[li + 2 * stride] : 0u;
+            rd_a = rd_b;
+            if (rd_a != NO_READ) ra = rd_a;
+            d_a = desc[ra >> 1];
+            fl_a = A.flags[ra >> 1];
+            cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
+            evw_a = hl < EV_K ? A.ev_list[(size_t)ra * EV_K + hl] : 0u;
+            rd_b = li + 2 * stride + hf < n_list ? A.read_list[li + 2 * stride + hf] : NO_READ;
         }
         DevGenome gl = g;  // the record of the pair: the launch's genome, or its slice of the arena (batch calls)
         int64_t arena_off = 0;
@@ -1184,9 +1192,9 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         uint32_t cnt = min(cnt_raw, (uint32_t)EV_K);
         if ((fl >> o) & 1u) cnt = 0;  // this mate is k_indel_fixup's (too many events / irregular pair)
         const MateGeom geo = mate_geom(o, d, RL, gl.L);
-        uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.row;
-        const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.row;
-        // ---- requests of this pair: its phreds and its genome windows (used after the event sort and the Philox blocks)
+        uint8_t *out_base = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
+        const uint8_t *out_qual = out_base + (row_array_off(1) - row_array_off(0));
+        // ---- requests of this read: its phreds and its genome window (used after the event sort and the Philox blocks)
         uint2 q8 = {0u, 0u};
         if (cnt && hl * 8 < pitch) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(hl * 8));
         uint2 gw = {0u, 0u};
@@ -1203,10 +1211,9 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         if (hl < EV_K) ev_raw[hl] = evw;
         for (int j = hl * 4; j < pitch; j += 128) *reinterpret_cast<uint2 *>(map + j) = make_uint2(0x7fff7fffu, 0x7fff7fffu);  // FIX_NONE
         for (int j = hl * 8; j < pitch; j += 256) *reinterpret_cast<uint2 *>(dsh + j) = make_uint2(0u, 0u);
-        for (int b = lane; b * 8 < pitch; b += 64) {  // one Philox block holds the digits of 8 positions of both mates
+        for (int b = hl; cnt && b * 8 < pitch; b += 32) {  // one Philox block holds the digits of 8 positions (of both mates)
             const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 1);
-            *reinterpret_cast<uint2 *>(wave0 + TL + b * 8) = make_uint2(w.x, w.z);                                  // mate 0
-            *reinterpret_cast<uint2 *>(wave0 + apply_wave_bytes(pitch) / 2 + TL + b * 8) = make_uint2(w.y, w.w);   // mate 1
+            *reinterpret_cast<uint2 *>(dqm + b * 8) = o == 0 ? make_uint2(w.x, w.z) : make_uint2(w.y, w.w);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();

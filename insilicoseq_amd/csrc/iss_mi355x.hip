@@ -182,8 +182,8 @@ struct iss_ctx {
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
-    uint32_t *ev_count = nullptr, *ev_list = nullptr, *pair_list = nullptr;  // indel events (k_indel_scan -> k_indel_apply), per row
-    uint32_t *pair_count = nullptr;  // FIX_SLOTS counters of the pair lists, like fix_count
+    uint32_t *ev_count = nullptr, *ev_list = nullptr, *read_list = nullptr;  // indel events (k_indel_scan -> k_indel_apply), per row
+    uint32_t *read_count = nullptr;  // FIX_SLOTS counters of the read lists, like fix_count
     int scan_every = 8;
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
     // custom fragment length on the Philox path
@@ -273,8 +273,8 @@ void free_outputs(iss_ctx *ctx) {
     if (ctx->fix_list) (void)hipFree(ctx->fix_list);
     if (ctx->ev_count) (void)hipFree(ctx->ev_count);
     if (ctx->ev_list) (void)hipFree(ctx->ev_list);
-    if (ctx->pair_list) (void)hipFree(ctx->pair_list);
-    ctx->ev_count = ctx->ev_list = ctx->pair_list = nullptr;
+    if (ctx->read_list) (void)hipFree(ctx->read_list);
+    ctx->ev_count = ctx->ev_list = ctx->read_list = nullptr;
     ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
     ctx->capacity = 0;
 }
@@ -713,7 +713,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
     HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * FIX_SLOTS));
-    ctx->pair_count = static_cast<uint32_t *>(p);
+    ctx->read_count = static_cast<uint32_t *>(p);
     HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * FIX_SLOTS));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
     *out = ctx;
@@ -732,7 +732,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     free_outputs(ctx);
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
-    if (ctx->pair_count) (void)hipFree(ctx->pair_count);
+    if (ctx->read_count) (void)hipFree(ctx->read_count);
     if (ctx->d_amb) (void)hipFree(ctx->d_amb);
     if (ctx->d_pmut) (void)hipFree(ctx->d_pmut);
     if (ctx->d_ov_pairs) (void)hipFree(ctx->d_ov_pairs);
@@ -1232,8 +1232,8 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     ctx->ev_count = static_cast<uint32_t *>(q);
     HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * iss::EV_K * (size_t)capacity_pairs));
     ctx->ev_list = static_cast<uint32_t *>(q);
-    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * (size_t)capacity_pairs));
-    ctx->pair_list = static_cast<uint32_t *>(q);
+    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
+    ctx->read_list = static_cast<uint32_t *>(q);
     ctx->capacity = capacity_pairs;
     return 0;
 }
@@ -1351,13 +1351,13 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         // are cleared by k_setup itself.)
         const unsigned slot_i = (unsigned)(ctx->chunk_seq++ % FIX_SLOTS);
         uint32_t *counter = ctx->fix_count + slot_i;
-        uint32_t *pair_counter = ctx->pair_count + slot_i;
+        uint32_t *read_counter = ctx->read_count + slot_i;
         if (ctx->overlap) {
             HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
-            HIP_TRY(ctx, hipMemsetAsync(pair_counter, 0, sizeof(uint32_t), s_main));
+            HIP_TRY(ctx, hipMemsetAsync(read_counter, 0, sizeof(uint32_t), s_main));
         } else if (slot_i == 0) {
             HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->pair_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->read_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
         }
         A.mut = ctx->d_pmut;
         A.mut_count = ctx->d_pmut_count;
@@ -1371,8 +1371,8 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.fix_count = counter;
         A.ev_count = M.n_scan > 0 ? ctx->ev_count + 2 * row0 : nullptr;
         A.ev_list = ctx->ev_list + 2 * (size_t)iss::EV_K * row0;
-        A.pair_list = ctx->pair_list + row0;
-        A.pair_count = pair_counter;
+        A.read_list = ctx->read_list + 2 * row0;
+        A.read_count = read_counter;
         A.has_frag = ctx->has_frag ? 1 : 0;
         A.frag_mu = ctx->frag_mu;
         A.frag_sd = ctx->frag_sd;
@@ -1472,7 +1472,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             HIP_TRY(ctx, mark(4, s_indel));
             if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
             HIP_TRY(ctx, mark(5, s_indel));
-            if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, one wavefront per pair
+            if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, half a wavefront per read
                 const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (n + iss::APPLY_WAVES - 1) / iss::APPLY_WAVES);
                 if (A.mut)
                     hipLaunchKernelGGL(iss::k_indel_apply<true>, dim3(blocks), dim3(64 * iss::APPLY_WAVES), iss::apply_lds_bytes(M.RL, M.pitch),
