@@ -77,10 +77,12 @@ typedef struct {
     const uint8_t *ins_letter;   /* [2][RL][4]       ASCII, in the dict's iteration order              */
     const uint64_t *del_thr;     /* [2][RL][4]       ceil : delete iff m < thr       __init__.py:209   */
     const uint64_t *mut_thr;     /* [n_q+1]          floor(phred_to_prob(q)*2^53): error iff m > thr   */
-    /* BasicErrorModel (iss/error_models/basic.py:18-63), quality_mode 1: constant insert size, phred scores
-     * int(round(-10 * log10(1 - min(np.random.normal(basic_mean, basic_sd), basic_cap)))) per position; the
-     * insert-size / bin / quality tables above are then unused (n_q + 1 must cover the phreds: 41 -> 0..41).
-     * Runs in the reference-compatible mode (iss_generate_mt) only; iss_generate refuses such a model. */
+    /* BasicErrorModel (iss/error_models/basic.py:18-63), quality_mode 1: constant insert size (no draw), phred
+     * scores int(round(-10 * log10(1 - min(np.random.normal(basic_mean, basic_sd), basic_cap)))) per position
+     * (n_q + 1 must cover the phreds: 41 -> 0..41).  The reference-compatible mode (iss_generate_mt) draws the
+     * normal deviates in the reference's order; iss_generate / iss_generate_batch invert q_thr like a KDE row, so
+     * the caller puts the distribution of that score there (the same row at every position, in every bin;
+     * insilicoseq_amd/model.py basic_phred_cdf).  The insert-size and bin tables are unused. */
     int32_t quality_mode;        /* 0: KDE tables (kde.py), 1: basic                                     */
     int32_t basic_insert_size;   /* basic.py:21 (200)                                                    */
     double basic_mean;           /* util.phred_to_prob(30), basic.py:24, :52                             */
@@ -139,7 +141,7 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
  * out_first_pair onwards), so the rows are identical to those calls' -- without a kernel launch sequence per record.
  * The records are laid side by side in one device arena (kept until a call names another list of records) and pair
  * descriptors carry arena coordinates; iss_output_download_coords returns record coordinates as before.  Custom
- * fragment lengths (iss_set_fragment) are not supported here: ISS_E_INVALID.  A record not longer than the read
+ * fragment lengths (iss_set_fragment) apply as in iss_generate.  A record not longer than the read
  * length: ISS_E_SHORT_RECORD, nothing generated (leave such records out, as reads_generator skips them).
  */
 int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids, const int64_t *n_pairs,

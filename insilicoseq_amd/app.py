@@ -200,9 +200,6 @@ def generate_reads(args):
     logger = logging.getLogger(__name__)
     error_model = load_error_model(args.mode, args.seed, args.model, args.fragment_length, args.fragment_length_sd,
                                    args.store_mutations, args.rng)
-    if args.mode == "basic" and args.rng != "mt":
-        logger.info("--mode basic runs in the reference-compatible RNG mode (--rng mt)")
-        args.rng = "mt"
     if not args.genomes:
         logger.error("One of --genomes/-g is required")
         sys.exit(1)

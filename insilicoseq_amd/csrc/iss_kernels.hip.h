@@ -128,7 +128,7 @@ struct DevModel {
     // reference-compatible MT mode, k_mt_resolve (iss_mt_compat.hip.h)
     int32_t mt_row_w;             // 32-bit words per row of mt_rows (odd)
     const uint16_t *mt_rows;      // [2][NB][RL] rows of n_q leading digits min(q_thr >> 37, 0xffff) (no merging: index == phred)
-    const uint32_t *mt_lim;       // [2][RL][5] thr >> 26 of the 4 insertion thresholds and the largest deletion threshold    // BasicErrorModel (iss/error_models/basic.py), reference-compatible mode only
+    const uint32_t *mt_lim;       // [2][RL][5] thr >> 26 of the 4 insertion thresholds and the largest deletion threshold    // BasicErrorModel (iss/error_models/basic.py)
     int32_t quality_mode;         // 0 KDE tables; 1 basic: phred = round(-10 log10(1 - min(N(basic_mean, basic_sd), basic_cap)))
     int32_t basic_insert_size;    // basic.py:21, :56-63 (no draw)
     double basic_mean, basic_sd, basic_cap;
@@ -262,15 +262,13 @@ __device__ __forceinline__ void mut_emit1(const RunArgs &A, const MutRecord &r) 
 
 // ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ uint8_t code_to_ascii(uint32_t code) { return (uint8_t)((0x47435441u >> (8 * code)) & 0xffu); }
-// A,T,C,G (either case) -> 0..3, anything else (IUPAC ambiguity codes) -> -1
+// A,T,C,G (either case) -> 0..3, anything else (IUPAC ambiguity codes) -> -1.  Branch-free: bits 1-2 of the upper-case
+// letter tell A, C, T, G apart (0, 1, 2, 3); the candidate is then checked against the letter itself.
 __device__ __forceinline__ int base_index(int c) {
-    switch (c) {
-        case 'A': case 'a': return 0;
-        case 'T': case 't': return 1;
-        case 'C': case 'c': return 2;
-        case 'G': case 'g': return 3;
-        default: return -1;
-    }
+    const int u = c & ~0x20;
+    const int i = (u >> 1) & 3;
+    const int bi = ((i << 1) & 2) | (i >> 1);  // A 0, T 1, C 2, G 3 (code_to_ascii's order)
+    return (int)code_to_ascii((uint32_t)bi) == u ? bi : -1;
 }
 // iss/util.py:57-88 (letters were validated at upload)
 __device__ __forceinline__ int complement_ascii(int c) {
@@ -495,6 +493,9 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
             frag = fabs(x) < 1e15 ? (int64_t)x : 0;  // int(): truncation toward zero
         }
         isz = frag - 2 * (int64_t)RL;
+    } else if (M.quality_mode == 1) {
+        isz = M.basic_insert_size;  // BasicErrorModel.random_insert_size: a constant, no draw (basic.py:56-63)
+        frag = isz + 2 * (int64_t)RL;
     } else {
         isz = count_lt(s_isize, M.n_isize, mk53(w0.x, w1.x));  // kde.py:97
         frag = isz + 2 * (int64_t)RL;
@@ -569,7 +570,13 @@ __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs 
 __global__ __launch_bounds__(64) void k_setup_override(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= A.n_ov) return;
-    setup_pair(M, g, A, desc, nullptr, (int64_t)A.ov_pairs[j], A.ov_frags + j);
+    const int64_t i = (int64_t)A.ov_pairs[j];
+    if (A.items) {  // (as k_setup)
+        const BatchItem it = A.items[batch_item_of(A, A.pair_base + i)];
+        setup_pair(M, batch_genome(g, it), A, desc, nullptr, i, A.ov_frags + j, it.off);
+        return;
+    }
+    setup_pair(M, g, A, desc, nullptr, i, A.ov_frags + j);
 }
 
 // ================================================================== k_main
@@ -1334,12 +1341,12 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                     shift += (int)(int8_t)(((c < 4 ? dw.x : dw.y) >> (8 * (c & 3))) & 0xffu);
                     const uint32_t mword = c < 2 ? mw.x : (c < 4 ? mw.y : (c < 6 ? mw.z : mw.w));
                     const int mtok = (int)(int16_t)((mword >> (16 * (c & 1))) & 0xffffu);
-                    int tok = mtok != (int)FIX_NONE ? mtok : j + shift;
-                    int base = -tok;
-                    if (tok >= 0) base = (int)tmpl[tok];  // (tok <= j + EV_K < TL: a step deletes at most one base)
+                    const int tok = mtok != (int)FIX_NONE ? mtok : j + shift;
+                    const int from_tmpl = (int)tmpl[max(tok, 0)];  // (tok <= j + EV_K < TL: a step deletes at most one base)
+                    const int base = tok >= 0 ? from_tmpl : -tok;
                     const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
                     const uint32_t q = ((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu;
-                    if (j < RL && e8 >= mut8[q]) cand |= 1u << c;
+                    cand |= (j < RL && e8 >= mut8[q & 63u] ? 1u : 0u) << c;
                     if (c < 4) ob0 |= (uint32_t)base << (8 * c); else ob1 |= (uint32_t)base << (8 * (c - 4));
                 }
                 while (cand) {  // rare per lane: the substitution test fires or ties (__init__.py:94)

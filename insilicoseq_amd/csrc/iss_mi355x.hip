@@ -1264,8 +1264,6 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
         return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
     const Genome &G = ctx->genomes[genome_id];
     const iss::DevModel &M = ctx->M;
-    if (M.quality_mode == 1)
-        return fail(ctx, ISS_E_INVALID, "BasicErrorModel runs in the reference-compatible mode only (iss_generate_mt / rng=\"mt\")");
     if (!(M.RL < G.L)) return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
     if (n_pairs == 0) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1579,9 +1577,6 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
     if (sequence_type != ISS_SEQ_METAGENOMICS && sequence_type != ISS_SEQ_AMPLICON)
         return fail(ctx, ISS_E_INVALID, "sequence type is not supported");
     const iss::DevModel &M = ctx->M;
-    if (M.quality_mode == 1)
-        return fail(ctx, ISS_E_INVALID, "BasicErrorModel runs in the reference-compatible mode only (iss_generate_mt / rng=\"mt\")");
-    if (ctx->has_frag) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: custom fragment lengths go through iss_generate");
     int64_t total = 0;
     std::vector<int64_t> first((size_t)n_items + 1, 0);
     for (int32_t k = 0; k < n_items; ++k) {

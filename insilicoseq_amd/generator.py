@@ -176,8 +176,6 @@ class Worker(object):
         self.seed = worker_seed(seed, cpu_number)
         self.engine = ReadEngine(self.cpu_number if device is None else device)
         self.dense = _dense_of(error_model)
-        if getattr(self.dense, "quality_mode", 0) == 1 and rng != "mt":
-            raise ValueError("BasicErrorModel runs in the reference-compatible RNG mode only: rng=\"mt\"")
         self.engine.load_model(self.dense)
         self.store_mutations = False
         self.device_fastq = os.environ.get("ISS_HOST_FASTQ", "") != "1"  # ISS_HOST_FASTQ=1: host formatter (iss_fastq_write)
@@ -415,8 +413,7 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
             w.engine.mutations_reserve(int(Worker.BATCH_PAIRS * per_pair) + (1 << 21))
     try:
         with forward_handle, reverse_handle, mutation_handle:
-            fragment = getattr(error_model, "fragment_length", None) is not None and getattr(error_model, "fragment_sd", None) is not None
-            if rng == "philox" and w.device_fastq and not fragment and os.environ.get("ISS_ITEMWISE", "") != "1":
+            if rng == "philox" and w.device_fastq and os.environ.get("ISS_ITEMWISE", "") != "1":
                 _simulate_work_batched(w, work, forward_handle, reverse_handle, mutation_handle, sequence_type, gc_bias)
             else:
                 for record, n_pairs, _mode in work:

@@ -35,6 +35,42 @@ def phred_to_prob(q):
     return 1 - p
 
 
+def basic_prob_to_phred(x, cap=0.9999):
+    """One phred score of ``BasicErrorModel.gen_phred_scores`` from its normal deviate ``x``:
+    ``prob_to_phred(min(x, 0.9999))`` = ``int(round(-10 * np.log10(1 - p)))`` (iss/error_models/basic.py:52-53,
+    iss/util.py:44)."""
+    return int(round(-10 * np.log10(1 - min(x, cap))))
+
+
+def basic_phred_cdf(mean_quality=30, sd=0.01, cap=0.9999, n_q=41):
+    """``P(phred <= k)``, k = 0 .. n_q-1, of one position of ``BasicErrorModel.gen_phred_scores``
+    (iss/error_models/basic.py:52-53): x ~ Normal(phred_to_prob(mean_quality), sd), phred = basic_prob_to_phred(x).
+    The score is a non-decreasing step function of x, so ``P(phred <= k) = Phi((b_k - mean) / sd)`` with b_k the
+    largest double whose score is <= k -- found by bisection on the reference's own expression (not on its algebraic
+    inverse ``1 - 10 ** (-(k + 0.5) / 10)``: the steps are where the FLOAT expression rounds).  This is the table the
+    position-addressable (Philox) path inverts, like a KDE quality row; the reference-compatible mode draws the normal
+    deviates themselves."""
+    import math
+    mean = float(phred_to_prob(mean_quality))
+    top = basic_prob_to_phred(cap, cap)  # the score of every x >= cap (40)
+    cdf = np.ones(n_q, dtype=np.float64)
+    for k in range(min(n_q, top)):
+        lo, hi = -1.0, float(cap)  # score(lo) = 0 <= k < score(hi) = top (-1.0: 1 - x = 2, log10 > 0, rounds to -3 .. 0)
+        if basic_prob_to_phred(lo, cap) > k:
+            cdf[k] = 0.0
+            continue
+        while True:
+            mid = 0.5 * (lo + hi)
+            if mid <= lo or mid >= hi:
+                break
+            if basic_prob_to_phred(mid, cap) <= k:
+                lo = mid
+            else:
+                hi = mid
+        cdf[k] = 0.5 * math.erfc(-((lo - mean) / sd) / math.sqrt(2.0)) if sd > 0 else float(lo >= mean)
+    return cdf
+
+
 def _choice_cdf(p):
     """The CDF ``np.random.choice(a, p=p)`` inverts (legacy RandomState.choice)."""
     p = np.array(p, dtype=np.float64)
@@ -70,8 +106,9 @@ class DenseModel(object):
         self.ins_letter = np.ascontiguousarray(ins_letter, dtype=np.uint8)
         self.dele = np.ascontiguousarray(dele, dtype=np.float64)
         self.phred_thr = np.ascontiguousarray(phred_thr, dtype=np.float64)
-        # 0: KDE tables.  1: BasicErrorModel (iss/error_models/basic.py) -- constant insert size, phred scores from a
-        # normal distribution around phred_to_prob(mean quality); the quality / bin / insert-size tables are unused.
+        # 0: KDE tables.  1: BasicErrorModel (iss/error_models/basic.py) -- constant insert size (no draw), phred scores
+        # from a normal distribution around phred_to_prob(mean quality): the reference-compatible mode draws the normal
+        # deviates, the Philox path inverts the quality rows (basic_phred_cdf); bin / insert-size tables are unused.
         self.quality_mode = 0
         self.basic_insert_size = 200
         self.basic_mean_quality = 30
@@ -208,8 +245,11 @@ class DenseModel(object):
         subst_alt = np.zeros((2, RL, 4, 3), dtype=np.uint8)
         for bi, b in enumerate(BASES):
             subst_alt[:, :, bi, :] = [ord(c) for c in alts[b]]
+        # the quality rows: the distribution of one basic phred score, the same at every position, in every bin and for
+        # both mates (inverted by the Philox path; the reference-compatible mode draws np.random.normal itself)
+        qrow = basic_phred_cdf(mean_quality)
         d = cls(RL, np.array([1.0]), np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (2, 1)),
-                np.tile(np.array([0, 0, 0, 1], dtype=np.uint8), (2, 1)), np.ones((2, N_BINS, RL, 41)),
+                np.tile(np.array([0, 0, 0, 1], dtype=np.uint8), (2, 1)), np.tile(qrow, (2, N_BINS, RL, 1)),
                 np.tile(cdf, (2, RL, 4, 1)), subst_alt, np.zeros((2, RL, 4)),
                 np.tile(np.frombuffer(BASES.encode(), dtype=np.uint8), (2, RL, 1)), np.zeros((2, RL, 4)),
                 np.array([phred_to_prob(q) for q in range(42)]))

@@ -489,8 +489,10 @@ static double py_round_half_even(double x) { return nearbyint(x); } /* default F
 
 static void gen_phred_scores(const iss_model *m, iss_rng *r, int o, uint8_t *qual) {
     const int RL = m->read_length;
-    if (m->quality_mode == 1) {
-        /* basic.py:52-53: np.random.normal(phred_to_prob(30), 0.01, RL) then prob_to_phred */
+    if (m->quality_mode == 1 && r->mode == ISS_RNG_MT) {
+        /* basic.py:52-53: np.random.normal(phred_to_prob(30), 0.01, RL) then prob_to_phred.  (The position-addressable
+         * mode below inverts the distribution of that score instead -- the model's quality rows hold it, the same
+         * at every position: insilicoseq_amd/model.py basic_phred_cdf -- one uniform per position like a KDE row.) */
         double mean = 1.0 - pow(10.0, -(double)m->basic_mean_quality / 10.0);
         for (int p = 0; p < RL; p++) {
             double q = iss_oracle_np_normal(r, mean, 0.01);

@@ -81,11 +81,11 @@ def test_worker_files_equal_reference(case, tmp_path):
 
 
 def test_generate_cli_basic_mode_equals_reference(tmp_path):
-    """`--mode basic` (BasicErrorModel on the device, MT mode implied) == `iss generate --mode basic --cpus 2`."""
+    """`--mode basic --rng mt` (BasicErrorModel on the device) == `iss generate --mode basic --cpus 2`."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "run")
     subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes",
-                           os.path.join(GOLDEN, "genomes.fasta"), "--mode", "basic", "-n", "400", "--seed", "42",
+                           os.path.join(GOLDEN, "genomes.fasta"), "--mode", "basic", "--rng", "mt", "-n", "400", "--seed", "42",
                            "--cpus", "2", "--devices", "1", "-o", out, "--quiet"], cwd=root)
     z = np.load(os.path.join(GOLDEN, "generate", "genomes_basic_n400_seed42_cpus2.npz"))
     assert open(out + "_abundance.txt", "rb").read() == z["abundance"].tobytes()

@@ -65,6 +65,11 @@ CASES = [
     ("novaseq", (1.0, 0.0), lambda: random_genome(28, 5000), 200, 22, 0, "metagenomics", False),
     ("novaseq", (0.0, 1.0), lambda: random_genome(29, 5000), 200, 23, 0, "metagenomics", False),
     ("novaseq", (1.0, 1.0), lambda: mixed_genome(30, 5000), 200, 24, 0, "amplicon", False),
+    # BasicErrorModel on the Philox path (basic.py:40-63): its score distribution as the quality rows, constant insert size
+    ("basic", None, lambda: random_genome(32, 150000), 5000, 25, 0, "metagenomics", False),
+    ("basic", None, lambda: mixed_genome(33, 20000), 3000, 26, 2**35 + 3, "metagenomics", True),
+    ("basic", None, lambda: random_genome(34, 460), 1500, 27, 0, "amplicon", False),
+    ("basic", None, lambda: random_genome(35, 300), 1000, 28, 0, "metagenomics", False),  # record < fragment: generator.py:144
 ]
 
 
@@ -792,6 +797,27 @@ def test_randomized_worker_lists(k, tmp_path):
     assert open(prefix + ".vcf").read() == evcf
 
 
+@pytest.mark.parametrize("frag", [None, (420.0, 25.0)])
+def test_basic_model_worker_philox(frag, tmp_path):
+    """`--mode basic` through the drop-in boundary on the parallel (Philox) path: FASTQ text and VCF == oracle."""
+    from insilicoseq_amd.generator import Record, worker_iterator
+    from insilicoseq_amd.model import BasicErrorModel
+
+    dense = dense_model("basic")
+    recs = [Record(random_genome(1200 + i, L), id="b%d" % i) for i, L in enumerate([5000, 126, 90, 40000, 700])]
+    counts = [800, 300, 5, 2500, 64]
+    em = BasicErrorModel(*(frag or (None, None)), True)
+    seed, cpu = 77, 3
+    prefix = str(tmp_path / "w")
+    worker_iterator([(x, n, "default") for x, n in zip(recs, counts)], em, cpu, prefix, seed, "metagenomics", False, device=0,
+                    rng="philox")
+    e1, e2, evcf = _expected_worker_files(dense, recs, counts, seed, cpu, "philox", "metagenomics", False, frag, tmp_path)
+    assert open(prefix + "_R1.fastq", "rb").read() == e1
+    assert open(prefix + "_R2.fastq", "rb").read() == e2
+    assert open(prefix + ".vcf").read() == evcf
+    assert e1.count(b"\n") == 4 * (800 + 300 + 2500 + 64)  # (the 90-base record is skipped: generator.py:130)
+
+
 def test_worker_drops_resident_genomes_over_budget(tmp_path, monkeypatch):
     """A work list larger than the HBM budget for genomes: uploaded records are dropped and the files do not change."""
     from insilicoseq_amd import generator as G
@@ -932,15 +958,22 @@ def test_letters_outside_the_rev_comp_alphabet_are_rejected(length):
         eng.close()
 
 
-@pytest.mark.parametrize("case", ["novaseq", "hiseq_gc", "miseq_mixed", "ecoli_amplicon", "indel", "novaseq_vcf"])
-def test_generate_batch_equals_consecutive_calls(case):
+@pytest.mark.parametrize("case", ["novaseq", "hiseq_gc", "miseq_mixed", "ecoli_amplicon", "indel", "novaseq_vcf",
+                                  "novaseq_frag_vcf", "basic_frag_guard", "hiseq_mixed_frag_gc"])
+def test_generate_batch_equals_consecutive_calls(case, monkeypatch):
     """iss_generate_batch (one set of launches for a work list) == consecutive iss_generate calls: bases, phreds,
     record coordinates, mutation rows; records repeated in the list, records with IUPAC / lower-case letters, zero-pair
-    items, gc_bias, amplicon mode, an indel-heavy model (every other read through the fix-up kernel)."""
+    items, gc_bias, amplicon mode, an indel-heavy model (every other read through the fix-up kernel), custom fragment
+    lengths (negative inserts, templates cut by the record's end; "guard": four pairs in ten get their fragment length
+    from the host and are set up again)."""
     from insilicoseq_amd.engine import ReadEngine
     from helpers import synthetic_model
 
-    model = {"novaseq": "novaseq", "hiseq_gc": "hiseq", "miseq_mixed": "miseq", "ecoli_amplicon": "ecoli", "novaseq_vcf": "novaseq"}.get(case)
+    model = {"novaseq": "novaseq", "hiseq_gc": "hiseq", "miseq_mixed": "miseq", "ecoli_amplicon": "ecoli", "novaseq_vcf": "novaseq",
+             "novaseq_frag_vcf": "novaseq", "basic_frag_guard": "basic", "hiseq_mixed_frag_gc": "hiseq"}.get(case)
+    frag = {"novaseq_frag_vcf": (330.0, 40.0), "basic_frag_guard": (420.0, 90.0), "hiseq_mixed_frag_gc": (500.0, 5.0)}.get(case)
+    if "guard" in case:
+        monkeypatch.setenv("ISS_MT_GUARD", "0.2")
     dense = synthetic_model(151, 41, 1000, 4, indel=(1e-3, 3e-3)) if case == "indel" else dense_model(model)
     genomes = [random_genome(300, 30000), mixed_genome(301, 9000) if "mixed" in case else random_genome(301, 9000),
                random_genome(302, 700), mixed_genome(303, 52000) if "mixed" in case else random_genome(303, 52000)]
@@ -952,6 +985,8 @@ def test_generate_batch_equals_consecutive_calls(case):
         eng = ReadEngine(0)
         try:
             eng.load_model(dense)
+            if frag:
+                eng.set_fragment(*frag)
             if "vcf" in case or case == "indel":
                 eng.mutations_reserve(1 << 23)  # (slots are handed out in chunks of 256 per wavefront)
             gids = [eng.add_genome(g) for g in genomes]

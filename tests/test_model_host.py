@@ -107,3 +107,51 @@ def test_dense_loaded_model_honours_in_place_edits():
     em3 = KDErrorModel(os.path.join(root, "insilicoseq_amd", "profiles", "ecoli.dense.npz"))
     em3.del_for[0]["A"] = 1.0
     assert em3.dense().dele[0, 0, 0] == 1.0
+
+
+def test_basic_phred_cdf_is_the_distribution_of_the_reference_expression():
+    """BasicErrorModel on the position-addressable path: the quality rows hold P(phred <= k) of
+    prob_to_phred(min(np.random.normal(phred_to_prob(q), 0.01), 0.9999)) (basic.py:52-53, util.py:44)."""
+    from insilicoseq_amd.model import basic_phred_cdf, basic_prob_to_phred, phred_to_prob
+
+    for mean_q in (30, 20):
+        cdf = basic_phred_cdf(mean_q)
+        assert cdf.shape == (41,) and cdf[-1] == 1.0 and (np.diff(cdf) >= 0).all() and cdf[0] == 0.0
+        x = np.random.RandomState(5).normal(phred_to_prob(mean_q), 0.01, 400000)
+        ph = np.array([basic_prob_to_phred(v) for v in x[:20000]])  # the scalar expression, as the reference evaluates it
+        vec = np.round(-10 * np.log10(1 - np.minimum(x, 0.9999))).astype(int)
+        assert (vec[:20000] == ph).all()
+        emp = np.array([(vec <= k).mean() for k in range(41)])
+        assert np.abs(emp - cdf).max() < 4e-3  # ~5 sigma of a 400 000-sample proportion
+        assert ph.max() <= 40
+    # every step of the score sits where the table says: Phi^-1 is not needed, check the boundaries themselves
+    import math
+    cdf = basic_phred_cdf(30)
+    mean = float(phred_to_prob(30))
+    for k in range(10, 40):
+        if not 0.0 < cdf[k] < 1.0:
+            continue
+        # invert Phi by bisection to get b_k back from the table, then the reference expression must step there
+        lo, hi = mean - 0.2, mean + 0.2
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            if 0.5 * math.erfc(-((mid - mean) / 0.01) / math.sqrt(2.0)) < cdf[k]:
+                lo = mid
+            else:
+                hi = mid
+        assert basic_prob_to_phred(lo - 1e-9) <= k < basic_prob_to_phred(hi + 1e-9)
+
+
+def test_basic_dense_model_carries_the_rows_and_round_trips(tmp_path):
+    from insilicoseq_amd.model import basic_phred_cdf
+
+    d = DenseModel.basic()
+    assert d.quality_mode == 1 and d.read_length == 125 and d.basic_insert_size == 200
+    row = basic_phred_cdf(30)
+    assert (d.qcdf == row).all()  # every position, bin and mate
+    p = str(tmp_path / "basic.npz")
+    d.save(p)
+    e = DenseModel.load(p)
+    assert e.quality_mode == 1 and (e.qcdf == d.qcdf).all()
+    t = d.device_tables()
+    assert (t["q_thr"][0, 0, 0] == np.floor(row * 2.0**53).astype(np.uint64)).all()
