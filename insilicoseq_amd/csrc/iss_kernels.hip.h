@@ -974,10 +974,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     __syncthreads();
     const uint32_t ns = (uint32_t)M.n_scan;
     const uint32_t n_items = (uint32_t)A.n_pairs * ns;
-    const uint32_t step = gridDim.x * blockDim.x;
+    // a workgroup takes a CONTIGUOUS range of lane-items, i.e. of pairs: the reads it lists at a flush are neighbours in
+    // every per-pair array (descriptors, flags, event lists, output rows), and k_indel_apply walks the list in order --
+    // its wavefronts then share cache lines, DRAM pages and TLB entries instead of touching one of each per read
+    const uint32_t step = blockDim.x;
     const uint32_t step_pair = step / ns, step_e = step - step_pair * ns;
-    const uint32_t first = blockIdx.x * blockDim.x;
-    const uint32_t n_iter = n_items > first ? (n_items - first + step - 1) / step : 0;  // uniform in the workgroup
+    const uint32_t n_iter = ((n_items + gridDim.x - 1) / gridDim.x + step - 1) / step;  // the same in every workgroup
+    const uint32_t first = blockIdx.x * n_iter * step;
+    const uint32_t last = min(n_items, first + n_iter * step);
     uint32_t it = first + threadIdx.x;
     uint32_t pair = it / ns, e = it - pair * ns;
     uint32_t since_flush = 0;
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
         }
     };
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
-        if (it < n_items) {
+        if (it < last) {
             const uint32_t *tab = tab0 + e * SCAN_W;
             const uint32_t c2 = tab[0];
             // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
@@ -1103,7 +1107,7 @@ constexpr int APPLY_WAVES = 4;    // wavefronts (2 reads each) per workgroup
 #ifndef ISS_APPLY_OCC
 #define ISS_APPLY_OCC 4           // wavefronts per SIMD the register budget is cut for (measured: 3 -> 4: -20 % time)
 #endif
-constexpr int APPLY_ITEMS = 512;  // batch calls: item_first of up to this many work items is cached in LDS
+constexpr int APPLY_ITEMS = 512;  // batch calls: the table of up to this many work items is cached in LDS (beyond: global loads)
 constexpr int16_t FIX_NONE = 0x7fff;
 
 __host__ __device__ inline int apply_tl(int pitch) { return pitch + 8; }  // staged template positions: a read of <= EV_K events reaches <= EV_K past its end
@@ -1112,9 +1116,10 @@ __host__ __device__ inline size_t apply_wave_bytes(int pitch) {
     //           + events (4 * EV_K * 2)
     return 2 * ((size_t)apply_tl(pitch) + 3 * (size_t)pitch + 4 * EV_K + 2 * (size_t)pitch + 8 * EV_K);
 }
-// [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+1 i64][per wave]
+// [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 i64][items APPLY_ITEMS][per wave]
+__host__ __device__ inline size_t apply_items_bytes() { return (APPLY_ITEMS + 2) * 8 + APPLY_ITEMS * sizeof(BatchItem); }
 __host__ __device__ inline size_t apply_tab_bytes(int RL) {
-    return 256 + (size_t)2 * RL * 4 * 4 + (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + (APPLY_ITEMS + 2) * 8;
+    return 256 + (size_t)2 * RL * 4 * 4 + (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + apply_items_bytes();
 }
 __host__ __device__ inline size_t apply_lds_bytes(int RL, int pitch) { return apply_tab_bytes(RL) + APPLY_WAVES * apply_wave_bytes(pitch); }
 
@@ -1126,7 +1131,8 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     uint32_t *mut8 = reinterpret_cast<uint32_t *>(apply_lds);  // [64] leading 8 bits of the substitution-test thresholds
     uint32_t *sub13 = mut8 + 64;                                // [2][RL][4] (see DevModel::subst13, position-major here)
     uint8_t *insl = reinterpret_cast<uint8_t *>(sub13 + 2 * RL * 4);  // [2][RL][4]
-    int64_t *ifirst = reinterpret_cast<int64_t *>(apply_lds + apply_tab_bytes(RL) - (APPLY_ITEMS + 2) * 8);
+    int64_t *ifirst = reinterpret_cast<int64_t *>(apply_lds + apply_tab_bytes(RL) - apply_items_bytes());
+    BatchItem *l_items = reinterpret_cast<BatchItem *>(ifirst + APPLY_ITEMS + 2);
     const uint32_t n_list = *A.read_count;
     if (blockIdx.x * APPLY_WAVES * 2 >= n_list) return;  // whole workgroup idle (uniform)
     for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut8[i] = (uint32_t)(M.mut_thr[i] >> 45);
@@ -1137,7 +1143,10 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         insl[i] = M.ins_letter[i];
     }
     const bool items_cached = A.items && A.n_items <= APPLY_ITEMS;
-    if (items_cached) for (int i = threadIdx.x; i <= A.n_items; i += blockDim.x) ifirst[i] = A.item_first[i];
+    if (items_cached) {
+        for (int i = threadIdx.x; i <= A.n_items; i += blockDim.x) ifirst[i] = A.item_first[i];
+        for (int i = threadIdx.x; i < A.n_items; i += blockDim.x) l_items[i] = A.items[i];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hf = lane >> 5, hl = lane & 31;  // half of the wavefront, lane within the half
@@ -1163,15 +1172,23 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     PairDesc d_a = desc[ra >> 1];
     uint32_t fl_a = A.flags[ra >> 1], cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
     uint32_t evw_a = hl < EV_K ? A.ev_list[(size_t)ra * EV_K + hl] : 0u;
+    // (the read's phreds hang on the read number only: requested with the rest; rows are padded to `pitch`)
+    auto phreds_of = [&](uint32_t r) {
+        return *reinterpret_cast<const uint2 *>(A.out[0] + (size_t)(r >> 1) * M.row + (row_array_off(2 * (int)(r & 1u) + 1) + xp(min(hl * 8, pitch - 8))));
+    };
+    uint2 q8_a = phreds_of(ra);
+    int item_k = 0;  // the work item of the half's previous read: the list is in pair order, more or less
     for (uint32_t li = li0; li < n_list; li += stride) {
         const uint32_t pair = ra >> 1;
         const int o = (int)(ra & 1u);  // mate
         PairDesc d = d_a;
         const uint32_t fl = fl_a, cnt_raw = cnt_a, evw = evw_a;
+        uint2 q8 = q8_a;
         {   // requests for the next two iterations
             rd_a = rd_b;
             if (rd_a != NO_READ) ra = rd_a;
             d_a = desc[ra >> 1];
+            q8_a = phreds_of(ra);
             fl_a = A.flags[ra >> 1];
             cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
             evw_a = hl < EV_K ? A.ev_list[(size_t)ra * EV_K + hl] : 0u;
@@ -1180,16 +1197,18 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         DevGenome gl = g;  // the record of the pair: the launch's genome, or its slice of the arena (batch calls)
         int64_t arena_off = 0;
         if (A.items) {
-            int k;
+            BatchItem it;
             if (items_cached) {
-                int lo = 0, hi = A.n_items;  // largest k with item_first[k] <= p
                 const int64_t p = A.pair_base + pair;
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ifirst[mid] <= p) lo = mid; else hi = mid; }
-                k = lo;
+                if (!(ifirst[item_k] <= p && p < ifirst[item_k + 1])) {
+                    int lo = 0, hi = A.n_items;  // largest k with item_first[k] <= p
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ifirst[mid] <= p) lo = mid; else hi = mid; }
+                    item_k = lo;
+                }
+                it = l_items[item_k];
             } else {
-                k = batch_item_of(A, A.pair_base + pair);
+                it = A.items[batch_item_of(A, A.pair_base + pair)];
             }
-            const BatchItem it = A.items[k];
             gl = batch_genome(g, it);
             arena_off = it.off;
             d.fs -= (int32_t)it.off;
@@ -1201,9 +1220,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         const MateGeom geo = mate_geom(o, d, RL, gl.L);
         uint8_t *out_base = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
         const uint8_t *out_qual = out_base + (row_array_off(1) - row_array_off(0));
-        // ---- requests of this read: its phreds and its genome window (used after the event sort and the Philox blocks)
-        uint2 q8 = {0u, 0u};
-        if (cnt && hl * 8 < pitch) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(hl * 8));
+        // ---- request of this read: its genome window (used after the event sort and the Philox blocks)
         uint2 gw = {0u, 0u};
         bool fast = false;
         {
