@@ -23,7 +23,9 @@ def main(src, tag):
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     stats = glob.glob(src + "/stats/*kernel_stats.csv")[0]
     with open(stats) as fh, open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as out:
-        out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline\n")
+        cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else \
+            "python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+        out.write("# rocprofv3 --kernel-trace --stats -- %s\n" % cmd)
         out.write(fh.read())
     acc, calls = counters(src)
     lines = ["# rocprofv3 --pmc <counters> --kernel-trace (separate passes), same bench command; totals over all dispatches",
@@ -32,6 +34,8 @@ def main(src, tag):
         for c in sorted(acc[k]):
             lines.append("%s,%s,%.6g,%.6g,%d" % (k, c, acc[k][c], acc[k][c] / calls[k][c], calls[k][c]))
     open(os.path.join(out_dir, tag + "_pmc.csv"), "w").write("\n".join(lines) + "\n")
+    if not any("FETCH_SIZE" in acc[k] for k in acc):  # tools/prof_indel.sh: SQ counters only, no traffic pass
+        return
     # HBM-side traffic of k_main per launch, corrected per MI355X_MICROARCH.md (FETCH_SIZE x2 for coalesced
     # reads, calibrated here on k_read_dwordx2; WRITE_SIZE x1, calibrated on k_fill_dword); unit KiB
     cal = {}

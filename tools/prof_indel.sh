@@ -3,6 +3,7 @@
 TAG=${1:-indel}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
+echo "python bench.py --indel 0.001 0.003 --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end" > $OUT/command.txt
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --indel 0.001 0.003 --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- $BENCH > $OUT/stats.log 2>&1
