@@ -83,6 +83,12 @@ __device__ __forceinline__ uint64_t lo37(const u32x4 &v, int pair) {
     return pair ? (((uint64_t)v.z << 5) | (v.w >> 27)) : (((uint64_t)v.x << 5) | (v.y >> 27));
 }
 __device__ __forceinline__ uint64_t mk_digit(uint32_t h16, uint64_t l37) { return ((uint64_t)h16 << 37) | l37; }
+// indel draws: m = (d8 << 45) | l45 -- sixteen 8-bit leading digits to a primary block
+__device__ __forceinline__ uint32_t digit8(const u32x4 &v, int d) { return (word_of(v, d >> 2) >> (8 * (d & 3))) & 0xffu; }
+__device__ __forceinline__ uint64_t lo45(const u32x4 &v, int pair) {
+    return pair ? (((uint64_t)v.z << 13) | (v.w >> 19)) : (((uint64_t)v.x << 13) | (v.y >> 19));
+}
+__device__ __forceinline__ uint64_t mk_digit8(uint32_t d8, uint64_t l45) { return ((uint64_t)d8 << 45) | l45; }
 
 // Output rows.  A pair owns ONE row of M.row bytes (a multiple of 128).  The 32 read positions 32 l .. 32 l + 31 are the
 // 128-byte line l of the row: bytes 0-63 the forward mate, 64-127 the reverse mate, each four 16-byte pieces
@@ -123,7 +129,7 @@ struct DevModel {
     const uint64_t *mut_thr;      // [n_q+1]
     const uint8_t *ins_any;       // [2][RL] any insertion threshold non-zero at (o, n)
     const uint32_t *fix_tab;      // [2][RL][8] (thr >> 37) + 1 of the 4 insertion + 4 deletion thresholds, 0 = zero probability
-    const uint32_t *scan_tab;      // [n_scan][SCAN_W]: groups of 4 loop steps with a non-zero indel probability (k_indel_scan)
+    const uint32_t *scan_tab;      // [n_scan][SCAN_W]: Philox blocks of indel digits with a non-zero probability (k_indel_scan)
     int32_t n_scan;
     // reference-compatible MT mode, k_mt_resolve (iss_mt_compat.hip.h)
     int32_t mt_row_w;             // 32-bit words per row of mt_rows (odd)
@@ -185,7 +191,6 @@ struct RunArgs {
     int32_t gc_bias;
     uint64_t gc_thr;  // ceil(0.90 * 2^53): accept iff m < gc_thr (generator.py:88)
     uint8_t *out[4];  // rows of this launch: R1 base, R1 qual, R2 base, R2 qual (out[k] = out[0] + row_array_off(k), see xp())
-    int32_t scan_every;  // k_indel_scan: flush period (iterations), chosen from the model's indel probabilities
     // custom fragment length (generator.py:121-123): fragment = int(mu + sd * gaussian), per-pair polar Box-Muller
     int32_t has_frag;
     double frag_mu, frag_sd, frag_guard;
@@ -942,39 +947,44 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
 }
 
 // ================================================================== k_indel_scan
-// One lane per (pair, Philox block holding an indel digit with a non-zero probability): exactly one block and eight
-// compares per lane-item, no divergence between the lanes of a wavefront whatever mix of table entries they hold.  The
-// limits (digit < lim  <=>  candidate; lim = (thr >> 37) + 1, 0 = never; max over bases for deletions) sit in LDS.
+// One lane per (pair, Philox block holding an indel digit with a non-zero probability): exactly one block and sixteen
+// byte compares per lane-item (a K_INS block: the 2 x 4 letter slots of two loop steps of both mates; a K_DEL block:
+// eight loop steps of both mates), no divergence between the lanes of a wavefront whatever mix of table entries they
+// hold.  The limits (digit < lim  <=>  candidate; lim = (thr >> 45) + 1, 0 = never; max over bases for deletions) sit in LDS.
 // A candidate is then decided exactly (rare): per (mate, loop step) the 8-bit EVENT MASK of the reference's loop --
 // bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b (__init__.py:193-196,
 // :209) -- and a non-empty mask is appended to the read's event list (EV_K words, step << 8 | mask).  k_indel_apply
 // replays the lists; no event => provably no indel, k_main's output stands.  A read with more than EV_K events goes to
-// the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  Reads with an event are collected in a
-// workgroup-local LDS list that is appended to the global read list with ONE atomic per flush.
-constexpr int SCAN_W = 9;         // words per table entry (odd: bank-conflict free): [0] kind << 24 | index,
-                                  // [1..8] limits of the block's 8 digits
+// the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  The reads a settling round lists reach the global read
+// list with one atomic per mate.
+constexpr int SCAN_W = 17;        // words per table entry (odd: bank-conflict free): [0] kind << 24 | index,
+                                  // [1..16] limits of the block's 16 digits
 constexpr int SCAN_THREADS = 512;
-constexpr int SCAN_CAND = 1024;   // candidate lane-items of the LDS buffer; flushed every RunArgs::scan_every iterations,
-                                  // chosen on the host from the model's indel probabilities (a candidate that finds
-                                  // the buffer full is settled on the spot)
+constexpr int SCAN_RING = 128;    // candidate lane-items a wavefront can hold (a private ring: 64 pending + 64 new at most)
+constexpr int SCAN_LIST = 256;    // newly listed reads a wavefront collects before they go to the global list (one atomic
+                                  // per >= 128 reads: a counter everybody adds to takes ~10 ns per add)
 constexpr int EV_K = 8;           // events kept per read
 constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
                                        // bits 4-5 mate is in read_list
+__host__ __device__ inline size_t scan_lds_bytes(int n_scan, int RL) {
+    return ((size_t)(SCAN_THREADS / 64) * (SCAN_RING * 2 + SCAN_LIST) + (size_t)n_scan * SCAN_W + (size_t)2 * RL * 8) * 4;
+}
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *l_count = lds;      // [0] candidates in the buffer, [1] newly listed reads, [2] global base of the current flush
-    uint2 *l_cand = reinterpret_cast<uint2 *>(lds + 4);  // SCAN_CAND x {pair, table entry << 8 | digits below their limits}
-    uint32_t *l_reads = lds + 4 + 2 * SCAN_CAND;         // newly listed reads (2 * pair + mate) of a flush: <= 2 per candidate
-    uint32_t *tab0 = l_reads + 2 * SCAN_CAND;
+    // candidates (a digit below its limit -- with 8-bit digits mostly ties of the leading digit, one lane-item in
+    // twenty): a private ring per wavefront, no atomics, no barriers; settled 64 at a time, one lane per candidate
+    uint2 *ring = reinterpret_cast<uint2 *>(lds) + (threadIdx.x >> 6) * SCAN_RING;  // {pair, table entry}
+    uint32_t *l_list = lds + (SCAN_THREADS / 64) * SCAN_RING * 2 + (threadIdx.x >> 6) * SCAN_LIST;  // this wavefront's newly listed reads
+    uint32_t *tab0 = lds + (SCAN_THREADS / 64) * (SCAN_RING * 2 + SCAN_LIST);
     uint32_t *fix0 = tab0 + M.n_scan * SCAN_W;  // [2][RL][8]: digit limits of the 4 insertion slots and the 4 bases' deletions
     for (int i = threadIdx.x; i < M.n_scan * SCAN_W; i += blockDim.x) tab0[i] = M.scan_tab[i];
     for (int i = threadIdx.x; i < 2 * M.RL * 8; i += blockDim.x) fix0[i] = M.fix_tab[i];
-    if (threadIdx.x < 2) l_count[threadIdx.x] = 0;
     __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ns = (uint32_t)M.n_scan;
     const uint32_t n_items = (uint32_t)A.n_pairs * ns;
-    // a workgroup takes a CONTIGUOUS range of lane-items, i.e. of pairs: the reads it lists at a flush are neighbours in
+    // a workgroup takes a CONTIGUOUS range of lane-items, i.e. of pairs: the reads a wavefront lists are neighbours in
     // every per-pair array (descriptors, flags, event lists, output rows), and k_indel_apply walks the list in order --
     // its wavefronts then share cache lines, DRAM pages and TLB entries instead of touching one of each per read
     const uint32_t step = blockDim.x;
@@ -984,32 +994,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     const uint32_t last = min(n_items, first + n_iter * step);
     uint32_t it = first + threadIdx.x;
     uint32_t pair = it / ns, e = it - pair * ns;
-    uint32_t since_flush = 0;
-    // One candidate lane-item, exactly (dense at flush time: one lane per candidate): the event masks of its (mate, step)s
-    // -- bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b -- go to their
-    // reads' lists; a read's first event lists it in l_reads.
-    auto settle = [&](uint32_t c_pair, uint32_t c_e, uint32_t hit) {
-        const uint32_t c2 = tab0[c_e * SCAN_W];
+    uint32_t q_head = 0, q_tail = 0, n_listed = 0;  // wave-uniform
+    const uint32_t NO_READ = 0xffffffffu;
+    // One candidate lane-item, exactly: the event masks of its (mate, step)s -- bits 0-3 insertion of letter slot x
+    // fires, bits 4-7 the deletion fires if the token is base b -- go to their reads' lists; a read's first event lists
+    // it (listed[mate]: the lane-item's steps belong to one pair).
+    auto settle = [&](uint32_t c_pair, uint32_t c_e, uint32_t (&listed)[2]) {
+        const uint32_t *tab = tab0 + c_e * SCAN_W;
+        const uint32_t c2 = tab[0];
         const Addr a = make_addr(A.seed, A.first_ordinal + c_pair, A.gc_bias ? desc[c_pair].meta >> 16 : 0u);
         const u32x4 w = philox4x32_10(a.c0, a.c1, c2, 0u, a.k0, a.k1);
+        uint32_t hit = 0;  // bit d: digit d is below its limit
+#pragma unroll
+        for (int dgt = 0; dgt < 16; ++dgt) hit |= (digit8(w, dgt) < tab[1 + dgt] ? 1u : 0u) << dgt;
         const bool is_del = (c2 >> 24) == K_DEL;
         const int idx = (int)(c2 & 0xffffffu);
         while (hit) {
             const int dg = __ffs(hit) - 1;
             hit &= hit - 1u;
-            // digit -> (mate, step): K_DEL (n & 3) * 2 + mate, K_INS mate * 4 + slot
-            const int o = is_del ? dg & 1 : dg >> 2;
-            const int n = is_del ? idx * 4 + (dg >> 1) : idx;
-            const uint32_t h = digit16(w, dg);
+            // digit -> (mate, step): K_DEL (n & 7) * 2 + mate, K_INS (n & 1) * 8 + mate * 4 + slot
+            const int o = is_del ? dg & 1 : (dg >> 2) & 1;
+            const int n = is_del ? idx * 8 + (dg >> 1) : idx * 2 + (dg >> 3);
+            const uint32_t h = digit8(w, dg);
             const uint32_t *t8 = fix0 + ((uint32_t)o * (uint32_t)M.RL + (uint32_t)n) * 8u;
             const size_t en = (size_t)o * M.RL + n;
             uint32_t m8 = 0;
             if (is_del) {  // (:209)
                 for (int b = 0; b < 4; ++b) {
-                    const uint32_t lim = t8[4 + b];  // (thr >> 37) + 1, 0 = zero probability
+                    const uint32_t lim = t8[4 + b];  // (thr >> 45) + 1, 0 = zero probability
                     bool fire = h + 1u < lim;
                     if (lim && h + 1u == lim)  // tie of the leading digit: exact
-                        fire = mk_digit(h, lo37(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < M.del_thr[en * 4 + b];
+                        fire = mk_digit8(h, lo45(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < M.del_thr[en * 4 + b];
                     if (fire) m8 |= 16u << b;
                 }
             } else {  // (:193-196)
@@ -1018,7 +1033,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
                 bool fire = h + 1u < lim;
                 if (lim && h + 1u == lim) {
                     const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)n, (uint32_t)(o * 2 + (x >> 1)));
-                    fire = mk_digit(h, lo37(l, x & 1)) < M.ins_thr[en * 4 + x];
+                    fire = mk_digit8(h, lo45(l, x & 1)) < M.ins_thr[en * 4 + x];
                 }
                 if (fire) m8 = 1u << x;
             }
@@ -1027,64 +1042,70 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
             const uint32_t at = atomicAdd(&A.ev_count[rd], 1u);
             if (at < (uint32_t)EV_K) {
                 A.ev_list[(size_t)rd * EV_K + at] = ((uint32_t)n << 8) | m8;
-                if (!(atomicOr(&A.flags[c_pair], FLAG_LISTED << o) & (FLAG_LISTED << o))) {
-                    const uint32_t lp = atomicAdd(&l_count[1], 1u);
-                    if (lp < 2u * (uint32_t)SCAN_CAND) l_reads[lp] = rd;
-                    else A.read_list[atomicAdd(A.read_count, 1u)] = rd;
-                }
+                if (!(atomicOr(&A.flags[c_pair], FLAG_LISTED << o) & (FLAG_LISTED << o))) listed[o] = rd;
             } else if (at == (uint32_t)EV_K) {  // too many events for the list: the wavefront-per-read kernel takes the read
                 if (!(atomicOr(&A.flags[c_pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
             }
         }
     };
+    auto flush_list = [&]() {  // this wavefront's newly listed reads -> the global list: one atomic
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A.read_count, n_listed);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < n_listed; i += 64u) A.read_list[base + i] = l_list[i];
+        n_listed = 0;
+    };
+    // the first n <= 64 pending candidates, one per lane
+    auto drain = [&](uint32_t n) {
+        uint32_t listed[2] = {NO_READ, NO_READ};
+        if (lane < n) {
+            const uint2 c = ring[(q_head + lane) & (SCAN_RING - 1)];
+            settle(c.x, c.y, listed);
+        }
+        q_head += n;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const unsigned long long m = __ballot(listed[o] != NO_READ);
+            if (!m) continue;
+            if (listed[o] != NO_READ)
+                l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = listed[o];
+            n_listed += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (n_listed >= (uint32_t)SCAN_LIST / 2) flush_list();  // (< 128 before the round + <= 2 x 64 new: fits)
+    };
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
+        unsigned long long any = 0;
         if (it < last) {
             const uint32_t *tab = tab0 + e * SCAN_W;
             const uint32_t c2 = tab[0];
             // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
             const Addr a = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
             const u32x4 w = philox4x32_10(a.c0, a.c1, c2, 0u, a.k0, a.k1);
-            // any digit below its limit?  Eight half-word compares whose lane masks the scalar unit ORs; the bit mask of
-            // the digits is only formed for a candidate
-            const unsigned long long any =
-                __builtin_amdgcn_ballot_w64((w.x & 0xffffu) < tab[1]) | __builtin_amdgcn_ballot_w64((w.x >> 16) < tab[2]) |
-                __builtin_amdgcn_ballot_w64((w.y & 0xffffu) < tab[3]) | __builtin_amdgcn_ballot_w64((w.y >> 16) < tab[4]) |
-                __builtin_amdgcn_ballot_w64((w.z & 0xffffu) < tab[5]) | __builtin_amdgcn_ballot_w64((w.z >> 16) < tab[6]) |
-                __builtin_amdgcn_ballot_w64((w.w & 0xffffu) < tab[7]) | __builtin_amdgcn_ballot_w64((w.w >> 16) < tab[8]);
-            if ((any >> (threadIdx.x & 63u)) & 1ull) {  // rare: remembered, settled when the buffer is flushed (one lane per candidate then)
-                uint32_t hit = 0;  // bit d: digit d is below its limit
-#pragma unroll
-                for (int dgt = 0; dgt < 8; ++dgt) hit |= (digit16(w, dgt) < tab[1 + dgt] ? 1u : 0u) << dgt;
-                const uint32_t at = atomicAdd(&l_count[0], 1u);
-                if (at < (uint32_t)SCAN_CAND) l_cand[at] = make_uint2(pair, (e << 8) | hit);
-                else settle(pair, e, hit);  // buffer full (rates far above the host's estimate)
-            }
+            // any digit below its limit?  Sixteen byte compares whose lane masks the scalar unit ORs
+#define ISS_SCAN_B(W, K) __builtin_amdgcn_ballot_w64(((W >> (8 * ((K) & 3))) & 0xffu) < tab[1 + (K)])
+            any = ISS_SCAN_B(w.x, 0) | ISS_SCAN_B(w.x, 1) | ISS_SCAN_B(w.x, 2) | ISS_SCAN_B(w.x, 3) |
+                  ISS_SCAN_B(w.y, 4) | ISS_SCAN_B(w.y, 5) | ISS_SCAN_B(w.y, 6) | ISS_SCAN_B(w.y, 7) |
+                  ISS_SCAN_B(w.z, 8) | ISS_SCAN_B(w.z, 9) | ISS_SCAN_B(w.z, 10) | ISS_SCAN_B(w.z, 11) |
+                  ISS_SCAN_B(w.w, 12) | ISS_SCAN_B(w.w, 13) | ISS_SCAN_B(w.w, 14) | ISS_SCAN_B(w.w, 15);
+#undef ISS_SCAN_B
         }
-        if (++since_flush == (uint32_t)A.scan_every || iter == n_iter - 1) {
-            since_flush = 0;
-            __syncthreads();
-            const uint32_t n_c = min(l_count[0], (uint32_t)SCAN_CAND);
-            for (uint32_t i = threadIdx.x; i < n_c; i += blockDim.x) {
-                const uint2 c = l_cand[i];
-                settle(c.x, c.y >> 8, c.y & 0xffu);
+        any = __builtin_amdgcn_ballot_w64((any >> lane) & 1ull);  // (lanes past the range hold 0; the result is wave-uniform)
+        if (any) {
+            if ((any >> lane) & 1ull) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                ring[(q_tail + rank) & (SCAN_RING - 1)] = make_uint2(pair, e);
             }
-            __syncthreads();
-            const uint32_t n_new = min(l_count[1], 2u * (uint32_t)SCAN_CAND);
-            if (n_new) {  // the reads listed for the first time: ONE global atomic
-                if (threadIdx.x == 0) l_count[2] = atomicAdd(A.read_count, n_new);
-                __syncthreads();
-                const uint32_t base = l_count[2];
-                for (uint32_t i = threadIdx.x; i < n_new; i += blockDim.x) A.read_list[base + i] = l_reads[i];
-            }
-            __syncthreads();
-            if (threadIdx.x < 2) l_count[threadIdx.x] = 0;
-            __syncthreads();
+            q_tail += (uint32_t)__popcll(any);
+            while (q_tail - q_head >= 64u) drain(64u);
         }
         it += step;
         pair += step_pair;
         e += step_e;
         if (e >= ns) { e -= ns; ++pair; }
     }
+    if (q_tail != q_head) drain(q_tail - q_head);
+    if (n_listed) flush_list();
 }
 
 // ================================================================== k_indel_apply
@@ -1483,11 +1504,11 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
         uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.row;
         const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.row;
         // ---- phase 0: the digits that several steps / positions share, one Philox block per LANE (a K_DEL block holds
-        //      the deletion digits of 4 steps, a K_QM block the error-test digits of 2 positions)
-        for (int b = lane; b * 4 < RL - 1; b += 64) {
+        //      the deletion digits of 8 steps, a K_QM block the error-test digits of 8 positions)
+        for (int b = lane; b * 8 < RL - 1; b += 64) {
             const u32x4 w = draw_block(a, K_DEL, (uint32_t)b, 0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ddel[b * 4 + c] = (uint16_t)digit16(w, c * 2 + o);
+            for (int c = 0; c < 8; ++c) ddel[b * 8 + c] = (uint16_t)digit8(w, c * 2 + o);
         }
         for (int b = lane; b * 8 < RL; b += 64) {
             const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 1);
@@ -1505,14 +1526,14 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
                 const uint32_t *t8 = tab + ((size_t)o * RL + n) * 8;
                 const size_t en = (size_t)o * RL + n;
                 if (t8[0] | t8[1] | t8[2] | t8[3]) {  // :193-196
-                    const u32x4 w = draw_block(a, K_INS, (uint32_t)n, 0);
+                    const u32x4 w = draw_block(a, K_INS, (uint32_t)n >> 1, 0);
                     for (int x = 0; x < 4; ++x) {
                         if (!t8[x]) continue;  // zero probability
-                        const uint32_t h = digit16(w, o * 4 + x), th = t8[x] - 1u;
+                        const uint32_t h = digit8(w, (n & 1) * 8 + o * 4 + x), th = t8[x] - 1u;
                         bool hit = h < th;
                         if (h == th) {  // tie of the leading digit: exact
                             const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)n, (uint32_t)(o * 2 + (x >> 1)));
-                            hit = mk_digit(h, lo37(l, x & 1)) < M.ins_thr[en * 4 + x];
+                            hit = mk_digit8(h, lo45(l, x & 1)) < M.ins_thr[en * 4 + x];
                         }
                         if (hit) m8 |= 1u << x;
                     }
@@ -1523,7 +1544,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
                         if (!t8[4 + b]) continue;
                         const uint32_t th = t8[4 + b] - 1u;
                         bool hit = h < th;
-                        if (h == th) hit = mk_digit(h, lo37(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < M.del_thr[en * 4 + b];
+                        if (h == th) hit = mk_digit8(h, lo45(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < M.del_thr[en * 4 + b];
                         if (hit) m8 |= 16u << b;
                     }
                 }

@@ -184,7 +184,6 @@ struct iss_ctx {
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
     uint32_t *ev_count = nullptr, *ev_list = nullptr, *read_list = nullptr;  // indel events (k_indel_scan -> k_indel_apply), per row
     uint32_t *read_count = nullptr;  // FIX_SLOTS counters of the read lists, like fix_count
-    int scan_every = 8;
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
     // custom fragment length on the Philox path
     bool has_frag = false;
@@ -995,40 +994,32 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             ins_any[e] = im ? 1 : 0;
         }
     // k_indel_scan table: one entry per Philox block that holds a digit with a non-zero limit -- the K_DEL block of a
-    // group of 4 loop steps n <= RL-2 (__init__.py:187; digit (n & 3) * 2 + mate) or the K_INS block of one step
-    // (digit mate * 4 + letter slot).  Entry = [kind << 24 | index, 8 limits]; limit = (thr >> 37) + 1, 0 = never.
+    // group of 8 loop steps n <= RL-2 (__init__.py:187; digit (n & 7) * 2 + mate) or the K_INS block of two steps
+    // (digit (n & 1) * 8 + mate * 4 + letter slot).  Entry = [kind << 24 | index, 16 limits]; limit = (thr >> 45) + 1,
+    // 0 = never.
     std::vector<uint32_t> scan_tab;
-    auto lim = [](uint64_t T) { return T ? (uint32_t)(T >> 37) + 1u : 0u; };
-    auto push_block = [&](uint32_t kind, uint32_t index, const uint32_t lims[8]) {
+    auto lim = [](uint64_t T) { return T ? (uint32_t)(T >> 45) + 1u : 0u; };
+    auto push_block = [&](uint32_t kind, uint32_t index, const uint32_t lims[16]) {
         bool any = false;
-        for (int k = 0; k < 8; ++k) any |= lims[k] != 0;
+        for (int k = 0; k < 16; ++k) any |= lims[k] != 0;
         if (!any) return;
         scan_tab.push_back((kind << 24) | index);
-        scan_tab.insert(scan_tab.end(), lims, lims + 8);
+        scan_tab.insert(scan_tab.end(), lims, lims + 16);
     };
-    for (int gI = 0; gI * 4 <= RL - 2; ++gI) {
-        uint32_t dl[8] = {0};
-        for (int c = 0; c < 4 && gI * 4 + c <= RL - 2; ++c)
-            for (int o = 0; o < 2; ++o) dl[c * 2 + o] = lim(del_max[(size_t)o * RL + gI * 4 + c]);
+    for (int gI = 0; gI * 8 <= RL - 2; ++gI) {
+        uint32_t dl[16] = {0};
+        for (int c = 0; c < 8 && gI * 8 + c <= RL - 2; ++c)
+            for (int o = 0; o < 2; ++o) dl[c * 2 + o] = lim(del_max[(size_t)o * RL + gI * 8 + c]);
         push_block(iss::K_DEL, (uint32_t)gI, dl);
-        for (int c = 0; c < 4 && gI * 4 + c <= RL - 2; ++c) {
-            uint32_t il[8];
-            for (int o = 0; o < 2; ++o)
-                for (int x = 0; x < 4; ++x) il[o * 4 + x] = lim(t->ins_thr[((size_t)o * RL + gI * 4 + c) * 4 + x]);
-            push_block(iss::K_INS, (uint32_t)(gI * 4 + c), il);
+        for (int c2 = 0; c2 < 4 && gI * 8 + c2 * 2 <= RL - 2; ++c2) {
+            uint32_t il[16] = {0};
+            for (int c = 0; c < 2 && gI * 8 + c2 * 2 + c <= RL - 2; ++c)
+                for (int o = 0; o < 2; ++o)
+                    for (int x = 0; x < 4; ++x) il[c * 8 + o * 4 + x] = lim(t->ins_thr[((size_t)o * RL + gI * 8 + c2 * 2 + c) * 4 + x]);
+            push_block(iss::K_INS, (uint32_t)(gI * 4 + c2), il);
         }
     }
     M.n_scan = (int32_t)(scan_tab.size() / iss::SCAN_W);
-    {   // expected flagged mates per scan item -> flush period of the LDS list (half-full on average)
-        double rate = 0;
-        for (size_t e = 0; e + iss::SCAN_W <= scan_tab.size(); e += iss::SCAN_W)
-            for (int k = 1; k <= 8; ++k) rate += (double)scan_tab[e + k] / 65536.0;
-        rate = M.n_scan ? rate / M.n_scan : 0.0;
-        const double per_iter = std::max(rate, 1e-6) * iss::SCAN_THREADS;
-        // (`rate` = expected events per lane-item; the period keeps the LDS buffer about half full on average, and an
-        //  event that finds it full goes to its list directly)
-        ctx->scan_every = (int)std::max(1.0, std::min(512.0, 0.5 * iss::SCAN_CAND / per_iter));
-    }
     std::vector<uint32_t> fix_tab((size_t)2 * RL * 8);
     for (size_t e = 0; e < (size_t)2 * RL; ++e)
         for (int x = 0; x < 4; ++x) {
@@ -1318,7 +1309,6 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.gc_bias = gc_bias ? 1 : 0;
         A.gc_thr = 8106479329266893ull;  // ceil(0.90 * 2^53), 0.90 being the f64 nearest to 0.9
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.row;
-        A.scan_every = ctx->scan_every;
         iss::PairDesc *desc = ctx->desc + row0;
         uint32_t *flags = ctx->flags + row0;
         uint32_t *fix_list = ctx->fix_list + 2 * row0;
@@ -1464,7 +1454,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                 const uint64_t items = (uint64_t)n * M.n_scan;
                 const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4,
                                                                      (items + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
-                const size_t lds = (4 + (size_t)4 * iss::SCAN_CAND + (size_t)M.n_scan * iss::SCAN_W + (size_t)2 * M.RL * 8) * 4;
+                const size_t lds = iss::scan_lds_bytes(M.n_scan, M.RL);
                 hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), lds, s_indel, M, A, desc);
             }
             HIP_TRY(ctx, mark(4, s_indel));

@@ -93,10 +93,10 @@ __global__ __launch_bounds__(64) void k_unit_indels(DevModel M, UnitArgs U, cons
         if (cu == 'R' || cu == 'Y' || cu == 'W' || cu == 'S' || cu == 'M' || cu == 'K' || cu == 'H' || cu == 'B' || cu == 'V' ||
             cu == 'D' || cu == 'N') { ++position; continue; }  // :190-192
         const size_t en = (size_t)o * RL + position;
-        const u32x4 wi = draw_block(a, K_INS, (uint32_t)position, 0);
+        const u32x4 wi = draw_block(a, K_INS, (uint32_t)position >> 1, 0);
         for (int x = 0; x < 4; ++x) {  // :193-196, dict order
             const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)position, (uint32_t)(2 * o + (x >> 1)));
-            if (mk_digit(digit16(wi, 4 * o + x), lo37(l, x & 1)) < M.ins_thr[en * 4 + x]) {
+            if (mk_digit8(digit8(wi, (position & 1) * 8 + 4 * o + x), lo45(l, x & 1)) < M.ins_thr[en * 4 + x]) {
                 for (int z = n_s; z > position + 1; --z) s[z] = s[z - 1];  // insert after the base read
                 s[position + 1] = M.ins_letter[en * 4 + x];
                 ++n_s;
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(64) void k_unit_indels(DevModel M, UnitArgs U, cons
         }
         const int bi = base_index(cu);
         if (bi < 0) { rc = 2; break; }  // deletions[position][X]: KeyError (:209)
-        const u32x4 wd = draw_block(a, K_DEL, (uint32_t)position >> 2, 0);
-        const uint64_t m = mk_digit(digit16(wd, (position & 3) * 2 + o), lo37(draw_block(a, K_DEL_LO, (uint32_t)position, 0), o));
+        const u32x4 wd = draw_block(a, K_DEL, (uint32_t)position >> 3, 0);
+        const uint64_t m = mk_digit8(digit8(wd, (position & 7) * 2 + o), lo45(draw_block(a, K_DEL_LO, (uint32_t)position, 0), o));
         if (m < M.del_thr[en * 4 + bi]) {
             for (int z = position; z + 1 < n_s; ++z) s[z] = s[z + 1];
             --n_s;

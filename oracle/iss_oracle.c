@@ -143,8 +143,8 @@ void iss_oracle_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t
  * A "digit draw" builds its 53-bit numerator as m = (digit << (53 - w)) | trailing bits: the w-bit leading
  * digit comes from a PRIMARY block shared by many draws (the device compares digits and needs three Philox
  * calls per 16 bases), the trailing bits from a SECONDARY block that the device only evaluates when the
- * digit ties with a threshold's.  w = 16 for the quality, insertion and deletion draws, 8 for the
- * substitution test (kde.py:84, __init__.py:94, :194, :209).  u = m / 2^53 exactly. */
+ * digit ties with a threshold's.  w = 16 for the quality draw, 8 for the substitution test and for the insertion
+ * and deletion draws (kde.py:84, __init__.py:94, :194, :209).  u = m / 2^53 exactly. */
 enum {
     K_PAIR = 0,   /* index 0; full draws mk53(sub0.word[s], sub1.word[s]), s = isize, bin_fwd, bin_rev, gc */
     K_FS = 1,     /* forward-start randbelow words: word t -> index t/4, word t%4        */
@@ -155,11 +155,11 @@ enum {
                    * half*2 + mate, byte cc.                                                        */
     K_SUB = 4,    /* index = p, sub = mate: (w0,w1) substitution choice (full draw); the 45 trailing bits of the
                    * error-test draw = (w2 & 0x1fff) << 32 | w3                                      */
-    K_INS = 5,    /* primary digits; index = n; digit mate*4 + letter slot               */
-    K_DEL = 6,    /* primary digits; index = n>>2; digit (n&3)*2 + mate                   */
+    K_INS = 5,    /* primary digits (8 bits); index = n>>1; digit (n&1)*8 + mate*4 + slot */
+    K_DEL = 6,    /* primary digits (8 bits); index = n>>3; digit (n&7)*2 + mate          */
     K_QM_LO = 7,  /* trailing 37 bits of the quality draw; index = p; sub = mate; (w0,w1)  */
-    K_INS_LO = 8, /* secondary; index = n; sub = mate*2 + (slot>>1); pair slot&1          */
-    K_DEL_LO = 9, /* secondary; index = n; sub 0; (w0,w1) fwd, (w2,w3) rev                */
+    K_INS_LO = 8, /* secondary (45 bits); index = n; sub = mate*2 + (slot>>1); pair slot&1 */
+    K_DEL_LO = 9, /* secondary (45 bits); index = n; sub 0; (w0,w1) fwd, (w2,w3) rev       */
     K_FRAG = 10   /* custom fragment length: polar candidate t -> index t; x1 from mk53(w0,w1), x2 from mk53(w2,w3) */
 };
 
@@ -245,19 +245,18 @@ static double draw_double(iss_rng *r, int stream, int kind, uint32_t index, uint
     return res53(w[2 * slot], w[2 * slot + 1]);
 }
 
-/* Digit draw (see the enum comment): primary block (kind_p, index_p, 0) digit `digit`,
- * secondary block (kind_l, index_l, sub_l) word pair `pair_l`. */
-static double draw_digit(iss_rng *r, int stream, int kind_p, uint32_t index_p, int digit, int kind_l,
-                         uint32_t index_l, uint32_t sub_l, int pair_l) {
+/* Indel draws: an 8-bit leading digit (16 to a primary block: indel probabilities are tiny, one Philox block decides 16
+ * tests at once and the 45 trailing bits are looked at on a tie of the leading digit only) + 45 bits of a secondary block. */
+static double draw_digit8(iss_rng *r, int stream, int kind_p, uint32_t index_p, int digit, int kind_l,
+                          uint32_t index_l, uint32_t sub_l, int pair_l) {
     if (r->mode == ISS_RNG_MT)
         return stream == STREAM_PY ? iss_oracle_py_random(r) : iss_oracle_np_random(r);
     uint32_t wp[4], wl[4];
     philox_at(r, kind_p, index_p, 0, wp);
     philox_at(r, kind_l, index_l, sub_l, wl);
-    uint64_t h16 = (wp[digit >> 1] >> (16 * (digit & 1))) & 0xffffu;
-    uint64_t l37 = ((uint64_t)wl[2 * pair_l] << 5) | (wl[2 * pair_l + 1] >> 27);
-    uint64_t m = (h16 << 37) | l37;
-    return (double)m * (1.0 / 9007199254740992.0);
+    uint64_t d8 = (wp[digit >> 2] >> (8 * (digit & 3))) & 0xffu;
+    uint64_t l45 = ((uint64_t)wl[2 * pair_l] << 13) | (wl[2 * pair_l + 1] >> 19);
+    return (double)((d8 << 45) | l45) * (1.0 / 9007199254740992.0);
 }
 
 /* The two hot draws of read position p of mate o (see K_QM / K_SUB / K_QM_LO in the enum). */
@@ -433,8 +432,8 @@ static int introduce_indels(const iss_model *m, iss_rng *r, int o, const uint8_t
         const double *insp = m->ins + ((size_t)o * RL + position) * 4;
         const uint8_t *insl = m->ins_letter + ((size_t)o * RL + position) * 4;
         for (int x = 0; x < 4; x++) { /* :193-196, dict order */
-            double u = draw_digit(r, STREAM_PY, K_INS, (uint32_t)position, 4 * o + x, K_INS_LO, (uint32_t)position,
-                                  (uint32_t)(2 * o + (x >> 1)), x & 1);
+            double u = draw_digit8(r, STREAM_PY, K_INS, (uint32_t)position >> 1, (position & 1) * 8 + 4 * o + x, K_INS_LO,
+                                   (uint32_t)position, (uint32_t)(2 * o + (x >> 1)), x & 1);
             if (u < insp[x]) {
                 memmove(s + position + 2, s + position + 1, (size_t)(n_s - position - 1));
                 s[position + 1] = insl[x];
@@ -445,8 +444,8 @@ static int introduce_indels(const iss_model *m, iss_rng *r, int o, const uint8_t
         }
         int bi = base_index(cu);
         if (bi < 0) { free(s); return ISS_ERR_KEY; } /* deletions[position][X] KeyError :209 */
-        double u = draw_digit(r, STREAM_PY, K_DEL, (uint32_t)position >> 2, (position & 3) * 2 + o, K_DEL_LO,
-                              (uint32_t)position, 0, o);
+        double u = draw_digit8(r, STREAM_PY, K_DEL, (uint32_t)position >> 3, (position & 7) * 2 + o, K_DEL_LO,
+                               (uint32_t)position, 0, o);
         if (u < m->del[((size_t)o * RL + position) * 4 + bi]) {
             memmove(s + position, s + position + 1, (size_t)(n_s - position - 1));
             n_s--;
