@@ -967,17 +967,19 @@ constexpr int EV_K = 8;           // events kept per read
 constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
                                        // bits 4-5 mate is in read_list
 __host__ __device__ inline size_t scan_lds_bytes(int n_scan, int RL) {
-    return ((size_t)(SCAN_THREADS / 64) * (SCAN_RING * 2 + SCAN_LIST) + (size_t)n_scan * SCAN_W + (size_t)2 * RL * 8) * 4;
+    return ((size_t)(SCAN_THREADS / 64) * (SCAN_RING * 2 + SCAN_LIST) + (size_t)n_scan * SCAN_W + (size_t)2 * RL * 8 + 1) * 4;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
+__global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // candidates (a digit below its limit -- with 8-bit digits mostly ties of the leading digit, one lane-item in
     // twenty): a private ring per wavefront, no atomics, no barriers; settled 64 at a time, one lane per candidate
-    uint2 *ring = reinterpret_cast<uint2 *>(lds) + (threadIdx.x >> 6) * SCAN_RING;  // {pair, table entry}
-    uint32_t *l_list = lds + (SCAN_THREADS / 64) * SCAN_RING * 2 + (threadIdx.x >> 6) * SCAN_LIST;  // this wavefront's newly listed reads
-    uint32_t *tab0 = lds + (SCAN_THREADS / 64) * (SCAN_RING * 2 + SCAN_LIST);
+    // (the table first: its reads then need no address arithmetic beyond the entry's offset)
+    uint32_t *tab0 = lds;
     uint32_t *fix0 = tab0 + M.n_scan * SCAN_W;  // [2][RL][8]: digit limits of the 4 insertion slots and the 4 bases' deletions
+    uint32_t *wave0 = fix0 + 2 * M.RL * 8 + (((M.n_scan * SCAN_W) & 1) ? 1 : 0);  // (8-byte aligned)
+    uint2 *ring = reinterpret_cast<uint2 *>(wave0) + (threadIdx.x >> 6) * SCAN_RING;  // {pair, byte offset of the table entry}
+    uint32_t *l_list = wave0 + (SCAN_THREADS / 64) * SCAN_RING * 2 + (threadIdx.x >> 6) * SCAN_LIST;  // this wavefront's newly listed reads
     for (int i = threadIdx.x; i < M.n_scan * SCAN_W; i += blockDim.x) tab0[i] = M.scan_tab[i];
     for (int i = threadIdx.x; i < 2 * M.RL * 8; i += blockDim.x) fix0[i] = M.fix_tab[i];
     __syncthreads();
@@ -993,14 +995,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     const uint32_t first = blockIdx.x * n_iter * step;
     const uint32_t last = min(n_items, first + n_iter * step);
     uint32_t it = first + threadIdx.x;
-    uint32_t pair = it / ns, e = it - pair * ns;
+    uint32_t pair = it / ns;
+    uint32_t eb = (it - pair * ns) * (uint32_t)(SCAN_W * 4);  // byte offset of the lane-item's table entry
+    const uint32_t ns_b = ns * (uint32_t)(SCAN_W * 4), step_eb = step_e * (uint32_t)(SCAN_W * 4);
     uint32_t q_head = 0, q_tail = 0, n_listed = 0;  // wave-uniform
     const uint32_t NO_READ = 0xffffffffu;
     // One candidate lane-item, exactly: the event masks of its (mate, step)s -- bits 0-3 insertion of letter slot x
     // fires, bits 4-7 the deletion fires if the token is base b -- go to their reads' lists; a read's first event lists
     // it (listed[mate]: the lane-item's steps belong to one pair).
-    auto settle = [&](uint32_t c_pair, uint32_t c_e, uint32_t (&listed)[2]) {
-        const uint32_t *tab = tab0 + c_e * SCAN_W;
+    auto settle = [&](uint32_t c_pair, uint32_t c_eb, uint32_t (&listed)[2]) {
+        const uint32_t *tab = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab0) + c_eb);
         const uint32_t c2 = tab[0];
         const Addr a = make_addr(A.seed, A.first_ordinal + c_pair, A.gc_bias ? desc[c_pair].meta >> 16 : 0u);
         const u32x4 w = philox4x32_10(a.c0, a.c1, c2, 0u, a.k0, a.k1);
@@ -1077,7 +1081,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     for (uint32_t iter = 0; iter < n_iter; ++iter) {
         unsigned long long any = 0;
         if (it < last) {
-            const uint32_t *tab = tab0 + e * SCAN_W;
+            const uint32_t *tab = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab0) + eb);
             const uint32_t c2 = tab[0];
             // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
             const Addr a = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
@@ -1094,15 +1098,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
         if (any) {
             if ((any >> lane) & 1ull) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                ring[(q_tail + rank) & (SCAN_RING - 1)] = make_uint2(pair, e);
+                ring[(q_tail + rank) & (SCAN_RING - 1)] = make_uint2(pair, eb);
             }
             q_tail += (uint32_t)__popcll(any);
             while (q_tail - q_head >= 64u) drain(64u);
         }
         it += step;
         pair += step_pair;
-        e += step_e;
-        if (e >= ns) { e -= ns; ++pair; }
+        eb += step_eb;
+        if (eb >= ns_b) { eb -= ns_b; ++pair; }
     }
     if (q_tail != q_head) drain(q_tail - q_head);
     if (n_listed) flush_list();
