@@ -1267,7 +1267,9 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t n_act = cnt;
-        {   // rank = events with a smaller step, or the same step and a smaller index (the walk merges equal steps)
+        if (!__builtin_amdgcn_ballot_w64(cnt > 1u)) {  // (most reads: one event)
+            if (hl == 0 && cnt) ev_srt[0] = evw;
+        } else {  // rank = events with a smaller step, or the same step and a smaller index (the walk merges equal steps)
             uint32_t rank = 0;
             for (uint32_t i = 0; i < (uint32_t)EV_K; ++i) {
                 const uint32_t other = ev_raw[i];
@@ -1376,7 +1378,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                 int shift = carry + incl - lane_sum;
                 carry += __shfl(incl, 31, 32);
                 if (!in) continue;
-                uint32_t ob0 = 0u, ob1 = 0u, cand = 0u;  // cand: positions whose substitution test fires or ties
+                uint32_t ob0 = 0u, ob1 = 0u, cand = 0u;  // cand: bit 7 - c <=> the substitution test of position j0 + c fires or ties
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const int j = j0 + c;
@@ -1388,12 +1390,13 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                     const int base = tok >= 0 ? from_tmpl : -tok;
                     const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
                     const uint32_t q = ((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu;
-                    cand |= (j < RL && e8 >= mut8[q & 63u] ? 1u : 0u) << c;
+                    cand = shift_in(cand, __builtin_amdgcn_ballot_w64(e8 >= mut8[q & 63u]));
                     if (c < 4) ob0 |= (uint32_t)base << (8 * c); else ob1 |= (uint32_t)base << (8 * (c - 4));
                 }
+                cand &= 0xffu & ~(0xffu >> min(max(RL - j0, 0), 8));  // positions inside the read
                 while (cand) {  // rare per lane: the substitution test fires or ties (__init__.py:94)
-                    const int c = __ffs(cand) - 1;
-                    cand &= cand - 1u;
+                    const int c = __clz(cand) - 24;
+                    cand &= ~(0x80u >> c);
                     const int j = j0 + c;
                     const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
                     const int q = (int)(((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu);
