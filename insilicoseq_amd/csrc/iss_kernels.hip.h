@@ -259,7 +259,7 @@ __device__ __forceinline__ void mut_emit(const RunArgs &A, MutChunk &c, bool hav
     if (have && at != 0xffffffffu) A.mut[at + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = r;
 }
 
-// one row from one lane (the two halves of a k_indel_apply wavefront walk different mates: no wave-uniform chunk there)
+// one row from one lane (the groups of a k_indel_apply wavefront walk different reads: no wave-uniform chunk there)
 __device__ __forceinline__ void mut_emit1(const RunArgs &A, const MutRecord &r) {
     const uint32_t at = atomicAdd(A.mut_count, 1u);
     if (at < A.mut_cap) A.mut[at] = r;
@@ -1113,22 +1113,23 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
 }
 
 // ================================================================== k_indel_apply
-// One half-wavefront (32 lanes) per listed READ -- a mate with at least one event; the two halves of a wavefront take
-// neighbouring list entries, whatever pairs and mates those are, so no lane idles on an event-free mate.  introduce_indels
+// GL lanes (16; 32 for read lengths beyond 248) per listed READ -- a mate with at least one event; the 64 / GL groups of
+// a wavefront take neighbouring list entries, whatever pairs and mates those are, so no lane idles on an event-free mate
+// and the per-read bookkeeping (requests, geometry, sort, walk) is shared by four reads.  introduce_indels
 // + adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
 // prefix [0, n) is final when step n starts; the not-yet-visited suffix is (stack of freshly inserted letters, LIFO)
 // ++ E(k), E(k+1), ...
 //   1. the read's events: sorted by step, masks of one step merged
 //   2. (all lanes) the template E(0 .. pitch+7) into LDS, 8 bases per lane from the 2-bit genome; the error-test digits
 //      (one Philox block per 8 positions)
-//   3. the walk over the steps with an event (the two reads side by side, one per half): explicit map[] entries for
+//   3. the walk over the steps with an event (the reads of the wavefront side by side, one per group): explicit map[] entries for
 //      those steps and for the steps that drain the insertion stack, "from step n0 on, source index = k0 + (n - n0)"
 //      records for everything in between
 //   4. (all lanes, 8 positions each) token -> base -> mut_sequence -> one 8-byte store
 // A pair is a chain of dependent loads (list entry -> descriptor, events, phreds -> genome windows) behind a write
 // stream, i.e. microseconds of latency: the list entry is requested two reads ahead, everything its address needs only
 // the read number for one read ahead, and the tables the walk and the substitutions read sit in LDS.
-constexpr int APPLY_WAVES = 4;    // wavefronts (2 reads each) per workgroup
+constexpr int APPLY_WAVES = 4;    // wavefronts (64 / GL reads each) per workgroup
 #ifndef ISS_APPLY_OCC
 #define ISS_APPLY_OCC 4           // wavefronts per SIMD the register budget is cut for (measured: 3 -> 4: -20 % time)
 #endif
@@ -1136,22 +1137,26 @@ constexpr int APPLY_ITEMS = 512;  // batch calls: the table of up to this many w
 constexpr int16_t FIX_NONE = 0x7fff;
 
 __host__ __device__ inline int apply_tl(int pitch) { return pitch + 8; }  // staged template positions: a read of <= EV_K events reaches <= EV_K past its end
-__host__ __device__ inline size_t apply_wave_bytes(int pitch) {
-    // per mate: tmpl (tl) + dqm (pitch) + stk (pitch + 4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + map (2 * pitch)
+__host__ __device__ inline int apply_gl(int pitch) { return apply_tl(pitch) <= 256 ? 16 : 32; }  // lanes per read: two passes of 8 positions per lane at most
+__host__ __device__ inline size_t apply_read_bytes(int pitch) {
+    // per read: tmpl (tl) + dqm (pitch) + stk (pitch + 4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + map (2 * pitch)
     //           + events (4 * EV_K * 2)
-    return 2 * ((size_t)apply_tl(pitch) + 3 * (size_t)pitch + 4 * EV_K + 2 * (size_t)pitch + 8 * EV_K);
+    return (size_t)apply_tl(pitch) + 3 * (size_t)pitch + 4 * EV_K + 2 * (size_t)pitch + 8 * EV_K;
 }
+__host__ __device__ inline size_t apply_wave_bytes(int pitch, int GL) { return (size_t)(64 / GL) * apply_read_bytes(pitch); }
 // [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 i64][items APPLY_ITEMS][per wave]
 __host__ __device__ inline size_t apply_items_bytes() { return (APPLY_ITEMS + 2) * 8 + APPLY_ITEMS * sizeof(BatchItem); }
 __host__ __device__ inline size_t apply_tab_bytes(int RL) {
     return 256 + (size_t)2 * RL * 4 * 4 + (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + apply_items_bytes();
 }
-__host__ __device__ inline size_t apply_lds_bytes(int RL, int pitch) { return apply_tab_bytes(RL) + APPLY_WAVES * apply_wave_bytes(pitch); }
+__host__ __device__ inline size_t apply_lds_bytes(int RL, int pitch, int GL) { return apply_tab_bytes(RL) + APPLY_WAVES * apply_wave_bytes(pitch, GL); }
 
-template <bool STORE_MUT>
+template <bool STORE_MUT, int GL>
 __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply(DevModel M, DevGenome g, RunArgs A,
                                                                   const PairDesc *__restrict__ desc, uint64_t *stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t apply_lds[];
+    constexpr int NG = 64 / GL;           // reads per wavefront
+    constexpr int NP = GL == 32 ? 1 : 2;  // passes (8 positions per lane each) whose genome window and phreds are requested ahead
     const int RL = M.RL, pitch = M.pitch, TL = apply_tl(pitch);
     uint32_t *mut8 = reinterpret_cast<uint32_t *>(apply_lds);  // [64] leading 8 bits of the substitution-test thresholds
     uint32_t *sub13 = mut8 + 64;                                // [2][RL][4] (see DevModel::subst13, position-major here)
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     int64_t *ifirst = reinterpret_cast<int64_t *>(apply_lds + apply_tab_bytes(RL) - apply_items_bytes());
     BatchItem *l_items = reinterpret_cast<BatchItem *>(ifirst + APPLY_ITEMS + 2);
     const uint32_t n_list = *A.read_count;
-    if (blockIdx.x * APPLY_WAVES * 2 >= n_list) return;  // whole workgroup idle (uniform)
+    if (blockIdx.x * APPLY_WAVES * NG >= n_list) return;  // whole workgroup idle (uniform)
     for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut8[i] = (uint32_t)(M.mut_thr[i] >> 45);
     for (int i = threadIdx.x; i < 2 * RL * 4; i += blockDim.x) {
         const int o = i / (RL * 4), r = i - o * RL * 4, p = r >> 2, bi = r & 3;
@@ -1174,9 +1179,9 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int hf = lane >> 5, hl = lane & 31;  // half of the wavefront, lane within the half
-    uint8_t *wave0 = apply_lds + apply_tab_bytes(RL) + (size_t)wv * apply_wave_bytes(pitch);
-    uint8_t *wbase = wave0 + (size_t)hf * (apply_wave_bytes(pitch) / 2);
+    const int rg = lane / GL, rl = lane % GL;  // group (read) of the wavefront, lane within the group
+    uint8_t *wave0 = apply_lds + apply_tab_bytes(RL) + (size_t)wv * apply_wave_bytes(pitch, GL);
+    uint8_t *wbase = wave0 + (size_t)rg * apply_read_bytes(pitch);
     uint8_t *tmpl = wbase;                                  // [TL]
     uint8_t *dqm = tmpl + TL;                               // [pitch] error-test digit (8 bits) of position j
     uint8_t *stk = dqm + pitch;                             // [pitch + 4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
@@ -1186,38 +1191,40 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     uint32_t *ev_srt = ev_raw + EV_K;                       // [EV_K]
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);
     uint64_t n_reads = 0;
-    const uint32_t stride = gridDim.x * APPLY_WAVES * 2;
-    const uint32_t li0 = (blockIdx.x * APPLY_WAVES + wv) * 2;  // the wavefront's first two list entries (one per half)
-    // software pipeline: the list entry two reads ahead, what hangs on the read number one read ahead.  (A half past the end
+    const uint32_t stride = gridDim.x * APPLY_WAVES * NG;
+    const uint32_t li0 = (blockIdx.x * APPLY_WAVES + wv) * NG;  // the wavefront's first list entries (one per group)
+    // software pipeline: the list entry two reads ahead, what hangs on the read number one read ahead.  (A group past the end
     // of the list repeats the last entry with no events.)
     const uint32_t NO_READ = 0xffffffffu;
-    uint32_t rd_a = li0 + hf < n_list ? A.read_list[li0 + hf] : NO_READ;                      // read of iteration `li`
-    uint32_t rd_b = li0 + stride + hf < n_list ? A.read_list[li0 + stride + hf] : NO_READ;   // ... of `li + stride`
+    uint32_t rd_a = li0 + rg < n_list ? A.read_list[li0 + rg] : NO_READ;                      // read of iteration `li`
+    uint32_t rd_b = li0 + stride + rg < n_list ? A.read_list[li0 + stride + rg] : NO_READ;   // ... of `li + stride`
     uint32_t ra = rd_a == NO_READ ? 0u : rd_a;
     PairDesc d_a = desc[ra >> 1];
     uint32_t fl_a = A.flags[ra >> 1], cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
-    uint32_t evw_a = hl < EV_K ? A.ev_list[(size_t)ra * EV_K + hl] : 0u;
+    uint32_t evw_a = rl < EV_K ? A.ev_list[(size_t)ra * EV_K + rl] : 0u;
     // (the read's phreds hang on the read number only: requested with the rest; rows are padded to `pitch`)
-    auto phreds_of = [&](uint32_t r) {
-        return *reinterpret_cast<const uint2 *>(A.out[0] + (size_t)(r >> 1) * M.row + (row_array_off(2 * (int)(r & 1u) + 1) + xp(min(hl * 8, pitch - 8))));
+    auto phreds_of = [&](uint32_t r, int pass) {
+        return *reinterpret_cast<const uint2 *>(A.out[0] + (size_t)(r >> 1) * M.row +
+                                                (row_array_off(2 * (int)(r & 1u) + 1) + xp(min((rl + pass * GL) * 8, pitch - 8))));
     };
-    uint2 q8_a = phreds_of(ra);
+    uint2 q8_a0 = phreds_of(ra, 0), q8_a1 = NP > 1 ? phreds_of(ra, 1) : make_uint2(0u, 0u);
     int item_k = 0;  // the work item of the half's previous read: the list is in pair order, more or less
     for (uint32_t li = li0; li < n_list; li += stride) {
         const uint32_t pair = ra >> 1;
         const int o = (int)(ra & 1u);  // mate
         PairDesc d = d_a;
         const uint32_t fl = fl_a, cnt_raw = cnt_a, evw = evw_a;
-        uint2 q8 = q8_a;
+        const uint2 q8_0 = q8_a0, q8_1 = q8_a1;
         {   // requests for the next two iterations
             rd_a = rd_b;
             if (rd_a != NO_READ) ra = rd_a;
             d_a = desc[ra >> 1];
-            q8_a = phreds_of(ra);
+            q8_a0 = phreds_of(ra, 0);
+            if (NP > 1) q8_a1 = phreds_of(ra, 1);
             fl_a = A.flags[ra >> 1];
             cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
-            evw_a = hl < EV_K ? A.ev_list[(size_t)ra * EV_K + hl] : 0u;
-            rd_b = li + 2 * stride + hf < n_list ? A.read_list[li + 2 * stride + hf] : NO_READ;
+            evw_a = rl < EV_K ? A.ev_list[(size_t)ra * EV_K + rl] : 0u;
+            rd_b = li + 2 * stride + rg < n_list ? A.read_list[li + 2 * stride + rg] : NO_READ;
         }
         DevGenome gl = g;  // the record of the pair: the launch's genome, or its slice of the arena (batch calls)
         int64_t arena_off = 0;
@@ -1245,22 +1252,26 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         const MateGeom geo = mate_geom(o, d, RL, gl.L);
         uint8_t *out_base = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
         const uint8_t *out_qual = out_base + (row_array_off(1) - row_array_off(0));
-        // ---- request of this read: its genome window (used after the event sort and the Philox blocks)
-        uint2 gw = {0u, 0u};
-        bool fast = false;
-        {
+        // ---- requests of this read: its genome windows (used after the event sort and the Philox blocks)
+        uint2 gw0 = {0u, 0u}, gw1 = {0u, 0u};
+        uint32_t fast = 0;  // bit p: the lane's 8 template positions of pass p come from its window
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
             // E(k) = g[fs + k] / comp(g[re - 1 - k]) for template and padding alike as long as the position is inside the
             // record (regular geometry: the mates of irregular pairs are k_indel_fixup's)
-            const int k0 = hl * 8;
+            const int k0 = (rl + pass * GL) * 8;
             const int64_t g0 = o == 0 ? geo.lo + k0 : geo.hi - 8 - k0;  // lowest genome position of the lane's 8 bases
-            fast = cnt && k0 < TL && geo.t_len == RL && g0 >= 0 && g0 + 8 <= gl.L && !gl.has_exceptions;
-            if (fast) gw = *reinterpret_cast<const uint2 *>(packed_b + (size_t)((((g0 + arena_off) >> 4) + 1) << 2));
+            const bool f = cnt && k0 < TL && geo.t_len == RL && g0 >= 0 && g0 + 8 <= gl.L && !gl.has_exceptions;
+            uint2 w = {0u, 0u};
+            if (f) w = *reinterpret_cast<const uint2 *>(packed_b + (size_t)((((g0 + arena_off) >> 4) + 1) << 2));
+            if (pass == 0) gw0 = w; else gw1 = w;
+            fast |= (f ? 1u : 0u) << pass;
         }
         // ---- 1. events: sorted by step, one word per step
-        if (hl < EV_K) ev_raw[hl] = evw;
-        for (int j = hl * 4; j < pitch; j += 128) *reinterpret_cast<uint2 *>(map + j) = make_uint2(0x7fff7fffu, 0x7fff7fffu);  // FIX_NONE
-        for (int j = hl * 8; j < pitch; j += 256) *reinterpret_cast<uint2 *>(dsh + j) = make_uint2(0u, 0u);
-        for (int b = hl; cnt && b * 8 < pitch; b += 32) {  // one Philox block holds the digits of 8 positions (of both mates)
+        if (rl < EV_K) ev_raw[rl] = evw;
+        for (int j = rl * 4; j < pitch; j += GL * 4) *reinterpret_cast<uint2 *>(map + j) = make_uint2(0x7fff7fffu, 0x7fff7fffu);  // FIX_NONE
+        for (int j = rl * 8; j < pitch; j += GL * 8) *reinterpret_cast<uint2 *>(dsh + j) = make_uint2(0u, 0u);
+        for (int b = rl; cnt && b * 8 < pitch; b += GL) {  // one Philox block holds the digits of 8 positions (of both mates)
             const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 1);
             *reinterpret_cast<uint2 *>(dqm + b * 8) = o == 0 ? make_uint2(w.x, w.z) : make_uint2(w.y, w.w);
         }
@@ -1268,20 +1279,21 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         __builtin_amdgcn_wave_barrier();
         const uint32_t n_act = cnt;
         if (!__builtin_amdgcn_ballot_w64(cnt > 1u)) {  // (most reads: one event)
-            if (hl == 0 && cnt) ev_srt[0] = evw;
+            if (rl == 0 && cnt) ev_srt[0] = evw;
         } else {  // rank = events with a smaller step, or the same step and a smaller index (the walk merges equal steps)
             uint32_t rank = 0;
             for (uint32_t i = 0; i < (uint32_t)EV_K; ++i) {
                 const uint32_t other = ev_raw[i];
-                rank += (i < cnt && ((other >> 8) < (evw >> 8) || ((other >> 8) == (evw >> 8) && (int)i < hl))) ? 1u : 0u;
+                rank += (i < cnt && ((other >> 8) < (evw >> 8) || ((other >> 8) == (evw >> 8) && (int)i < rl))) ? 1u : 0u;
             }
-            if (hl < (int)cnt) ev_srt[rank] = evw;
+            if (rl < (int)cnt) ev_srt[rank] = evw;
         }
         // ---- 2. templates: 8 read-direction positions per lane
-        for (int b = hl; cnt && b * 8 < TL; b += 32) {
+        for (int b = rl, pass = 0; cnt && b * 8 < TL; b += GL, ++pass) {
             const int k0 = b * 8;
-            if (b == hl && fast) {  // the 8 positions are template bases inside the record, plain A/C/G/T: from the window
+            if (pass < NP && ((fast >> pass) & 1u)) {  // the 8 positions are template bases inside the record, plain A/C/G/T: from the window
                 const int64_t ga = (o == 0 ? geo.lo + k0 : geo.hi - 8 - k0) + arena_off;
+                const uint2 gw = pass == 0 ? gw0 : gw1;
                 uint32_t w16 = funnel_r(gw.x, gw.y, (uint32_t)(ga & 15) * 2);
                 uint2 v;
                 if (o == 0) {
@@ -1298,7 +1310,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- 3. the walk: every lane of a half runs the same walk (half-uniform values); lane 0 of the half does the LDS writes
+        // ---- 3. the walk: every lane of a group runs the same walk (group-uniform values); lane 0 of the group does the LDS writes
         MutRecord row;  // --store_mutations row being built
         row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
         int sp = 0, k = 0, last = -1, cur_shift = 0;  // `last`: last step whose map entry / run is settled
@@ -1318,12 +1330,12 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                     for (int x = 0; x < 4; ++x)
                         if ((m8 >> x) & 1u) {
                             const int letter = insl[((size_t)o * RL + n) * 4 + x];
-                            if (hl == 0) stk[sp] = (uint8_t)letter;
+                            if (rl == 0) stk[sp] = (uint8_t)letter;
                             ++sp;
                             if (STORE_MUT) {  // ref = mutable_seq[position], alt = ref + letter (__init__.py:197-207)
                                 row.type = (int8_t)(1 | (x << 2) | 32); row.position = (int16_t)n;
                                 row.ref = (uint8_t)ch; row.alt = (uint8_t)letter;
-                                if (hl == 0) mut_emit1(A, row);
+                                if (rl == 0) mut_emit1(A, row);
                             }
                         }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1334,33 +1346,34 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                             row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
                             row.ref = (uint8_t)(tok < 0 ? -tok : (int)tmpl[min(tok, TL - 1)]);
                             row.alt = '.';
-                            if (hl == 0) mut_emit1(A, row);
+                            if (rl == 0) mut_emit1(A, row);
                         }
                     }
                 }
             }
-            if (hl == 0) map[n] = (int16_t)tok;
+            if (rl == 0) map[n] = (int16_t)tok;
             last = n;
             // steps after n drain the insertion stack until it is empty or the next step with an event
             while (sp > 0 && last + 1 < RL && last + 1 != next_n) {
                 ++last;
                 --sp;
-                if (hl == 0) map[last] = (int16_t)(-(int)stk[sp]);
+                if (rl == 0) map[last] = (int16_t)(-(int)stk[sp]);
             }
             // from step last + 1 on: token = step + (k - (last + 1)) until the next step with an event
-            if (hl == 0 && last + 1 < pitch) dsh[last + 1] = (int8_t)(k - (last + 1) - cur_shift);
+            if (rl == 0 && last + 1 < pitch) dsh[last + 1] = (int8_t)(k - (last + 1) - cur_shift);
             cur_shift = k - (last + 1);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- 4. the read: 8 positions per lane
         if (n_act) {
-            if (hl == 0) { ++n_reads; atomicOr(&A.flags[pair], 4u << o); }  // (bits 2-3: this kernel rebuilt the mate)
-            int carry = 0;  // (token - step) at the end of the previous pass (read_length > 256)
-            for (int b = hl; (b - hl) * 8 < pitch; b += 32) {  // (every lane of the half takes part in the prefix sums)
+            if (rl == 0) { ++n_reads; atomicOr(&A.flags[pair], 4u << o); }  // (bits 2-3: this kernel rebuilt the mate)
+            int carry = 0;  // (token - step) at the end of the previous pass
+            for (int b = rl, pass = 0; (b - rl) * 8 < pitch; b += GL, ++pass) {  // (every lane of the group takes part in the prefix sums)
                 const int j0 = b * 8;
                 const bool in = j0 < pitch;
-                if (b != hl && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (read_length > 256)
+                uint2 q8 = pass == 0 ? q8_0 : q8_1;
+                if (pass >= NP && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (read_length > 248)
                 uint2 e8w = {0u, 0u}, dw = {0u, 0u};
                 uint4 mw = {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
                 if (in) {
@@ -1368,15 +1381,16 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                     dw = *reinterpret_cast<const uint2 *>(dsh + j0);
                     mw = *reinterpret_cast<const uint4 *>(map + j0);
                 }
-                // (token - step) in front of the lane's first position: prefix sum of the changes over the half's lanes
+                // (token - step) in front of the lane's first position: prefix sum of the changes over the group's lanes
                 const int lane_sum = __builtin_amdgcn_sdot4((int)dw.x, 0x01010101, __builtin_amdgcn_sdot4((int)dw.y, 0x01010101, 0, false), false);
                 int incl = lane_sum;
-                for (int dd = 1; dd < 32; dd <<= 1) {
-                    const int t = __shfl_up(incl, dd, 32);
-                    if (hl >= dd) incl += t;
+#pragma unroll
+                for (int dd = 1; dd < GL; dd <<= 1) {
+                    const int t = __shfl_up(incl, dd, GL);
+                    if (rl >= dd) incl += t;
                 }
                 int shift = carry + incl - lane_sum;
-                carry += __shfl(incl, 31, 32);
+                carry += __shfl(incl, GL - 1, GL);
                 if (!in) continue;
                 uint32_t ob0 = 0u, ob1 = 0u, cand = 0u;  // cand: bit 7 - c <=> the substitution test of position j0 + c fires or ties
 #pragma unroll
@@ -1434,7 +1448,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (hl == 0 && n_reads) atomicAdd((unsigned long long *)stats, (unsigned long long)n_reads);
+    if (rl == 0 && n_reads) atomicAdd((unsigned long long *)stats, (unsigned long long)n_reads);
 }
 
 // ================================================================== k_indel_fixup

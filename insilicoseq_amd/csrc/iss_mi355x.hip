@@ -697,10 +697,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_apply<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_apply<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        const void *applies[] = {reinterpret_cast<const void *>(iss::k_indel_apply<false, 16>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 16>),
+                                 reinterpret_cast<const void *>(iss::k_indel_apply<false, 32>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 32>)};
+        for (const void *f : applies) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
@@ -1460,14 +1459,16 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             HIP_TRY(ctx, mark(4, s_indel));
             if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
             HIP_TRY(ctx, mark(5, s_indel));
-            if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, half a wavefront per read
-                const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (n + iss::APPLY_WAVES - 1) / iss::APPLY_WAVES);
-                if (A.mut)
-                    hipLaunchKernelGGL(iss::k_indel_apply<true>, dim3(blocks), dim3(64 * iss::APPLY_WAVES), iss::apply_lds_bytes(M.RL, M.pitch),
-                                       s_indel, M, dg, A, desc, ctx->stats);
-                else
-                    hipLaunchKernelGGL(iss::k_indel_apply<false>, dim3(blocks), dim3(64 * iss::APPLY_WAVES), iss::apply_lds_bytes(M.RL, M.pitch),
-                                       s_indel, M, dg, A, desc, ctx->stats);
+            if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, 16 (32) lanes per read
+                const int GL = iss::apply_gl(M.pitch);
+                const int64_t per_wg = (int64_t)iss::APPLY_WAVES * (64 / GL);  // reads per workgroup pass; at most 2 n reads
+                const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
+                const size_t lds = iss::apply_lds_bytes(M.RL, M.pitch, GL);
+                const dim3 grid(blocks), block(64 * iss::APPLY_WAVES);
+#define ISS_LAUNCH_APPLY(MUT, G) hipLaunchKernelGGL((iss::k_indel_apply<MUT, G>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats)
+                if (A.mut) { if (GL == 16) ISS_LAUNCH_APPLY(true, 16); else ISS_LAUNCH_APPLY(true, 32); }
+                else { if (GL == 16) ISS_LAUNCH_APPLY(false, 16); else ISS_LAUNCH_APPLY(false, 32); }
+#undef ISS_LAUNCH_APPLY
             }
             {   // the rest (irregular pairs, reads with more events than a list holds): one wavefront per read
                 const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
