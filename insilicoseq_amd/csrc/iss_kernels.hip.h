@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
 // A pair is a chain of dependent loads (list entry -> descriptor, events, phreds -> genome windows) behind a write
 // stream, i.e. microseconds of latency: the list entry is requested two reads ahead, everything its address needs only
 // the read number for one read ahead, and the tables the walk and the substitutions read sit in LDS.
-constexpr int APPLY_WAVES = 4;    // wavefronts (64 / GL reads each) per workgroup
+constexpr int APPLY_WAVES = 8;    // wavefronts (64 / GL reads each) per workgroup
 #ifndef ISS_APPLY_OCC
 #define ISS_APPLY_OCC 4           // wavefronts per SIMD the register budget is cut for (measured: 3 -> 4: -20 % time)
 #endif
@@ -1137,11 +1137,15 @@ constexpr int APPLY_ITEMS = 512;  // batch calls: the table of up to this many w
 constexpr int16_t FIX_NONE = 0x7fff;
 
 __host__ __device__ inline int apply_tl(int pitch) { return pitch + 8; }  // staged template positions: a read of <= EV_K events reaches <= EV_K past its end
-__host__ __device__ inline int apply_gl(int pitch) { return apply_tl(pitch) <= 256 ? 16 : 32; }  // lanes per read: two passes of 8 positions per lane at most
+#ifndef ISS_APPLY_GL
+#define ISS_APPLY_GL 8
+#endif
+// lanes per read: three passes of 8 positions per lane at most
+__host__ __device__ inline int apply_gl(int pitch) { return apply_tl(pitch) <= 24 * ISS_APPLY_GL ? ISS_APPLY_GL : (apply_tl(pitch) <= 256 ? 16 : 32); }
 __host__ __device__ inline size_t apply_read_bytes(int pitch) {
-    // per read: tmpl (tl) + dqm (pitch) + stk (pitch + 4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + map (2 * pitch)
+    // per read: tmpl (tl) + dqm (pitch) + stk (4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + map (2 * pitch)
     //           + events (4 * EV_K * 2)
-    return (size_t)apply_tl(pitch) + 3 * (size_t)pitch + 4 * EV_K + 2 * (size_t)pitch + 8 * EV_K;
+    return (size_t)apply_tl(pitch) + 2 * (size_t)pitch + 4 * EV_K + 2 * (size_t)pitch + 8 * EV_K;
 }
 __host__ __device__ inline size_t apply_wave_bytes(int pitch, int GL) { return (size_t)(64 / GL) * apply_read_bytes(pitch); }
 // [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 i64][items APPLY_ITEMS][per wave]
@@ -1156,7 +1160,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                                                                   const PairDesc *__restrict__ desc, uint64_t *stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t apply_lds[];
     constexpr int NG = 64 / GL;           // reads per wavefront
-    constexpr int NP = GL == 32 ? 1 : 2;  // passes (8 positions per lane each) whose genome window and phreds are requested ahead
+    constexpr int NP = GL == 32 ? 1 : (GL == 16 ? 2 : 3);  // passes (8 positions per lane each) whose genome window and phreds are requested ahead
     const int RL = M.RL, pitch = M.pitch, TL = apply_tl(pitch);
     uint32_t *mut8 = reinterpret_cast<uint32_t *>(apply_lds);  // [64] leading 8 bits of the substitution-test thresholds
     uint32_t *sub13 = mut8 + 64;                                // [2][RL][4] (see DevModel::subst13, position-major here)
@@ -1184,8 +1188,8 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     uint8_t *wbase = wave0 + (size_t)rg * apply_read_bytes(pitch);
     uint8_t *tmpl = wbase;                                  // [TL]
     uint8_t *dqm = tmpl + TL;                               // [pitch] error-test digit (8 bits) of position j
-    uint8_t *stk = dqm + pitch;                             // [pitch + 4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
-    int8_t *dsh = reinterpret_cast<int8_t *>(stk + pitch + 4 * EV_K);   // [pitch] change of (token - step) at the steps where a new run starts
+    uint8_t *stk = dqm + pitch;                             // [4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
+    int8_t *dsh = reinterpret_cast<int8_t *>(stk + 4 * EV_K);   // [pitch] change of (token - step) at the steps where a new run starts
     int16_t *map = reinterpret_cast<int16_t *>(dsh + pitch);  // [pitch] explicit tokens (steps with an event, stack drains)
     uint32_t *ev_raw = reinterpret_cast<uint32_t *>(map + pitch);  // [EV_K]
     uint32_t *ev_srt = ev_raw + EV_K;                       // [EV_K]
@@ -1207,20 +1211,20 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         return *reinterpret_cast<const uint2 *>(A.out[0] + (size_t)(r >> 1) * M.row +
                                                 (row_array_off(2 * (int)(r & 1u) + 1) + xp(min((rl + pass * GL) * 8, pitch - 8))));
     };
-    uint2 q8_a0 = phreds_of(ra, 0), q8_a1 = NP > 1 ? phreds_of(ra, 1) : make_uint2(0u, 0u);
+    uint2 q8_a0 = phreds_of(ra, 0);
     int item_k = 0;  // the work item of the half's previous read: the list is in pair order, more or less
     for (uint32_t li = li0; li < n_list; li += stride) {
         const uint32_t pair = ra >> 1;
         const int o = (int)(ra & 1u);  // mate
         PairDesc d = d_a;
         const uint32_t fl = fl_a, cnt_raw = cnt_a, evw = evw_a;
-        const uint2 q8_0 = q8_a0, q8_1 = q8_a1;
+        const uint2 q8_0 = q8_a0;
+        const uint32_t ra_now = ra;
         {   // requests for the next two iterations
             rd_a = rd_b;
             if (rd_a != NO_READ) ra = rd_a;
             d_a = desc[ra >> 1];
             q8_a0 = phreds_of(ra, 0);
-            if (NP > 1) q8_a1 = phreds_of(ra, 1);
             fl_a = A.flags[ra >> 1];
             cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
             evw_a = rl < EV_K ? A.ev_list[(size_t)ra * EV_K + rl] : 0u;
@@ -1253,7 +1257,9 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         uint8_t *out_base = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
         const uint8_t *out_qual = out_base + (row_array_off(1) - row_array_off(0));
         // ---- requests of this read: its genome windows (used after the event sort and the Philox blocks)
-        uint2 gw0 = {0u, 0u}, gw1 = {0u, 0u};
+        uint2 gw0 = {0u, 0u}, gw1 = {0u, 0u}, gw2 = {0u, 0u};
+        const uint2 q8_1 = NP > 1 && cnt ? phreds_of(ra_now, 1) : make_uint2(0u, 0u);
+        const uint2 q8_2 = NP > 2 && cnt ? phreds_of(ra_now, 2) : make_uint2(0u, 0u);
         uint32_t fast = 0;  // bit p: the lane's 8 template positions of pass p come from its window
 #pragma unroll
         for (int pass = 0; pass < NP; ++pass) {
@@ -1264,7 +1270,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
             const bool f = cnt && k0 < TL && geo.t_len == RL && g0 >= 0 && g0 + 8 <= gl.L && !gl.has_exceptions;
             uint2 w = {0u, 0u};
             if (f) w = *reinterpret_cast<const uint2 *>(packed_b + (size_t)((((g0 + arena_off) >> 4) + 1) << 2));
-            if (pass == 0) gw0 = w; else gw1 = w;
+            if (pass == 0) gw0 = w; else if (pass == 1) gw1 = w; else gw2 = w;
             fast |= (f ? 1u : 0u) << pass;
         }
         // ---- 1. events: sorted by step, one word per step
@@ -1293,7 +1299,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
             const int k0 = b * 8;
             if (pass < NP && ((fast >> pass) & 1u)) {  // the 8 positions are template bases inside the record, plain A/C/G/T: from the window
                 const int64_t ga = (o == 0 ? geo.lo + k0 : geo.hi - 8 - k0) + arena_off;
-                const uint2 gw = pass == 0 ? gw0 : gw1;
+                const uint2 gw = pass == 0 ? gw0 : (pass == 1 ? gw1 : gw2);
                 uint32_t w16 = funnel_r(gw.x, gw.y, (uint32_t)(ga & 15) * 2);
                 uint2 v;
                 if (o == 0) {
@@ -1372,7 +1378,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
             for (int b = rl, pass = 0; (b - rl) * 8 < pitch; b += GL, ++pass) {  // (every lane of the group takes part in the prefix sums)
                 const int j0 = b * 8;
                 const bool in = j0 < pitch;
-                uint2 q8 = pass == 0 ? q8_0 : q8_1;
+                uint2 q8 = pass == 0 ? q8_0 : (pass == 1 ? q8_1 : q8_2);
                 if (pass >= NP && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (read_length > 248)
                 uint2 e8w = {0u, 0u}, dw = {0u, 0u};
                 uint4 mw = {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};

@@ -697,7 +697,8 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        const void *applies[] = {reinterpret_cast<const void *>(iss::k_indel_apply<false, 16>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 16>),
+        const void *applies[] = {reinterpret_cast<const void *>(iss::k_indel_apply<false, 8>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 8>),
+                                 reinterpret_cast<const void *>(iss::k_indel_apply<false, 16>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 16>),
                                  reinterpret_cast<const void *>(iss::k_indel_apply<false, 32>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 32>)};
         for (const void *f : applies) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
@@ -1466,8 +1467,8 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                 const size_t lds = iss::apply_lds_bytes(M.RL, M.pitch, GL);
                 const dim3 grid(blocks), block(64 * iss::APPLY_WAVES);
 #define ISS_LAUNCH_APPLY(MUT, G) hipLaunchKernelGGL((iss::k_indel_apply<MUT, G>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats)
-                if (A.mut) { if (GL == 16) ISS_LAUNCH_APPLY(true, 16); else ISS_LAUNCH_APPLY(true, 32); }
-                else { if (GL == 16) ISS_LAUNCH_APPLY(false, 16); else ISS_LAUNCH_APPLY(false, 32); }
+                if (A.mut) { if (GL == 8) ISS_LAUNCH_APPLY(true, 8); else if (GL == 16) ISS_LAUNCH_APPLY(true, 16); else ISS_LAUNCH_APPLY(true, 32); }
+                else { if (GL == 8) ISS_LAUNCH_APPLY(false, 8); else if (GL == 16) ISS_LAUNCH_APPLY(false, 16); else ISS_LAUNCH_APPLY(false, 32); }
 #undef ISS_LAUNCH_APPLY
             }
             {   // the rest (irregular pairs, reads with more events than a list holds): one wavefront per read
