@@ -1122,9 +1122,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
 //   1. the read's events: sorted by step, masks of one step merged
 //   2. (all lanes) the template E(0 .. pitch+7) into LDS, 8 bases per lane from the 2-bit genome; the error-test digits
 //      (one Philox block per 8 positions)
-//   3. the walk over the steps with an event (the reads of the wavefront side by side, one per group): explicit map[] entries for
-//      those steps and for the steps that drain the insertion stack, "from step n0 on, source index = k0 + (n - n0)"
-//      records for everything in between
+//   3. the walk over the steps with an event (the reads of the wavefront side by side, one per group): the letters of
+//      those steps and of the steps that drain the insertion stack go to ovr[] (0 = no override), "from step n0 on,
+//      source index = k0 + (n - n0)" for everything in between is the change of (token - step) at n0, in dsh[]
 //   4. (all lanes, 8 positions each) token -> base -> mut_sequence -> one 8-byte store
 // A pair is a chain of dependent loads (list entry -> descriptor, events, phreds -> genome windows) behind a write
 // stream, i.e. microseconds of latency: the list entry is requested two reads ahead, everything its address needs only
@@ -1143,9 +1143,9 @@ __host__ __device__ inline int apply_tl(int pitch) { return pitch + 8; }  // sta
 // lanes per read: three passes of 8 positions per lane at most
 __host__ __device__ inline int apply_gl(int pitch) { return apply_tl(pitch) <= 24 * ISS_APPLY_GL ? ISS_APPLY_GL : (apply_tl(pitch) <= 256 ? 16 : 32); }
 __host__ __device__ inline size_t apply_read_bytes(int pitch) {
-    // per read: tmpl (tl) + dqm (pitch) + stk (4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + map (2 * pitch)
+    // per read: tmpl (tl) + dqm (pitch) + stk (4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + ovr (pitch)
     //           + events (4 * EV_K * 2)
-    return (size_t)apply_tl(pitch) + 2 * (size_t)pitch + 4 * EV_K + 2 * (size_t)pitch + 8 * EV_K;
+    return (size_t)apply_tl(pitch) + 2 * (size_t)pitch + 4 * EV_K + (size_t)pitch + 8 * EV_K;
 }
 __host__ __device__ inline size_t apply_wave_bytes(int pitch, int GL) { return (size_t)(64 / GL) * apply_read_bytes(pitch); }
 // [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 i64][items APPLY_ITEMS][per wave]
@@ -1190,8 +1190,8 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     uint8_t *dqm = tmpl + TL;                               // [pitch] error-test digit (8 bits) of position j
     uint8_t *stk = dqm + pitch;                             // [4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
     int8_t *dsh = reinterpret_cast<int8_t *>(stk + 4 * EV_K);   // [pitch] change of (token - step) at the steps where a new run starts
-    int16_t *map = reinterpret_cast<int16_t *>(dsh + pitch);  // [pitch] explicit tokens (steps with an event, stack drains)
-    uint32_t *ev_raw = reinterpret_cast<uint32_t *>(map + pitch);  // [EV_K]
+    uint8_t *ovr = reinterpret_cast<uint8_t *>(dsh + pitch);  // [pitch] letters of the steps with an explicit token (steps with an event, stack drains); 0 = none
+    uint32_t *ev_raw = reinterpret_cast<uint32_t *>(ovr + pitch);  // [EV_K]
     uint32_t *ev_srt = ev_raw + EV_K;                       // [EV_K]
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);
     uint64_t n_reads = 0;
@@ -1275,8 +1275,10 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         }
         // ---- 1. events: sorted by step, one word per step
         if (rl < EV_K) ev_raw[rl] = evw;
-        for (int j = rl * 4; j < pitch; j += GL * 4) *reinterpret_cast<uint2 *>(map + j) = make_uint2(0x7fff7fffu, 0x7fff7fffu);  // FIX_NONE
-        for (int j = rl * 8; j < pitch; j += GL * 8) *reinterpret_cast<uint2 *>(dsh + j) = make_uint2(0u, 0u);
+        for (int j = rl * 8; j < pitch; j += GL * 8) {
+            *reinterpret_cast<uint2 *>(ovr + j) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(dsh + j) = make_uint2(0u, 0u);
+        }
         for (int b = rl; cnt && b * 8 < pitch; b += GL) {  // one Philox block holds the digits of 8 positions (of both mates)
             const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 1);
             *reinterpret_cast<uint2 *>(dqm + b * 8) = o == 0 ? make_uint2(w.x, w.z) : make_uint2(w.y, w.w);
@@ -1319,7 +1321,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         // ---- 3. the walk: every lane of a group runs the same walk (group-uniform values); lane 0 of the group does the LDS writes
         MutRecord row;  // --store_mutations row being built
         row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
-        int sp = 0, k = 0, last = -1, cur_shift = 0;  // `last`: last step whose map entry / run is settled
+        int sp = 0, k = 0, last = -1, cur_shift = 0;  // `last`: last step whose letter / run is settled
         for (uint32_t ei = 0; ei < (uint32_t)EV_K; ++ei) {
             if (ei >= n_act) break;
             const uint32_t evs = ev_srt[ei];
@@ -1357,13 +1359,13 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                     }
                 }
             }
-            if (rl == 0) map[n] = (int16_t)tok;
+            if (rl == 0) ovr[n] = (uint8_t)(tok < 0 ? -tok : (int)tmpl[tok]);  // (tok <= n + EV_K < TL)
             last = n;
             // steps after n drain the insertion stack until it is empty or the next step with an event
             while (sp > 0 && last + 1 < RL && last + 1 != next_n) {
                 ++last;
                 --sp;
-                if (rl == 0) map[last] = (int16_t)(-(int)stk[sp]);
+                if (rl == 0) ovr[last] = stk[sp];
             }
             // from step last + 1 on: token = step + (k - (last + 1)) until the next step with an event
             if (rl == 0 && last + 1 < pitch) dsh[last + 1] = (int8_t)(k - (last + 1) - cur_shift);
@@ -1380,12 +1382,11 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                 const bool in = j0 < pitch;
                 uint2 q8 = pass == 0 ? q8_0 : (pass == 1 ? q8_1 : q8_2);
                 if (pass >= NP && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (read_length > 248)
-                uint2 e8w = {0u, 0u}, dw = {0u, 0u};
-                uint4 mw = {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu};
+                uint2 e8w = {0u, 0u}, dw = {0u, 0u}, ov = {0u, 0u};
                 if (in) {
                     e8w = *reinterpret_cast<const uint2 *>(dqm + j0);
                     dw = *reinterpret_cast<const uint2 *>(dsh + j0);
-                    mw = *reinterpret_cast<const uint4 *>(map + j0);
+                    ov = *reinterpret_cast<const uint2 *>(ovr + j0);
                 }
                 // (token - step) in front of the lane's first position: prefix sum of the changes over the group's lanes
                 const int lane_sum = __builtin_amdgcn_sdot4((int)dw.x, 0x01010101, __builtin_amdgcn_sdot4((int)dw.y, 0x01010101, 0, false), false);
@@ -1403,15 +1404,19 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                 for (int c = 0; c < 8; ++c) {
                     const int j = j0 + c;
                     shift += (int)(int8_t)(((c < 4 ? dw.x : dw.y) >> (8 * (c & 3))) & 0xffu);
-                    const uint32_t mword = c < 2 ? mw.x : (c < 4 ? mw.y : (c < 6 ? mw.z : mw.w));
-                    const int mtok = (int)(int16_t)((mword >> (16 * (c & 1))) & 0xffffu);
-                    const int tok = mtok != (int)FIX_NONE ? mtok : j + shift;
-                    const int from_tmpl = (int)tmpl[max(tok, 0)];  // (tok <= j + EV_K < TL: a step deletes at most one base)
-                    const int base = tok >= 0 ? from_tmpl : -tok;
+                    // (0 <= j + shift <= j + EV_K < TL: a step deletes at most one base; at a step with an explicit letter it
+                    //  is the previous run continued, and the letter read there is overridden below)
+                    const int base = (int)tmpl[j + shift];
                     const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
                     const uint32_t q = ((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu;
                     cand = shift_in(cand, __builtin_amdgcn_ballot_w64(e8 >= mut8[q & 63u]));
                     if (c < 4) ob0 |= (uint32_t)base << (8 * c); else ob1 |= (uint32_t)base << (8 * (c - 4));
+                }
+                {   // the explicit letters: byte-wise ov ? ov : ob
+                    auto nonzero_bytes = [](uint32_t v) { return (((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u; };  // 0x80 per non-zero byte
+                    const uint32_t m0 = (nonzero_bytes(ov.x) >> 7) * 0xffu, m1 = (nonzero_bytes(ov.y) >> 7) * 0xffu;
+                    ob0 = (ov.x & m0) | (ob0 & ~m0);
+                    ob1 = (ov.y & m1) | (ob1 & ~m1);
                 }
                 cand &= 0xffu & ~(0xffu >> min(max(RL - j0, 0), 8));  // positions inside the read
                 while (cand) {  // rare per lane: the substitution test fires or ties (__init__.py:94)
