@@ -18,8 +18,8 @@
 //              Digits that tie with a table entry, and positions whose error test fires, are queued in a
 //              per-wave LDS ring and settled exactly (no global loads) every few iterations.
 //              Assumes "no indel in this read".
-//   k_indel_scan : 1 lane / (pair, Philox block of indel digits with a non-zero probability): lists every
-//              read in which an indel fires, with its events (step, event mask), exactly.
+//   k_indel_scan : 1 lane / read: the read's indel events (step, event mask), sampled by skipping from one firing
+//              test to the next; lists every read with an event.
 //   k_indel_apply: half a wavefront / listed read: replays the read's event list through the token
 //              transducer, re-derives the read (template, substitutions) and rewrites its base row.
 //   k_indel_fixup: 1 wavefront / flagged read (irregular pairs, reads with more events than a list
@@ -36,7 +36,7 @@ namespace iss {
 // ---------------------------------------------------------------- RNG address map
 enum : uint32_t {
     K_PAIR = 0, K_FS = 1, K_RS = 2, K_QM = 3, K_SUB = 4, K_INS = 5, K_DEL = 6, K_QM_LO = 7, K_INS_LO = 8,
-    K_DEL_LO = 9, K_FRAG = 10
+    K_DEL_LO = 9, K_FRAG = 10, K_EV = 11  // (K_INS .. K_DEL_LO: retired)
 };
 
 struct u32x4 {
@@ -83,12 +83,50 @@ __device__ __forceinline__ uint64_t lo37(const u32x4 &v, int pair) {
     return pair ? (((uint64_t)v.z << 5) | (v.w >> 27)) : (((uint64_t)v.x << 5) | (v.y >> 27));
 }
 __device__ __forceinline__ uint64_t mk_digit(uint32_t h16, uint64_t l37) { return ((uint64_t)h16 << 37) | l37; }
-// indel draws: m = (d8 << 45) | l45 -- sixteen 8-bit leading digits to a primary block
-__device__ __forceinline__ uint32_t digit8(const u32x4 &v, int d) { return (word_of(v, d >> 2) >> (8 * (d & 3))) & 0xffu; }
-__device__ __forceinline__ uint64_t lo45(const u32x4 &v, int pair) {
-    return pair ? (((uint64_t)v.z << 13) | (v.w >> 19)) : (((uint64_t)v.x << 13) | (v.y >> 19));
+// ---------------------------------------------------------------- indel events
+// introduce_indels runs, per loop step n <= RL-2, four insertion tests `random() < p_ins[n][x]` and one deletion test
+// `random() < p_del[n][base]` (__init__.py:193-196, :209): 5 (RL - 1) independent Bernoulli tests per read, all but a
+// handful failing.  The position-addressable path samples the SAME joint distribution by skipping from one firing
+// test to the next ("indel event process"; all integer arithmetic):
+//   S[t] = prod over the slots of t's segment up to t of (1 - T / 2^53), 0.64 fixed point; one uniform r in (0, 1] per
+//   draw (K_EV block j, sub = mate, words 0-1): the next firing test after slot `cur` is the first t of its segment
+//   with S[t] <= r * S[cur]; none: the next segment, with the next draw.  A firing deletion slot fires for base b iff
+//   floor(v * T_max / 2^53) < T_b, v from words 2-3 of the same block (the reference's one uniform for the four bases).
+// emit(n, mask): step n, bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b;
+// steps come in ascending order (several calls for one step are possible).
+constexpr uint64_t EV_ONE = 0xffffffffffffffffull;
+template <class Emit>
+__device__ __forceinline__ void indel_events(const uint64_t *S, const uint16_t *E, const uint64_t *T, const uint64_t *del_thr /* [RL][4] of the mate */,
+                                             int ns, const Addr &a, int o, Emit emit) {
+    int cur = -1;
+    uint32_t j = 0;
+    while (cur < ns - 1) {
+        const int seg_last = E[cur + 1];
+        uint64_t base = EV_ONE;
+        if (cur >= 0 && E[cur] == seg_last) base = S[cur];
+        const u32x4 w = draw_block(a, K_EV, j++, (uint32_t)o);
+        const uint64_t rr = ((((uint64_t)1 << 53) - mk53(w.x, w.y)) << 11) - 1u;  // (1 - u) in 0.64 fixed point
+        const uint64_t target = __umul64hi(rr, base);
+        if (S[seg_last] > target) { cur = seg_last; continue; }  // nothing fires in the rest of the segment
+        int lo = cur + 1, hi = seg_last;  // first slot with S <= target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (S[mid] <= target) hi = mid; else lo = mid + 1;
+        }
+        const int n = lo / 5, k = lo - 5 * n;
+        uint32_t mask;
+        if (k < 4) {
+            mask = 1u << k;
+        } else {
+            const uint64_t v = mk53(w.z, w.w), tm = T[lo];
+            const uint64_t scaled = (__umul64hi(v, tm) << 11) | ((v * tm) >> 53);  // floor(v * T_max / 2^53)
+            mask = 0;
+            for (int b = 0; b < 4; ++b) mask |= (scaled < del_thr[(size_t)n * 4 + b] ? 16u : 0u) << b;
+        }
+        emit(n, mask);
+        cur = lo;
+    }
 }
-__device__ __forceinline__ uint64_t mk_digit8(uint32_t d8, uint64_t l45) { return ((uint64_t)d8 << 45) | l45; }
 
 // Output rows.  A pair owns ONE row of M.row bytes (a multiple of 128).  The 32 read positions 32 l .. 32 l + 31 are the
 // 128-byte line l of the row: bytes 0-63 the forward mate, 64-127 the reverse mate, each four 16-byte pieces
@@ -127,10 +165,13 @@ struct DevModel {
     const uint64_t *del_thr;    // [2][RL][4]
     const uint64_t *del_thr_max;  // [2][RL]  max over bases
     const uint64_t *mut_thr;      // [n_q+1]
-    const uint8_t *ins_any;       // [2][RL] any insertion threshold non-zero at (o, n)
-    const uint32_t *fix_tab;      // [2][RL][8] (thr >> 37) + 1 of the 4 insertion + 4 deletion thresholds, 0 = zero probability
-    const uint32_t *scan_tab;      // [n_scan][SCAN_W]: Philox blocks of indel digits with a non-zero probability (k_indel_scan)
-    int32_t n_scan;
+    // indel events (k_indel_scan; see indel_events()): per mate the 5 * (RL - 1) test slots 5 n + k (k = 0..3 insertion of letter
+    // slot k at loop step n, k = 4 the deletion with the largest of its four thresholds)
+    const uint64_t *ev_S;         // [2][ev_ns] survival inside the slot's segment, 0.64 fixed point
+    const uint16_t *ev_E;         // [2][ev_ns] last slot of the slot's segment
+    const uint64_t *ev_T;         // [2][ev_ns] threshold of the slot
+    int32_t ev_ns;
+    int32_t n_scan;               // 1: some indel probability is non-zero (the indel pass runs), 0: none
     // reference-compatible MT mode, k_mt_resolve (iss_mt_compat.hip.h)
     int32_t mt_row_w;             // 32-bit words per row of mt_rows (odd)
     const uint16_t *mt_rows;      // [2][NB][RL] rows of n_q leading digits min(q_thr >> 37, 0xffff) (no merging: index == phred)
@@ -947,168 +988,72 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
 }
 
 // ================================================================== k_indel_scan
-// One lane per (pair, Philox block holding an indel digit with a non-zero probability): exactly one block and sixteen
-// byte compares per lane-item (a K_INS block: the 2 x 4 letter slots of two loop steps of both mates; a K_DEL block:
-// eight loop steps of both mates), no divergence between the lanes of a wavefront whatever mix of table entries they
-// hold.  The limits (digit < lim  <=>  candidate; lim = (thr >> 45) + 1, 0 = never; max over bases for deletions) sit in LDS.
-// A candidate is then decided exactly (rare): per (mate, loop step) the 8-bit EVENT MASK of the reference's loop --
-// bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b (__init__.py:193-196,
-// :209) -- and a non-empty mask is appended to the read's event list (EV_K words, step << 8 | mask).  k_indel_apply
-// replays the lists; no event => provably no indel, k_main's output stands.  A read with more than EV_K events goes to
-// the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  The reads a settling round lists reach the global read
-// list with one atomic per mate.
-constexpr int SCAN_W = 17;        // words per table entry (odd: bank-conflict free): [0] kind << 24 | index,
-                                  // [1..16] limits of the block's 16 digits
-constexpr int SCAN_THREADS = 512;
-constexpr int SCAN_RING = 128;    // candidate lane-items a wavefront can hold (a private ring: 64 pending + 64 new at most)
-constexpr int SCAN_LIST = 256;    // newly listed reads a wavefront collects before they go to the global list (one atomic
-                                  // per >= 128 reads: a counter everybody adds to takes ~10 ns per add)
+// One lane per READ: the read's indel events (indel_events above: a draw per firing test + one per segment of the
+// survival table, i.e. one for a read without events) in step order into its event list (EV_K words, step << 8 | event
+// mask); no event => provably no indel, k_main's output stands.  k_indel_apply replays the lists.  A read with more than
+// EV_K events goes to the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  The reads with events
+// are collected per wavefront in LDS and reach the global read list with one atomic per >= 128 reads (a counter
+// everybody adds to takes ~10 ns per add).  Consecutive lanes take consecutive reads, so the list is in pair order,
+// more or less, and k_indel_apply's wavefronts share cache lines, DRAM pages and TLB entries.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_LIST = 256;    // listed reads a wavefront collects before they go to the global list
 constexpr int EV_K = 8;           // events kept per read
 constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
                                        // bits 4-5 mate is in read_list
-__host__ __device__ inline size_t scan_lds_bytes(int n_scan, int RL) {
-    return ((size_t)(SCAN_THREADS / 64) * (SCAN_RING * 2 + SCAN_LIST) + (size_t)n_scan * SCAN_W + (size_t)2 * RL * 8 + 1) * 4;
+__host__ __device__ inline size_t scan_lds_bytes(int ev_ns) {
+    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 7) & ~(size_t)7) + (size_t)(SCAN_THREADS / 64) * SCAN_LIST * 4;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // candidates (a digit below its limit -- with 8-bit digits mostly ties of the leading digit, one lane-item in
-    // twenty): a private ring per wavefront, no atomics, no barriers; settled 64 at a time, one lane per candidate
-    // (the table first: its reads then need no address arithmetic beyond the entry's offset)
-    uint32_t *tab0 = lds;
-    uint32_t *fix0 = tab0 + M.n_scan * SCAN_W;  // [2][RL][8]: digit limits of the 4 insertion slots and the 4 bases' deletions
-    uint32_t *wave0 = fix0 + 2 * M.RL * 8 + (((M.n_scan * SCAN_W) & 1) ? 1 : 0);  // (8-byte aligned)
-    uint2 *ring = reinterpret_cast<uint2 *>(wave0) + (threadIdx.x >> 6) * SCAN_RING;  // {pair, byte offset of the table entry}
-    uint32_t *l_list = wave0 + (SCAN_THREADS / 64) * SCAN_RING * 2 + (threadIdx.x >> 6) * SCAN_LIST;  // this wavefront's newly listed reads
-    for (int i = threadIdx.x; i < M.n_scan * SCAN_W; i += blockDim.x) tab0[i] = M.scan_tab[i];
-    for (int i = threadIdx.x; i < 2 * M.RL * 8; i += blockDim.x) fix0[i] = M.fix_tab[i];
+__global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t scan_lds[];
+    const int ns = M.ev_ns;
+    uint64_t *l_S = scan_lds;                                         // [2][ns]
+    uint16_t *l_E = reinterpret_cast<uint16_t *>(l_S + 2 * ns);       // [2][ns]
+    uint32_t *l_list = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(scan_lds) + (size_t)2 * ns * 8 + (((size_t)2 * ns * 2 + 7) & ~(size_t)7)) +
+                       (threadIdx.x >> 6) * SCAN_LIST;                // this wavefront's listed reads
+    for (int i = threadIdx.x; i < 2 * ns; i += blockDim.x) { l_S[i] = M.ev_S[i]; l_E[i] = M.ev_E[i]; }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t ns = (uint32_t)M.n_scan;
-    const uint32_t n_items = (uint32_t)A.n_pairs * ns;
-    // a workgroup takes a CONTIGUOUS range of lane-items, i.e. of pairs: the reads a wavefront lists are neighbours in
-    // every per-pair array (descriptors, flags, event lists, output rows), and k_indel_apply walks the list in order --
-    // its wavefronts then share cache lines, DRAM pages and TLB entries instead of touching one of each per read
-    const uint32_t step = blockDim.x;
-    const uint32_t step_pair = step / ns, step_e = step - step_pair * ns;
-    const uint32_t n_iter = ((n_items + gridDim.x - 1) / gridDim.x + step - 1) / step;  // the same in every workgroup
-    const uint32_t first = blockIdx.x * n_iter * step;
-    const uint32_t last = min(n_items, first + n_iter * step);
-    uint32_t it = first + threadIdx.x;
-    uint32_t pair = it / ns;
-    uint32_t eb = (it - pair * ns) * (uint32_t)(SCAN_W * 4);  // byte offset of the lane-item's table entry
-    const uint32_t ns_b = ns * (uint32_t)(SCAN_W * 4), step_eb = step_e * (uint32_t)(SCAN_W * 4);
-    uint32_t q_head = 0, q_tail = 0, n_listed = 0;  // wave-uniform
-    const uint32_t NO_READ = 0xffffffffu;
-    // One candidate lane-item, exactly: the event masks of its (mate, step)s -- bits 0-3 insertion of letter slot x
-    // fires, bits 4-7 the deletion fires if the token is base b -- go to their reads' lists; a read's first event lists
-    // it (listed[mate]: the lane-item's steps belong to one pair).
-    auto settle = [&](uint32_t c_pair, uint32_t c_eb, uint32_t (&listed)[2]) {
-        const uint32_t *tab = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab0) + c_eb);
-        const uint32_t c2 = tab[0];
-        const Addr a = make_addr(A.seed, A.first_ordinal + c_pair, A.gc_bias ? desc[c_pair].meta >> 16 : 0u);
-        const u32x4 w = philox4x32_10(a.c0, a.c1, c2, 0u, a.k0, a.k1);
-        uint32_t hit = 0;  // bit d: digit d is below its limit
-#pragma unroll
-        for (int dgt = 0; dgt < 16; ++dgt) hit |= (digit8(w, dgt) < tab[1 + dgt] ? 1u : 0u) << dgt;
-        const bool is_del = (c2 >> 24) == K_DEL;
-        const int idx = (int)(c2 & 0xffffffu);
-        while (hit) {
-            const int dg = __ffs(hit) - 1;
-            hit &= hit - 1u;
-            // digit -> (mate, step): K_DEL (n & 7) * 2 + mate, K_INS (n & 1) * 8 + mate * 4 + slot
-            const int o = is_del ? dg & 1 : (dg >> 2) & 1;
-            const int n = is_del ? idx * 8 + (dg >> 1) : idx * 2 + (dg >> 3);
-            const uint32_t h = digit8(w, dg);
-            const uint32_t *t8 = fix0 + ((uint32_t)o * (uint32_t)M.RL + (uint32_t)n) * 8u;
-            const size_t en = (size_t)o * M.RL + n;
-            uint32_t m8 = 0;
-            if (is_del) {  // (:209)
-                for (int b = 0; b < 4; ++b) {
-                    const uint32_t lim = t8[4 + b];  // (thr >> 45) + 1, 0 = zero probability
-                    bool fire = h + 1u < lim;
-                    if (lim && h + 1u == lim)  // tie of the leading digit: exact
-                        fire = mk_digit8(h, lo45(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < M.del_thr[en * 4 + b];
-                    if (fire) m8 |= 16u << b;
-                }
-            } else {  // (:193-196)
-                const int x = dg & 3;
-                const uint32_t lim = t8[x];
-                bool fire = h + 1u < lim;
-                if (lim && h + 1u == lim) {
-                    const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)n, (uint32_t)(o * 2 + (x >> 1)));
-                    fire = mk_digit8(h, lo45(l, x & 1)) < M.ins_thr[en * 4 + x];
-                }
-                if (fire) m8 = 1u << x;
-            }
-            if (!m8) continue;
-            const uint32_t rd = 2u * c_pair + (uint32_t)o;
-            const uint32_t at = atomicAdd(&A.ev_count[rd], 1u);
-            if (at < (uint32_t)EV_K) {
-                A.ev_list[(size_t)rd * EV_K + at] = ((uint32_t)n << 8) | m8;
-                if (!(atomicOr(&A.flags[c_pair], FLAG_LISTED << o) & (FLAG_LISTED << o))) listed[o] = rd;
-            } else if (at == (uint32_t)EV_K) {  // too many events for the list: the wavefront-per-read kernel takes the read
-                if (!(atomicOr(&A.flags[c_pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
-            }
-        }
-    };
-    auto flush_list = [&]() {  // this wavefront's newly listed reads -> the global list: one atomic
+    uint32_t n_listed = 0;  // wave-uniform
+    auto flush_list = [&]() {  // this wavefront's listed reads -> the global list: one atomic
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(A.read_count, n_listed);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         for (uint32_t i = lane; i < n_listed; i += 64u) A.read_list[base + i] = l_list[i];
         n_listed = 0;
     };
-    // the first n <= 64 pending candidates, one per lane
-    auto drain = [&](uint32_t n) {
-        uint32_t listed[2] = {NO_READ, NO_READ};
-        if (lane < n) {
-            const uint2 c = ring[(q_head + lane) & (SCAN_RING - 1)];
-            settle(c.x, c.y, listed);
-        }
-        q_head += n;
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const unsigned long long m = __ballot(listed[o] != NO_READ);
-            if (!m) continue;
-            if (listed[o] != NO_READ)
-                l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = listed[o];
-            n_listed += (uint32_t)__popcll(m);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (n_listed >= (uint32_t)SCAN_LIST / 2) flush_list();  // (< 128 before the round + <= 2 x 64 new: fits)
-    };
-    for (uint32_t iter = 0; iter < n_iter; ++iter) {
-        unsigned long long any = 0;
-        if (it < last) {
-            const uint32_t *tab = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(tab0) + eb);
-            const uint32_t c2 = tab[0];
+    const uint32_t n_reads = 2u * (uint32_t)A.n_pairs;
+    const uint32_t per_wg = ((n_reads + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;  // contiguous ranges
+    const uint32_t first = blockIdx.x * per_wg, last = min(n_reads, first + per_wg);
+    for (uint32_t rd0 = first; rd0 < last; rd0 += blockDim.x) {  // (uniform trip count in the workgroup)
+        const uint32_t rd = rd0 + threadIdx.x;
+        uint32_t cnt = 0;
+        // (the mates of irregular pairs -- custom fragment lengths -- are the fix-up kernel's already: k_setup)
+        if (rd < last && !(A.has_frag && ((A.flags[rd >> 1] >> (rd & 1u)) & 1u))) {
+            const uint32_t pair = rd >> 1;
+            const int o = (int)(rd & 1u);
             // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
             const Addr a = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
-            const u32x4 w = philox4x32_10(a.c0, a.c1, c2, 0u, a.k0, a.k1);
-            // any digit below its limit?  Sixteen byte compares whose lane masks the scalar unit ORs
-#define ISS_SCAN_B(W, K) __builtin_amdgcn_ballot_w64(((W >> (8 * ((K) & 3))) & 0xffu) < tab[1 + (K)])
-            any = ISS_SCAN_B(w.x, 0) | ISS_SCAN_B(w.x, 1) | ISS_SCAN_B(w.x, 2) | ISS_SCAN_B(w.x, 3) |
-                  ISS_SCAN_B(w.y, 4) | ISS_SCAN_B(w.y, 5) | ISS_SCAN_B(w.y, 6) | ISS_SCAN_B(w.y, 7) |
-                  ISS_SCAN_B(w.z, 8) | ISS_SCAN_B(w.z, 9) | ISS_SCAN_B(w.z, 10) | ISS_SCAN_B(w.z, 11) |
-                  ISS_SCAN_B(w.w, 12) | ISS_SCAN_B(w.w, 13) | ISS_SCAN_B(w.w, 14) | ISS_SCAN_B(w.w, 15);
-#undef ISS_SCAN_B
-        }
-        any = __builtin_amdgcn_ballot_w64((any >> lane) & 1ull);  // (lanes past the range hold 0; the result is wave-uniform)
-        if (any) {
-            if ((any >> lane) & 1ull) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
-                ring[(q_tail + rank) & (SCAN_RING - 1)] = make_uint2(pair, eb);
+            uint32_t *list = A.ev_list + (size_t)rd * EV_K;
+            indel_events(l_S + o * ns, l_E + o * ns, M.ev_T + (size_t)o * ns, M.del_thr + (size_t)o * M.RL * 4, ns, a, o,
+                         [&](int n, uint32_t mask) {
+                             if (cnt < (uint32_t)EV_K) list[cnt] = ((uint32_t)n << 8) | mask;
+                             ++cnt;
+                         });
+            A.ev_count[rd] = cnt;
+            if (cnt > (uint32_t)EV_K) {  // too many events for the list: the wavefront-per-read kernel takes the read
+                if (!(atomicOr(&A.flags[pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
+                cnt = 0;
             }
-            q_tail += (uint32_t)__popcll(any);
-            while (q_tail - q_head >= 64u) drain(64u);
         }
-        it += step;
-        pair += step_pair;
-        eb += step_eb;
-        if (eb >= ns_b) { eb -= ns_b; ++pair; }
+        const unsigned long long m = __ballot(cnt != 0u);
+        if (m) {
+            if (cnt) l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rd;
+            n_listed += (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (n_listed >= (uint32_t)SCAN_LIST - 64u) flush_list();  // (room for the next 64)
+        }
     }
-    if (q_tail != q_head) drain(q_tail - q_head);
     if (n_listed) flush_list();
 }
 
@@ -1119,7 +1064,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
 // + adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
 // prefix [0, n) is final when step n starts; the not-yet-visited suffix is (stack of freshly inserted letters, LIFO)
 // ++ E(k), E(k+1), ...
-//   1. the read's events: sorted by step, masks of one step merged
+//   1. the read's events (in step order already), masks of one step merged
 //   2. (all lanes) the template E(0 .. pitch+7) into LDS, 8 bases per lane from the 2-bit genome; the error-test digits
 //      (one Philox block per 8 positions)
 //   3. the walk over the steps with an event (the reads of the wavefront side by side, one per group): the letters of
@@ -1144,8 +1089,8 @@ __host__ __device__ inline int apply_tl(int pitch) { return pitch + 8; }  // sta
 __host__ __device__ inline int apply_gl(int pitch) { return apply_tl(pitch) <= 24 * ISS_APPLY_GL ? ISS_APPLY_GL : (apply_tl(pitch) <= 256 ? 16 : 32); }
 __host__ __device__ inline size_t apply_read_bytes(int pitch) {
     // per read: tmpl (tl) + dqm (pitch) + stk (4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + ovr (pitch)
-    //           + events (4 * EV_K * 2)
-    return (size_t)apply_tl(pitch) + 2 * (size_t)pitch + 4 * EV_K + (size_t)pitch + 8 * EV_K;
+    //           + events (4 * EV_K)
+    return (size_t)apply_tl(pitch) + 2 * (size_t)pitch + 4 * EV_K + (size_t)pitch + 4 * EV_K;
 }
 __host__ __device__ inline size_t apply_wave_bytes(int pitch, int GL) { return (size_t)(64 / GL) * apply_read_bytes(pitch); }
 // [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 i64][items APPLY_ITEMS][per wave]
@@ -1191,8 +1136,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     uint8_t *stk = dqm + pitch;                             // [4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
     int8_t *dsh = reinterpret_cast<int8_t *>(stk + 4 * EV_K);   // [pitch] change of (token - step) at the steps where a new run starts
     uint8_t *ovr = reinterpret_cast<uint8_t *>(dsh + pitch);  // [pitch] letters of the steps with an explicit token (steps with an event, stack drains); 0 = none
-    uint32_t *ev_raw = reinterpret_cast<uint32_t *>(ovr + pitch);  // [EV_K]
-    uint32_t *ev_srt = ev_raw + EV_K;                       // [EV_K]
+    uint32_t *ev_srt = reinterpret_cast<uint32_t *>(ovr + pitch);  // [EV_K] the read's events, in step order
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);
     uint64_t n_reads = 0;
     const uint32_t stride = gridDim.x * APPLY_WAVES * NG;
@@ -1273,8 +1217,8 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
             if (pass == 0) gw0 = w; else if (pass == 1) gw1 = w; else gw2 = w;
             fast |= (f ? 1u : 0u) << pass;
         }
-        // ---- 1. events: sorted by step, one word per step
-        if (rl < EV_K) ev_raw[rl] = evw;
+        // ---- 1. events (k_indel_scan lists them in step order)
+        if (rl < EV_K) ev_srt[rl] = evw;
         for (int j = rl * 8; j < pitch; j += GL * 8) {
             *reinterpret_cast<uint2 *>(ovr + j) = make_uint2(0u, 0u);
             *reinterpret_cast<uint2 *>(dsh + j) = make_uint2(0u, 0u);
@@ -1286,16 +1230,6 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t n_act = cnt;
-        if (!__builtin_amdgcn_ballot_w64(cnt > 1u)) {  // (most reads: one event)
-            if (rl == 0 && cnt) ev_srt[0] = evw;
-        } else {  // rank = events with a smaller step, or the same step and a smaller index (the walk merges equal steps)
-            uint32_t rank = 0;
-            for (uint32_t i = 0; i < (uint32_t)EV_K; ++i) {
-                const uint32_t other = ev_raw[i];
-                rank += (i < cnt && ((other >> 8) < (evw >> 8) || ((other >> 8) == (evw >> 8) && (int)i < rl))) ? 1u : 0u;
-            }
-            if (rl < (int)cnt) ev_srt[rank] = evw;
-        }
         // ---- 2. templates: 8 read-direction positions per lane
         for (int b = rl, pass = 0; cnt && b * 8 < TL; b += GL, ++pass) {
             const int k0 = b * 8;
@@ -1466,9 +1400,9 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
 // One wavefront per flagged read.  Exact introduce_indels + adjust_seq_length as a token transducer:
 // the list prefix [0, n) is final when step n starts; the not-yet-visited suffix is
 // (stack of freshly inserted letters, LIFO) ++ E(k), E(k+1), ...   (DESIGN.md "indel transducer").
-//   phase 1 (all lanes): event mask per loop step n, independent of the token (bits 0-3 insertion of
-//            letter slot x fires, bits 4-7 deletion fires if the token is base b); ballots of the
-//            steps with a non-empty mask; the template E(0 .. RL+63) is staged in LDS.
+//   phase 1: event mask per loop step n, independent of the token (bits 0-3 insertion of letter slot x fires,
+//            bits 4-7 deletion fires if the token is base b) from the read's event process (indel_events, run
+//            wave-uniformly); ballots of the steps with a non-empty mask; the template E(0 .. RL+63) is staged in LDS.
 //   phase 2 (wave-uniform walk over the ACTIVE steps only): explicit map[] entries for active steps
 //            and for the steps that drain the insertion stack; "from step n0 on, source index =
 //            k0 + (n - n0)" records for everything in between.
@@ -1481,11 +1415,11 @@ __host__ __device__ inline int fix_rlp(int RL) { return (RL + 63) & ~63; }
 __host__ __device__ inline size_t fix_wave_bytes(int RL) {
     const size_t rlp = (size_t)fix_rlp(RL);
     return rlp * 4 /* ev, stk, qual, (pad) */ + (rlp + 64) /* tmpl */ + 3 * 2 * (rlp + 64) /* map, rec_n0, rec_k0 */ +
-           2 * 2 * rlp /* ddel, dqm: the mate's deletion / error-test digits, one Philox block per lane */ +
+           2 * rlp /* dqm: the mate's error-test digits, one Philox block per lane */ +
            (FIX_MAX_RL / 64) * 8 /* act: the steps with an event, one 64-bit mask per chunk (wave-uniform, out of the registers) */;
 }
 __host__ __device__ inline size_t fix_lds_bytes(int RL) {
-    return (size_t)2 * RL * 8 * 4 + 64 * 4 + FIX_WAVES * fix_wave_bytes(RL);
+    return 64 * 4 + FIX_WAVES * fix_wave_bytes(RL);
 }
 
 __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, DevGenome g, RunArgs A,
@@ -1496,12 +1430,10 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
     extern __shared__ __attribute__((aligned(16))) uint8_t fix_lds[];
     const int RL = M.RL;
     const int rlp = fix_rlp(RL);
-    uint32_t *tab = reinterpret_cast<uint32_t *>(fix_lds);            // [2][RL][8]: digit limits of ins x4, del x4
-    uint32_t *mut8 = tab + (size_t)2 * RL * 8;                         // [64] leading 8 bits of the substitution-test thresholds
+    uint32_t *mut8 = reinterpret_cast<uint32_t *>(fix_lds);           // [64] leading 8 bits of the substitution-test thresholds
     const uint32_t n_fix = *fix_count;
     if (blockIdx.x * FIX_WAVES >= n_fix) return;                       // whole workgroup idle (uniform)
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)stats, (unsigned long long)n_fix);
-    for (int i = threadIdx.x; i < 2 * RL * 8; i += blockDim.x) tab[i] = M.fix_tab[i];
     for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut8[i] = (uint32_t)(M.mut_thr[i] >> 45);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1513,8 +1445,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
     int16_t *map = reinterpret_cast<int16_t *>(tmpl + rlp + 64);
     int16_t *rec_n0 = map + (rlp + 64);
     int16_t *rec_k0 = rec_n0 + (rlp + 64);
-    uint16_t *ddel = reinterpret_cast<uint16_t *>(rec_k0 + (rlp + 64));  // [rlp] deletion digit of step n (K_DEL)
-    uint16_t *dqm = ddel + rlp;                                           // [rlp] error-test digit (8 bits) of position j (K_QM)
+    uint16_t *dqm = reinterpret_cast<uint16_t *>(rec_k0 + (rlp + 64));    // [rlp] error-test digit (8 bits) of position j (K_QM)
     uint64_t *act = reinterpret_cast<uint64_t *>(dqm + rlp);              // [FIX_MAX_RL / 64] steps with an event
     const int n_pre = RL + 64;
     const int n_chunks = rlp / 64;  // 64-step chunks covering indices 0 .. RL-1
@@ -1535,53 +1466,26 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
         const MateGeom geo = mate_geom(o, d, RL, gl.L);
         uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.row;
         const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.row;
-        // ---- phase 0: the digits that several steps / positions share, one Philox block per LANE (a K_DEL block holds
-        //      the deletion digits of 8 steps, a K_QM block the error-test digits of 8 positions)
-        for (int b = lane; b * 8 < RL - 1; b += 64) {
-            const u32x4 w = draw_block(a, K_DEL, (uint32_t)b, 0);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) ddel[b * 8 + c] = (uint16_t)digit8(w, c * 2 + o);
-        }
+        // ---- phase 0: the error-test digits, one Philox block per LANE (a K_QM block holds those of 8 positions)
         for (int b = lane; b * 8 < RL; b += 64) {
             const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 1);
 #pragma unroll
             for (int c = 0; c < 8; ++c) dqm[b * 8 + c] = (uint16_t)((word_of(w, (c >> 2) * 2 + o) >> (8 * (c & 3))) & 0xffu);
         }
+        // ---- phase 1: event masks (every lane runs the read's event process -- wave-uniform -- lane 0 writes), template,
+        //      phred row
+        for (int n = lane; n < rlp; n += 64) ev[n] = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- phase 1: event masks, template, phred row
+        indel_events(M.ev_S + (size_t)o * M.ev_ns, M.ev_E + (size_t)o * M.ev_ns, M.ev_T + (size_t)o * M.ev_ns, M.del_thr + (size_t)o * RL * 4,
+                     M.ev_ns, a, o, [&](int n, uint32_t mask) { if (lane == 0) ev[n] |= (uint8_t)mask; });
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
         for (int c = 0; c < n_chunks; ++c) {
             const int n = c * 64 + lane;
-            uint32_t m8 = 0;
-            if (n < RL - 1) {
-                const uint32_t *t8 = tab + ((size_t)o * RL + n) * 8;
-                const size_t en = (size_t)o * RL + n;
-                if (t8[0] | t8[1] | t8[2] | t8[3]) {  // :193-196
-                    const u32x4 w = draw_block(a, K_INS, (uint32_t)n >> 1, 0);
-                    for (int x = 0; x < 4; ++x) {
-                        if (!t8[x]) continue;  // zero probability
-                        const uint32_t h = digit8(w, (n & 1) * 8 + o * 4 + x), th = t8[x] - 1u;
-                        bool hit = h < th;
-                        if (h == th) {  // tie of the leading digit: exact
-                            const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)n, (uint32_t)(o * 2 + (x >> 1)));
-                            hit = mk_digit8(h, lo45(l, x & 1)) < M.ins_thr[en * 4 + x];
-                        }
-                        if (hit) m8 |= 1u << x;
-                    }
-                }
-                if (t8[4] | t8[5] | t8[6] | t8[7]) {  // :209-210
-                    const uint32_t h = ddel[n];
-                    for (int b = 0; b < 4; ++b) {
-                        if (!t8[4 + b]) continue;
-                        const uint32_t th = t8[4 + b] - 1u;
-                        bool hit = h < th;
-                        if (h == th) hit = mk_digit8(h, lo45(draw_block(a, K_DEL_LO, (uint32_t)n, 0), o)) < M.del_thr[en * 4 + b];
-                        if (hit) m8 |= 16u << b;
-                    }
-                }
-            }
-            if (n < RL) { ev[n] = (uint8_t)m8; map[n] = FIX_NONE; qual[n] = out_qual[xp(n)]; }
+            const uint32_t m8 = n < RL - 1 ? (uint32_t)ev[n] : 0u;
+            if (n < RL) { map[n] = FIX_NONE; qual[n] = out_qual[xp(n)]; }
             { const uint64_t am = __ballot(m8 != 0); if (lane == 0) act[c] = am; }
         }
         for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)geom_base(gl, o, geo, k);

@@ -984,48 +984,44 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         M.alt_letters = (uint32_t)letters[0] | ((uint32_t)letters[1] << 8) | ((uint32_t)letters[2] << 16) | ((uint32_t)letters[3] << 24);
     }
     std::vector<uint64_t> del_max((size_t)2 * RL);
-    std::vector<uint8_t> ins_any((size_t)2 * RL);
     for (int o = 0; o < 2; ++o)
         for (int n = 0; n < RL; ++n) {
             const size_t e = (size_t)o * RL + n;
-            uint64_t dm = 0, im = 0;
-            for (int x = 0; x < 4; ++x) { dm = std::max(dm, t->del_thr[e * 4 + x]); im = std::max(im, t->ins_thr[e * 4 + x]); }
+            uint64_t dm = 0;
+            for (int x = 0; x < 4; ++x) dm = std::max(dm, t->del_thr[e * 4 + x]);
             del_max[e] = dm;
-            ins_any[e] = im ? 1 : 0;
         }
-    // k_indel_scan table: one entry per Philox block that holds a digit with a non-zero limit -- the K_DEL block of a
-    // group of 8 loop steps n <= RL-2 (__init__.py:187; digit (n & 7) * 2 + mate) or the K_INS block of two steps
-    // (digit (n & 1) * 8 + mate * 4 + letter slot).  Entry = [kind << 24 | index, 16 limits]; limit = (thr >> 45) + 1,
-    // 0 = never.
-    std::vector<uint32_t> scan_tab;
-    auto lim = [](uint64_t T) { return T ? (uint32_t)(T >> 45) + 1u : 0u; };
-    auto push_block = [&](uint32_t kind, uint32_t index, const uint32_t lims[16]) {
-        bool any = false;
-        for (int k = 0; k < 16; ++k) any |= lims[k] != 0;
-        if (!any) return;
-        scan_tab.push_back((kind << 24) | index);
-        scan_tab.insert(scan_tab.end(), lims, lims + 16);
-    };
-    for (int gI = 0; gI * 8 <= RL - 2; ++gI) {
-        uint32_t dl[16] = {0};
-        for (int c = 0; c < 8 && gI * 8 + c <= RL - 2; ++c)
-            for (int o = 0; o < 2; ++o) dl[c * 2 + o] = lim(del_max[(size_t)o * RL + gI * 8 + c]);
-        push_block(iss::K_DEL, (uint32_t)gI, dl);
-        for (int c2 = 0; c2 < 4 && gI * 8 + c2 * 2 <= RL - 2; ++c2) {
-            uint32_t il[16] = {0};
-            for (int c = 0; c < 2 && gI * 8 + c2 * 2 + c <= RL - 2; ++c)
-                for (int o = 0; o < 2; ++o)
-                    for (int x = 0; x < 4; ++x) il[c * 8 + o * 4 + x] = lim(t->ins_thr[((size_t)o * RL + gI * 8 + c2 * 2 + c) * 4 + x]);
-            push_block(iss::K_INS, (uint32_t)(gI * 4 + c2), il);
+    // the indel event process (iss_kernels.hip.h indel_events): per mate the slots
+    // 5 n + k of the loop steps n <= RL-2 (__init__.py:187) -- k = 0..3 the insertion tests, k = 4 the deletion test with
+    // the largest of its four thresholds -- their survival products in 0.64 fixed point (floor after every factor; a
+    // new segment after a slot that leaves less than 2^-16) and the last slot of each slot's segment
+    const int ev_ns = 5 * (RL - 1);
+    if (ev_ns > 0xffff) return fail(ctx, ISS_E_INVALID, "read_length too large for the indel event tables");
+    std::vector<uint64_t> ev_S((size_t)2 * ev_ns), ev_T((size_t)2 * ev_ns);
+    std::vector<uint16_t> ev_E((size_t)2 * ev_ns);
+    bool any_indel = false;
+    for (int o = 0; o < 2; ++o) {
+        uint64_t prev = iss::EV_ONE;
+        int seg_start = 0;
+        for (int sl = 0; sl < ev_ns; ++sl) {
+            const int n = sl / 5, k = sl % 5;
+            const uint64_t T = k < 4 ? t->ins_thr[((size_t)o * RL + n) * 4 + k] : del_max[(size_t)o * RL + n];
+            if (T > ((uint64_t)1 << 53)) return fail(ctx, ISS_E_INVALID, "an indel threshold exceeds 2^53");
+            any_indel |= T != 0;
+            const uint64_t cur = (uint64_t)(((unsigned __int128)prev * (((uint64_t)1 << 53) - T)) >> 53);
+            ev_T[(size_t)o * ev_ns + sl] = T;
+            ev_S[(size_t)o * ev_ns + sl] = cur;
+            if (cur < ((uint64_t)1 << 48) || sl == ev_ns - 1) {  // the segment ends here
+                for (int q = seg_start; q <= sl; ++q) ev_E[(size_t)o * ev_ns + q] = (uint16_t)sl;
+                seg_start = sl + 1;
+                prev = iss::EV_ONE;
+            } else {
+                prev = cur;
+            }
         }
     }
-    M.n_scan = (int32_t)(scan_tab.size() / iss::SCAN_W);
-    std::vector<uint32_t> fix_tab((size_t)2 * RL * 8);
-    for (size_t e = 0; e < (size_t)2 * RL; ++e)
-        for (int x = 0; x < 4; ++x) {
-            fix_tab[e * 8 + x] = lim(t->ins_thr[e * 4 + x]);
-            fix_tab[e * 8 + 4 + x] = lim(t->del_thr[e * 4 + x]);
-        }
+    M.ev_ns = ev_ns;
+    M.n_scan = any_indel ? 1 : 0;
     // k_mt_resolve tables: un-merged 16-bit leading digits per (orientation, bin slot, position) -- a row of n_q
     // digits padded to an odd number of words -- and 27-bit leading parts of the indel thresholds
     M.mt_row_w = (nq + 2) / 2;  // >= one 0xffff padding digit after the n_q digits
@@ -1064,9 +1060,9 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(del_thr, t->del_thr, (size_t)2 * RL * 4, uint64_t);
     UP(del_thr_max, del_max.data(), del_max.size(), uint64_t);
     UP(mut_thr, t->mut_thr, (size_t)nq + 1, uint64_t);
-    UP(ins_any, ins_any.data(), ins_any.size(), uint8_t);
-    UP(scan_tab, scan_tab.data(), scan_tab.size(), uint32_t);
-    UP(fix_tab, fix_tab.data(), fix_tab.size(), uint32_t);
+    UP(ev_S, ev_S.data(), ev_S.size(), uint64_t);
+    UP(ev_E, ev_E.data(), ev_E.size(), uint16_t);
+    UP(ev_T, ev_T.data(), ev_T.size(), uint64_t);
     UP(mt_rows, mt_rows.data(), mt_rows.size(), uint16_t);
     UP(mt_lim, mt_lim.data(), mt_lim.size(), uint32_t);
 #undef UP
@@ -1450,12 +1446,10 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                 HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_setup, 0));  // the scan needs the pair descriptors only
             }
             HIP_TRY(ctx, mark(3, s_indel));
-            if (M.n_scan > 0) {
-                const uint64_t items = (uint64_t)n * M.n_scan;
-                const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 4,
-                                                                     (items + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
-                const size_t lds = iss::scan_lds_bytes(M.n_scan, M.RL);
-                hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), lds, s_indel, M, A, desc);
+            if (M.n_scan > 0) {  // one lane per read
+                const uint64_t reads = 2 * (uint64_t)n;
+                const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 8, (reads + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
+                hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), s_indel, M, A, desc);
             }
             HIP_TRY(ctx, mark(4, s_indel));
             if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
@@ -1463,8 +1457,11 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, 16 (32) lanes per read
                 const int GL = iss::apply_gl(M.pitch);
                 const int64_t per_wg = (int64_t)iss::APPLY_WAVES * (64 / GL);  // reads per workgroup pass; at most 2 n reads
-                const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
                 const size_t lds = iss::apply_lds_bytes(M.RL, M.pitch, GL);
+                // as many workgroups as are resident at once (4 wavefronts / SIMD, LDS permitting): the list is usually far
+                // shorter than 2 n, and a workgroup with this much LDS is not cheap to start only to find nothing to do
+                const int64_t resident = std::max<int64_t>(1, std::min<int64_t>(16 / iss::APPLY_WAVES, (int64_t)(160 * 1024) / (int64_t)lds));
+                const unsigned blocks = (unsigned)std::min<int64_t>(resident * ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
                 const dim3 grid(blocks), block(64 * iss::APPLY_WAVES);
 #define ISS_LAUNCH_APPLY(MUT, G) hipLaunchKernelGGL((iss::k_indel_apply<MUT, G>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats)
                 if (A.mut) { if (GL == 8) ISS_LAUNCH_APPLY(true, 8); else if (GL == 16) ISS_LAUNCH_APPLY(true, 16); else ISS_LAUNCH_APPLY(true, 32); }
@@ -1763,7 +1760,7 @@ int iss_introduce_indels(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t 
     const int RL = ctx->M.RL;
     for (int64_t i = 0; i < n; ++i)
         if (seq_len[i] < 0 || seq_len[i] > RL) return fail(ctx, ISS_E_INVALID, "iss_introduce_indels: a read longer than read_length");
-    const int32_t cap = 5 * RL + 8;
+    const int32_t cap = 6 * RL + 8;  // letters (<= 5 RL + 8) + the event masks of the steps
     const size_t bytes = (size_t)n * RL;
     DevBuf ds, dl, dg, db, dw, dout, dst;
     HIP_TRY(ctx, hipMalloc(&ds.p, bytes));

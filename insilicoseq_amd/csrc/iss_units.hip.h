@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void k_unit_isize(DevModel M, UnitArgs U, int64
 
 // ErrorModel.introduce_indels + adjust_seq_length (__init__.py:158-228, 114-156): read i = seq[i][0 .. len[i]) (the
 // perfect read, <= RL letters, already in read direction), bounds[i] = (start, end) in `genome` (length L) for the
-// padding; out[i][0 .. RL).  work: [n][cap] scratch letters, cap = 5 * RL + 8.  status: 0 ok, 2 KeyError, 3 IndexError.
+// padding; out[i][0 .. RL).  work: [n][cap] scratch letters + event masks, cap = 6 * RL + 8.  status: 0 ok, 2 KeyError, 3 IndexError.
 __global__ __launch_bounds__(64) void k_unit_indels(DevModel M, UnitArgs U, const uint8_t *__restrict__ seq, const int32_t *__restrict__ len,
                                                     const uint8_t *__restrict__ genome, int64_t L, const int64_t *__restrict__ bounds,
                                                     uint8_t *__restrict__ work, int32_t cap, uint8_t *__restrict__ out,
@@ -87,16 +87,20 @@ __global__ __launch_bounds__(64) void k_unit_indels(DevModel M, UnitArgs U, cons
     for (int k = 0; k < n_s; ++k) s[k] = seq[(size_t)i * RL + k];
     const int64_t start = bounds[2 * i], end = bounds[2 * i + 1];
     int position = 0, rc = 0;
+    // which tests fire at every step (the read's event process, iss_kernels.hip.h indel_events): bits 0-3 insertion of
+    // letter slot x, bits 4-7 the deletion if the token is base b
+    uint8_t *evm = s + cap - RL;  // (the tail of the read's scratch row)
+    for (int k = 0; k < RL; ++k) evm[k] = 0;
+    indel_events(M.ev_S + (size_t)o * M.ev_ns, M.ev_E + (size_t)o * M.ev_ns, M.ev_T + (size_t)o * M.ev_ns, M.del_thr + (size_t)o * RL * 4, M.ev_ns,
+                 a, o, [&](int n, uint32_t mask) { evm[n] |= (uint8_t)mask; });
     for (int nucl = 0; nucl < RL - 1; ++nucl) {
         if (nucl >= n_s) continue;  // IndexError swallowed, :223-224 (position not advanced)
         const int cu = s[nucl] & ~0x20;
         if (cu == 'R' || cu == 'Y' || cu == 'W' || cu == 'S' || cu == 'M' || cu == 'K' || cu == 'H' || cu == 'B' || cu == 'V' ||
             cu == 'D' || cu == 'N') { ++position; continue; }  // :190-192
         const size_t en = (size_t)o * RL + position;
-        const u32x4 wi = draw_block(a, K_INS, (uint32_t)position >> 1, 0);
         for (int x = 0; x < 4; ++x) {  // :193-196, dict order
-            const u32x4 l = draw_block(a, K_INS_LO, (uint32_t)position, (uint32_t)(2 * o + (x >> 1)));
-            if (mk_digit8(digit8(wi, (position & 1) * 8 + 4 * o + x), lo45(l, x & 1)) < M.ins_thr[en * 4 + x]) {
+            if ((evm[position] >> x) & 1) {
                 for (int z = n_s; z > position + 1; --z) s[z] = s[z - 1];  // insert after the base read
                 s[position + 1] = M.ins_letter[en * 4 + x];
                 ++n_s;
@@ -104,9 +108,7 @@ __global__ __launch_bounds__(64) void k_unit_indels(DevModel M, UnitArgs U, cons
         }
         const int bi = base_index(cu);
         if (bi < 0) { rc = 2; break; }  // deletions[position][X]: KeyError (:209)
-        const u32x4 wd = draw_block(a, K_DEL, (uint32_t)position >> 3, 0);
-        const uint64_t m = mk_digit8(digit8(wd, (position & 7) * 2 + o), lo45(draw_block(a, K_DEL_LO, (uint32_t)position, 0), o));
-        if (m < M.del_thr[en * 4 + bi]) {
+        if ((evm[position] >> (4 + bi)) & 1) {
             for (int z = position; z + 1 < n_s; ++z) s[z] = s[z + 1];
             --n_s;
         }

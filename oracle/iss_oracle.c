@@ -143,8 +143,9 @@ void iss_oracle_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t
  * A "digit draw" builds its 53-bit numerator as m = (digit << (53 - w)) | trailing bits: the w-bit leading
  * digit comes from a PRIMARY block shared by many draws (the device compares digits and needs three Philox
  * calls per 16 bases), the trailing bits from a SECONDARY block that the device only evaluates when the
- * digit ties with a threshold's.  w = 16 for the quality draw, 8 for the substitution test and for the insertion
- * and deletion draws (kde.py:84, __init__.py:94, :194, :209).  u = m / 2^53 exactly. */
+ * digit ties with a threshold's.  w = 16 for the quality draw, 8 for the substitution test (kde.py:84,
+ * __init__.py:94).  u = m / 2^53 exactly.  The insertion / deletion tests (__init__.py:194, :209) are not drawn one
+ * by one in this mode: see ev_tab below. */
 enum {
     K_PAIR = 0,   /* index 0; full draws mk53(sub0.word[s], sub1.word[s]), s = isize, bin_fwd, bin_rev, gc */
     K_FS = 1,     /* forward-start randbelow words: word t -> index t/4, word t%4        */
@@ -155,12 +156,14 @@ enum {
                    * half*2 + mate, byte cc.                                                        */
     K_SUB = 4,    /* index = p, sub = mate: (w0,w1) substitution choice (full draw); the 45 trailing bits of the
                    * error-test draw = (w2 & 0x1fff) << 32 | w3                                      */
-    K_INS = 5,    /* primary digits (8 bits); index = n>>1; digit (n&1)*8 + mate*4 + slot */
-    K_DEL = 6,    /* primary digits (8 bits); index = n>>3; digit (n&7)*2 + mate          */
+    K_INS = 5,    /* (retired: the indel tests are sampled by K_EV)                      */
+    K_DEL = 6,    /* (retired)                                                           */
     K_QM_LO = 7,  /* trailing 37 bits of the quality draw; index = p; sub = mate; (w0,w1)  */
-    K_INS_LO = 8, /* secondary (45 bits); index = n; sub = mate*2 + (slot>>1); pair slot&1 */
-    K_DEL_LO = 9, /* secondary (45 bits); index = n; sub 0; (w0,w1) fwd, (w2,w3) rev       */
-    K_FRAG = 10   /* custom fragment length: polar candidate t -> index t; x1 from mk53(w0,w1), x2 from mk53(w2,w3) */
+    K_INS_LO = 8, /* (retired)                                                           */
+    K_DEL_LO = 9, /* (retired)                                                           */
+    K_FRAG = 10,  /* custom fragment length: polar candidate t -> index t; x1 from mk53(w0,w1), x2 from mk53(w2,w3) */
+    K_EV = 11     /* indel events of a read: draw j of the event process (see ev_tab) -> index j, sub = mate;
+                   * (w0,w1): where the next test fires; (w2,w3): which bases a deletion test fires for       */
 };
 
 /* ------------------------------------------------------------- RNG provider */
@@ -243,20 +246,6 @@ static double draw_double(iss_rng *r, int stream, int kind, uint32_t index, uint
         return res53(w[slot], w2[slot]);
     }
     return res53(w[2 * slot], w[2 * slot + 1]);
-}
-
-/* Indel draws: an 8-bit leading digit (16 to a primary block: indel probabilities are tiny, one Philox block decides 16
- * tests at once and the 45 trailing bits are looked at on a tie of the leading digit only) + 45 bits of a secondary block. */
-static double draw_digit8(iss_rng *r, int stream, int kind_p, uint32_t index_p, int digit, int kind_l,
-                          uint32_t index_l, uint32_t sub_l, int pair_l) {
-    if (r->mode == ISS_RNG_MT)
-        return stream == STREAM_PY ? iss_oracle_py_random(r) : iss_oracle_np_random(r);
-    uint32_t wp[4], wl[4];
-    philox_at(r, kind_p, index_p, 0, wp);
-    philox_at(r, kind_l, index_l, sub_l, wl);
-    uint64_t d8 = (wp[digit >> 2] >> (8 * (digit & 3))) & 0xffu;
-    uint64_t l45 = ((uint64_t)wl[2 * pair_l] << 13) | (wl[2 * pair_l + 1] >> 19);
-    return (double)((d8 << 45) | l45) * (1.0 / 9007199254740992.0);
 }
 
 /* The two hot draws of read position p of mate o (see K_QM / K_SUB / K_QM_LO in the enum). */
@@ -411,6 +400,114 @@ static void mut_push(mut_sink *s, int mate, int type, int pos, int ref, int alt,
     s->n++;
 }
 
+/* ------------------------------------------------------------ indel events (position-addressable mode)
+ * introduce_indels runs, per loop step n <= RL-2, four insertion tests `random() < p_ins[n][x]` and one deletion test
+ * `random() < p_del[n][base]` (__init__.py:193-196, :209): 5 (RL - 1) independent Bernoulli tests per read, all but a
+ * handful failing.  Drawing them one by one is what the reference (and the MT mode here) does; in the
+ * position-addressable mode the SAME joint distribution is sampled by skipping from one firing test to the next:
+ *   slot t = 5 n + k, k = 0..3 insertion of letter slot k, k = 4 the deletion; its probability is T[t] / 2^53 with
+ *   T = ceil(p * 2^53) (`u < p`  <=>  `m < T` for the 53-bit numerator m of u), the deletion slot carrying the
+ *   largest of its four bases' thresholds;
+ *   S[t] = prod_{t' <= t, same segment} (1 - T[t'] / 2^53) in 0.64 fixed point (floor after every factor) -- the
+ *   probability that no test of the segment up to t fires; a new segment starts after a slot that leaves S below
+ *   2^-16 (precision) -- in particular after a test that always fires;
+ *   one uniform r in (0, 1] per draw: the next firing test after slot `cur` is the first t of cur's segment with
+ *   S[t] <= r * S[cur] (P(none up to t | none up to cur) = S[t] / S[cur]); none: the draw is spent, go on with the
+ *   next segment.  A firing deletion slot fires for base b iff v * T_max < T_b * 2^53 with a second uniform numerator
+ *   v of the same block (the four bases share the reference's ONE uniform: nested events).
+ * All of it is integer arithmetic (64 x 64 -> 128 bit products): the device repeats it bit for bit.  The result is the
+ * event mask of every step -- bits 0-3: insertion of letter slot x fires, bits 4-7: the deletion fires if the token is
+ * base b -- whether or not the loop visits the step. */
+typedef struct {
+    int ns;          /* 5 * (RL - 1) slots */
+    uint64_t *S;     /* [ns]   survival inside the segment, 0.64 fixed point */
+    uint16_t *E;     /* [ns]   last slot of the slot's segment               */
+    uint64_t *T;     /* [ns]   threshold of the slot (deletion: the largest) */
+    uint64_t *Tdel;  /* [RL-1][4] deletion thresholds per base                */
+    int any;         /* some T != 0 */
+} ev_tab;
+#define EV_ONE 0xffffffffffffffffull
+#define EV_RESTART (1ull << 48)
+
+static uint64_t thr_of(double p) { /* ceil(p * 2^53): u < p  <=>  m < thr */
+    double x = ceil(p * 9007199254740992.0);
+    if (!(x > 0.0)) return 0;
+    if (x >= 9007199254740992.0) return 1ull << 53;
+    return (uint64_t)x;
+}
+static void ev_tab_build(const iss_model *m, int o, ev_tab *t) {
+    const int RL = m->read_length, ns = 5 * (RL - 1);
+    t->ns = ns;
+    t->S = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(ns > 0 ? ns : 1));
+    t->T = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(ns > 0 ? ns : 1));
+    t->E = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(ns > 0 ? ns : 1));
+    t->Tdel = (uint64_t *)malloc(sizeof(uint64_t) * 4 * (size_t)(RL > 1 ? RL - 1 : 1));
+    t->any = 0;
+    uint64_t prev = EV_ONE;
+    int seg_start = 0;
+    for (int s = 0; s < ns; s++) {
+        const int n = s / 5, k = s % 5;
+        uint64_t T;
+        if (k < 4) {
+            T = thr_of(m->ins[((size_t)o * RL + n) * 4 + k]);
+        } else {
+            T = 0;
+            for (int b = 0; b < 4; b++) {
+                uint64_t tb = thr_of(m->del[((size_t)o * RL + n) * 4 + b]);
+                t->Tdel[(size_t)n * 4 + b] = tb;
+                if (tb > T) T = tb;
+            }
+        }
+        t->T[s] = T;
+        if (T) t->any = 1;
+        const uint64_t cur = (uint64_t)(((unsigned __int128)prev * ((1ull << 53) - T)) >> 53);
+        t->S[s] = cur;
+        if (cur < EV_RESTART || s == ns - 1) { /* the segment ends here */
+            for (int q = seg_start; q <= s; q++) t->E[q] = (uint16_t)s;
+            seg_start = s + 1;
+            prev = EV_ONE;
+        } else {
+            prev = cur;
+        }
+    }
+}
+static void ev_tab_free(ev_tab *t) { free(t->S); free(t->T); free(t->E); free(t->Tdel); }
+
+/* the event masks of one read: mask[0 .. RL-1) */
+static void sample_indel_events(const ev_tab *t, const iss_rng *r, int o, uint8_t *mask, int RL) {
+    memset(mask, 0, (size_t)RL);
+    if (!t->any) return;
+    int cur = -1;
+    uint32_t j = 0;
+    while (cur < t->ns - 1) {
+        const int seg_last = t->E[cur + 1];
+        const uint64_t base = (cur >= 0 && t->E[cur] == seg_last) ? t->S[cur] : EV_ONE;
+        uint32_t w[4];
+        philox_at(r, K_EV, j++, (uint32_t)o, w);
+        const uint64_t m53 = ((uint64_t)(w[0] >> 5) << 26) | (w[1] >> 6);
+        const uint64_t rr = (((1ull << 53) - m53) << 11) - 1; /* (1 - u) in 0.64 fixed point, (0, 1] */
+        const uint64_t target = (uint64_t)(((unsigned __int128)rr * base) >> 64);
+        if (t->S[seg_last] > target) { cur = seg_last; continue; } /* nothing fires in the rest of the segment */
+        int lo = cur + 1, hi = seg_last; /* first slot with S <= target */
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (t->S[mid] <= target) hi = mid; else lo = mid + 1;
+        }
+        const int n = lo / 5, k = lo % 5;
+        if (k < 4) {
+            mask[n] |= (uint8_t)(1u << k);
+        } else {
+            const uint64_t v = ((uint64_t)(w[2] >> 5) << 26) | (w[3] >> 6);
+            const uint64_t scaled = (uint64_t)(((unsigned __int128)v * t->T[lo]) >> 53); /* floor(v * T_max / 2^53) */
+            for (int b = 0; b < 4; b++)
+                if (scaled < t->Tdel[(size_t)n * 4 + b]) mask[n] |= (uint8_t)(16u << b);
+        }
+        cur = lo;
+    }
+}
+/* the tables of the call in progress (built by the exported entry points; one call per thread at a time) */
+static __thread const ev_tab *g_ev = NULL;
+
 /* ------------------------------------------------------------ introduce_indels
  * __init__.py:158-228 + adjust_seq_length :114-156.
  * seq/len: the perfect read (<= RL chars); out: exactly RL chars.
@@ -425,6 +522,12 @@ static int introduce_indels(const iss_model *m, iss_rng *r, int o, const uint8_t
     memcpy(s, seq, (size_t)len);
     int n_s = len;
     int position = 0;
+    const int philox = r->mode != ISS_RNG_MT;
+    uint8_t *evm = NULL; /* position-addressable mode: which tests fire at every step (see ev_tab) */
+    if (philox) {
+        evm = (uint8_t *)malloc((size_t)RL);
+        sample_indel_events(&g_ev[o], r, o, evm, RL);
+    }
     for (int nucl = 0; nucl < RL - 1; nucl++) {
         if (nucl >= n_s) continue; /* IndexError swallowed, :223-224 (position not advanced) */
         int cu = upper_c(s[nucl]);
@@ -432,9 +535,8 @@ static int introduce_indels(const iss_model *m, iss_rng *r, int o, const uint8_t
         const double *insp = m->ins + ((size_t)o * RL + position) * 4;
         const uint8_t *insl = m->ins_letter + ((size_t)o * RL + position) * 4;
         for (int x = 0; x < 4; x++) { /* :193-196, dict order */
-            double u = draw_digit8(r, STREAM_PY, K_INS, (uint32_t)position >> 1, (position & 1) * 8 + 4 * o + x, K_INS_LO,
-                                   (uint32_t)position, (uint32_t)(2 * o + (x >> 1)), x & 1);
-            if (u < insp[x]) {
+            const int fires = philox ? (evm[position] >> x) & 1 : iss_oracle_py_random(r) < insp[x];
+            if (fires) {
                 memmove(s + position + 2, s + position + 1, (size_t)(n_s - position - 1));
                 s[position + 1] = insl[x];
                 n_s++;
@@ -443,10 +545,10 @@ static int introduce_indels(const iss_model *m, iss_rng *r, int o, const uint8_t
             }
         }
         int bi = base_index(cu);
-        if (bi < 0) { free(s); return ISS_ERR_KEY; } /* deletions[position][X] KeyError :209 */
-        double u = draw_digit8(r, STREAM_PY, K_DEL, (uint32_t)position >> 3, (position & 7) * 2 + o, K_DEL_LO,
-                               (uint32_t)position, 0, o);
-        if (u < m->del[((size_t)o * RL + position) * 4 + bi]) {
+        if (bi < 0) { free(s); free(evm); return ISS_ERR_KEY; } /* deletions[position][X] KeyError :209 */
+        const int del_fires = philox ? (evm[position] >> (4 + bi)) & 1
+                                     : iss_oracle_py_random(r) < m->del[((size_t)o * RL + position) * 4 + bi];
+        if (del_fires) {
             memmove(s + position, s + position + 1, (size_t)(n_s - position - 1));
             n_s--;
             if (sink && sink->buf) {
@@ -471,15 +573,16 @@ static int introduce_indels(const iss_model *m, iss_rng *r, int o, const uint8_t
                 int64_t idx = start - 1 - i;
                 if (idx < 0) c = 'A';
                 else {
-                    if (idx >= L) { free(s); return ISS_ERR_INDEX; }
+                    if (idx >= L) { free(s); free(evm); return ISS_ERR_INDEX; }
                     c = complement_char(genome[idx]);
-                    if (!c) { free(s); return ISS_ERR_KEY; }
+                    if (!c) { free(s); free(evm); return ISS_ERR_KEY; }
                 }
             }
             out[n_s + i] = (uint8_t)c;
         }
     }
     free(s);
+    free(evm);
     return ISS_OK;
 }
 
@@ -653,6 +756,8 @@ int iss_oracle_simulate(const iss_model *m, iss_rng *r, const iss_run_params *rp
     int64_t i = 0;
     int rc = ISS_OK;
     uint32_t attempt = 0;
+    ev_tab ev[2];
+    if (r->mode != ISS_RNG_MT) { ev_tab_build(m, 0, &ev[0]); ev_tab_build(m, 1, &ev[1]); g_ev = ev; }
     while (i < n_pairs) {
         r->ordinal = first_ordinal + (uint64_t)i;
         r->attempt = attempt;
@@ -669,6 +774,7 @@ int iss_oracle_simulate(const iss_model *m, iss_rng *r, const iss_run_params *rp
             i++;
         }
     }
+    if (r->mode != ISS_RNG_MT) { g_ev = NULL; ev_tab_free(&ev[0]); ev_tab_free(&ev[1]); }
     if (n_done) *n_done = i;
     if (n_mut) *n_mut = sink.n;
     return rc;
@@ -677,7 +783,20 @@ int iss_oracle_simulate(const iss_model *m, iss_rng *r, const iss_run_params *rp
 /* ---- function-level entry points (pin the reference's unit goldens) -------- */
 int iss_oracle_introduce_indels(const iss_model *m, iss_rng *r, int orientation, const uint8_t *seq, int len,
                                 const uint8_t *genome, int64_t L, int64_t start, int64_t end, uint8_t *out) {
-    return introduce_indels(m, r, orientation, seq, len, genome, L, start, end, out, NULL);
+    ev_tab ev[2];
+    if (r->mode != ISS_RNG_MT) { ev_tab_build(m, 0, &ev[0]); ev_tab_build(m, 1, &ev[1]); g_ev = ev; }
+    const int rc = introduce_indels(m, r, orientation, seq, len, genome, L, start, end, out, NULL);
+    if (r->mode != ISS_RNG_MT) { g_ev = NULL; ev_tab_free(&ev[0]); ev_tab_free(&ev[1]); }
+    return rc;
+}
+/* the event masks of the read at the rng's current address (position-addressable mode): mask[0 .. RL) */
+int iss_oracle_indel_event_masks(const iss_model *m, iss_rng *r, int orientation, uint8_t *mask) {
+    if (r->mode == ISS_RNG_MT) return ISS_ERR_KEY;
+    ev_tab ev;
+    ev_tab_build(m, orientation, &ev);
+    sample_indel_events(&ev, r, orientation, mask, m->read_length);
+    ev_tab_free(&ev);
+    return ISS_OK;
 }
 void iss_oracle_gen_phred_scores(const iss_model *m, iss_rng *r, int orientation, uint8_t *qual) {
     gen_phred_scores(m, r, orientation, qual);

@@ -214,6 +214,18 @@ class Oracle(object):
                                                g.ctypes.data, len(g), bounds[0], bounds[1], out.ctypes.data)
         return rc, out.tobytes().decode("ascii")
 
+    def indel_event_masks(self, rng, orientation, ordinals):
+        """Position-addressable mode: the event masks (bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion
+        fires if the token is base b) of the reads at the given ordinals: [len(ordinals)][read_length]."""
+        L = lib()
+        L.iss_oracle_indel_event_masks.restype = C.c_int
+        L.iss_oracle_indel_event_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        out = np.zeros((len(ordinals), self.read_length), dtype=np.uint8)
+        for i, k in enumerate(ordinals):
+            rng.set_address(int(k))
+            assert L.iss_oracle_indel_event_masks(C.byref(self._m), rng._h, int(orientation), out[i].ctypes.data) == 0
+        return out
+
     def gen_phred_scores(self, rng, orientation):
         q = np.zeros(self.read_length, dtype=np.uint8)
         lib().iss_oracle_gen_phred_scores(C.byref(self._m), rng._h, int(orientation), q.ctypes.data)

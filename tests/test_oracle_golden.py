@@ -217,3 +217,49 @@ def test_basic_model_in_philox_mode_inverts_its_score_distribution():
     # the same seed again: addressable, not a stream
     again = orc.simulate(O.Rng().seed_philox(9), genome, 100, first_ordinal=3900)
     assert (again["r1_qual"] == res["r1_qual"][3900:]).all() and (again["r2_base"] == res["r2_base"][3900:]).all()
+
+
+def test_indel_event_process_is_the_product_of_the_reference_tests():
+    """Position-addressable mode: the indel tests of a read (4 insertion tests + 1 deletion test per loop step,
+    __init__.py:193-196, :209) are sampled by skipping from one firing test to the next.  The joint distribution must be
+    that of independent Bernoulli tests: per-test frequencies, the nesting of the four bases' deletion events (one
+    uniform in the reference), pairs of tests, tests that never / always fire, segment restarts after a certain event."""
+    from helpers import dense_model
+
+    d = dense_model("hiseq")  # (any shipped model: the probabilities are overwritten)
+    RL = d.read_length
+    rs = np.random.RandomState(11)
+    d.ins[:] = 0.0
+    d.dele[:] = 0.0
+    d.ins[0, :, :] = rs.choice([0.0, 1e-4, 3e-3, 0.05], size=(RL, 4), p=[0.4, 0.3, 0.2, 0.1])
+    d.dele[0, :, :] = rs.choice([0.0, 2e-4, 1e-2, 0.2], size=(RL, 4), p=[0.3, 0.3, 0.3, 0.1])
+    d.ins[0, 7, 2] = 1.0    # a test that always fires: the survival table restarts after it
+    d.dele[0, 40, :] = [0.5, 1.0, 0.0, 0.25]
+    d.ins[0, 60:64, :] = 0.9  # a stretch where "nothing fires" is rarer than 2^-16: several segments
+    orc = O.Oracle(d)
+    N = 60000
+    masks = orc.indel_event_masks(O.Rng().seed_philox(77), 0, range(N)).astype(np.uint32)
+    assert masks.shape == (N, RL) and (masks[:, RL - 1] == 0).all()  # (the loop stops at step RL - 2)
+    for x in range(4):
+        f = ((masks >> x) & 1).mean(axis=0)[: RL - 1]
+        p = d.ins[0, : RL - 1, x]
+        assert (np.abs(f - p) <= 5 * np.sqrt(p * (1 - p) / N) + 1e-12).all(), ("insertion slot", x)
+        f = ((masks >> (4 + x)) & 1).mean(axis=0)[: RL - 1]
+        p = d.dele[0, : RL - 1, x]
+        assert (np.abs(f - p) <= 5 * np.sqrt(p * (1 - p) / N) + 1e-12).all(), ("deletion base", x)
+    # one uniform for the four bases of a step: the events are nested by probability
+    for n in range(RL - 1):
+        order = np.argsort(d.dele[0, n])
+        for a, b in zip(order[:-1], order[1:]):
+            assert not (((masks[:, n] >> (4 + a)) & 1) & ~((masks[:, n] >> (4 + b)) & 1)).any()
+    # independence of distinct tests: a few pairs with sizeable probabilities
+    hot = [(n, x) for n in range(RL - 1) for x in range(4) if 0.04 < d.ins[0, n, x] < 0.95][:12]
+    for (n1, x1), (n2, x2) in zip(hot[:-1], hot[1:]):
+        a = (masks[:, n1] >> x1) & 1
+        b = (masks[:, n2] >> x2) & 1
+        p12 = d.ins[0, n1, x1] * d.ins[0, n2, x2]
+        assert abs((a & b).mean() - p12) <= 5 * np.sqrt(p12 * (1 - p12) / N)
+    # the other mate has no events at all, and the same address gives the same answer
+    assert not orc.indel_event_masks(O.Rng().seed_philox(77), 1, range(50)).any()
+    again = orc.indel_event_masks(O.Rng().seed_philox(77), 0, [5, 17, 5])
+    assert (again[0] == masks[5]).all() and (again[1] == masks[17]).all() and (again[2] == masks[5]).all()
