@@ -20,13 +20,14 @@
 //              Assumes "no indel in this read".
 //   k_indel_scan : 1 lane / read: the read's indel events (step, event mask), sampled by skipping from one firing
 //              test to the next; lists every read with an event.
-//   k_indel_apply: half a wavefront / listed read: replays the read's event list through the token
+//   k_indel_apply: 8 lanes (16 / 32 for long reads) / listed read: replays the read's event list through the token
 //              transducer, re-derives the read (template, substitutions) and rewrites its base row.
 //   k_indel_fixup: 1 wavefront / flagged read (irregular pairs, reads with more events than a list
-//              holds): exact sequential indel semantics (lane 0 walks the token transducer over an
-//              event mask computed by all lanes) + re-mutation by all lanes, rewrites that read's base row.
+//              holds): exact sequential indel semantics (lane 0 walks the token transducer over the
+//              read's event masks) + re-mutation by all lanes, rewrites that read's base row.
 // No MFMA anywhere: this is sampling/indexing.  All f64 comparisons of the reference are exact
-// integer comparisons here (thresholds prepared on the host, see iss_mi355x.h / DESIGN.md).
+// integer comparisons here (thresholds prepared on the host, see iss_mi355x.h / DESIGN.md); the indel tests are
+// sampled as an event process with the same joint distribution (indel_events below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -163,7 +164,6 @@ struct DevModel {
     const uint64_t *ins_thr;    // [2][RL][4]
     const uint8_t *ins_letter;  // [2][RL][4]
     const uint64_t *del_thr;    // [2][RL][4]
-    const uint64_t *del_thr_max;  // [2][RL]  max over bases
     const uint64_t *mut_thr;      // [n_q+1]
     // indel events (k_indel_scan; see indel_events()): per mate the 5 * (RL - 1) test slots 5 n + k (k = 0..3 insertion of letter
     // slot k at loop step n, k = 4 the deletion with the largest of its four thresholds)

@@ -1058,7 +1058,6 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     UP(ins_thr, t->ins_thr, (size_t)2 * RL * 4, uint64_t);
     UP(ins_letter, t->ins_letter, (size_t)2 * RL * 4, uint8_t);
     UP(del_thr, t->del_thr, (size_t)2 * RL * 4, uint64_t);
-    UP(del_thr_max, del_max.data(), del_max.size(), uint64_t);
     UP(mut_thr, t->mut_thr, (size_t)nq + 1, uint64_t);
     UP(ev_S, ev_S.data(), ev_S.size(), uint64_t);
     UP(ev_E, ev_E.data(), ev_E.size(), uint16_t);
