@@ -1092,7 +1092,8 @@ __host__ __device__ inline size_t apply_read_bytes(int pitch) {
     //           + events (4 * EV_K)
     return (size_t)apply_tl(pitch) + 2 * (size_t)pitch + 4 * EV_K + (size_t)pitch + 4 * EV_K;
 }
-__host__ __device__ inline size_t apply_wave_bytes(int pitch, int GL) { return (size_t)(64 / GL) * apply_read_bytes(pitch); }
+constexpr int APPLY_RING = 128;   // substitution candidates a wavefront can hold (a private ring: 63 pending + 64 new at most)
+__host__ __device__ inline size_t apply_wave_bytes(int pitch, int GL) { return (size_t)(64 / GL) * apply_read_bytes(pitch) + APPLY_RING * 12; }
 // [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 i64][items APPLY_ITEMS][per wave]
 __host__ __device__ inline size_t apply_items_bytes() { return (APPLY_ITEMS + 2) * 8 + APPLY_ITEMS * sizeof(BatchItem); }
 __host__ __device__ inline size_t apply_tab_bytes(int RL) {
@@ -1131,6 +1132,50 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     const int rg = lane / GL, rl = lane % GL;  // group (read) of the wavefront, lane within the group
     uint8_t *wave0 = apply_lds + apply_tab_bytes(RL) + (size_t)wv * apply_wave_bytes(pitch, GL);
     uint8_t *wbase = wave0 + (size_t)rg * apply_read_bytes(pitch);
+    // substitution candidates (the test fires or ties, __init__.py:94: ~0.7 % of the positions): deferred to a private ring
+    // of the wavefront and settled 64 at a time, one lane each -- a loop in place would run whenever ONE of the wave's
+    // 512 positions is a candidate, i.e. always, for a lane or two of work.  Entry: {pair, attempt << 16 | mate << 15 |
+    // "past the template" << 14 | position, original letter << 24 | base << 16 | phred << 8 | error-test digit}
+    uint32_t *cring = reinterpret_cast<uint32_t *>(wave0 + (size_t)NG * apply_read_bytes(pitch));
+    uint32_t c_head = 0, c_tail = 0;  // wave-uniform
+    auto settle_candidates = [&](uint32_t n) {  // the first n <= 64 pending candidates, one per lane
+        if ((uint32_t)lane < n) {
+            const uint32_t *e = cring + ((c_head + (uint32_t)lane) & (APPLY_RING - 1)) * 3;
+            const uint32_t c_pair = e[0], w1 = e[1], w2 = e[2];
+            const int c_o = (int)((w1 >> 15) & 1u), j = (int)(w1 & 0x3fffu);
+            const uint32_t e8 = w2 & 0xffu;
+            const int q = (int)((w2 >> 8) & 0xffu), before = (int)((w2 >> 16) & 0xffu);
+            const uint32_t t8 = mut8[q];
+            const Addr ca = make_addr(A.seed, A.first_ordinal + c_pair, w1 >> 16);
+            const u32x4 sb = draw_block(ca, K_SUB, (uint32_t)j, (uint32_t)c_o);
+            bool err = e8 > t8;
+            if (e8 == t8) err = error_test_draw(e8, sb) > M.mut_thr[q];
+            const int bi = base_index(before);
+            if (err && bi >= 0) {  // (else nucl.upper() in "RYWSMKHBVDN": left alone)
+                const uint64_t m = mk53(sb.x, sb.y);
+                const uint32_t sd = sub13[((uint32_t)(c_o * RL + j)) * 4u + (uint32_t)bi];
+                const uint32_t hs = (uint32_t)(m >> 40), t0 = sd & 0x1fffu, t1 = (sd >> 13) & 0x1fffu;
+                int kk = (hs > t0) + (hs > t1);
+                if (hs == t0 || hs == t1) {  // tie of a leading digit: exact thresholds
+                    const size_t srow = ((size_t)(c_o * RL + j) * 4 + bi) * 3;
+                    kk = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
+                }
+                const int base = (int)((M.alt_letters >> (8 * ((sd >> (26 + 2 * kk)) & 3u))) & 0xffu);
+                // (a byte patch after this wavefront's own 8-byte store of the piece: stores of one wavefront reach an
+                //  address in order)
+                A.out[0][(size_t)c_pair * M.row + row_array_off(2 * c_o) + xp(j)] = (uint8_t)base;
+                if (STORE_MUT) {  // only if the new letter differs from the ORIGINAL read at this index (__init__.py:98)
+                    MutRecord sub;
+                    sub.pair = (int32_t)(A.pair_base + c_pair); sub.mate = (int8_t)c_o; sub.type = (int8_t)32; sub.position = (int16_t)j;
+                    sub.ref = (uint8_t)before; sub.alt = (uint8_t)base; sub.quality = (int16_t)q;
+                    // (a read position past a template the genome end cut short has no "original" letter: the
+                    //  reference raises IndexError there; the row is kept)
+                    if (((w1 >> 14) & 1u) || base != (int)(w2 >> 24)) mut_emit1(A, sub);
+                }
+            }
+        }
+        c_head += n;
+    };
     uint8_t *tmpl = wbase;                                  // [TL]
     uint8_t *dqm = tmpl + TL;                               // [pitch] error-test digit (8 bits) of position j
     uint8_t *stk = dqm + pitch;                             // [4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
@@ -1307,13 +1352,14 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- 4. the read: 8 positions per lane
-        if (n_act) {
-            if (rl == 0) { ++n_reads; atomicOr(&A.flags[pair], 4u << o); }  // (bits 2-3: this kernel rebuilt the mate)
+        // ---- 4. the read: 8 positions per lane and pass.  (Every lane of the wavefront runs the pass loop -- the groups
+        //      without events with nothing to do: the candidate ring's head and tail stay wave-uniform.)
+        if (n_act && rl == 0) { ++n_reads; atomicOr(&A.flags[pair], 4u << o); }  // (bits 2-3: this kernel rebuilt the mate)
+        {
             int carry = 0;  // (token - step) at the end of the previous pass
             for (int b = rl, pass = 0; (b - rl) * 8 < pitch; b += GL, ++pass) {  // (every lane of the group takes part in the prefix sums)
                 const int j0 = b * 8;
-                const bool in = j0 < pitch;
+                const bool in = n_act && j0 < pitch;
                 uint2 q8 = pass == 0 ? q8_0 : (pass == 1 ? q8_1 : q8_2);
                 if (pass >= NP && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (read_length > 248)
                 uint2 e8w = {0u, 0u}, dw = {0u, 0u}, ov = {0u, 0u};
@@ -1332,8 +1378,8 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                 }
                 int shift = carry + incl - lane_sum;
                 carry += __shfl(incl, GL - 1, GL);
-                if (!in) continue;
                 uint32_t ob0 = 0u, ob1 = 0u, cand = 0u;  // cand: bit 7 - c <=> the substitution test of position j0 + c fires or ties
+                if (in) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const int j = j0 + c;
@@ -1353,46 +1399,35 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                     ob1 = (ov.y & m1) | (ob1 & ~m1);
                 }
                 cand &= 0xffu & ~(0xffu >> min(max(RL - j0, 0), 8));  // positions inside the read
-                while (cand) {  // rare per lane: the substitution test fires or ties (__init__.py:94)
-                    const int c = __clz(cand) - 24;
-                    cand &= ~(0x80u >> c);
-                    const int j = j0 + c;
-                    const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
-                    const int q = (int)(((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu);
-                    const uint32_t t8 = mut8[q];
-                    const int before = (int)(((c < 4 ? ob0 : ob1) >> (8 * (c & 3))) & 0xffu);
-                    const u32x4 sb = draw_block(a, K_SUB, (uint32_t)j, (uint32_t)o);
-                    bool err = e8 > t8;
-                    if (e8 == t8) err = error_test_draw(e8, sb) > M.mut_thr[q];
-                    const int bi = base_index(before);
-                    if (err && bi >= 0) {  // (else nucl.upper() in "RYWSMKHBVDN": left alone)
-                        const uint64_t m = mk53(sb.x, sb.y);
-                        const uint32_t sd = sub13[((uint32_t)(o * RL + j)) * 4u + (uint32_t)bi];
-                        const uint32_t hs = (uint32_t)(m >> 40), t0 = sd & 0x1fffu, t1 = (sd >> 13) & 0x1fffu;
-                        int kk = (hs > t0) + (hs > t1);
-                        if (hs == t0 || hs == t1) {  // tie of a leading digit: exact thresholds
-                            const size_t srow = ((size_t)(o * RL + j) * 4 + bi) * 3;
-                            kk = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
-                        }
-                        const int base = (int)((M.alt_letters >> (8 * ((sd >> (26 + 2 * kk)) & 3u))) & 0xffu);
-                        if (c < 4) ob0 = (ob0 & ~(0xffu << (8 * c))) | ((uint32_t)base << (8 * c));
-                        else ob1 = (ob1 & ~(0xffu << (8 * (c - 4)))) | ((uint32_t)base << (8 * (c - 4)));
-                        if (STORE_MUT) {  // only if the new letter differs from the ORIGINAL read at this index (__init__.py:98)
-                            MutRecord sub;
-                            sub.pair = (int32_t)(A.pair_base + pair); sub.mate = (int8_t)o; sub.type = (int8_t)32; sub.position = (int16_t)j;
-                            sub.ref = (uint8_t)before; sub.alt = (uint8_t)base; sub.quality = (int16_t)q;
-                            // (a read position past a template the genome end cut short has no "original" letter: the
-                            //  reference raises IndexError there; the row is kept)
-                            if (j >= geo.t_len || base != (int)tmpl[j]) mut_emit1(A, sub);
-                        }
-                    }
-                }
                 *reinterpret_cast<uint2 *>(out_base + xp(j0)) = make_uint2(ob0, ob1);
+                }
+                // the candidates of this piece, one ring entry each (after the store: they are settled by byte patches)
+                for (;;) {
+                    const unsigned long long pm = __ballot(cand != 0u);
+                    if (!pm) break;
+                    if (cand) {
+                        const int c = __clz(cand) - 24;
+                        cand &= ~(0x80u >> c);
+                        const int j = j0 + c;
+                        const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
+                        const uint32_t q = ((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu;
+                        const uint32_t before = ((c < 4 ? ob0 : ob1) >> (8 * (c & 3))) & 0xffu;
+                        const uint32_t orig = STORE_MUT ? (uint32_t)tmpl[j] : 0u;
+                        uint32_t *e = cring + ((c_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))) & (APPLY_RING - 1)) * 3;
+                        e[0] = pair;
+                        e[1] = ((d.meta >> 16) << 16) | ((uint32_t)o << 15) | (j >= geo.t_len ? 1u << 14 : 0u) | (uint32_t)j;
+                        e[2] = (orig << 24) | (before << 16) | (q << 8) | e8;
+                    }
+                    c_tail += (uint32_t)__popcll(pm);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    while (c_tail - c_head >= 64u) settle_candidates(64u);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if (c_tail != c_head) settle_candidates(c_tail - c_head);
     if (rl == 0 && n_reads) atomicAdd((unsigned long long *)stats, (unsigned long long)n_reads);
 }
 
