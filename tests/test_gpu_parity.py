@@ -649,6 +649,7 @@ def _fuzz_config(k):
     """Random but reproducible (model shape, tables, genome, options) for the differential test below."""
     from helpers import synthetic_model
 
+    k += int(os.environ.get("ISS_FUZZ_OFFSET", "0"))  # (a soak run: other configurations than the 200 of the suite)
     r = np.random.RandomState(1000 + k)
     RL = int(r.choice([2, 3, 7, 20, 36, 75, 100, 126, 151, 200, 251, 301]))
     n_q = int(r.choice([1, 2, 8, 41, 41, 41, 60]))
