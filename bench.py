@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--indel", type=float, nargs=2, default=None, metavar=("P_INS", "P_DEL"),
                     help="override every insertion / deletion probability (BASELINE configs[4]-like indel-heavy model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short legs on the other shipped models and the indel-heavy model (rank 0, N = 1, default workload only)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTQ-on-tmpfs leg (rank 0, N = 1 only)")
     ap.add_argument("--e2e-pairs", type=int, default=20_000_000)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo: a dry run of "
@@ -247,6 +249,15 @@ def main():
         }
         if world > 1:
             out["per_rank_pairs_per_sec"] = [n * args.steps / e if e > 0 else None for n, e in per_rank]
+        if world == 1 and not args.no_other_workloads and not strong and args.model == "novaseq" and args.indel is None:
+            # the same work list on the other models of the parity suite (a few steps each; BASELINE's metric stays the line above)
+            out["other_workloads"] = {}
+            for name, model, indel in (("indel_heavy", "novaseq", (0.001, 0.003)), ("hiseq", "hiseq", None),
+                                       ("nextseq", "nextseq", None), ("miseq", "miseq", None)):
+                try:
+                    out["other_workloads"][name] = side_workload(local_rank, model, indel, genomes, records, abundance, args.reads)
+                except Exception as e:  # (never let a side leg take the line down)
+                    out["other_workloads"][name] = {"error": repr(e)}
         if world == 1 and not args.no_end_to_end:
             e2e_records = [Record(letters[id(r)], id=r.id) for r in records]
             out["end_to_end"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs)
@@ -295,6 +306,68 @@ def parity_window(eng, dense, work, letters, step_first_ordinal, worker_seed, n=
             checked += cnt
             i += cnt
     return "ok (%d pairs of the last timed step, item boundaries included, bit-identical to the CPU oracle)" % checked
+
+
+def side_workload(device, model, indel, genomes, records, abundance, reads, steps=6, warmup=2):
+    """bench.py's step on another model (own engine, the same genomes, work divider and seed): read-pairs/s over `steps`
+    steps without kernel events, then the kernel split and k_main's roofline fraction over three steps with events, and
+    the oracle check of windows of the last step."""
+    from insilicoseq_amd.distributed import rank_work
+    from insilicoseq_amd.engine import ReadEngine
+    from insilicoseq_amd.model import DenseModel
+
+    dense = DenseModel.load(os.path.join(ROOT, "insilicoseq_amd", "profiles", model + ".dense.npz"))
+    if indel is not None:
+        dense.ins[:] = indel[0]
+        dense.dele[:] = indel[1]
+    eng = ReadEngine(device)
+    try:
+        eng.load_model(dense)
+        gids = [eng.add_genome(g) for g in genomes]
+        chunk, _, _ = rank_work(records, None, abundance, reads, None, None, dense, "bench", 1, 0)
+        work = [(r, n) for r, n, _ in (chunk or [])]
+        gid_of = {id(r): g for r, g in zip(records, gids)}
+        letters = {id(r): g for r, g in zip(records, genomes)}
+        ids, pairs = [gid_of[id(r)] for r, _ in work], [n for _, n in work]
+        total = sum(pairs)
+        eng.reserve(max(total, 1))
+        ordinal = [0]
+
+        def step():
+            eng.generate_batch(ids, pairs, first_ordinal=ordinal[0], seed=SEED, out_first_pair=0)
+            ordinal[0] += total
+
+        eng.timing_enable(0)
+        for _ in range(warmup):
+            step()
+        eng.synchronize()
+        eng.timing_read()
+        eng.timing_enable(2)  # (events around k_main only, as in the main leg)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        eng.synchronize()
+        elapsed = time.perf_counter() - t0
+        main_ms = eng.timing_read()["main_ms"] / steps
+        eng.timing_enable(1)
+        for _ in range(3):
+            step()
+        eng.synchronize()
+        tm = eng.timing_read()
+        eng.timing_enable(0)
+        parity = parity_window(eng, dense, work, letters, ordinal[0] - total, SEED)
+        return {
+            "value": total * steps / elapsed, "unit": "read-pairs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "model": model, "read_length": dense.read_length, "indel_override": indel, "pairs_per_step": total,
+            "kernel_ms_per_step": {"main_ms": main_ms, "setup_ms": tm["setup_ms"] / 3, "indel_scan_ms": tm["indel_scan_ms"] / 3,
+                                   "indel_apply_fixup_ms": tm["indel_fixup_ms"] / 3,
+                                   "note": "main_ms: HIP events over the timed steps; the others: events around every kernel over three further steps"},
+            "k_main_frac_of_hbm_peak": (total * algorithmic_bytes_per_pair(dense.read_length)) / (main_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
+            if main_ms > 0 else None,
+            "parity_window": parity,
+        }
+    finally:
+        eng.close()
 
 
 def kernel_source_hash():
