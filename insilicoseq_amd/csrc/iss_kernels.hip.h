@@ -580,10 +580,8 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
         for (int64_t w = (rs - 3) >> 5; w <= (re - 1) >> 5; ++w) any |= g.mask[w];
         exc |= any ? 32u : 0u;
     }
-    if (!ov_frag) {  // first pass: the pair's indel / irregular flags and event counters start clean (no separate memset)
-        A.flags[i] = 0u;
-        if (A.ev_count) *reinterpret_cast<uint2 *>(A.ev_count + 2 * i) = make_uint2(0u, 0u);
-    }
+    if (!ov_frag) A.flags[i] = 0u;  // first pass: the pair's indel / irregular flags start clean (no separate memset; the
+                                    // event counters are written by k_indel_scan, every one of them)
     if (irregular && !(A.flags[i] & 3u)) {
         A.flags[i] = 3u;
         const uint32_t at = atomicAdd(A.fix_count, 2u);
@@ -1040,12 +1038,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
                              if (cnt < (uint32_t)EV_K) list[cnt] = ((uint32_t)n << 8) | mask;
                              ++cnt;
                          });
-            A.ev_count[rd] = cnt;
             if (cnt > (uint32_t)EV_K) {  // too many events for the list: the wavefront-per-read kernel takes the read
                 if (!(atomicOr(&A.flags[pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
                 cnt = 0;
             }
         }
+        if (rd < last) A.ev_count[rd] = cnt;  // (every read: nothing else initialises the counters)
         const unsigned long long m = __ballot(cnt != 0u);
         if (m) {
             if (cnt) l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rd;
@@ -1058,9 +1056,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
 }
 
 // ================================================================== k_indel_apply
-// GL lanes (16; 32 for read lengths beyond 248) per listed READ -- a mate with at least one event; the 64 / GL groups of
-// a wavefront take neighbouring list entries, whatever pairs and mates those are, so no lane idles on an event-free mate
-// and the per-read bookkeeping (requests, geometry, sort, walk) is shared by four reads.  introduce_indels
+// GL lanes (8; 16 / 32 for read lengths beyond 184 / 248) per listed READ -- a mate with at least one event; the 64 / GL
+// groups of a wavefront take neighbouring list entries, whatever pairs and mates those are, so no lane idles on an
+// event-free mate and the per-read bookkeeping (requests, geometry, walk) is shared by eight reads.  introduce_indels
 // + adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
 // prefix [0, n) is final when step n starts; the not-yet-visited suffix is (stack of freshly inserted letters, LIFO)
 // ++ E(k), E(k+1), ...
@@ -1070,7 +1068,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
 //   3. the walk over the steps with an event (the reads of the wavefront side by side, one per group): the letters of
 //      those steps and of the steps that drain the insertion stack go to ovr[] (0 = no override), "from step n0 on,
 //      source index = k0 + (n - n0)" for everything in between is the change of (token - step) at n0, in dsh[]
-//   4. (all lanes, 8 positions each) token -> base -> mut_sequence -> one 8-byte store
+//   4. (all lanes, 8 positions each and pass) token -> base -> one 8-byte store; the positions whose substitution test
+//      fires or ties go to a ring of the wavefront and are settled 64 at a time (byte patches)
 // A pair is a chain of dependent loads (list entry -> descriptor, events, phreds -> genome windows) behind a write
 // stream, i.e. microseconds of latency: the list entry is requested two reads ahead, everything its address needs only
 // the read number for one read ahead, and the tables the walk and the substitutions read sit in LDS.

@@ -24,7 +24,7 @@ def main(src, tag):
     stats = glob.glob(src + "/stats/*kernel_stats.csv")[0]
     with open(stats) as fh, open(os.path.join(out_dir, tag + "_kernel_stats.csv"), "w") as out:
         cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else \
-            "python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+            "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads"
         out.write("# rocprofv3 --kernel-trace --stats -- %s\n" % cmd)
         out.write(fh.read())
     acc, calls = counters(src)
@@ -54,7 +54,7 @@ def main(src, tag):
                "kernel_source_hash": kernel_source_hash(),
                "fetch_bytes_per_launch": fetch,
                "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
-               "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline (5,000,000 pairs per step in one k_main launch)",
+               "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads (5,000,000 pairs per step in one k_main launch)",
                "pairs_per_launch_avg": 5_000_000}
     json.dump(summary, open(os.path.join(out_dir, tag + "_traffic.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))

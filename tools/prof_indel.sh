@@ -3,9 +3,9 @@
 TAG=${1:-indel}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-echo "python bench.py --indel 0.001 0.003 --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end" > $OUT/command.txt
+echo "python bench.py --indel 0.001 0.003 --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads" > $OUT/command.txt
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --indel 0.001 0.003 --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --indel 0.001 0.003 --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/sq1 -o p --output-format csv -- $BENCH > $OUT/sq1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_BRANCH --kernel-trace -d $OUT/sq2 -o p --output-format csv -- $BENCH > $OUT/sq2.log 2>&1
