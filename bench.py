@@ -508,7 +508,16 @@ def cpu_baseline_all_cores(dense, work, threads, one_core_rate, budget_s=5.0):
     wall = time.perf_counter() - t0
     if errors:
         raise RuntimeError(errors[0])
+    quota = None
+    try:  # (a container's CPU quota, when there is one: the threads may have fewer cores than os.cpu_count() says)
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+            quota = None if q == "max" else float(q) / float(period)
+    except Exception:  # noqa: BLE001
+        pass
     return {"value": sum(done) / wall, "unit": "read-pairs/s", "cores": cores, "kind": "port",
+            "speedup_over_one_core": (sum(done) / wall) / one_core_rate if one_core_rate else None, "host_cpu_count": os.cpu_count(),
+            "cgroup_cpu_quota_cores": quota,
             "sample": "%d pairs on %d threads (%d each), %.1f s wall (slowest thread %.1f s)" % (
                 sum(done), cores, sum(shares), wall, max(secs)),
             "note": "reference-vs-port ratio measured in the build container: the Python reference 873 pairs/s per process, "
