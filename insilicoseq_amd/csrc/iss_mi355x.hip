@@ -1973,10 +1973,14 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     m.mut_n = 0;
     bool ov_valid = false, walk_one = false;
     int64_t ov_frag = 0;
+    // words wanted for a turn: those of n + 1 pairs, plus `boost` more when a turn made no progress on them -- with
+    // gc_bias every rejected candidate pair (generator.py:82-92) consumes a whole pair's draws, and a turn of one pair that
+    // meets three rejections in a row needs more than two pairs' worth
+    int64_t boost = gc_bias ? 4 : 0;
     while (done < n_pairs) {
         const int64_t n = walk_one ? 1 : std::min(CH, n_pairs - done);
-        const size_t want[2] = {std::min(m.cap[0] / 624 * 624 - 624, (size_t)(n + 1) * py_need),
-                                std::min(m.cap[1] / 624 * 624 - 624, (size_t)(n + 1) * np_need)};
+        const size_t want[2] = {std::min(m.cap[0] / 624 * 624 - 624, (size_t)(n + 1 + boost) * py_need),
+                                std::min(m.cap[1] / 624 * 624 - 624, (size_t)(n + 1 + boost) * np_need)};
         { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
         MtPrefetch pf;
         if (!walk_one && done + n < n_pairs) {  // produce the next chunk's words while this chunk runs
@@ -2050,8 +2054,10 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
             m.n_resolved += res.n_done;
             if (res.pad) { walk_one = true; continue; }  // the next pair is not plain: one turn of the walker
             if (res.n_done == 0 && res.starved && (size_t)(R.py_fill - R.py_off) >= want[0] &&
-                (size_t)(R.np_fill - R.np_off) >= want[1])
-                return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+                (size_t)(R.np_fill - R.np_off) >= want[1]) {
+                if (boost >= 256) return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+                boost = 2 * boost + 4;
+            }
             continue;
         }
         iss::MtWalkArgs A{};
@@ -2122,8 +2128,10 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
             ov_valid = true;
             continue;
         }
-        if (res.n_done == 0 && res.starved && A.py_avail >= want[0] && A.np_avail >= want[1])
-            return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+        if (res.n_done == 0 && res.starved && A.py_avail >= want[0] && A.np_avail >= want[1]) {
+            if (boost >= 256) return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+            boost = 2 * boost + 4;
+        }
         if (res.n_done > 0) walk_one = false;
     }
     if (n_done) *n_done = done;

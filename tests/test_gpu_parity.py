@@ -729,6 +729,32 @@ def test_randomized_differential_both_paths(k):
                 assert np.array_equal(rows[f], exp["mutations"][f]), ("mt rows", f)
 
 
+def test_mt_single_pairs_with_gc_bias_rejections():
+    """MT mode, one pair per call, gc_bias: a candidate pair that is rejected (generator.py:82-92, one time in ten) costs a
+    whole pair's draws, and two or three rejections in a row need more stream words than the two pairs' worth a turn of
+    one pair starts with (found by a soak run of the randomized test: "MT stream buffers too small for one read pair")."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    dense = dense_model("miseq")  # (long reads: many words per pair)
+    genome = random_genome(4242, 900)
+    orc = O.Oracle(dense)
+    most = 0
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        for seed in range(400):
+            rng = O.Rng().seed_mt(seed)
+            exp = orc.simulate(rng, genome, 1, gc_bias=True)
+            most = max(most, rng.words_used()[1])
+            eng.seed_mt(seed)
+            assert eng.generate_mt(gid, 1, gc_bias=True) == 1
+            got = eng.download(0, 1)
+            for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                assert np.array_equal(got[key], exp[key]), (seed, key)
+    assert most >= 3 * 1212  # (a MiSeq pair draws >= 1212 numpy words: some seed met at least three candidate pairs)
+
+
 def _expected_worker_files(dense, recs, counts, seed, cpu, rng_mode, seq_type, gc_bias, frag, tmp_path):
     """worker_iterator's three files as the oracle + the host formatter + the reference's VCF line format give them."""
     from insilicoseq_amd.engine import fastq_write
@@ -768,7 +794,7 @@ def test_randomized_worker_lists(k, tmp_path):
     from insilicoseq_amd.generator import Record, worker_iterator
     from insilicoseq_amd.model import BasicErrorModel
 
-    r = np.random.RandomState(500 + k)
+    r = np.random.RandomState(500 + k + int(os.environ.get("ISS_FUZZ_OFFSET", "0")))  # (soak runs: other lists)
     rng_mode = "philox" if k % 2 == 0 else "mt"
     model = str(r.choice(["novaseq", "hiseq", "ecoli", "miseq-36"] + (["basic"] if rng_mode == "mt" else [])))
     dense = dense_model(model)
