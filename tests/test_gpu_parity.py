@@ -729,6 +729,45 @@ def test_randomized_differential_both_paths(k):
                 assert np.array_equal(rows[f], exp["mutations"][f]), ("mt rows", f)
 
 
+@pytest.mark.parametrize("model", ["miseq-36", "novaseq", "hiseq"])
+def test_batch_with_more_work_items_than_the_indel_kernels_cache(model):
+    """iss_generate_batch over 700 small records with an indel-heavy model: k_indel_apply keeps the table of up to 512 work
+    items in LDS and searches it in global memory beyond that; --store_mutations rows included.  (Read lengths 301, 151,
+    126: 32 and 8 lanes per read.)"""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    dense = dense_model(model, (0.01, 0.02))
+    r = np.random.RandomState(8)
+    RL = dense.read_length
+    genomes = [random_genome(5000 + i, RL + int(r.randint(1, 300))) for i in range(700)]
+    pairs = [int(r.choice([0, 1, 3, 9])) for _ in genomes]
+    orc = O.Oracle(dense)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        eng.mutations_reserve(1 << 22)
+        gids = [eng.add_genome(g) for g in genomes]
+        total = sum(pairs)
+        eng.reserve(total)
+        eng.generate_batch(gids, pairs, first_ordinal=77, seed=5)
+        eng.synchronize()
+        got = eng.download(0, total)
+        rows = eng.mutations()
+        assert eng.stats_read()["fixup_reads"] > 0
+    at, exp_rows = 0, []
+    for g, n in zip(genomes, pairs):
+        if not n:
+            continue
+        exp = orc.simulate(O.Rng().seed_philox(5), g, n, first_ordinal=77 + at, store_mutations=True)
+        assert exp["status"] == 0
+        for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(got[key][at:at + n], exp[key]), (at, key)
+        exp_rows += [(int(m["pair"]) + at,) + tuple(int(m[k]) for k in ("mate", "type", "position", "ref", "alt", "quality"))
+                     for m in exp["mutations"]]
+        at += n
+    assert [tuple(int(m[k]) for k in ("pair", "mate", "type", "position", "ref", "alt", "quality")) for m in rows] == exp_rows
+
+
 def test_mt_single_pairs_with_gc_bias_rejections():
     """MT mode, one pair per call, gc_bias: a candidate pair that is rejected (generator.py:82-92, one time in ten) costs a
     whole pair's draws, and two or three rejections in a row need more stream words than the two pairs' worth a turn of
