@@ -254,10 +254,12 @@ def test_device_genome_packing_roundtrip(engine):
             assert np.array_equal(got[k], exp[k]), (L, k)
 
 
-def test_chunked_launches_compose(engine):
+@pytest.mark.parametrize("indel", [None, (0.001, 0.003)])
+def test_chunked_launches_compose(engine, indel):
     """One call larger than the library's per-launch chunk (row byte offsets are 32 bits wide) == two smaller calls with
-    consecutive ordinals; spot-checked around the chunk boundary and at both ends."""
-    dense = dense_model("hiseq")  # rows of 512 bytes -> chunk = (2^32 - 1) / 512 = 8,388,607 pairs
+    consecutive ordinals; spot-checked around the chunk boundary and at both ends.  (The indel-heavy variant: event
+    lists, read lists and their counters are per chunk.)"""
+    dense = dense_model("hiseq", indel)  # rows of 512 bytes -> chunk = (2^32 - 1) / 512 = 8,388,607 pairs
     chunk = ((1 << 32) - 1) // 512
     n = chunk + 300_000
     genome = random_genome(123, 2_000_000)
