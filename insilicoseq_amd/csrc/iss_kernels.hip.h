@@ -1084,8 +1084,8 @@ __host__ __device__ inline int apply_tl(int pitch) { return pitch + 8; }  // sta
 #ifndef ISS_APPLY_GL
 #define ISS_APPLY_GL 8
 #endif
-// lanes per read: three passes of 8 positions per lane at most
-__host__ __device__ inline int apply_gl(int pitch) { return apply_tl(pitch) <= 24 * ISS_APPLY_GL ? ISS_APPLY_GL : (apply_tl(pitch) <= 256 ? 16 : 32); }
+// lanes per read: three passes of 8 positions per lane at most (8 lanes up to read length 184, 16 up to 376)
+__host__ __device__ inline int apply_gl(int pitch) { return apply_tl(pitch) <= 24 * ISS_APPLY_GL ? ISS_APPLY_GL : (apply_tl(pitch) <= 24 * 16 ? 16 : 32); }
 __host__ __device__ inline size_t apply_read_bytes(int pitch) {
     // per read: tmpl (tl) + dqm (pitch) + stk (4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + ovr (pitch)
     //           + events (4 * EV_K)
@@ -1093,8 +1093,8 @@ __host__ __device__ inline size_t apply_read_bytes(int pitch) {
 }
 constexpr int APPLY_RING = 128;   // substitution candidates a wavefront can hold (a private ring: 63 pending + 64 new at most)
 __host__ __device__ inline size_t apply_wave_bytes(int pitch, int GL) { return (size_t)(64 / GL) * apply_read_bytes(pitch) + APPLY_RING * 12; }
-// [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 i64][items APPLY_ITEMS][per wave]
-__host__ __device__ inline size_t apply_items_bytes() { return (APPLY_ITEMS + 2) * 8 + APPLY_ITEMS * sizeof(BatchItem); }
+// [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 u32][items APPLY_ITEMS][per wave]
+__host__ __device__ inline size_t apply_items_bytes() { return (APPLY_ITEMS + 2) * 4 + APPLY_ITEMS * sizeof(BatchItem); }
 __host__ __device__ inline size_t apply_tab_bytes(int RL) {
     return 256 + (size_t)2 * RL * 4 * 4 + (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + apply_items_bytes();
 }
@@ -1105,12 +1105,12 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                                                                   const PairDesc *__restrict__ desc, uint64_t *stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t apply_lds[];
     constexpr int NG = 64 / GL;           // reads per wavefront
-    constexpr int NP = GL == 32 ? 1 : (GL == 16 ? 2 : 3);  // passes (8 positions per lane each) whose genome window and phreds are requested ahead
+    constexpr int NP = GL == 32 ? 1 : 3;  // passes (8 positions per lane each) whose genome window and phreds are requested ahead
     const int RL = M.RL, pitch = M.pitch, TL = apply_tl(pitch);
     uint32_t *mut8 = reinterpret_cast<uint32_t *>(apply_lds);  // [64] leading 8 bits of the substitution-test thresholds
     uint32_t *sub13 = mut8 + 64;                                // [2][RL][4] (see DevModel::subst13, position-major here)
     uint8_t *insl = reinterpret_cast<uint8_t *>(sub13 + 2 * RL * 4);  // [2][RL][4]
-    int64_t *ifirst = reinterpret_cast<int64_t *>(apply_lds + apply_tab_bytes(RL) - apply_items_bytes());
+    uint32_t *ifirst = reinterpret_cast<uint32_t *>(apply_lds + apply_tab_bytes(RL) - apply_items_bytes());  // (a call holds < 2^31 pairs)
     BatchItem *l_items = reinterpret_cast<BatchItem *>(ifirst + APPLY_ITEMS + 2);
     const uint32_t n_list = *A.read_count;
     if (blockIdx.x * APPLY_WAVES * NG >= n_list) return;  // whole workgroup idle (uniform)
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
     }
     const bool items_cached = A.items && A.n_items <= APPLY_ITEMS;
     if (items_cached) {
-        for (int i = threadIdx.x; i <= A.n_items; i += blockDim.x) ifirst[i] = A.item_first[i];
+        for (int i = threadIdx.x; i <= A.n_items; i += blockDim.x) ifirst[i] = (uint32_t)A.item_first[i];
         for (int i = threadIdx.x; i < A.n_items; i += blockDim.x) l_items[i] = A.items[i];
     }
     __syncthreads();
@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
         if (A.items) {
             BatchItem it;
             if (items_cached) {
-                const int64_t p = A.pair_base + pair;
+                const uint32_t p = (uint32_t)(A.pair_base + pair);
                 if (!(ifirst[item_k] <= p && p < ifirst[item_k + 1])) {
                     int lo = 0, hi = A.n_items;  // largest k with item_first[k] <= p
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ifirst[mid] <= p) lo = mid; else hi = mid; }
