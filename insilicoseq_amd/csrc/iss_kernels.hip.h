@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
 }
 
 // ================================================================== k_indel_apply
-// GL lanes (8; 16 / 32 for read lengths beyond 184 / 248) per listed READ -- a mate with at least one event; the 64 / GL
+// GL lanes (8; 16 / 32 for read lengths beyond 184 / 376) per listed READ -- a mate with at least one event; the 64 / GL
 // groups of a wavefront take neighbouring list entries, whatever pairs and mates those are, so no lane idles on an
 // event-free mate and the per-read bookkeeping (requests, geometry, walk) is shared by eight reads.  introduce_indels
 // + adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
                 const int j0 = b * 8;
                 const bool in = n_act && j0 < pitch;
                 uint2 q8 = pass == 0 ? q8_0 : (pass == 1 ? q8_1 : q8_2);
-                if (pass >= NP && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (read_length > 248)
+                if (pass >= NP && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (32 lanes per read: read_length > 376)
                 uint2 e8w = {0u, 0u}, dw = {0u, 0u}, ov = {0u, 0u};
                 if (in) {
                     e8w = *reinterpret_cast<const uint2 *>(dqm + j0);
