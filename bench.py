@@ -371,14 +371,19 @@ def side_workload(device, model, indel, genomes, records, abundance, reads, step
 
 
 def kernel_source_hash():
-    """Hash of the HIP sources: a committed PMC summary says which sources it was measured on."""
+    """Hash of the HIP sources (comments and white space aside): a committed PMC summary says which sources it was
+    measured on."""
     import hashlib
+    import re
 
     h = hashlib.sha256()
     d = os.path.join(ROOT, "insilicoseq_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(d, f), "r", errors="replace") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)  # (no string literal of these sources holds "//")
+        h.update(f.encode() + b"\0" + " ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
