@@ -1453,7 +1453,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             HIP_TRY(ctx, mark(4, s_indel));
             if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
             HIP_TRY(ctx, mark(5, s_indel));
-            if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, 16 (32) lanes per read
+            if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, 8 (16 / 32 for long reads) lanes per read
                 const int GL = iss::apply_gl(M.pitch);
                 const int64_t per_wg = (int64_t)iss::APPLY_WAVES * (64 / GL);  // reads per workgroup pass; at most 2 n reads
                 const size_t lds = iss::apply_lds_bytes(M.RL, M.pitch, GL);
