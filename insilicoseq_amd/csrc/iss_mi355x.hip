@@ -7,6 +7,7 @@
 #include "iss_mi355x.h"
 
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -103,6 +104,7 @@ struct FastqJob {
     int threads;
     bool gzip;
     uint32_t n_blocks;
+    std::vector<uint64_t> item_off;  // text offsets of the job's work items (the writer checks the record structure there)
 };
 struct FastqPipe {
     bool ready = false;
@@ -117,7 +119,13 @@ struct FastqPipe {
     size_t cap = 0;
     int next = 0;
     int fd[2] = {-1, -1};
+    // Offsets of the next byte of each file.  ONLY touched with `mu` held once the writer thread runs: in text mode the
+    // caller advances them when it queues a job, in compressed mode the writer does when it knows a member's size
+    // (round 2 advanced them outside the lock in text mode while the writer added its -- zero -- byte count under it:
+    // a lost update there made the next job overwrite the previous one's bytes).
     int64_t off[2] = {0, 0};
+    int64_t attached_off[2] = {0, 0};  // offsets when the files were attached ...
+    int64_t accounted[2] = {0, 0};     // ... and the bytes queued (text) / written (gzip) since: off == attached_off + accounted
     std::thread writer;
     std::mutex mu;
     std::condition_variable cv;
@@ -552,19 +560,27 @@ void fastq_writer_loop(iss_ctx *ctx) {
                 }
             }
         } else if (err.empty()) {
+            // invariant: every work item's text starts with '@' right behind a line feed and the job ends with one (the
+            // closed-form sizes the host computed are the layout the device wrote)
+            for (int mate = 0; mate < 2 && err.empty(); ++mate) {
+                const uint8_t *t = q.h_text[job.slot][mate];
+                bool ok = job.bytes > 0 && t[job.bytes - 1] == '\n';
+                for (uint64_t at : job.item_off) ok = ok && at < job.bytes && t[at] == '@' && (at == 0 || t[at - 1] == '\n');
+                if (!ok) err = "FASTQ text does not have the record layout its size was computed from";
+            }
             // both files in parallel, each cut into pieces written with pwrite at their final offsets (a small job --
             // one record of a long work list -- is written by this thread: spawning threads would cost more)
             const bool small_job = job.bytes <= (1u << 20);
             for (int mate = 0; small_job && mate < 2 && err.empty(); ++mate)
-                if (pwrite_all(job.fd[mate], q.h_text[job.slot][mate], job.bytes, job.off[mate]))
+                if (err.empty() && pwrite_all(job.fd[mate], q.h_text[job.slot][mate], job.bytes, job.off[mate]))
                     err = std::string("write failed: ") + strerror(errno);
             const size_t piece = std::max<size_t>((job.bytes + (size_t)job.threads - 1) / (size_t)job.threads, 1 << 20);
             std::vector<std::thread> th;
             std::vector<int> rc;
-            for (int mate = 0; mate < 2 && !small_job; ++mate)
+            for (int mate = 0; mate < 2 && !small_job && err.empty(); ++mate)
                 for (size_t at = 0; at < job.bytes; at += piece) rc.push_back(0);
             size_t k = 0;
-            for (int mate = 0; mate < 2 && !small_job; ++mate)
+            for (int mate = 0; mate < 2 && !small_job && !rc.empty(); ++mate)
                 for (size_t at = 0; at < job.bytes; at += piece, ++k) {
                     const size_t n = std::min(piece, job.bytes - at);
                     const uint8_t *src = q.h_text[job.slot][mate] + at;
@@ -586,8 +602,8 @@ void fastq_writer_loop(iss_ctx *ctx) {
             std::lock_guard<std::mutex> lk(q.mu);
             q.jobs.pop_front();
             q.busy[job.slot] = false;
-            q.off[0] += gz_wrote[0];
-            q.off[1] += gz_wrote[1];
+            if (job.gzip)  // (text jobs were accounted for when they were queued)
+                for (int mate = 0; mate < 2; ++mate) { q.off[mate] += gz_wrote[mate]; q.accounted[mate] += gz_wrote[mate]; }
             if (!err.empty() && q.error.empty()) q.error = err;
         }
         q.cv.notify_all();
@@ -605,8 +621,15 @@ int fastq_flush(iss_ctx *ctx) {
         err = q.error;
         q.error.clear();
     }
-    for (int m = 0; m < 2; ++m)
-        if (q.fd[m] >= 0) (void)lseek(q.fd[m], (off_t)q.off[m], SEEK_SET);
+    for (int m = 0; m < 2; ++m) {
+        if (q.fd[m] < 0) continue;
+        // invariants: the offset is the attach offset plus every job's bytes, and the file holds at least that much
+        struct stat st;
+        if (err.empty() && q.off[m] != q.attached_off[m] + q.accounted[m]) err = "FASTQ pipeline: file offset and queued bytes disagree";
+        if (err.empty() && fstat(q.fd[m], &st) == 0 && S_ISREG(st.st_mode) && (int64_t)st.st_size < q.off[m])
+            err = "FASTQ pipeline: file shorter than the bytes written to it";
+        (void)lseek(q.fd[m], (off_t)q.off[m], SEEK_SET);
+    }
     q.fd[0] = q.fd[1] = -1;
     if (!err.empty()) return fail(ctx, ISS_E_IO, err);
     return 0;
@@ -617,7 +640,7 @@ int fastq_flush_keep(iss_ctx *ctx) {
     FastqPipe &q = ctx->fq;
     const int fd_keep[2] = {q.fd[0], q.fd[1]};
     { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
-    q.fd[0] = fd_keep[0]; q.fd[1] = fd_keep[1];  // (q.off is where the writer left it)
+    q.fd[0] = fd_keep[0]; q.fd[1] = fd_keep[1];  // (q.off, attached_off and accounted stand as they were)
     return 0;
 }
 
@@ -2320,7 +2343,8 @@ static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, 
         for (int m = 0; m < 2; ++m) {
             const off_t at = lseek(q.fd[m], 0, SEEK_CUR);
             if (at < 0) return fail(ctx, ISS_E_IO, std::string("lseek failed: ") + strerror(errno));
-            q.off[m] = at;
+            q.off[m] = q.attached_off[m] = at;
+            q.accounted[m] = 0;
         }
     }
     const uint32_t n_blocks = (uint32_t)((bytes + iss::DEFLATE_BLOCK - 1) / iss::DEFLATE_BLOCK);
@@ -2447,15 +2471,15 @@ static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, 
         std::lock_guard<std::mutex> lk(q.mu);
         if (const char *e = getenv("ISS_FASTQ_PIECES")) n_threads = atoi(e);  // tuning aid
         FastqJob job{slot, bytes, {q.fd[0], q.fd[1]}, {q.off[0], q.off[1]}, std::max(1, std::min<int>(n_threads, 128)),
-                     q.gzip != 0, n_blocks};
-        q.jobs.push_back(job);
+                     q.gzip != 0, n_blocks, {}};
+        if (!q.gzip) {  // (compressed members: the writer thread advances the offsets by what it wrote)
+            for (const auto &it : items) job.item_off.push_back(it.text_off);
+            for (int m = 0; m < 2; ++m) { q.off[m] += (int64_t)bytes; q.accounted[m] += (int64_t)bytes; }
+        }
+        q.jobs.push_back(std::move(job));
         q.busy[slot] = true;
     }
     q.cv.notify_all();
-    if (!q.gzip) {  // (compressed members: the writer thread advances the offsets by what it wrote)
-        q.off[0] += (int64_t)bytes;
-        q.off[1] += (int64_t)bytes;
-    }
     q.next ^= 1;
     return 0;
 }

@@ -32,13 +32,27 @@
  * (tests/golden/tooling/make_golden.py), and against the reference's own unit
  * goldens (iss/test/test_error_model.py, iss/test/test_generator.py).
  *
- * Two uniform-stream providers feed the SAME semantic function:
+ * Two uniform-stream providers:
  *   ISS_RNG_MT      two sequential MT19937 streams (CPython `random` + numpy),
  *                   consumed in the reference's exact order -> equals the
  *                   reference for a given seed;
  *   ISS_RNG_PHILOX  Philox4x32-10, every draw addressed by
  *                   (pair ordinal, attempt, kind, index, sub, word) -> equals the
  *                   HIP kernels (which use the same address map).
+ * They feed the same semantic function draw for draw EXCEPT in two places, where the
+ * Philox provider samples the same distribution from fewer uniforms (branches the MT
+ * goldens cannot reach, pinned separately):
+ *   - introduce_indels: MT mode draws `random() < p` per test (:193-196, :209);
+ *     Philox mode reads the tests' outcomes from the indel event process
+ *     (ev_step / sample_indel_events: one uniform per FIRING test).  Pin:
+ *     tests/test_oracle_golden.py::test_event_process_exact derives, for every
+ *     state and slot, the exact set of uniforms for which ev_step fires there and
+ *     compares its measure with the reference's p_t * prod(1 - p_s) in exact
+ *     rational arithmetic (bound: 2^-52 absolute + 2^-47 relative), plus the
+ *     nesting and measure of the per-base deletion events;
+ *   - BasicErrorModel phreds: MT mode draws the legacy-gauss vector (basic.py:52-53),
+ *     Philox mode inverts the score's CDF (insilicoseq_amd/model.py
+ *     basic_phred_cdf; pinned at every step boundary of the reference expression).
  * All comparisons here are IEEE f64 on the raw model tables (the device uses an
  * integer-threshold formulation instead -- an independent computation).
  */
@@ -473,6 +487,37 @@ static void ev_tab_build(const iss_model *m, int o, ev_tab *t) {
 }
 static void ev_tab_free(ev_tab *t) { free(t->S); free(t->T); free(t->E); free(t->Tdel); }
 
+/* ONE draw of the event process.  State `cur`: the last slot decided (-1: none yet).  m53: the numerator of the draw's
+ * uniform (words 0-1 of the K_EV block), v53: that of the deletion sub-draw (words 2-3).  Returns the new state; *slot =
+ * the slot that fired (then *mask = its event mask) or -1 (nothing fires in the rest of cur's segment; the state is the
+ * segment's last slot and the next draw starts the next segment).  sample_indel_events() below is a loop over this
+ * function, and iss_oracle_ev_step exports it: tests/test_oracle_golden.py::test_event_process_exact walks its
+ * interval boundaries in m53 with exact integer arithmetic against the reference's per-test probabilities. */
+static int ev_step(const ev_tab *t, int cur, uint64_t m53, uint64_t v53, int *slot, uint32_t *mask) {
+    const int seg_last = t->E[cur + 1];
+    const uint64_t base = (cur >= 0 && t->E[cur] == seg_last) ? t->S[cur] : EV_ONE;
+    const uint64_t rr = (((1ull << 53) - m53) << 11) - 1; /* (1 - u) in 0.64 fixed point, (0, 1] */
+    const uint64_t target = (uint64_t)(((unsigned __int128)rr * base) >> 64);
+    *slot = -1;
+    *mask = 0;
+    if (t->S[seg_last] > target) return seg_last; /* nothing fires in the rest of the segment */
+    int lo = cur + 1, hi = seg_last; /* first slot with S <= target */
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (t->S[mid] <= target) hi = mid; else lo = mid + 1;
+    }
+    const int n = lo / 5, k = lo % 5;
+    if (k < 4) {
+        *mask = 1u << k;
+    } else {
+        const uint64_t scaled = (uint64_t)(((unsigned __int128)v53 * t->T[lo]) >> 53); /* floor(v * T_max / 2^53) */
+        for (int b = 0; b < 4; b++)
+            if (scaled < t->Tdel[(size_t)n * 4 + b]) *mask |= 16u << b;
+    }
+    *slot = lo;
+    return lo;
+}
+
 /* the event masks of one read: mask[0 .. RL-1) */
 static void sample_indel_events(const ev_tab *t, const iss_rng *r, int o, uint8_t *mask, int RL) {
     memset(mask, 0, (size_t)RL);
@@ -480,29 +525,11 @@ static void sample_indel_events(const ev_tab *t, const iss_rng *r, int o, uint8_
     int cur = -1;
     uint32_t j = 0;
     while (cur < t->ns - 1) {
-        const int seg_last = t->E[cur + 1];
-        const uint64_t base = (cur >= 0 && t->E[cur] == seg_last) ? t->S[cur] : EV_ONE;
-        uint32_t w[4];
+        uint32_t w[4], m8;
+        int slot;
         philox_at(r, K_EV, j++, (uint32_t)o, w);
-        const uint64_t m53 = ((uint64_t)(w[0] >> 5) << 26) | (w[1] >> 6);
-        const uint64_t rr = (((1ull << 53) - m53) << 11) - 1; /* (1 - u) in 0.64 fixed point, (0, 1] */
-        const uint64_t target = (uint64_t)(((unsigned __int128)rr * base) >> 64);
-        if (t->S[seg_last] > target) { cur = seg_last; continue; } /* nothing fires in the rest of the segment */
-        int lo = cur + 1, hi = seg_last; /* first slot with S <= target */
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (t->S[mid] <= target) hi = mid; else lo = mid + 1;
-        }
-        const int n = lo / 5, k = lo % 5;
-        if (k < 4) {
-            mask[n] |= (uint8_t)(1u << k);
-        } else {
-            const uint64_t v = ((uint64_t)(w[2] >> 5) << 26) | (w[3] >> 6);
-            const uint64_t scaled = (uint64_t)(((unsigned __int128)v * t->T[lo]) >> 53); /* floor(v * T_max / 2^53) */
-            for (int b = 0; b < 4; b++)
-                if (scaled < t->Tdel[(size_t)n * 4 + b]) mask[n] |= (uint8_t)(16u << b);
-        }
-        cur = lo;
+        cur = ev_step(t, cur, ((uint64_t)(w[0] >> 5) << 26) | (w[1] >> 6), ((uint64_t)(w[2] >> 5) << 26) | (w[3] >> 6), &slot, &m8);
+        if (slot >= 0) mask[slot / 5] |= (uint8_t)m8;
     }
 }
 /* the tables of the call in progress (built by the exported entry points; one call per thread at a time) */
@@ -790,6 +817,34 @@ int iss_oracle_introduce_indels(const iss_model *m, iss_rng *r, int orientation,
     return rc;
 }
 /* the event masks of the read at the rng's current address (position-addressable mode): mask[0 .. RL) */
+/* The event process, one draw at a time, for n independent (state, uniform) inputs: next[i] = the new state, slot[i] the slot that
+ * fired or -1, mask[i] its event mask (see ev_step).  cur[i] in [-1, ns - 2]. */
+int iss_oracle_ev_step(const iss_model *m, int orientation, int64_t n, const int32_t *cur, const uint64_t *m53, const uint64_t *v53,
+                       int32_t *next, int32_t *slot, uint8_t *mask) {
+    ev_tab ev;
+    ev_tab_build(m, orientation, &ev);
+    int rc = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (cur[i] < -1 || cur[i] > ev.ns - 2 || m53[i] >> 53 || v53[i] >> 53) { rc = 1; break; }
+        int sl;
+        uint32_t m8;
+        next[i] = ev_step(&ev, cur[i], m53[i], v53[i], &sl, &m8);
+        slot[i] = sl;
+        mask[i] = (uint8_t)m8;
+    }
+    ev_tab_free(&ev);
+    return rc;
+}
+/* the segment ends of the sampler's tables (E[s] = last slot of slot s's segment), ns = 5 (RL - 1) entries */
+int iss_oracle_ev_segments(const iss_model *m, int orientation, int32_t *seg_last) {
+    ev_tab ev;
+    ev_tab_build(m, orientation, &ev);
+    for (int s = 0; s < ev.ns; s++) seg_last[s] = ev.E[s];
+    const int ns = ev.ns;
+    ev_tab_free(&ev);
+    return ns;
+}
+
 int iss_oracle_indel_event_masks(const iss_model *m, iss_rng *r, int orientation, uint8_t *mask) {
     if (r->mode == ISS_RNG_MT) return ISS_ERR_KEY;
     ev_tab ev;

@@ -226,6 +226,31 @@ class Oracle(object):
             assert L.iss_oracle_indel_event_masks(C.byref(self._m), rng._h, int(orientation), out[i].ctypes.data) == 0
         return out
 
+    def ev_step(self, orientation, cur, m53, v53=None):
+        """One draw of the indel event process (iss_oracle.c: ev_step) for arrays of (state, uniform numerator[, numerator
+        of the deletion sub-draw]): (next state, fired slot or -1, event mask)."""
+        L = lib()
+        L.iss_oracle_ev_step.restype = C.c_int
+        L.iss_oracle_ev_step.argtypes = [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 6
+        cur = np.ascontiguousarray(cur, dtype=np.int32)
+        m53 = np.ascontiguousarray(m53, dtype=np.uint64)
+        v53 = np.zeros_like(m53) if v53 is None else np.ascontiguousarray(v53, dtype=np.uint64)
+        assert cur.shape == m53.shape == v53.shape
+        nxt, slot, mask = np.zeros_like(cur), np.zeros_like(cur), np.zeros(cur.shape, dtype=np.uint8)
+        rc = L.iss_oracle_ev_step(C.byref(self._m), int(orientation), cur.size, cur.ctypes.data, m53.ctypes.data, v53.ctypes.data,
+                                  nxt.ctypes.data, slot.ctypes.data, mask.ctypes.data)
+        assert rc == 0, "state or numerator out of range"
+        return nxt, slot, mask
+
+    def ev_segments(self, orientation):
+        """Last slot of every slot's segment of the sampler's survival tables ([5 (RL - 1)])."""
+        L = lib()
+        L.iss_oracle_ev_segments.restype = C.c_int
+        L.iss_oracle_ev_segments.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        out = np.zeros(5 * max(self.read_length - 1, 0), dtype=np.int32)
+        assert L.iss_oracle_ev_segments(C.byref(self._m), int(orientation), out.ctypes.data) == out.size
+        return out
+
     def gen_phred_scores(self, rng, orientation):
         q = np.zeros(self.read_length, dtype=np.uint8)
         lib().iss_oracle_gen_phred_scores(C.byref(self._m), rng._h, int(orientation), q.ctypes.data)

@@ -531,6 +531,48 @@ def test_device_fastq_equals_host_formatter(model, rid, cpu, first_i, counts, tm
     assert os.path.getsize(paths[0]) > 100 * sum(counts) // 4
 
 
+@pytest.mark.parametrize("compress", [False, True])
+def test_fastq_pipeline_many_tiny_jobs(compress, tmp_path):
+    """Regression (round 3): the file offsets of the FASTQ pipeline were advanced by the caller outside the pipe's
+    mutex while the writer thread added its own (zero, in text mode) byte count under it -- a lost update let a job
+    overwrite its predecessor's bytes, once in ~1e4 runs of the randomized worker tests.  Thousands of tiny jobs back to
+    back keep the writer finishing a job while the caller queues the next; the files must be the concatenation of the
+    jobs' text, and iss_fastq_flush checks offset == attach offset + queued bytes."""
+    import gzip
+    from helpers import random_genome
+    from insilicoseq_amd.engine import ReadEngine, fastq_write
+
+    n, jobs = 512, int(os.environ.get("ISS_TINY_JOBS", "6000"))
+    dense = dense_model("ecoli")  # read length 20: a job is a few hundred bytes
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(random_genome(3, 50000))
+        eng.reserve(n)
+        eng.generate(gid, n, first_ordinal=0, seed=5)
+        eng.synchronize()
+        rows = eng.download(0, n)["_pitched"]
+        paths = [str(tmp_path / p) for p in ("d1.fq", "d2.fq", "h1.fq", "h2.fq")]
+        fh = [open(p, "wb") for p in paths]
+        if compress:
+            eng.fastq_compress(True)
+        r = np.random.RandomState(7)
+        first = r.randint(0, n - 3, size=jobs)
+        count = r.randint(1, 4, size=jobs)
+        for j in range(jobs):
+            eng.fastq_emit(fh[0].fileno(), fh[1].fileno(), "g", j, 1, int(first[j]), int(count[j]), n_threads=1)
+        eng.fastq_flush()
+        assert os.lseek(fh[0].fileno(), 0, os.SEEK_CUR) == os.path.getsize(paths[0])
+        for j in range(jobs):  # the same text from the host formatter, job by job
+            a, c = int(first[j]), int(count[j])
+            fastq_write(fh[2].fileno(), fh[3].fileno(), "g", j, 1, c, eng.read_length, eng.pitch, rows[0][a:a + c],
+                        rows[1][a:a + c], rows[2][a:a + c], rows[3][a:a + c], n_threads=1)
+        for f in fh:
+            f.close()
+    rd = (lambda p: gzip.open(p, "rb").read()) if compress else (lambda p: open(p, "rb").read())
+    assert rd(paths[0]) == open(paths[2], "rb").read()
+    assert rd(paths[1]) == open(paths[3], "rb").read()
+
+
 @pytest.mark.parametrize("model,n_genomes,pairs_total,batch", [("novaseq", 5, 5_000_000, True), ("hiseq", 50, 6_250_000, True),
                                                                ("novaseq", 5, 5_000_000, False)])
 def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total, batch):
