@@ -32,7 +32,7 @@ extern "C" {
  *    Philox address map of the hot draws: three blocks per 16 bases.
  * 3: iss_fastq_compress / iss_deflate_code_build (gzip members built on the device), iss_generate_batch,
  *    iss_fastq_emit_batch (a whole work list per call).  2: iss_fastq_emit / iss_fastq_flush, MT-mode path counters. */
-#define ISS_ABI_VERSION 4
+#define ISS_ABI_VERSION 5
 
 #define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
 #define ISS_E_HIP (-2)         /* HIP runtime failure (message has the hip error)  */
@@ -179,6 +179,14 @@ int iss_random_insert_size(iss_ctx *ctx, int64_t n, uint64_t first_ordinal, uint
 int iss_introduce_indels(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t first_ordinal, uint64_t seed, const uint8_t *seq,
                          const int32_t *seq_len, const uint8_t *full_seq, int64_t full_len, const int64_t *bounds, uint8_t *out,
                          int32_t *status);
+/* One draw of the Philox path's indel event process, the sampler behind the tests `random() < p` of introduce_indels
+ * (iss/error_models/__init__.py:193-196, :209), for n independent inputs: state cur[i] (the last test
+ * slot decided, -1 .. 5 (read_length - 1) - 2), numerator m53[i] of the draw's uniform and v53[i] of the deletion sub-draw
+ * (< 2^53) -> next[i] (new state), slot[i] (the test that fires, or -1: none in the rest of the state's segment), mask[i]
+ * (bits 0-3: insertion of letter slot x, bits 4-7: the deletion fires if the base is A, T, C, G).  A test hook: the kernels
+ * loop over the same device function; the CPU tests pin its CPU twin to the reference's probabilities. */
+int iss_ev_step(iss_ctx *ctx, int32_t orientation, int64_t n, const int32_t *cur, const uint64_t *m53, const uint64_t *v53,
+                int32_t *next, int32_t *slot, uint8_t *mask);
 
 /* --store_mutations: one VCF row of the reference (iss/error_models/__init__.py:98-108, 197-221, written by
  * write_mutations, iss/generator.py:598-620). */

@@ -22,7 +22,7 @@ EXPORTS = (
     "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
     "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush", "iss_fastq_compress", "iss_deflate_code_build",
     "iss_generate_batch", "iss_fastq_emit_batch", "iss_gen_phred_scores", "iss_mut_sequence", "iss_random_insert_size",
-    "iss_introduce_indels",
+    "iss_introduce_indels", "iss_ev_step",
 )
 
 
@@ -106,6 +106,7 @@ def lib():
     L.iss_mut_sequence.argtypes = [vp, i32, i64, u64, u64, vp, vp, vp]
     L.iss_random_insert_size.argtypes = [vp, i64, u64, u64, vp]
     L.iss_introduce_indels.argtypes = [vp, i32, i64, u64, u64, vp, vp, vp, i64, vp, vp, vp]
+    L.iss_ev_step.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
     L.iss_fastq_write.argtypes = [C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i32, i32, vp, vp, vp, vp, i32]
     for name in EXPORTS:
         if name not in ("iss_ctx_destroy", "iss_last_error"):

@@ -36,8 +36,7 @@ namespace iss {
 
 // ---------------------------------------------------------------- RNG address map
 enum : uint32_t {
-    K_PAIR = 0, K_FS = 1, K_RS = 2, K_QM = 3, K_SUB = 4, K_INS = 5, K_DEL = 6, K_QM_LO = 7, K_INS_LO = 8,
-    K_DEL_LO = 9, K_FRAG = 10, K_EV = 11  // (K_INS .. K_DEL_LO: retired)
+    K_PAIR = 0, K_FS = 1, K_RS = 2, K_QM = 3, K_SUB = 4, K_QM_LO = 7, K_FRAG = 10, K_EV = 11  // (5, 6, 8, 9: retired)
 };
 
 struct u32x4 {
@@ -96,36 +95,47 @@ __device__ __forceinline__ uint64_t mk_digit(uint32_t h16, uint64_t l37) { retur
 // emit(n, mask): step n, bits 0-3 insertion of letter slot x fires, bits 4-7 the deletion fires if the token is base b;
 // steps come in ascending order (several calls for one step are possible).
 constexpr uint64_t EV_ONE = 0xffffffffffffffffull;
+// ONE draw of the event process (the CPU oracle holds its twin; exported through iss_ev_step, iss_units.hip.h).  State
+// `cur`: the last slot decided (-1: none yet); m53 / v53: numerators of the draw's uniform and of the deletion sub-draw.
+// Returns the new state; slot = the slot that fired (mask = its event mask) or -1 (nothing fires in the rest of cur's
+// segment: the state is the segment's last slot and the next draw starts the next segment).
+__device__ __forceinline__ int ev_step(const uint64_t *S, const uint16_t *E, const uint64_t *T, const uint64_t *del_thr /* [RL][4] of the mate */,
+                                       int cur, uint64_t m53, uint64_t v53, int &slot, uint32_t &mask) {
+    const int seg_last = E[cur + 1];
+    uint64_t base = EV_ONE;
+    if (cur >= 0 && E[cur] == seg_last) base = S[cur];
+    const uint64_t rr = ((((uint64_t)1 << 53) - m53) << 11) - 1u;  // (1 - u) in 0.64 fixed point
+    const uint64_t target = __umul64hi(rr, base);
+    slot = -1;
+    mask = 0;
+    if (S[seg_last] > target) return seg_last;  // nothing fires in the rest of the segment
+    int lo = cur + 1, hi = seg_last;  // first slot with S <= target
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (S[mid] <= target) hi = mid; else lo = mid + 1;
+    }
+    const int n = lo / 5, k = lo - 5 * n;
+    if (k < 4) {
+        mask = 1u << k;
+    } else {
+        const uint64_t tm = T[lo];
+        const uint64_t scaled = (__umul64hi(v53, tm) << 11) | ((v53 * tm) >> 53);  // floor(v * T_max / 2^53)
+        for (int b = 0; b < 4; ++b) mask |= (scaled < del_thr[(size_t)n * 4 + b] ? 16u : 0u) << b;
+    }
+    slot = lo;
+    return lo;
+}
 template <class Emit>
 __device__ __forceinline__ void indel_events(const uint64_t *S, const uint16_t *E, const uint64_t *T, const uint64_t *del_thr /* [RL][4] of the mate */,
                                              int ns, const Addr &a, int o, Emit emit) {
     int cur = -1;
     uint32_t j = 0;
     while (cur < ns - 1) {
-        const int seg_last = E[cur + 1];
-        uint64_t base = EV_ONE;
-        if (cur >= 0 && E[cur] == seg_last) base = S[cur];
         const u32x4 w = draw_block(a, K_EV, j++, (uint32_t)o);
-        const uint64_t rr = ((((uint64_t)1 << 53) - mk53(w.x, w.y)) << 11) - 1u;  // (1 - u) in 0.64 fixed point
-        const uint64_t target = __umul64hi(rr, base);
-        if (S[seg_last] > target) { cur = seg_last; continue; }  // nothing fires in the rest of the segment
-        int lo = cur + 1, hi = seg_last;  // first slot with S <= target
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (S[mid] <= target) hi = mid; else lo = mid + 1;
-        }
-        const int n = lo / 5, k = lo - 5 * n;
+        int slot;
         uint32_t mask;
-        if (k < 4) {
-            mask = 1u << k;
-        } else {
-            const uint64_t v = mk53(w.z, w.w), tm = T[lo];
-            const uint64_t scaled = (__umul64hi(v, tm) << 11) | ((v * tm) >> 53);  // floor(v * T_max / 2^53)
-            mask = 0;
-            for (int b = 0; b < 4; ++b) mask |= (scaled < del_thr[(size_t)n * 4 + b] ? 16u : 0u) << b;
-        }
-        emit(n, mask);
-        cur = lo;
+        cur = ev_step(S, E, T, del_thr, cur, mk53(w.x, w.y), mk53(w.z, w.w), slot, mask);
+        if (slot >= 0) emit(slot / 5, mask);
     }
 }
 

@@ -1178,15 +1178,17 @@ int iss_genome_upload_packed(iss_ctx *ctx, const uint32_t *codes, int64_t length
     const size_t n_mk = (size_t)(length + 31) / 32, n_pk = 2 * n_mk, n_in = (size_t)(length + 15) / 16;
     Genome G;
     G.L = length;
+    auto release = [&]() {  // (whatever was allocated so far: hipFree(nullptr) is a no-op)
+        (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii);
+        G.packed_alloc = G.mask_alloc = nullptr; G.ascii = nullptr;
+    };
     void *p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, (n_pk + 4) * sizeof(uint32_t)));
-    G.packed_alloc = static_cast<uint32_t *>(p);
-    HIP_TRY(ctx, hipMalloc(&p, (n_mk + 4) * sizeof(uint32_t)));
-    G.mask_alloc = static_cast<uint32_t *>(p);
-    HIP_TRY(ctx, hipMalloc(&p, (size_t)length));
-    G.ascii = static_cast<uint8_t *>(p);
-    auto release = [&]() { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); };
-    hipError_t he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + 4) * sizeof(uint32_t), ctx->stream);
+    hipError_t he = hipMalloc(&p, (n_pk + 4) * sizeof(uint32_t));
+    if (he == hipSuccess) { G.packed_alloc = static_cast<uint32_t *>(p); he = hipMalloc(&p, (n_mk + 4) * sizeof(uint32_t)); }
+    if (he == hipSuccess) { G.mask_alloc = static_cast<uint32_t *>(p); he = hipMalloc(&p, (size_t)length); }
+    if (he == hipSuccess) G.ascii = static_cast<uint8_t *>(p);
+    if (he != hipSuccess) { release(); return fail(ctx, he == hipErrorOutOfMemory ? ISS_E_NOMEM : ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he)); }
+    he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + 4) * sizeof(uint32_t), ctx->stream);
     if (he == hipSuccess) he = hipMemsetAsync(G.mask_alloc, 0, (n_mk + 4) * sizeof(uint32_t), ctx->stream);
     if (he == hipSuccess)
         he = hipMemcpyAsync(G.packed_alloc + 1, codes, n_in * sizeof(uint32_t), codes_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -1772,6 +1774,35 @@ int iss_random_insert_size(iss_ctx *ctx, int64_t n, uint64_t first_ordinal, uint
     return 0;
 }
 
+int iss_ev_step(iss_ctx *ctx, int32_t orientation, int64_t n, const int32_t *cur, const uint64_t *m53, const uint64_t *v53,
+                int32_t *next, int32_t *slot, uint8_t *mask) {
+    if (int rc = unit_prologue(ctx, orientation, n, "iss_ev_step")) return rc;
+    if (!n) return 0;
+    if (!cur || !m53 || !v53 || !next || !slot || !mask) return fail(ctx, ISS_E_INVALID, "iss_ev_step: NULL argument");
+    for (int64_t i = 0; i < n; ++i)
+        if (cur[i] < -1 || cur[i] > ctx->M.ev_ns - 2 || (m53[i] >> 53) || (v53[i] >> 53))
+            return fail(ctx, ISS_E_INVALID, "iss_ev_step: state or numerator out of range");
+    DevBuf dc, dm, dv, dn, ds, dk;
+    HIP_TRY(ctx, hipMalloc(&dc.p, (size_t)n * 4));
+    HIP_TRY(ctx, hipMalloc(&dm.p, (size_t)n * 8));
+    HIP_TRY(ctx, hipMalloc(&dv.p, (size_t)n * 8));
+    HIP_TRY(ctx, hipMalloc(&dn.p, (size_t)n * 4));
+    HIP_TRY(ctx, hipMalloc(&ds.p, (size_t)n * 4));
+    HIP_TRY(ctx, hipMalloc(&dk.p, (size_t)n));
+    HIP_TRY(ctx, hipMemcpyAsync(dc.p, cur, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dm.p, m53, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dv.p, v53, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(iss::k_unit_ev_step, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->M, orientation, (int32_t)n,
+                       static_cast<const int32_t *>(dc.p), static_cast<const uint64_t *>(dm.p), static_cast<const uint64_t *>(dv.p),
+                       static_cast<int32_t *>(dn.p), static_cast<int32_t *>(ds.p), static_cast<uint8_t *>(dk.p));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(next, dn.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(slot, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(mask, dk.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int iss_introduce_indels(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t first_ordinal, uint64_t seed, const uint8_t *seq,
                          const int32_t *seq_len, const uint8_t *full_seq, int64_t full_len, const int64_t *bounds, uint8_t *out,
                          int32_t *status) {
@@ -1782,6 +1813,9 @@ int iss_introduce_indels(iss_ctx *ctx, int32_t orientation, int64_t n, uint64_t 
     const int RL = ctx->M.RL;
     for (int64_t i = 0; i < n; ++i)
         if (seq_len[i] < 0 || seq_len[i] > RL) return fail(ctx, ISS_E_INVALID, "iss_introduce_indels: a read longer than read_length");
+    for (int64_t i = 0; i < n; ++i)  // (read_start, read_end) index full_seq in adjust_seq_length; beyond its end is handled
+        if (bounds[2 * i] < 0 || bounds[2 * i + 1] < 0)  // ('A' / IndexError as in the reference), a negative bound is not
+            return fail(ctx, ISS_E_INVALID, "iss_introduce_indels: negative read bounds");
     const int32_t cap = 6 * RL + 8;  // letters (<= 5 RL + 8) + the event masks of the steps
     const size_t bytes = (size_t)n * RL;
     DevBuf ds, dl, dg, db, dw, dout, dst;
@@ -1932,8 +1966,42 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     auto &m = ctx->mt;
     if (!(M.RL < G.L)) {
         // the reference draws the insert size BEFORE its assertion fails (generator.py:121-126, 130)
-        if (m.has_frag)
-            return fail(ctx, ISS_E_INVALID, "short record with a custom fragment length: stream alignment not supported");
+        if (m.has_frag) {
+            // np.random.normal(mu, sd) (generator.py:122): numpy's legacy polar Box-Muller -- a cached second value is used up,
+            // else candidates of two doubles each are drawn until 0 < r2 < 1 and f * x1 is cached -- replayed on the host (libm)
+            iss::MtGauss gs;
+            HIP_TRY(ctx, hipMemcpy(&gs, m.d_gauss, sizeof gs, hipMemcpyDeviceToHost));
+            if (gs.has_gauss) {
+                gs.has_gauss = 0;
+            } else {
+                for (size_t used = 0;;) {
+                    const size_t want[2] = {0, used + 256};
+                    { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
+                    uint32_t w[256];
+                    HIP_TRY(ctx, hipMemcpy(w, m.buf[1][m.cur[1]] + m.used[1] + used, sizeof w, hipMemcpyDeviceToHost));
+                    bool done = false;
+                    for (int c = 0; c < 64 && !done; ++c) {
+                        auto res53 = [](uint32_t a, uint32_t b) { return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0); };
+                        volatile double x1 = 2.0 * res53(w[4 * c], w[4 * c + 1]) - 1.0, x2 = 2.0 * res53(w[4 * c + 2], w[4 * c + 3]) - 1.0;
+                        volatile double a2 = x1 * x1, b2 = x2 * x2;
+                        volatile double r2 = a2 + b2;
+                        used += 4;
+                        if (r2 >= 1.0 || r2 == 0.0) continue;
+                        volatile double f = -2.0 * log(r2);
+                        f = f / r2;
+                        f = sqrt(f);
+                        gs.gauss = f * x1;
+                        gs.has_gauss = 1;
+                        gs.x1 = x1;
+                        gs.x2 = x2;
+                        done = true;
+                    }
+                    if (done) { m.used[1] += used; break; }
+                }
+            }
+            HIP_TRY(ctx, hipMemcpy(m.d_gauss, &gs, sizeof gs, hipMemcpyHostToDevice));
+            return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
+        }
         if (!basic) {  // (BasicErrorModel.random_insert_size is a constant: nothing is drawn)
             const size_t want[2] = {0, 2};
             { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }

@@ -71,6 +71,22 @@ __global__ __launch_bounds__(64) void k_unit_isize(DevModel M, UnitArgs U, int64
     out[i] = count_lt(M.isize_thr, M.n_isize, mk53(draw_block(a, K_PAIR, 0, 0).x, draw_block(a, K_PAIR, 0, 1).x));
 }
 
+// One draw of the indel event process (ev_step, iss_kernels.hip.h) for n independent (state, uniform) inputs -- the
+// function the scan / fix-up kernels loop over, exported so that the tests can compare it with the CPU oracle's twin, whose
+// interval structure the CPU tests pin to the reference's per-test probabilities exactly.
+__global__ __launch_bounds__(64) void k_unit_ev_step(DevModel M, int32_t o, int32_t n, const int32_t *__restrict__ cur,
+                                                     const uint64_t *__restrict__ m53, const uint64_t *__restrict__ v53,
+                                                     int32_t *__restrict__ next, int32_t *__restrict__ slot, uint8_t *__restrict__ mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int sl;
+    uint32_t m8;
+    next[i] = ev_step(M.ev_S + (size_t)o * M.ev_ns, M.ev_E + (size_t)o * M.ev_ns, M.ev_T + (size_t)o * M.ev_ns, M.del_thr + (size_t)o * M.RL * 4,
+                      cur[i], m53[i], v53[i], sl, m8);
+    slot[i] = sl;
+    mask[i] = (uint8_t)m8;
+}
+
 // ErrorModel.introduce_indels + adjust_seq_length (__init__.py:158-228, 114-156): read i = seq[i][0 .. len[i]) (the
 // perfect read, <= RL letters, already in read direction), bounds[i] = (start, end) in `genome` (length L) for the
 // padding; out[i][0 .. RL).  work: [n][cap] scratch letters + event masks, cap = 6 * RL + 8.  status: 0 ok, 2 KeyError, 3 IndexError.

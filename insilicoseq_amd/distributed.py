@@ -24,16 +24,27 @@ for _i, _c in enumerate(b"ATCG"):  # the engine's 2-bit alphabet: A,T,C,G = 0..3
     _CODE_OF[_c] = _i
 
 
-def pack_2bit(ascii_u8):
+def pack_2bit(ascii_u8, block=1 << 24):
     """uint8 letters -> uint32 words of 2-bit codes (16 bases per word, base i in bits 2*(i % 16)...), or None when the
-    record holds anything but plain A/C/G/T (it is shipped as ASCII then)."""
-    codes = _CODE_OF[np.asarray(ascii_u8, dtype=np.uint8)]
-    if codes.size == 0 or int(codes.max()) > 3:
+    record holds anything but plain A/C/G/T (it is shipped as ASCII then).  Packed ``block`` bases at a time: the
+    temporaries stay at a few bytes per base of ONE block whatever the record's length (the engine takes 1.2 Gbp records)."""
+    a = np.asarray(ascii_u8, dtype=np.uint8).reshape(-1)
+    if a.size == 0:
         return None
-    n = (codes.size + 15) // 16
-    buf = np.zeros(n * 16, dtype=np.uint32)
-    buf[:codes.size] = codes
-    return (buf.reshape(n, 16) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+    block = max(16, int(block) & ~15)
+    out = np.zeros((a.size + 15) // 16, dtype=np.uint32)
+    shifts = 2 * np.arange(16, dtype=np.uint32)
+    for at in range(0, a.size, block):
+        codes = _CODE_OF[a[at:at + block]]
+        if int(codes.max()) > 3:
+            return None
+        n = (codes.size + 15) // 16
+        buf = np.zeros(n * 16, dtype=np.uint32)
+        buf[:codes.size] = codes
+        buf = buf.reshape(n, 16)
+        buf <<= shifts
+        out[at // 16:at // 16 + n] = np.bitwise_or.reduce(buf, axis=1)
+    return out
 
 
 def unpack_2bit(words, length):
@@ -47,20 +58,28 @@ class BroadcastGenome(object):
     """One record as a rank holds it after the broadcast: ``length`` letters, either 2-bit codes (``packed`` True) or
     ASCII, as a uint8 view ``raw`` on the host and -- when the payload lives on a GPU -- the device address ``dev_ptr``."""
 
-    def __init__(self, length, packed, raw, dev_ptr=None):
+    def __init__(self, length, packed, raw, dev_ptr=None, dev_bytes=None):
         self.length, self.packed, self.raw, self.dev_ptr = int(length), bool(packed), raw, dev_ptr
+        self._dev_bytes = dev_bytes  # the record's slice of the device payload (a torch uint8 tensor), when raw is None
+
+    def _host_raw(self):
+        if self.raw is None:
+            if self._dev_bytes is None:
+                raise ValueError("BroadcastGenome: neither a host copy nor a device slice of the record is held")
+            self.raw = self._dev_bytes.cpu().numpy()  # (a packed record left on the GPU by as_refs=True: fetched on demand)
+        return self.raw
 
     def ascii(self):
         if not self.packed:
-            return np.asarray(self.raw, dtype=np.uint8)[:self.length]
-        return unpack_2bit(np.asarray(self.raw).view(np.uint32), self.length)
+            return np.asarray(self._host_raw(), dtype=np.uint8)[:self.length]
+        return unpack_2bit(np.asarray(self._host_raw()).view(np.uint32), self.length)
 
     def upload(self, engine):
         """To the engine's HBM: straight from the broadcast buffer on the device when there is one."""
         if self.packed:
-            return engine.add_genome_packed(None if self.dev_ptr is not None else np.asarray(self.raw).view(np.uint32),
+            return engine.add_genome_packed(None if self.dev_ptr is not None else np.asarray(self._host_raw()).view(np.uint32),
                                             self.length, device_ptr=self.dev_ptr)
-        return engine.add_genome(np.asarray(self.raw, dtype=np.uint8)[:self.length])
+        return engine.add_genome(np.asarray(self._host_raw(), dtype=np.uint8)[:self.length])
 
 
 def _align16(n):
@@ -86,6 +105,10 @@ def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, 
 
     import torch
 
+    backend = dist.get_backend()
+    if str(backend).lower() == "nccl" and not str(device).startswith("cuda"):
+        # RCCL moves device memory only: a CPU tensor would fail inside the collective with a far less readable message
+        raise ValueError("broadcast_model_and_genomes: backend 'nccl' (RCCL) needs device='cuda:<n>', got %r" % (device,))
     rank = dist.get_rank()
     if rank == src:
         fields = [np.ascontiguousarray(getattr(dense, k)) for k in DenseModel.FIELDS]
@@ -134,7 +157,8 @@ def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, 
             raw = host[off:off + nbytes]
         else:  # on a GPU only the ASCII records (IUPAC / lower-case letters: validated and packed by iss_genome_upload) come back
             raw = None if packed else t[off:off + nbytes].cpu().numpy()
-        refs.append(BroadcastGenome(length, packed, raw, dev_ptr=(t.data_ptr() + off) if on_gpu else None))
+        refs.append(BroadcastGenome(length, packed, raw, dev_ptr=(t.data_ptr() + off) if on_gpu else None,
+                                    dev_bytes=t[off:off + nbytes] if on_gpu else None))
         off += _align16(nbytes)
     if rank != src:
         dense = DenseModel(meta["read_length"], *out_fields)

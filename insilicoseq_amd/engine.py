@@ -191,6 +191,19 @@ class ReadEngine(object):
                                                    b.ctypes.data, out.ctypes.data, st.ctypes.data))
         return out, st
 
+    def ev_step(self, orientation, cur, m53, v53=None):
+        """One draw of the indel event process (the sampler behind the tests of introduce_indels,
+        iss/error_models/__init__.py:193-196, :209) for arrays of (state, uniform numerator[, numerator of the deletion
+        sub-draw]): (next state, slot that fires or -1, event mask).  A test hook (include/iss_mi355x.h: iss_ev_step)."""
+        cur = np.ascontiguousarray(cur, dtype=np.int32)
+        m53 = np.ascontiguousarray(m53, dtype=np.uint64)
+        v53 = np.zeros_like(m53) if v53 is None else np.ascontiguousarray(v53, dtype=np.uint64)
+        assert cur.shape == m53.shape == v53.shape
+        nxt, slot, mask = np.zeros_like(cur), np.zeros_like(cur), np.zeros(cur.shape, dtype=np.uint8)
+        self._check(self._lib.iss_ev_step(self._ctx, int(orientation), cur.size, cur.ctypes.data, m53.ctypes.data, v53.ctypes.data,
+                                          nxt.ctypes.data, slot.ctypes.data, mask.ctypes.data))
+        return nxt, slot, mask
+
     def set_fragment(self, fragment_length=None, fragment_sd=None):
         """Custom fragment length for generate() (None, None: the model's insert sizes)."""
         on = fragment_length is not None and fragment_sd is not None

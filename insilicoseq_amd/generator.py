@@ -235,17 +235,13 @@ class Worker(object):
             logger.warning("%s shorter than read length for this ErrorModel" % record.id)
             logger.warning("Skipping %s. You will have less reads than specified" % record.id)
             if self.rng == "mt" and n_pairs > 0:
-                # the reference has already drawn the insert size when its assertion fails: keep the streams aligned
+                # the reference has already drawn the insert size (or, with --fragment-length, its gaussian) when its
+                # assertion fails (generator.py:121-130): the engine consumes the same draw and reports the short record
+                gid = self.genome_id(record)  # (upload errors -- letters outside the alphabet, an empty record -- propagate)
                 try:
-                    eng.generate_mt(self.genome_id(record), 1)
+                    eng.generate_mt(gid, 1)
                 except _native.EngineError as e:
-                    if e.code == _native.E_INVALID and getattr(self, "has_fragment", False):
-                        # --fragment-length: the reference would consume one legacy-gauss draw (and cache the second) here;
-                        # the device cannot replay that for a record it refuses, so the streams are no longer the
-                        # reference's from this point on (documented in INTEGRATION.md)
-                        logger.warning("%s: skipped; with --fragment-length the MT streams are no longer aligned with the "
-                                       "reference's after a record shorter than the read length" % record.id)
-                    elif e.code != _native.E_SHORT_RECORD:
+                    if e.code != _native.E_SHORT_RECORD:
                         raise
             return 0
         gid = self.genome_id(record)
@@ -259,10 +255,12 @@ class Worker(object):
                 if self.store_mutations:
                     write_mutations(eng.mt_mutations(), mutations_handle, record.id, done, self.cpu_number)
             else:
-                eng.generate(gid, n, first_ordinal=self.ordinal, seed=self.seed, sequence_type=sequence_type,
-                             gc_bias=gc_bias, out_first_pair=0)
+                def gen():
+                    eng.generate(gid, n, first_ordinal=self.ordinal, seed=self.seed, sequence_type=sequence_type,
+                                 gc_bias=gc_bias, out_first_pair=0)
+                gen()
                 if self.store_mutations:
-                    write_mutations(eng.mutations(), mutations_handle, record.id, done, self.cpu_number)
+                    write_mutations(mutation_rows(eng, gen), mutations_handle, record.id, done, self.cpu_number)
             if self.device_fastq:
                 # text built on the device, copied and written behind the next batch's generation
                 # (one pwrite stream per file: tmpfs gets slower with concurrent writers to one file)
@@ -280,6 +278,24 @@ class Worker(object):
         return done
 
 
+def mutation_rows(eng, regenerate):
+    """--store_mutations rows of the generate call just made (Philox path).  The row buffer is sized from the model's
+    expected rows; when a batch overflows it (ISS_E_NOMEM: a heavy-indel or edited model, rows written twice for reads
+    the indel kernels rebuild) the reservation doubles and ``regenerate()`` repeats the call -- generation is a pure
+    function of seed and ordinal, so the rows and the reads are the same ones."""
+    while True:
+        try:
+            return eng.mutations()
+        except _native.EngineError as e:
+            if e.code != _native.E_NOMEM:
+                raise
+            cap = int(getattr(eng, "_pmut_cap", 0))
+            if cap >= 0x7fffffff:
+                raise
+            eng.mutations_reserve(min(2 * max(cap, 1 << 16), 0x7fffffff))
+            regenerate()
+
+
 def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_handle, sequence_type, gc_bias):
     """The worker's loop over its work items (iss/generator.py:245-249) with the parallel path's batches cut across
     items: up to BATCH_PAIRS pairs of consecutive items go through ONE set of launches (engine.generate_batch; the
@@ -295,10 +311,12 @@ def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_ha
             return
         rows = None
         try:
-            eng.generate_batch([p[1] for p in pending], [p[2] for p in pending], first_ordinal=w.ordinal, seed=w.seed,
-                               sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0)
+            def gen():
+                eng.generate_batch([p[1] for p in pending], [p[2] for p in pending], first_ordinal=w.ordinal, seed=w.seed,
+                                   sequence_type=sequence_type, gc_bias=gc_bias, out_first_pair=0)
+            gen()
             if w.store_mutations:
-                rows = eng.mutations()
+                rows = mutation_rows(eng, gen)
         except _native.EngineError as e:
             if e.code != _native.E_INVALID or "2^31" not in str(e):
                 raise
@@ -306,10 +324,12 @@ def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_ha
             eng.reserve(sum(p[2] for p in pending))
             parts, row, ordinal = [], 0, w.ordinal
             for _rid, gid, n, _first_i in pending:
-                eng.generate(gid, n, first_ordinal=ordinal, seed=w.seed, sequence_type=sequence_type, gc_bias=gc_bias,
-                             out_first_pair=row)
+                def gen1(gid=gid, n=n, ordinal=ordinal, row=row):
+                    eng.generate(gid, n, first_ordinal=ordinal, seed=w.seed, sequence_type=sequence_type, gc_bias=gc_bias,
+                                 out_first_pair=row)
+                gen1()
                 if w.store_mutations:
-                    part = eng.mutations()
+                    part = mutation_rows(eng, gen1)
                     part["pair"] += row
                     parts.append(part)
                 row += n

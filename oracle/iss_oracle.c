@@ -170,11 +170,8 @@ enum {
                    * half*2 + mate, byte cc.                                                        */
     K_SUB = 4,    /* index = p, sub = mate: (w0,w1) substitution choice (full draw); the 45 trailing bits of the
                    * error-test draw = (w2 & 0x1fff) << 32 | w3                                      */
-    K_INS = 5,    /* (retired: the indel tests are sampled by K_EV)                      */
-    K_DEL = 6,    /* (retired)                                                           */
+    /* 5, 6, 8, 9: retired (per-test indel draws, replaced by K_EV) */
     K_QM_LO = 7,  /* trailing 37 bits of the quality draw; index = p; sub = mate; (w0,w1)  */
-    K_INS_LO = 8, /* (retired)                                                           */
-    K_DEL_LO = 9, /* (retired)                                                           */
     K_FRAG = 10,  /* custom fragment length: polar candidate t -> index t; x1 from mk53(w0,w1), x2 from mk53(w2,w3) */
     K_EV = 11     /* indel events of a read: draw j of the event process (see ev_tab) -> index j, sub = mate;
                    * (w0,w1): where the next test fires; (w2,w3): which bases a deletion test fires for       */

@@ -65,8 +65,11 @@ def test_pairs_equal_reference(engine, case):
     assert list(_res53(py)) == list(z["tail_py"]) and list(_res53(npw)) == list(z["tail_np"])
 
 
-@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc", "genomes_basic_cpu2"])
+@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc", "genomes_basic_cpu2",
+                                  "syn_novaseq_frag_short"])
 def test_worker_files_equal_reference(case, tmp_path):
+    """(syn_novaseq_frag_short: --fragment-length with records the worker skips after their fragment-length draw,
+    iss/generator.py:121-130 -- the gaussian is replayed on the host and the streams stay the reference's.)"""
     from insilicoseq_amd.generator import Record, worker_iterator
 
     z = np.load(os.path.join(GOLDEN, "worker", case + ".npz"))
@@ -74,7 +77,10 @@ def test_worker_files_equal_reference(case, tmp_path):
     recs = [Record(z["genome_%d" % i].tobytes().decode(), id=rid) for i, rid in enumerate(meta["ids"])]
     work = [(r, n, "default") for r, n in zip(recs, meta["counts"])]
     prefix = str(tmp_path / "w")
-    worker_iterator(work, dense_model(meta["model"]), meta["cpu_number"], prefix, meta["seed"], meta["sequence_type"],
+    em = dense_model(meta["model"])
+    if meta.get("fragment_length") is not None:
+        em.fragment_length, em.fragment_sd = meta["fragment_length"], meta["fragment_sd"]
+    worker_iterator(work, em, meta["cpu_number"], prefix, meta["seed"], meta["sequence_type"],
                     meta["gc_bias"], device=0, rng="mt")
     assert open(prefix + "_R1.fastq", "rb").read() == z["r1"].tobytes()
     assert open(prefix + "_R2.fastq", "rb").read() == z["r2"].tobytes()

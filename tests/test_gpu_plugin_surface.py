@@ -132,3 +132,52 @@ def test_kd_error_model_methods_match_the_generated_pair(engine):
             seq = em.mut_sequence(rec, orientation)
             assert seq == rows[key_b][i].tobytes().decode(), (i, orientation)
             assert rec.letter_annotations["phred_quality"] == rows[key_q][i].tolist(), (i, orientation)
+
+
+@pytest.mark.parametrize("case", ["novaseq", "miseq-legacy", "configs4", "extremes"])
+def test_event_process_step_equals_oracle(engine, case):
+    """iss_ev_step: the device function the indel kernels loop over (one draw of the event process: state + uniform ->
+    next firing test + event mask) against the oracle's ev_step, whose interval structure
+    tests/test_oracle_golden.py::test_event_process_exact_* pins to the reference's per-test probabilities
+    (iss/error_models/__init__.py:193-196, :209).  Random states x numerators of every magnitude, both mates."""
+    from oracle import oracle as O
+
+    if case in ("novaseq", "miseq-legacy"):
+        dense = dense_model(case)
+    elif case == "configs4":
+        dense = dense_model("novaseq", (0.001, 0.003))
+    else:
+        dense = dense_model("hiseq")
+        rs = np.random.RandomState(11)
+        dense.ins[:] = rs.choice([0.0, 1e-4, 3e-3, 0.05], size=dense.ins.shape, p=[0.4, 0.3, 0.2, 0.1])
+        dense.dele[:] = rs.choice([0.0, 2e-4, 1e-2, 0.2], size=dense.dele.shape, p=[0.3, 0.3, 0.3, 0.1])
+        dense.ins[0, 7, 2] = 1.0
+        dense.dele[0, 40, :] = [0.5, 1.0, 0.0, 0.25]
+        dense.ins[0, 60:64, :] = 0.9
+        dense.dele[1, 3, :] = float("nan")
+        dense.ins[1, 5, 1] = 5e-324
+    engine.load_model(dense)
+    orc = O.Oracle(dense)
+    ns = 5 * (dense.read_length - 1)
+    rs = np.random.RandomState(3)
+    n = 400000
+    cur = rs.randint(-1, ns - 1, size=n).astype(np.int32)
+
+    def numerators():
+        full = rs.randint(0, 1 << 30, size=n).astype(np.uint64) << np.uint64(23) | rs.randint(0, 1 << 23, size=n).astype(np.uint64)
+        return full >> rs.randint(0, 53, size=n).astype(np.uint64)
+
+    m53, v53 = numerators(), numerators()
+    m53[:1000] = 0                      # fires at the first test with p > 0
+    m53[1000:2000] = (1 << 53) - 1      # the largest numerator
+    for o in (0, 1):
+        got = engine.ev_step(o, cur, m53, v53)
+        exp = orc.ev_step(o, cur, m53, v53)
+        for g, e, what in zip(got, exp, ("next state", "slot", "mask")):
+            assert np.array_equal(g, e), (case, o, what)
+        if case != "novaseq":
+            assert (exp[1] >= 0).mean() > 0.01  # (the sample does reach firing tests)
+    with pytest.raises(Exception):
+        engine.ev_step(0, [ns - 1], [0])
+    with pytest.raises(Exception):
+        engine.ev_step(0, [0], [1 << 53])

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(native):
     assert declared == set(native.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.iss_abi_version() == 4
+    assert lib.iss_abi_version() == 5
 
 
 def test_no_gpu_means_loud_failure(native):
@@ -61,11 +61,13 @@ def _worker_case(name):
     return z, meta, genomes
 
 
-@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc", "genomes_basic_cpu2"])
+@pytest.mark.parametrize("case", ["genomes_hiseq_cpu0", "genomes_miseq_cpu1", "syn_novaseq_cpu3_gc", "genomes_basic_cpu2",
+                                  "syn_novaseq_frag_short"])
 def test_worker_fastq_matches_reference(native, case, tmp_path):
     """Oracle (MT streams, seeded like worker_iterator: seed + cpu_number) + the product's FASTQ
     formatter reproduce the reference worker's R1/R2 files byte for byte (ids, order, skipped
-    records, gc_bias rejections, stream carry-over between work items)."""
+    records, gc_bias rejections, stream carry-over between work items; syn_novaseq_frag_short: --fragment-length with
+    records the worker skips AFTER their fragment-length draw, iss/generator.py:121-130)."""
     from insilicoseq_amd.engine import fastq_write
     from oracle import oracle as O
 
@@ -76,7 +78,8 @@ def test_worker_fastq_matches_reference(native, case, tmp_path):
     p1, p2 = tmp_path / "r1.fastq", tmp_path / "r2.fastq"
     with open(p1, "wb") as f1, open(p2, "wb") as f2:
         for rid, n, g in zip(meta["ids"], meta["counts"], genomes):
-            res = orc.simulate(rng, g, n, sequence_type=meta["sequence_type"], gc_bias=meta["gc_bias"])
+            res = orc.simulate(rng, g, n, sequence_type=meta["sequence_type"], gc_bias=meta["gc_bias"],
+                               fragment_length=meta.get("fragment_length"), fragment_sd=meta.get("fragment_sd"))
             if res["status"] == O.SKIP_RECORD:
                 continue
             assert res["status"] == 0
@@ -592,6 +595,37 @@ def test_batched_worker_loop_falls_back_to_single_calls():
     assert [c for c in w.engine.calls if c[0] == "emit"] == [("emit", [("a", 0, 0, 40), ("b", 0, 40, 25)])]
     ids = [line.split("\t")[0] for line in vcf.getvalue().splitlines()]
     assert ids == ["a_0_4/1", "a_39_4/1", "b_0_4/1", "b_24_4/1"] and w.ordinal == 65
+
+
+def test_mutation_rows_retry_on_overflow():
+    """A --store_mutations batch that overflows its row buffer (ISS_E_NOMEM) is repeated with twice the reservation
+    instead of aborting the worker (generation is a pure function of seed and ordinal); other errors propagate."""
+    import insilicoseq_amd.generator as G
+    from insilicoseq_amd import _native
+
+    class FakeEngine:
+        def __init__(self, need):
+            self._pmut_cap, self.need, self.calls = 1 << 17, need, []
+
+        def mutations(self):
+            if self._pmut_cap < self.need:
+                raise _native.EngineError(_native.E_NOMEM, "mutation rows overflow")
+            return "rows"
+
+        def mutations_reserve(self, cap):
+            self.calls.append(("reserve", cap))
+            self._pmut_cap = cap
+
+    eng, regen = FakeEngine(1 << 19), []
+    assert G.mutation_rows(eng, lambda: regen.append(1)) == "rows"
+    assert eng.calls == [("reserve", 1 << 18), ("reserve", 1 << 19)] and len(regen) == 2
+
+    class Broken(FakeEngine):
+        def mutations(self):
+            raise _native.EngineError(_native.E_HIP, "device lost")
+
+    with pytest.raises(_native.EngineError):
+        G.mutation_rows(Broken(0), lambda: None)
 
 
 def test_worker_resolves_records_by_ordinal_not_by_id(tmp_path, monkeypatch):

@@ -263,3 +263,156 @@ def test_indel_event_process_is_the_product_of_the_reference_tests():
     assert not orc.indel_event_masks(O.Rng().seed_philox(77), 1, range(50)).any()
     again = orc.indel_event_masks(O.Rng().seed_philox(77), 0, [5, 17, 5])
     assert (again[0] == masks[5]).all() and (again[1] == masks[17]).all() and (again[2] == masks[5]).all()
+
+
+def _ceil_thr(p):
+    """ceil(p * 2^53) for the f64 p, in exact rational arithmetic: `random() < p` <=> numerator < this (NaN, <= 0: never)."""
+    from fractions import Fraction
+    p = float(p)
+    if not (p > 0.0):
+        return 0
+    if p >= 1.0:
+        return 1 << 53
+    f = Fraction(p) * (1 << 53)
+    return -((-f.numerator) // f.denominator)
+
+
+def _event_process_exact(d, o, all_pairs):
+    """Walks the interval boundaries of the oracle's per-draw event sampler (iss_oracle.c: ev_step) for EVERY state `cur`
+    and every slot t of cur's segment: the set of uniform numerators m53 for which the next firing test is <= t is an
+    initial interval [0, C(cur, t)) (found by bisection on the exported function, checked on random numerators), so
+    P_sampler(first fire = t | cur) = (C(cur, t) - C(cur, t - 1)) / 2^53 exactly.  The reference runs independent tests
+    `random() < p_s` (__init__.py:193-196, :209), P(test s fires) = T_s / 2^53 with T_s = ceil(p_s 2^53), hence
+    P_ref(first fire = t | none up to cur) = T_t / 2^53 * prod_{cur < s < t} (1 - T_s / 2^53) -- compared in integer
+    arithmetic over the common denominator 2^(53 (t - cur)).  Returns (pairs checked, largest absolute difference)."""
+    ONE = 1 << 53
+    orc = O.Oracle(d)
+    RL = d.read_length
+    ns = 5 * (RL - 1)
+    T, Tdel = [0] * ns, []
+    for n in range(RL - 1):
+        for k in range(4):
+            T[5 * n + k] = _ceil_thr(d.ins[o, n, k])
+        Tdel.append([_ceil_thr(d.dele[o, n, b]) for b in range(4)])
+        T[5 * n + 4] = max(Tdel[n])
+    seg = orc.ev_segments(o)
+    assert seg[-1] == ns - 1 and (np.diff(seg) >= 0).all() and (seg >= np.arange(ns)).all()
+    want = [(cur, t) for cur in range(-1, ns - 1) for t in range(cur + 1, int(seg[cur + 1]) + 1)
+            if all_pairs or T[t] or t == seg[cur + 1]]
+    curs = np.array([c for c, _ in want], dtype=np.int32)
+    ts = np.array([t for _, t in want], dtype=np.int32)
+    lo, hi = np.zeros(len(want), dtype=np.uint64), np.full(len(want), ONE, dtype=np.uint64)
+    for _ in range(54):  # C = the first numerator for which the draw does NOT fire at a slot <= t
+        act = lo < hi
+        mid = (lo + hi) // np.uint64(2)
+        _nxt, slot, _mask = orc.ev_step(o, curs, np.minimum(mid, np.uint64(ONE - 1)))
+        fires = (slot >= 0) & (slot <= ts)
+        lo = np.where(act & fires, mid + np.uint64(1), lo)
+        hi = np.where(act & ~fires, mid, hi)
+    assert (lo == hi).all()
+    count = lo.tolist()
+    worst, j = 0.0, 0
+    table = {}
+    for cur in range(-1, ns - 1):
+        surv, k, c_prev = 1, 0, 0  # surv = prod (2^53 - T_s) over the k slots cur < s < t with T_s != 0 (the others are factors 1)
+        for t in range(cur + 1, int(seg[cur + 1]) + 1):
+            if all_pairs or T[t] or t == seg[cur + 1]:
+                C = count[j]
+                j += 1
+                table[(cur, t)] = C
+                exact = surv * T[t]                # / 2^(53 (k + 1))
+                sampler = (C - c_prev) << (53 * k)  # / 2^(53 (k + 1))
+                assert C >= c_prev and (exact or not sampler), (cur, t)  # a test with p = 0 never fires
+                worst = max(worst, abs(sampler - exact) / (1 << (53 * (k + 1))))
+                c_prev = C
+            if T[t]:
+                surv *= ONE - T[t]
+                k += 1
+    # the intervals really are the sampler's answer: random numerators land in the interval of the slot they fire at, and a draw
+    # beyond the segment's last interval fires nothing and moves the state to the segment's end
+    rs = np.random.RandomState(5 + o)
+    if all_pairs:
+        rc = rs.randint(-1, ns - 1, size=200000).astype(np.int32)
+        # numerators spread over all magnitudes (events are rare: uniform numerators alone would all say "nothing fires")
+        rm = (rs.randint(0, 1 << 30, size=rc.size).astype(np.uint64) << np.uint64(23) | rs.randint(0, 1 << 23, size=rc.size).astype(np.uint64)) \
+            >> rs.randint(0, 40, size=rc.size).astype(np.uint64)
+        nxt, slot, _ = orc.ev_step(o, rc, rm)
+        for c, m, nx, sl in zip(rc.tolist(), rm.tolist(), nxt.tolist(), slot.tolist()):
+            e = int(seg[c + 1])
+            if sl < 0:
+                assert nx == e and m >= table[(c, e)]
+            else:
+                assert nx == sl and c < sl <= e and m < table[(c, sl)] and (sl == c + 1 or m >= table[(c, sl - 1)])
+    # the deletion slot's per-base events: bit b <=> floor(v T_max / 2^53) < T_b, one uniform for the four bases as in the
+    # reference: initial intervals of v (nested by construction), of measure ceil(T_b 2^53 / T_max) / 2^53 -- within 2^-53 of
+    # T_b / T_max, so P(deletion fires for base b) = T_max / 2^53 * that is T_b / 2^53 up to 2^-106 T_max
+    steps = [n for n in range(RL - 1) if T[5 * n + 4]]
+    steps = steps if len(steps) <= 64 else [steps[i] for i in sorted(rs.choice(len(steps), 64, replace=False))]
+    for n in steps:
+        t = 5 * n + 4
+        for b in range(4):
+            lo_v, hi_v = 0, ONE
+            while lo_v < hi_v:  # first v for which bit b is clear (m53 = 0 fires at the first slot with T > 0 after the state)
+                mid = (lo_v + hi_v) // 2
+                nx, sl, mk = orc.ev_step(o, [t - 1], [0], [mid])
+                assert sl[0] == t
+                if (mk[0] >> (4 + b)) & 1:
+                    lo_v = mid + 1
+                else:
+                    hi_v = mid
+            assert lo_v == -((-Tdel[n][b] * ONE) // T[t]), (n, b)
+            # (an initial interval: every sampled v below the boundary sets the bit, every one above clears it)
+            vs = np.concatenate([rs.randint(0, max(lo_v, 1), size=16), rs.randint(lo_v, ONE, size=16) if lo_v < ONE else []]).astype(np.uint64)
+            _, _, mk = orc.ev_step(o, np.full(vs.size, t - 1, dtype=np.int32), np.zeros(vs.size, dtype=np.uint64), vs)
+            assert (((mk >> (4 + b)) & 1) == (vs < lo_v)).all()
+    return len(want), worst
+
+
+@pytest.mark.parametrize("name", ["novaseq", "hiseq", "miseq", "miseq-legacy", "nextseq", "ecoli"])
+def test_event_process_exact_shipped_models(name):
+    """The Philox path's indel sampler against the reference's 5 (RL - 1) independent tests per read
+    (/root/reference/iss/error_models/__init__.py:193-196, :209), exactly (see _event_process_exact): every state and
+    every slot a test can fire at.  One draw has 2^53 outcomes, so a first-passage probability -- not a multiple of
+    2^-53 in the reference either once it is a product -- is matched to within one outcome: 2^-52 covers the two interval
+    ends; the 0.64 fixed-point survival products add < 2^-64 per factor, amplified by at most 2^16 (a segment restarts
+    when its survival drops below 2^-16)."""
+    import glob
+    path = os.path.join(os.path.dirname(__file__), "..", "insilicoseq_amd", "profiles", name + ".dense.npz")
+    if not os.path.exists(path):
+        pytest.skip("profile not shipped under that name: %s" % sorted(os.path.basename(p) for p in glob.glob(os.path.dirname(path) + "/*.npz")))
+    from helpers import dense_model
+    d = dense_model(name)
+    for o in (0, 1):
+        n, worst = _event_process_exact(d, o, all_pairs=False)
+        assert n >= 5 * (d.read_length - 1) - 1 and worst <= 2.0 ** -52, (name, o, worst)
+
+
+@pytest.mark.parametrize("case", ["configs4", "heavy", "extremes"])
+def test_event_process_exact_synthetic_models(case):
+    """The same for indel-heavy tables, ALL (state, slot) pairs: BASELINE configs[4]'s rates, ten times those (segments
+    restart on precision), and a table with tests that never / always fire, a certain deletion and stretches where
+    'nothing fires' is rarer than 2^-16."""
+    from helpers import dense_model
+    d = dense_model("novaseq")
+    if case == "configs4":
+        d.ins[:], d.dele[:], bound = 0.001, 0.003, 2.0 ** -52
+    elif case == "heavy":
+        rs = np.random.RandomState(3)
+        d.ins[:] = 0.01 * rs.random_sample(d.ins.shape)
+        d.dele[:] = 0.03 * rs.random_sample(d.dele.shape)
+        bound = 2.0 ** -47
+    else:
+        d = dense_model("hiseq")
+        rs = np.random.RandomState(11)
+        RL = d.read_length
+        d.ins[:] = rs.choice([0.0, 1e-4, 3e-3, 0.05], size=d.ins.shape, p=[0.4, 0.3, 0.2, 0.1])
+        d.dele[:] = rs.choice([0.0, 2e-4, 1e-2, 0.2], size=d.dele.shape, p=[0.3, 0.3, 0.3, 0.1])
+        d.ins[0, 7, 2] = 1.0
+        d.dele[0, 40, :] = [0.5, 1.0, 0.0, 0.25]
+        d.ins[0, 60:64, :] = 0.9
+        d.dele[1, 3, :] = float("nan")  # (a BAM-built model can hold NaN: `u < NaN` is False)
+        d.ins[1, 5, 1] = 5e-324         # the smallest positive double: fires for numerator 0 only
+        bound = 2.0 ** -47
+    for o in (0, 1):
+        n, worst = _event_process_exact(d, o, all_pairs=True)
+        assert worst <= bound, (case, o, worst)
