@@ -169,6 +169,8 @@ struct DevModel {
     const uint32_t *subst13;    // [n_tiles][2][TP][4]: t0_13 | t1_13 << 13 | (alt0 | alt1 << 2 | alt2 << 4) << 26: leading 13 bits of
                                 // subst_thr, alternatives as indices into alt_letters
     uint32_t alt_letters;       // the (<= 4) distinct letters of subst_alt
+    float exp_subs;             // expected substitutions per pair (sizes RunArgs::sub_list)
+    float p_read_event;         // probability that a read has an indel event (the larger of the two mates')
     const uint64_t *subst_thr;  // [2][RL][4][3]
     const uint8_t *subst_alt;   // [2][RL][4][3]
     const uint64_t *ins_thr;    // [2][RL][4]
@@ -254,6 +256,14 @@ struct RunArgs {
     // indel events (k_indel_scan -> k_indel_apply): per read a counter and EV_K event words (step << 8 | event mask); reads
     // (2 * pair + mate) with an event are listed once in read_list
     uint32_t *ev_count, *ev_list, *read_list, *read_count;
+    // substitutions k_main applied (models with indels only): {pair, position | mate << 15 | template letter << 16}, appended in
+    // chunks of SUB_CHUNK entries per wavefront (unused entries: pair == 0xffffffff); sub_count[0] = entries reserved,
+    // sub_count[1] != 0: the list overflowed (k_indel_apply then hands every listed read to k_indel_fixup)
+    uint2 *sub_list;
+    uint32_t *sub_count;
+    uint32_t sub_cap;
+    int32_t light;  // 1: reads with an indel are rare (DevModel::p_read_event): k_indel_scan hands every one of them to k_indel_fixup
+                    // (no substitution list, no k_indel_apply / k_indel_resub launches)
     uint16_t tile_wg0[MAX_TILES + 2];  // k_main: workgroups [tile_wg0[t], tile_wg0[t + 1]) work on position tile t
     MutRecord *mut;               // --store_mutations rows (NULL: off)
     uint32_t *mut_count;          // slots reserved so far
@@ -308,6 +318,31 @@ __device__ __forceinline__ void mut_emit(const RunArgs &A, MutChunk &c, bool hav
     if (!m) return;
     const uint32_t at = mut_alloc(A, c, (uint32_t)__popcll(m));
     if (have && at != 0xffffffffu) A.mut[at + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = r;
+}
+
+// The list of applied substitutions (RunArgs::sub_list): ALL 64 lanes of the wavefront call this; lanes with `have` append
+// their entry.  A chunk that cannot take a round's entries is closed (its unused entries marked) and a new one reserved.
+constexpr uint32_t SUB_CHUNK = 256;
+__device__ __forceinline__ void sub_close(const RunArgs &A, const MutChunk &c) {
+    if (c.base + SUB_CHUNK <= A.sub_cap)
+        for (uint32_t i = c.used + (threadIdx.x & 63u); i < SUB_CHUNK; i += 64u) A.sub_list[c.base + i] = make_uint2(0xffffffffu, 0u);
+}
+__device__ __forceinline__ void sub_emit(const RunArgs &A, MutChunk &c, bool have, uint32_t pair, uint32_t word) {
+    const unsigned long long m = __ballot(have);
+    if (!m) return;
+    const uint32_t n = (uint32_t)__popcll(m);
+    if (c.used + n > SUB_CHUNK) {
+        sub_close(A, c);
+        uint32_t b = 0;
+        if ((threadIdx.x & 63u) == 0u) b = atomicAdd(A.sub_count, SUB_CHUNK);
+        c.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        c.used = 0;
+        if (c.base + SUB_CHUNK > A.sub_cap && (threadIdx.x & 63u) == 0u) A.sub_count[1] = 1u;
+    }
+    const uint32_t at = c.base + c.used;
+    c.used += n;
+    if (have && c.base + SUB_CHUNK <= A.sub_cap)
+        A.sub_list[at + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = make_uint2(pair, word);
 }
 
 // one row from one lane (the groups of a k_indel_apply wavefront walk different reads: no wave-uniform chunk there)
@@ -692,16 +727,17 @@ struct MainTile {  // per-workgroup constants of k_main
 // stream takes microseconds: so the common case touches NO global memory except for the two byte stores -- the queue
 // entry carries the lane-item's two 8-base genome windows and the pair's bin slots, the thresholds sit in LDS.
 // (Records with IUPAC / lower-case letters, gc_bias and digit ties do load: descriptor, ASCII genome, full thresholds.)
-// Returns true and fills `rec` when the base was substituted by a different letter (a --store_mutations row).
+// Returns 0 (no substitution), 1 (substituted, by the letter it had) or 3 (by a different letter: a --store_mutations row);
+// `rec` is filled whenever a substitution was applied.
 template <bool PLAIN>
-__device__ __forceinline__ bool main_slow_base(const DevModel &M, const DevGenome &g, const RunArgs &A,
+__device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome &g, const RunArgs &A,
                                                const PairDesc *__restrict__ desc, const uint32_t *lds, const MainTile &T,
                                                uint32_t pair, uint32_t sl, int half, int s, uint32_t slots, uint32_t windows,
                                                MutRecord &rec) {
     const int o = s >> 2, cc = s & 3, c = half * 4 + cc;
     const uint32_t s_abs = (uint32_t)T.s0 + sl;
     const int p = (int)s_abs * 8 + c;
-    if (p >= M.RL) return false;
+    if (p >= M.RL) return 0;
     uint32_t attempt = 0;
     if (A.gc_bias) attempt = desc[pair].meta >> 16;  // (the only use of the attempt number)
     const Addr a = make_addr(A.seed, A.first_ordinal + pair, attempt);
@@ -722,19 +758,19 @@ __device__ __forceinline__ bool main_slow_base(const DevModel &M, const DevGenom
     // substitution test (__init__.py:94)
     const uint64_t thr = reinterpret_cast<const uint64_t *>(lds + M.tile_words)[q];
     const uint32_t t8 = (uint32_t)(thr >> 45);
-    if (e8 < t8) return false;
+    if (e8 < t8) return 0;
     const u32x4 sb = draw_block(a, K_SUB, (uint32_t)p, (uint32_t)o);
-    if (e8 == t8 && !(error_test_draw(e8, sb) > thr)) return false;
+    if (e8 == t8 && !(error_test_draw(e8, sb) > thr)) return 0;
     // the template base: forward window bit pair c; reverse window (already complemented) bit pair 7 - c
     const uint32_t code = o ? ((windows >> (16 + 2 * (7 - c))) & 3u) : ((windows >> (2 * c)) & 3u);
     int base = code_to_ascii(code), bi = (int)code;
     if (!PLAIN) {  // the letter may be IUPAC / lower case, the pair irregular (custom fragment lengths)
         const PairDesc d = desc[pair];
-        if (A.has_frag && (d.meta & 64u)) return false;  // irregular pair: the fix-up kernel builds its bases
+        if (A.has_frag && (d.meta & 64u)) return 0;  // irregular pair: the fix-up kernel builds its bases
         base = fetch_ascii(g, o ? (int64_t)d.re - 1 - p : (int64_t)d.fs + p);
         if (o) base = complement_ascii(base);
         bi = base_index(base);
-        if (bi < 0) return false;  // nucl.upper() in "RYWSMKHBVDN": left alone
+        if (bi < 0) return 0;  // nucl.upper() in "RYWSMKHBVDN": left alone
     }
     const uint64_t m = mk53(sb.x, sb.y);
     // leading 13 bits of the two thresholds + the three alternatives (two bits each; model_alt: their letters)
@@ -750,7 +786,7 @@ __device__ __forceinline__ bool main_slow_base(const DevModel &M, const DevGenom
     // without indels the original read equals the template, i.e. the base just replaced (__init__.py:98)
     rec.pair = (int32_t)(A.pair_base + pair); rec.mate = (int8_t)o; rec.type = 0; rec.position = (int16_t)p;
     rec.ref = (uint8_t)base; rec.alt = (uint8_t)nb; rec.quality = (int16_t)q;
-    return (int)nb != base;
+    return (int)nb != base ? 3 : 1;
 }
 
 // One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive entries -> select.
@@ -791,7 +827,8 @@ __device__ __forceinline__ uint32_t shift_in(uint32_t r, unsigned long long flag
 #ifndef ISS_MAIN_OCC
 #define ISS_MAIN_OCC 4   // wavefronts per SIMD the register budget is cut for: one 1024-lane workgroup per CU, 128 VGPRs (measured against 8 / 64: -12 % time)
 #endif
-template <bool STORE_MUT, bool PLAIN>
+// SUBLIST: the launch lists the substitutions it applies (RunArgs::sub_list: models whose reads often have indels).
+template <bool STORE_MUT, bool PLAIN, bool SUBLIST>
 __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -834,6 +871,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     for (int c = 0; c < 8; ++c) off_g[c] = sgpr((uint32_t)(c >> 2) * gs_b + (uint32_t)(c & 3) * stride_b);
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // the leading padding word: offsets >= 0
     MutChunk mchunk = {0u, MUT_CHUNK};  // --store_mutations: forces a reservation at first use
+    MutChunk schunk = {0xffffffffu - SUB_CHUNK, SUB_CHUNK};  // the list of applied substitutions, likewise
     const uint32_t wave_pair0 = (threadIdx.x >> 6) * 16u;
     // one round of the exact path: lane k takes ONE base of the k-th pending entry of this wavefront (n <= 64 of them);
     // an entry with more bases (noisy models: NextSeq, MiSeq) goes back into the ring, so every round runs full
@@ -842,6 +880,10 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         // (the byte patches below follow this wavefront's own stores of the same lines: vector memory instructions of
         //  one wavefront reach a given address in issue order, no wait is needed)
         uint2 rest = {0u, 0u};
+        int subst = 0;
+        uint32_t sub_pair = 0;
+        MutRecord rec;
+        rec.position = 0; rec.mate = 0; rec.ref = 0;
         if (lane < n) {
             const uint2 ent = ring[(q_head + lane) & (SLOW_RING - 1)];
             const uint32_t e_pass = ent.x >> (19u + it_bits), e_it = (ent.x >> 19) & ((1u << it_bits) - 1u), e_lane = (ent.x >> 13) & 63u;
@@ -849,11 +891,13 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
             const uint32_t mask = ent.x & 0xffu;  // never empty
             const int bit = 31 - __clz(mask);
             if (mask & (mask - 1u)) rest = make_uint2(ent.x & ~(1u << bit), ent.y);
-            MutRecord rec;
-            const bool have = main_slow_base<PLAIN>(M, g, A, desc, lds, T, e_pair, 4u * e_it + (e_lane & 3u), (int)((ent.x >> 12) & 1u),
+            subst = main_slow_base<PLAIN>(M, g, A, desc, lds, T, e_pair, 4u * e_it + (e_lane & 3u), (int)((ent.x >> 12) & 1u),
                                                     7 - bit, (ent.x >> 8) & 15u, ent.y, rec);
-            if (STORE_MUT) mut_emit(A, mchunk, have, rec);
+            if (STORE_MUT) mut_emit(A, mchunk, subst == 3, rec);
+            sub_pair = e_pair;
         }
+        // (models with indels: the reads k_indel_apply shifts have their substitutions re-applied from this list)
+        if (SUBLIST) sub_emit(A, schunk, subst != 0, sub_pair, (uint32_t)rec.position | ((uint32_t)rec.mate << 15) | ((uint32_t)rec.ref << 16));
         q_head += n;
         const unsigned long long again = __ballot(rest.x != 0u);
         if (again) {
@@ -993,6 +1037,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         }
     }
     while (q_tail != q_head) drain_round(min(64u, q_tail - q_head));
+    if (SUBLIST) sub_close(A, schunk);  // the rest of this wavefront's last chunk: unused
 }
 
 // ================================================================== k_indel_scan
@@ -1008,8 +1053,9 @@ constexpr int SCAN_LIST = 256;    // listed reads a wavefront collects before th
 constexpr int EV_K = 8;           // events kept per read
 constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
                                        // bits 4-5 mate is in read_list
+constexpr int SCAN_RANGE = 2048;  // reads of a wavefront's range whose event counts are staged in LDS (written out in whole lines)
 __host__ __device__ inline size_t scan_lds_bytes(int ev_ns) {
-    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 7) & ~(size_t)7) + (size_t)(SCAN_THREADS / 64) * SCAN_LIST * 4;
+    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 7) & ~(size_t)7) + (size_t)(SCAN_THREADS / 64) * (SCAN_LIST * 4 + SCAN_RANGE);
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
@@ -1019,6 +1065,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     uint16_t *l_E = reinterpret_cast<uint16_t *>(l_S + 2 * ns);       // [2][ns]
     uint32_t *l_list = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(scan_lds) + (size_t)2 * ns * 8 + (((size_t)2 * ns * 2 + 7) & ~(size_t)7)) +
                        (threadIdx.x >> 6) * SCAN_LIST;                // this wavefront's listed reads
+    uint8_t *l_cnt = reinterpret_cast<uint8_t *>(scan_lds) + (size_t)2 * ns * 8 + (((size_t)2 * ns * 2 + 7) & ~(size_t)7) +
+                     (size_t)(SCAN_THREADS / 64) * SCAN_LIST * 4 + (threadIdx.x >> 6) * SCAN_RANGE;  // this wavefront's event counts
     for (int i = threadIdx.x; i < 2 * ns; i += blockDim.x) { l_S[i] = M.ev_S[i]; l_E[i] = M.ev_E[i]; }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1032,412 +1080,451 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     };
     const uint32_t n_reads = 2u * (uint32_t)A.n_pairs;
     const uint32_t per_wg = ((n_reads + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;  // contiguous ranges
-    const uint32_t first = blockIdx.x * per_wg, last = min(n_reads, first + per_wg);
-    for (uint32_t rd0 = first; rd0 < last; rd0 += blockDim.x) {  // (uniform trip count in the workgroup)
-        const uint32_t rd = rd0 + threadIdx.x;
-        uint32_t cnt = 0;
-        // (the mates of irregular pairs -- custom fragment lengths -- are the fix-up kernel's already: k_setup)
-        if (rd < last && !(A.has_frag && ((A.flags[rd >> 1] >> (rd & 1u)) & 1u))) {
-            const uint32_t pair = rd >> 1;
-            const int o = (int)(rd & 1u);
-            // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
-            const Addr a = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
-            uint32_t *list = A.ev_list + (size_t)rd * EV_K;
-            indel_events(l_S + o * ns, l_E + o * ns, M.ev_T + (size_t)o * ns, M.del_thr + (size_t)o * M.RL * 4, ns, a, o,
-                         [&](int n, uint32_t mask) {
-                             if (cnt < (uint32_t)EV_K) list[cnt] = ((uint32_t)n << 8) | mask;
-                             ++cnt;
-                         });
-            if (cnt > (uint32_t)EV_K) {  // too many events for the list: the wavefront-per-read kernel takes the read
-                if (!(atomicOr(&A.flags[pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
-                cnt = 0;
+    const uint32_t per_wave = per_wg / (blockDim.x >> 6);
+    const uint32_t w_first = min(n_reads, blockIdx.x * per_wg + (threadIdx.x >> 6) * per_wave), w_last = min(n_reads, w_first + per_wave);
+    // A read needs one draw per event and per segment of the survival table -- one for most reads, half a dozen for the
+    // unluckiest of 64: the lanes of a wavefront therefore do not walk the range in lockstep.  Every iteration is ONE draw
+    // of every lane's current read; a lane whose read is finished takes the next read of the wavefront's range.
+    uint32_t next = w_first;  // wave-uniform
+    bool busy = false;
+    uint32_t rd = 0, cnt = 0, prev = 0, j = 0;
+    int cur = -1, o = 0;
+    Addr a = make_addr(A.seed, A.first_ordinal, 0u);
+    for (;;) {
+        const unsigned long long need = __ballot(!busy);
+        if (need && next < w_last) {
+            const uint32_t cand = next + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (!busy && cand < w_last) {
+                rd = cand; cnt = 0; prev = 0; j = 0; cur = -1; busy = true;
+                o = (int)(rd & 1u);
+                // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
+                a = make_addr(A.seed, A.first_ordinal + (rd >> 1), A.gc_bias ? desc[rd >> 1].meta >> 16 : 0u);
+                // (the mates of irregular pairs -- custom fragment lengths -- are the fix-up kernel's already: k_setup)
+                if (A.has_frag && ((A.flags[rd >> 1] >> (rd & 1u)) & 1u)) cur = ns;
+            }
+            next = min(w_last, next + (uint32_t)__popcll(need));
+        }
+        if (!__ballot(busy)) break;
+        bool fin = false;
+        if (busy) {
+            if (cur < ns - 1) {
+                const u32x4 w = draw_block(a, K_EV, j++, (uint32_t)o);
+                int slot;
+                uint32_t mask;
+                cur = ev_step(l_S + o * ns, l_E + o * ns, M.ev_T + (size_t)o * ns, M.del_thr + (size_t)o * M.RL * 4, cur, mk53(w.x, w.y), mk53(w.z, w.w), slot, mask);
+                if (slot >= 0) {  // (one list entry per step: a step's tests come one after the other)
+                    uint32_t *list = A.ev_list + (size_t)rd * EV_K;
+                    const int n = slot / 5;
+                    if (cnt && (int)(prev >> 8) == n) {
+                        prev |= mask;
+                        if (cnt <= (uint32_t)EV_K) list[cnt - 1] = prev;
+                    } else {
+                        prev = ((uint32_t)n << 8) | mask;
+                        if (cnt < (uint32_t)EV_K) list[cnt] = prev;
+                        ++cnt;
+                    }
+                }
+            }
+            if (cur >= ns - 1) {  // the read is done
+                if (cnt > (uint32_t)EV_K || (A.light && cnt)) {  // too many events for the list (or few such reads at all): the wavefront-per-read kernel takes the read
+                    if (!(atomicOr(&A.flags[rd >> 1], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
+                    cnt = 0;
+                }
+                // (every read's counter is written: nothing else initialises them -- staged, so that they leave in whole lines)
+                if (rd - w_first < (uint32_t)SCAN_RANGE) l_cnt[rd - w_first] = (uint8_t)cnt; else A.ev_count[rd] = cnt;
+                fin = true;
+                busy = false;
             }
         }
-        if (rd < last) A.ev_count[rd] = cnt;  // (every read: nothing else initialises the counters)
-        const unsigned long long m = __ballot(cnt != 0u);
+        const unsigned long long m = __ballot(fin && cnt != 0u);
         if (m) {
-            if (cnt) l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rd;
+            if (fin && cnt) l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rd;
             n_listed += (uint32_t)__popcll(m);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             if (n_listed >= (uint32_t)SCAN_LIST - 64u) flush_list();  // (room for the next 64)
         }
     }
     if (n_listed) flush_list();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (uint32_t i = lane; i < min(w_last - w_first, (uint32_t)SCAN_RANGE); i += 64u) A.ev_count[w_first + i] = l_cnt[i];
 }
 
 // ================================================================== k_indel_apply
-// GL lanes (8; 16 / 32 for read lengths beyond 184 / 376) per listed READ -- a mate with at least one event; the 64 / GL
-// groups of a wavefront take neighbouring list entries, whatever pairs and mates those are, so no lane idles on an
-// event-free mate and the per-read bookkeeping (requests, geometry, walk) is shared by eight reads.  introduce_indels
-// + adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
+// The reads k_indel_scan listed (a mate with at least one event), 64 per wavefront block.  introduce_indels +
+// adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
 // prefix [0, n) is final when step n starts; the not-yet-visited suffix is (stack of freshly inserted letters, LIFO)
-// ++ E(k), E(k+1), ...
-//   1. the read's events (in step order already), masks of one step merged
-//   2. (all lanes) the template E(0 .. pitch+7) into LDS, 8 bases per lane from the 2-bit genome; the error-test digits
-//      (one Philox block per 8 positions)
-//   3. the walk over the steps with an event (the reads of the wavefront side by side, one per group): the letters of
-//      those steps and of the steps that drain the insertion stack go to ovr[] (0 = no override), "from step n0 on,
-//      source index = k0 + (n - n0)" for everything in between is the change of (token - step) at n0, in dsh[]
-//   4. (all lanes, 8 positions each and pass) token -> base -> one 8-byte store; the positions whose substitution test
-//      fires or ties go to a ring of the wavefront and are settled 64 at a time (byte patches)
-// A pair is a chain of dependent loads (list entry -> descriptor, events, phreds -> genome windows) behind a write
-// stream, i.e. microseconds of latency: the list entry is requested two reads ahead, everything its address needs only
-// the read number for one read ahead, and the tables the walk and the substitutions read sit in LDS.
-constexpr int APPLY_WAVES = 8;    // wavefronts (64 / GL reads each) per workgroup
+// ++ E(k), E(k+1), ...  Round 3 design -- the kernel does only what an indel changes, the letters:
+//   * mut_sequence's error test of a position (__init__.py:94) depends on the position's phred and uniform, not on its
+//     letter.  k_main lists the substitutions it applies (RunArgs::sub_list); this kernel writes template letters only
+//     and k_indel_resub re-applies the listed substitutions of the rebuilt reads to the letters that stand there now.
+//     No digit is redrawn, no phred and no old letter is read here.
+//   * phase 1, ONE LANE PER READ: descriptor, events (registers), the read's window of the 2-bit genome into LDS, the
+//     walk over the steps with an event.  It leaves an edit script in LDS: runs (from step s on, token = step + shift),
+//     explicit letters (event steps, stack drains), a bitmap of the 8-position pieces that hold an explicit letter.
+//   * phase 2, FOUR LANES PER READ (the four 16-byte pieces of a 64-byte half line), 16 reads at a time: a piece
+//     without explicit letter lies inside one run -- its 8 letters are one funnel shift of the window, like in k_main;
+//     pieces in front of the first event are k_main's already and are skipped.  The ~2 pieces per read with an explicit
+//     letter go to a ring of the wavefront and are built 64 at a time (run merges + letter inserts).
+// Reads this cannot take -- records with IUPAC / lower-case letters, a window that leaves the record, more explicit
+// letters or stacked insertions than the script holds, read lengths beyond AP_MAX_PITCH, an overflowed substitution
+// list -- join the irregular pairs and the reads with more than EV_K events in k_indel_fixup's list (one wavefront per
+// read, exact, slow).
+constexpr int AP_WAVES = 16;            // wavefronts per workgroup at most (ONE workgroup per CU: the tables are staged once; fewer when
+                                        // the records of long reads need the LDS)
 #ifndef ISS_APPLY_OCC
-#define ISS_APPLY_OCC 4           // wavefronts per SIMD the register budget is cut for (measured: 3 -> 4: -20 % time)
+#define ISS_APPLY_OCC 4                 // wavefronts per SIMD the register budget is cut for
 #endif
-constexpr int APPLY_ITEMS = 512;  // batch calls: the table of up to this many work items is cached in LDS (beyond: global loads)
-constexpr int16_t FIX_NONE = 0x7fff;
+constexpr int AP_RUNS = EV_K + 1;       // runs of a read: the initial one + one per step with an event
+constexpr int AP_LETTERS = 12;          // explicit letters kept per read
+constexpr int AP_EVP = 8;               // pieces with an explicit letter kept per read (their 8 letters take the letters' place in the record)
+constexpr int AP_HDR = 5;               // header words of a read's record
+constexpr int AP_ITEMS = 128;           // batch calls: the table of up to this many work items is cached in LDS (beyond: global loads)
+constexpr int AP_MAX_PITCH = 384;       // longer reads: k_indel_fixup
+constexpr int AP_STACK = 8;             // inserted letters waiting to surface (a 64-bit register)
+constexpr int AP_CH = 5;                // passes whose pieces are requested together
 
-__host__ __device__ inline int apply_tl(int pitch) { return pitch + 8; }  // staged template positions: a read of <= EV_K events reaches <= EV_K past its end
-#ifndef ISS_APPLY_GL
-#define ISS_APPLY_GL 8
-#endif
-// lanes per read: three passes of 8 positions per lane at most (8 lanes up to read length 184, 16 up to 376)
-__host__ __device__ inline int apply_gl(int pitch) { return apply_tl(pitch) <= 24 * ISS_APPLY_GL ? ISS_APPLY_GL : (apply_tl(pitch) <= 24 * 16 ? 16 : 32); }
-__host__ __device__ inline size_t apply_read_bytes(int pitch) {
-    // per read: tmpl (tl) + dqm (pitch) + stk (4 * EV_K: a step inserts <= 4 letters) + dsh (pitch) + ovr (pitch)
-    //           + events (4 * EV_K)
-    return (size_t)apply_tl(pitch) + 2 * (size_t)pitch + 4 * EV_K + (size_t)pitch + 4 * EV_K;
+__host__ __device__ inline int ap_pitch(int pitch) { return pitch < AP_MAX_PITCH ? pitch : AP_MAX_PITCH; }
+__host__ __device__ inline int ap_win(int pitch) { return ap_pitch(pitch) + 8; }  // template positions a read of <= EV_K events reaches
+__host__ __device__ inline int ap_ww(int pitch) { return (ap_win(pitch) + 15) / 16 + 1; }  // window words (16 bases each)
+__host__ __device__ inline int ap_rec_words(int pitch) { return (AP_HDR + ap_ww(pitch) + AP_RUNS + 2 * AP_EVP) | 1; }  // odd: no bank conflicts between lanes
+__host__ __device__ inline size_t ap_items_bytes() { return (AP_ITEMS + 2) * 4 + AP_ITEMS * sizeof(BatchItem); }
+// [ins_letter 2*RL*4 u8, padded][item_first AP_ITEMS+2 u32][items AP_ITEMS][per wave: 64 records]
+__host__ __device__ inline size_t ap_tab_bytes(int RL) { return (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + ap_items_bytes(); }
+__host__ __device__ inline size_t ap_wave_bytes(int pitch) { return (size_t)64 * ap_rec_words(pitch) * 4; }
+__host__ __device__ inline int apply_waves(int RL, int pitch) {
+    const size_t room = (size_t)160 * 1024 - 512 - ap_tab_bytes(RL);
+    const int w = (int)(room / ap_wave_bytes(pitch));
+    return w < 1 ? 1 : (w > AP_WAVES ? AP_WAVES : w);
 }
-constexpr int APPLY_RING = 128;   // substitution candidates a wavefront can hold (a private ring: 63 pending + 64 new at most)
-__host__ __device__ inline size_t apply_wave_bytes(int pitch, int GL) { return (size_t)(64 / GL) * apply_read_bytes(pitch) + APPLY_RING * 12; }
-// [mut8 64 u32][subst13 2*RL*4 u32][ins_letter 2*RL*4 u8, padded][item_first APPLY_ITEMS+2 u32][items APPLY_ITEMS][per wave]
-__host__ __device__ inline size_t apply_items_bytes() { return (APPLY_ITEMS + 2) * 4 + APPLY_ITEMS * sizeof(BatchItem); }
-__host__ __device__ inline size_t apply_tab_bytes(int RL) {
-    return 256 + (size_t)2 * RL * 4 * 4 + (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + apply_items_bytes();
-}
-__host__ __device__ inline size_t apply_lds_bytes(int RL, int pitch, int GL) { return apply_tab_bytes(RL) + APPLY_WAVES * apply_wave_bytes(pitch, GL); }
+__host__ __device__ inline size_t apply_lds_bytes(int RL, int pitch) { return ap_tab_bytes(RL) + (size_t)apply_waves(RL, pitch) * ap_wave_bytes(pitch); }
 
-template <bool STORE_MUT, int GL>
-__global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply(DevModel M, DevGenome g, RunArgs A,
-                                                                  const PairDesc *__restrict__ desc, uint64_t *stats) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t apply_lds[];
-    constexpr int NG = 64 / GL;           // reads per wavefront
-    constexpr int NP = GL == 32 ? 1 : 3;  // passes (8 positions per lane each) whose genome window and phreds are requested ahead
-    const int RL = M.RL, pitch = M.pitch, TL = apply_tl(pitch);
-    uint32_t *mut8 = reinterpret_cast<uint32_t *>(apply_lds);  // [64] leading 8 bits of the substitution-test thresholds
-    uint32_t *sub13 = mut8 + 64;                                // [2][RL][4] (see DevModel::subst13, position-major here)
-    uint8_t *insl = reinterpret_cast<uint8_t *>(sub13 + 2 * RL * 4);  // [2][RL][4]
-    uint32_t *ifirst = reinterpret_cast<uint32_t *>(apply_lds + apply_tab_bytes(RL) - apply_items_bytes());  // (a call holds < 2^31 pairs)
-    BatchItem *l_items = reinterpret_cast<BatchItem *>(ifirst + APPLY_ITEMS + 2);
+template <bool STORE_MUT>
+__global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(DevModel M, DevGenome g, RunArgs A,
+                                                                              const PairDesc *__restrict__ desc, uint64_t *stats) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t ap_lds[];
+    const int RL = M.RL, pitch = M.pitch, S = M.S, WW = ap_ww(pitch), RW = ap_rec_words(pitch), WIN = ap_win(pitch);
+    uint8_t *insl = reinterpret_cast<uint8_t *>(ap_lds);                  // [2][RL][4]
+    uint32_t *ifirst = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ap_lds) + ap_tab_bytes(RL) - ap_items_bytes());  // (a call holds < 2^31 pairs)
+    BatchItem *l_items = reinterpret_cast<BatchItem *>(ifirst + AP_ITEMS + 2);
     const uint32_t n_list = *A.read_count;
-    if (blockIdx.x * APPLY_WAVES * NG >= n_list) return;  // whole workgroup idle (uniform)
-    for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut8[i] = (uint32_t)(M.mut_thr[i] >> 45);
-    for (int i = threadIdx.x; i < 2 * RL * 4; i += blockDim.x) {
-        const int o = i / (RL * 4), r = i - o * RL * 4, p = r >> 2, bi = r & 3;
-        const int tl = p / M.TP, pp = p - tl * M.TP;
-        sub13[i] = M.subst13[(size_t)tl * 2 * M.TP * 4 + ((size_t)(o * M.TP + pp) * 4 + bi)];
-        insl[i] = M.ins_letter[i];
-    }
-    const bool items_cached = A.items && A.n_items <= APPLY_ITEMS;
+    const uint32_t n_blocks = (n_list + 63u) / 64u;
+    const uint32_t n_waves = blockDim.x >> 6;
+    if (blockIdx.x * n_waves >= n_blocks) return;  // whole workgroup idle (uniform)
+    for (int i = threadIdx.x; i < 2 * RL * 4; i += blockDim.x) insl[i] = M.ins_letter[i];
+    const bool items_cached = A.items && A.n_items <= AP_ITEMS;
     if (items_cached) {
         for (int i = threadIdx.x; i <= A.n_items; i += blockDim.x) ifirst[i] = (uint32_t)A.item_first[i];
         for (int i = threadIdx.x; i < A.n_items; i += blockDim.x) l_items[i] = A.items[i];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int rg = lane / GL, rl = lane % GL;  // group (read) of the wavefront, lane within the group
-    uint8_t *wave0 = apply_lds + apply_tab_bytes(RL) + (size_t)wv * apply_wave_bytes(pitch, GL);
-    uint8_t *wbase = wave0 + (size_t)rg * apply_read_bytes(pitch);
-    // substitution candidates (the test fires or ties, __init__.py:94: ~0.7 % of the positions): deferred to a private ring
-    // of the wavefront and settled 64 at a time, one lane each -- a loop in place would run whenever ONE of the wave's
-    // 512 positions is a candidate, i.e. always, for a lane or two of work.  Entry: {pair, attempt << 16 | mate << 15 |
-    // "past the template" << 14 | position, original letter << 24 | base << 16 | phred << 8 | error-test digit}
-    uint32_t *cring = reinterpret_cast<uint32_t *>(wave0 + (size_t)NG * apply_read_bytes(pitch));
-    uint32_t c_head = 0, c_tail = 0;  // wave-uniform
-    auto settle_candidates = [&](uint32_t n) {  // the first n <= 64 pending candidates, one per lane
-        if ((uint32_t)lane < n) {
-            const uint32_t *e = cring + ((c_head + (uint32_t)lane) & (APPLY_RING - 1)) * 3;
-            const uint32_t c_pair = e[0], w1 = e[1], w2 = e[2];
-            const int c_o = (int)((w1 >> 15) & 1u), j = (int)(w1 & 0x3fffu);
-            const uint32_t e8 = w2 & 0xffu;
-            const int q = (int)((w2 >> 8) & 0xffu), before = (int)((w2 >> 16) & 0xffu);
-            const uint32_t t8 = mut8[q];
-            const Addr ca = make_addr(A.seed, A.first_ordinal + c_pair, w1 >> 16);
-            const u32x4 sb = draw_block(ca, K_SUB, (uint32_t)j, (uint32_t)c_o);
-            bool err = e8 > t8;
-            if (e8 == t8) err = error_test_draw(e8, sb) > M.mut_thr[q];
-            const int bi = base_index(before);
-            if (err && bi >= 0) {  // (else nucl.upper() in "RYWSMKHBVDN": left alone)
-                const uint64_t m = mk53(sb.x, sb.y);
-                const uint32_t sd = sub13[((uint32_t)(c_o * RL + j)) * 4u + (uint32_t)bi];
-                const uint32_t hs = (uint32_t)(m >> 40), t0 = sd & 0x1fffu, t1 = (sd >> 13) & 0x1fffu;
-                int kk = (hs > t0) + (hs > t1);
-                if (hs == t0 || hs == t1) {  // tie of a leading digit: exact thresholds
-                    const size_t srow = ((size_t)(c_o * RL + j) * 4 + bi) * 3;
-                    kk = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
-                }
-                const int base = (int)((M.alt_letters >> (8 * ((sd >> (26 + 2 * kk)) & 3u))) & 0xffu);
-                // (a byte patch after this wavefront's own 8-byte store of the piece: stores of one wavefront reach an
-                //  address in order)
-                A.out[0][(size_t)c_pair * M.row + row_array_off(2 * c_o) + xp(j)] = (uint8_t)base;
-                if (STORE_MUT) {  // only if the new letter differs from the ORIGINAL read at this index (__init__.py:98)
-                    MutRecord sub;
-                    sub.pair = (int32_t)(A.pair_base + c_pair); sub.mate = (int8_t)c_o; sub.type = (int8_t)32; sub.position = (int16_t)j;
-                    sub.ref = (uint8_t)before; sub.alt = (uint8_t)base; sub.quality = (int16_t)q;
-                    // (a read position past a template the genome end cut short has no "original" letter: the
-                    //  reference raises IndexError there; the row is kept)
-                    if (((w1 >> 14) & 1u) || base != (int)(w2 >> 24)) mut_emit1(A, sub);
-                }
-            }
-        }
-        c_head += n;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t *wave0 = ap_lds + ap_tab_bytes(RL) / 4 + (size_t)wv * (ap_wave_bytes(pitch) / 4);
+    // (then every listed read is k_indel_fixup's: the substitutions of a shifted read cannot be re-applied without their list)
+    const bool all_to_fixup = pitch > AP_MAX_PITCH || !A.sub_list || A.sub_count[1] != 0u;
+    const int n_pass = (S + 3) >> 2;
+    auto rank_of = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    // the 8 template letters of tokens t .. t + 7 in read direction, from a read's window (branch-free in the mate)
+    auto decode8 = [&](const uint32_t *win, int t0pos, int o, int t) {
+        const int b = 2 * (o ? t0pos - t - 7 : t0pos + t);
+        uint32_t w16 = funnel_r(win[b >> 5], win[(b >> 5) + 1], (uint32_t)b) ^ (o ? 0x5555u : 0u);  // complement: code ^ 1
+        const uint32_t lo = codes_to_ascii4(w16 & 0xffu), hi = codes_to_ascii4((w16 >> 8) & 0xffu);
+        const uint32_t sel = o ? 0x00010203u : 0x03020100u;  // reverse mate: read position c <-> window position 7 - c
+        return make_uint2(__builtin_amdgcn_perm(0u, o ? hi : lo, sel), __builtin_amdgcn_perm(0u, o ? lo : hi, sel));
     };
-    uint8_t *tmpl = wbase;                                  // [TL]
-    uint8_t *dqm = tmpl + TL;                               // [pitch] error-test digit (8 bits) of position j
-    uint8_t *stk = dqm + pitch;                             // [4 * EV_K] insertion stack (never full: <= 4 * EV_K pushes)
-    int8_t *dsh = reinterpret_cast<int8_t *>(stk + 4 * EV_K);   // [pitch] change of (token - step) at the steps where a new run starts
-    uint8_t *ovr = reinterpret_cast<uint8_t *>(dsh + pitch);  // [pitch] letters of the steps with an explicit token (steps with an event, stack drains); 0 = none
-    uint32_t *ev_srt = reinterpret_cast<uint32_t *>(ovr + pitch);  // [EV_K] the read's events, in step order
-    const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);
-    uint64_t n_reads = 0;
-    const uint32_t stride = gridDim.x * APPLY_WAVES * NG;
-    const uint32_t li0 = (blockIdx.x * APPLY_WAVES + wv) * NG;  // the wavefront's first list entries (one per group)
-    // software pipeline: the list entry two reads ahead, what hangs on the read number one read ahead.  (A group past the end
-    // of the list repeats the last entry with no events.)
-    const uint32_t NO_READ = 0xffffffffu;
-    uint32_t rd_a = li0 + rg < n_list ? A.read_list[li0 + rg] : NO_READ;                      // read of iteration `li`
-    uint32_t rd_b = li0 + stride + rg < n_list ? A.read_list[li0 + stride + rg] : NO_READ;   // ... of `li + stride`
+    const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // (the leading padding word: offsets >= 0)
+    uint32_t n_rebuilt = 0;
+    // software pipeline of the block loop: the list entry is requested two blocks ahead, what hangs on the read number
+    // (descriptor, flags, events) one block ahead -- a chain of dependent loads behind the chip's write stream
+    const uint32_t NO_READ = 0xffffffffu, stride = gridDim.x * n_waves;
+    const uint32_t blk0 = blockIdx.x * n_waves + wv;
+    auto list_entry = [&](uint32_t b) { return b < n_blocks && b * 64u + lane < n_list ? A.read_list[b * 64u + lane] : NO_READ; };
+    uint32_t rd_a = list_entry(blk0), rd_b = list_entry(blk0 + stride);
     uint32_t ra = rd_a == NO_READ ? 0u : rd_a;
     PairDesc d_a = desc[ra >> 1];
     uint32_t fl_a = A.flags[ra >> 1], cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
-    uint32_t evw_a = rl < EV_K ? A.ev_list[(size_t)ra * EV_K + rl] : 0u;
-    // (the read's phreds hang on the read number only: requested with the rest; rows are padded to `pitch`)
-    auto phreds_of = [&](uint32_t r, int pass) {
-        return *reinterpret_cast<const uint2 *>(A.out[0] + (size_t)(r >> 1) * M.row +
-                                                (row_array_off(2 * (int)(r & 1u) + 1) + xp(min((rl + pass * GL) * 8, pitch - 8))));
-    };
-    uint2 q8_a0 = phreds_of(ra, 0);
-    int item_k = 0;  // the work item of the half's previous read: the list is in pair order, more or less
-    for (uint32_t li = li0; li < n_list; li += stride) {
-        const uint32_t pair = ra >> 1;
-        const int o = (int)(ra & 1u);  // mate
-        PairDesc d = d_a;
-        const uint32_t fl = fl_a, cnt_raw = cnt_a, evw = evw_a;
-        const uint2 q8_0 = q8_a0;
-        const uint32_t ra_now = ra;
-        {   // requests for the next two iterations
-            rd_a = rd_b;
-            if (rd_a != NO_READ) ra = rd_a;
-            d_a = desc[ra >> 1];
-            q8_a0 = phreds_of(ra, 0);
-            fl_a = A.flags[ra >> 1];
-            cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
-            evw_a = rl < EV_K ? A.ev_list[(size_t)ra * EV_K + rl] : 0u;
-            rd_b = li + 2 * stride + rg < n_list ? A.read_list[li + 2 * stride + rg] : NO_READ;
-        }
-        DevGenome gl = g;  // the record of the pair: the launch's genome, or its slice of the arena (batch calls)
-        int64_t arena_off = 0;
-        if (A.items) {
-            BatchItem it;
-            if (items_cached) {
-                const uint32_t p = (uint32_t)(A.pair_base + pair);
-                if (!(ifirst[item_k] <= p && p < ifirst[item_k + 1])) {
+    uint4 ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0], eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
+    for (uint32_t blk = blk0; blk < n_blocks; blk += stride) {
+        // ================ phase 1: one lane per read
+        {
+            const uint32_t rd = ra;
+            const uint32_t pair = rd >> 1;
+            const int o = (int)(rd & 1u);
+            const PairDesc d = d_a;
+            const uint32_t fl = fl_a, cnt = cnt_a;
+            uint32_t e[EV_K];
+            e[0] = ea_a.x; e[1] = ea_a.y; e[2] = ea_a.z; e[3] = ea_a.w; e[4] = eb_a.x; e[5] = eb_a.y; e[6] = eb_a.z; e[7] = eb_a.w;
+            {   // requests for the next two blocks
+                rd_a = rd_b;
+                ra = rd_a == NO_READ ? 0u : rd_a;
+                d_a = desc[ra >> 1];
+                fl_a = A.flags[ra >> 1];
+                cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
+                ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
+                eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
+                rd_b = list_entry(blk + 2u * stride);
+            }
+            bool ok = cnt > 0u && cnt <= (uint32_t)EV_K && !((fl >> o) & 1u);  // (else: no event, or the mate is k_indel_fixup's already)
+            // the record of the pair: the launch's genome, or its slice of the arena (batch calls); descriptors hold arena coordinates
+            int64_t rec_lo = 0, rec_hi = g.L;
+            bool plain = !g.has_exceptions;
+            if (A.items) {
+                BatchItem it;
+                if (items_cached) {
+                    const uint32_t p = (uint32_t)(A.pair_base + pair);
                     int lo = 0, hi = A.n_items;  // largest k with item_first[k] <= p
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ifirst[mid] <= p) lo = mid; else hi = mid; }
-                    item_k = lo;
+                    it = l_items[lo];
+                } else {
+                    it = A.items[batch_item_of(A, A.pair_base + pair)];
                 }
-                it = l_items[item_k];
-            } else {
-                it = A.items[batch_item_of(A, A.pair_base + pair)];
+                rec_lo = it.off; rec_hi = it.off + it.L; plain = !it.has_exceptions;
             }
-            gl = batch_genome(g, it);
-            arena_off = it.off;
-            d.fs -= (int32_t)it.off;
-            d.re -= (int32_t)it.off;
-        }
-        const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
-        uint32_t cnt = min(cnt_raw, (uint32_t)EV_K);
-        if ((fl >> o) & 1u) cnt = 0;  // this mate is k_indel_fixup's (too many events / irregular pair)
-        const MateGeom geo = mate_geom(o, d, RL, gl.L);
-        uint8_t *out_base = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
-        const uint8_t *out_qual = out_base + (row_array_off(1) - row_array_off(0));
-        // ---- requests of this read: its genome windows (used after the event sort and the Philox blocks)
-        uint2 gw0 = {0u, 0u}, gw1 = {0u, 0u}, gw2 = {0u, 0u};
-        const uint2 q8_1 = NP > 1 && cnt ? phreds_of(ra_now, 1) : make_uint2(0u, 0u);
-        const uint2 q8_2 = NP > 2 && cnt ? phreds_of(ra_now, 2) : make_uint2(0u, 0u);
-        uint32_t fast = 0;  // bit p: the lane's 8 template positions of pass p come from its window
+            // window: tokens 0 .. WIN - 1 = genome positions fs .. fs + WIN - 1 (forward) / re - 1 down to re - WIN (reverse)
+            const int64_t w_lo = o ? (int64_t)d.re - WIN : (int64_t)d.fs;
+            const bool simple = plain && !all_to_fixup && w_lo >= rec_lo && w_lo + WIN <= rec_hi;
+            auto to_fixup = [&]() {
+                if (!(atomicOr(&A.flags[pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
+            };
+            if (ok && !simple) { to_fixup(); ok = false; }
+            uint32_t *R = wave0 + lane * RW, *win = R + AP_HDR, *runs = win + WW, *let = runs + AP_RUNS;
+            const int64_t wpos = (w_lo >> 4) << 4;  // genome position of bit 0 of the window
+            const int t0pos = (int)((o ? (int64_t)d.re - 1 : (int64_t)d.fs) - wpos);  // window position of token 0 (token t: t0pos +/- t)
+            if (ok) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(((wpos >> 4) + 1) << 2));
+                for (int k = 0; k < WW; ++k) win[k] = src[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // the walk over the steps with an event (k_indel_scan lists them in step order, one entry per step)
+            auto letter_at = [&](int tk) {
+                const int b = 2 * (o ? t0pos - tk : t0pos + tk);
+                const uint32_t c = (win[b >> 5] >> (b & 31)) & 3u;
+                return (int)code_to_ascii(o ? c ^ 1u : c);
+            };
+            uint64_t evmask = 0;  // pieces with an explicit letter
+            uint32_t n_runs = 1, n_let = 0;
+            bool bad = false;
+            const int first_step = (int)(e[0] >> 8);
+            // (--store_mutations: a dry walk first -- a read whose script overflows goes to k_indel_fixup, which writes ALL of its
+            //  rows: none may come from here)
+            auto walk = [&](bool emit_rows) {
+                uint32_t ev[EV_K];
 #pragma unroll
-        for (int pass = 0; pass < NP; ++pass) {
-            // E(k) = g[fs + k] / comp(g[re - 1 - k]) for template and padding alike as long as the position is inside the
-            // record (regular geometry: the mates of irregular pairs are k_indel_fixup's)
-            const int k0 = (rl + pass * GL) * 8;
-            const int64_t g0 = o == 0 ? geo.lo + k0 : geo.hi - 8 - k0;  // lowest genome position of the lane's 8 bases
-            const bool f = cnt && k0 < TL && geo.t_len == RL && g0 >= 0 && g0 + 8 <= gl.L && !gl.has_exceptions;
-            uint2 w = {0u, 0u};
-            if (f) w = *reinterpret_cast<const uint2 *>(packed_b + (size_t)((((g0 + arena_off) >> 4) + 1) << 2));
-            if (pass == 0) gw0 = w; else if (pass == 1) gw1 = w; else gw2 = w;
-            fast |= (f ? 1u : 0u) << pass;
-        }
-        // ---- 1. events (k_indel_scan lists them in step order)
-        if (rl < EV_K) ev_srt[rl] = evw;
-        for (int j = rl * 8; j < pitch; j += GL * 8) {
-            *reinterpret_cast<uint2 *>(ovr + j) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2 *>(dsh + j) = make_uint2(0u, 0u);
-        }
-        for (int b = rl; cnt && b * 8 < pitch; b += GL) {  // one Philox block holds the digits of 8 positions (of both mates)
-            const u32x4 w = draw_block(a, K_QM, (uint32_t)b, 1);
-            *reinterpret_cast<uint2 *>(dqm + b * 8) = o == 0 ? make_uint2(w.x, w.z) : make_uint2(w.y, w.w);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n_act = cnt;
-        // ---- 2. templates: 8 read-direction positions per lane
-        for (int b = rl, pass = 0; cnt && b * 8 < TL; b += GL, ++pass) {
-            const int k0 = b * 8;
-            if (pass < NP && ((fast >> pass) & 1u)) {  // the 8 positions are template bases inside the record, plain A/C/G/T: from the window
-                const int64_t ga = (o == 0 ? geo.lo + k0 : geo.hi - 8 - k0) + arena_off;
-                const uint2 gw = pass == 0 ? gw0 : (pass == 1 ? gw1 : gw2);
-                uint32_t w16 = funnel_r(gw.x, gw.y, (uint32_t)(ga & 15) * 2);
-                uint2 v;
-                if (o == 0) {
-                    v = make_uint2(codes_to_ascii4(w16 & 0xffu), codes_to_ascii4((w16 >> 8) & 0xffu));
-                } else {  // read position k0 + c <-> genome position g0 + 7 - c, complemented
-                    w16 ^= 0x5555u;
-                    v = make_uint2(__builtin_amdgcn_perm(0u, codes_to_ascii4((w16 >> 8) & 0xffu), 0x00010203u),
-                                   __builtin_amdgcn_perm(0u, codes_to_ascii4(w16 & 0xffu), 0x00010203u));
-                }
-                *reinterpret_cast<uint2 *>(tmpl + k0) = v;
-            } else {
-                for (int c = 0; c < 8; ++c) tmpl[k0 + c] = (uint8_t)geom_base(gl, o, geo, k0 + c);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- 3. the walk: every lane of a group runs the same walk (group-uniform values); lane 0 of the group does the LDS writes
-        MutRecord row;  // --store_mutations row being built
-        row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
-        int sp = 0, k = 0, last = -1, cur_shift = 0;  // `last`: last step whose letter / run is settled
-        for (uint32_t ei = 0; ei < (uint32_t)EV_K; ++ei) {
-            if (ei >= n_act) break;
-            const uint32_t evs = ev_srt[ei];
-            const int n = (int)(evs >> 8);
-            uint32_t m8 = evs & 0xffu;
-            while (ei + 1 < n_act && (int)(ev_srt[ei + 1] >> 8) == n) m8 |= ev_srt[++ei] & 0xffu;  // the step's other digits
-            const int next_n = ei + 1 < n_act ? (int)(ev_srt[ei + 1] >> 8) : RL;
-            k += n - (last + 1);  // the settled record covers steps last+1 .. n-1 from the source
-            int tok = sp > 0 ? -(int)stk[--sp] : k++;
-            if (tok < geo.t_len) {  // tok >= len(template): n >= len(seq), IndexError swallowed (:223): emitted unvisited
-                const int ch = tok < 0 ? -tok : (int)tmpl[tok];
-                const int bi = base_index(ch);
-                if (bi >= 0) {  // else ambiguous: skipped (:190-192)
-                    for (int x = 0; x < 4; ++x)
-                        if ((m8 >> x) & 1u) {
-                            const int letter = insl[((size_t)o * RL + n) * 4 + x];
-                            if (rl == 0) stk[sp] = (uint8_t)letter;
-                            ++sp;
-                            if (STORE_MUT) {  // ref = mutable_seq[position], alt = ref + letter (__init__.py:197-207)
-                                row.type = (int8_t)(1 | (x << 2) | 32); row.position = (int16_t)n;
-                                row.ref = (uint8_t)ch; row.alt = (uint8_t)letter;
-                                if (rl == 0) mut_emit1(A, row);
+                for (int z = 0; z < EV_K; ++z) ev[z] = e[z];
+                uint64_t stk = 0;  // inserted letters waiting to surface (LIFO, a byte each)
+                int sp = 0, k = 0, last = -1;
+                evmask = 0; n_runs = 1; n_let = 0; bad = false;
+                if (ok) runs[0] = 0u;
+                MutRecord row;  // --store_mutations row being built
+                row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
+                auto put_letter = [&](int pos, int ch) {
+                    if (n_let < (uint32_t)AP_LETTERS) let[n_let] = ((uint32_t)pos << 8) | (uint32_t)ch; else bad = true;
+                    ++n_let;
+                    evmask |= (uint64_t)1 << (pos >> 3);
+                };
+                for (uint32_t left = ok ? cnt : 0u; left > 0u; --left) {
+                    const int n = (int)(ev[0] >> 8);
+                    const uint32_t m8 = ev[0] & 0xffu;
+#pragma unroll
+                    for (int z = 0; z + 1 < EV_K; ++z) ev[z] = ev[z + 1];
+                    const int next_n = left > 1u ? (int)(ev[0] >> 8) : RL;
+                    k += n - (last + 1);  // the settled run covers steps last+1 .. n-1 from the template
+                    int ch;
+                    bool visit;  // tok < len(template): else n >= len(seq), IndexError swallowed (:223): emitted unvisited
+                    if (sp > 0) { ch = (int)(stk & 0xffu); stk >>= 8; --sp; visit = true; }
+                    else { visit = k < RL; ch = letter_at(k); ++k; }
+                    if (visit) {
+                        const int bi = base_index(ch);
+                        if (bi >= 0) {  // else ambiguous: skipped (:190-192)
+                            for (int x = 0; x < 4; ++x)
+                                if ((m8 >> x) & 1u) {
+                                    const int letter = insl[((size_t)o * RL + n) * 4 + x];
+                                    if (sp < AP_STACK) stk = (stk << 8) | (uint64_t)letter; else bad = true;
+                                    ++sp;
+                                    if (STORE_MUT && emit_rows) {  // ref = mutable_seq[position], alt = ref + letter (__init__.py:197-207)
+                                        row.type = (int8_t)(1 | (x << 2) | 32); row.position = (int16_t)n;
+                                        row.ref = (uint8_t)ch; row.alt = (uint8_t)letter;
+                                        mut_emit1(A, row);
+                                    }
+                                }
+                            if (bad) break;
+                            if ((m8 >> (4 + bi)) & 1u) {  // deleted: the next token slides in
+                                const bool exists = sp > 0 || k < RL;  // else mutable_seq[position] raises IndexError: no row
+                                if (sp > 0) { ch = (int)(stk & 0xffu); stk >>= 8; --sp; }
+                                else { ch = letter_at(k); ++k; }
+                                if (STORE_MUT && emit_rows && exists) {  // ref = mutable_seq[position] after the pop (__init__.py:211-221)
+                                    row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
+                                    row.ref = (uint8_t)ch; row.alt = '.';
+                                    mut_emit1(A, row);
+                                }
                             }
                         }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if ((m8 >> (4 + bi)) & 1u) {  // deleted: next token slides in
-                        const bool exists = sp > 0 || k < geo.t_len;  // else mutable_seq[position] raises IndexError: no row
-                        tok = sp > 0 ? -(int)stk[--sp] : k++;
-                        if (STORE_MUT && exists) {  // ref = mutable_seq[position] after the pop (__init__.py:211-221)
-                            row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
-                            row.ref = (uint8_t)(tok < 0 ? -tok : (int)tmpl[min(tok, TL - 1)]);
-                            row.alt = '.';
-                            if (rl == 0) mut_emit1(A, row);
+                    }
+                    put_letter(n, ch);
+                    last = n;
+                    // steps after n drain the insertion stack until it is empty or the next step with an event
+                    while (sp > 0 && last + 1 < RL && last + 1 != next_n) {
+                        ++last;
+                        put_letter(last, (int)(stk & 0xffu));
+                        stk >>= 8; --sp;
+                    }
+                    // from step last + 1 on: token = step + (k - (last + 1)) until the next step with an event
+                    if (last + 1 < pitch) { runs[n_runs] = (uint32_t)(last + 1) | ((uint32_t)(k - (last + 1)) << 16); ++n_runs; }
+                }
+            };
+            if (STORE_MUT) { walk(false); if (ok && (bad || __popcll(evmask) > AP_EVP)) { to_fixup(); ok = false; } }
+            walk(true);
+            if (ok && __popcll(evmask) > AP_EVP) bad = true;
+            if (ok && bad) { to_fixup(); ok = false; }
+            // the pieces with an explicit letter, built here by the read's own lane (the run the piece starts in, the runs that
+            // start inside it merged from their first position on, the explicit letters) and left in the record in the
+            // letters' place: in phase 2 the four lanes of a read then store WHOLE 64-byte sectors together
+            {
+                uint2 evp[AP_EVP];
+                uint64_t todo = ok ? evmask : 0;
+#pragma unroll
+                for (int i = 0; i < AP_EVP; ++i) {
+                    evp[i] = make_uint2(0u, 0u);
+                    if (!__ballot(todo != 0)) continue;  // (uniform)
+                    if (todo) {
+                        const int j0 = 8 * (__ffsll((unsigned long long)todo) - 1);
+                        todo &= todo - 1;
+                        int k0 = 0;
+                        while (k0 + 1 < (int)n_runs && (int)(runs[k0 + 1] & 0xffffu) <= j0) ++k0;
+                        uint2 nw = decode8(win, t0pos, o, j0 + ((int)runs[k0] >> 16));
+                        for (int k = k0 + 1; k < (int)n_runs && (int)(runs[k] & 0xffffu) < j0 + 8; ++k) {
+                            const int c = (int)(runs[k] & 0xffffu) - j0;
+                            const uint2 v = decode8(win, t0pos, o, j0 + ((int)runs[k] >> 16));
+                            const uint32_t mx = c < 4 ? 0xffffffffu << (8 * c) : 0u, my = c < 4 ? 0xffffffffu : 0xffffffffu << (8 * (c - 4));
+                            nw.x = (v.x & mx) | (nw.x & ~mx);
+                            nw.y = (v.y & my) | (nw.y & ~my);
                         }
+                        for (uint32_t z = 0; z < n_let; ++z) {
+                            const int c = (int)(let[z] >> 8) - j0;
+                            if (c >= 0 && c < 8) {
+                                const uint32_t sh8 = 8u * (uint32_t)(c & 3), ins = (let[z] & 0xffu) << sh8, keep = ~(0xffu << sh8);
+                                if (c < 4) nw.x = (nw.x & keep) | ins; else nw.y = (nw.y & keep) | ins;
+                            }
+                        }
+                        evp[i] = nw;
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the letters are read above, their place is written below)
+#pragma unroll
+                for (int i = 0; i < AP_EVP; ++i) { let[2 * i] = evp[i].x; let[2 * i + 1] = evp[i].y; }
             }
-            if (rl == 0) ovr[n] = (uint8_t)(tok < 0 ? -tok : (int)tmpl[tok]);  // (tok <= n + EV_K < TL)
-            last = n;
-            // steps after n drain the insertion stack until it is empty or the next step with an event
-            while (sp > 0 && last + 1 < RL && last + 1 != next_n) {
-                ++last;
-                --sp;
-                if (rl == 0) ovr[last] = stk[sp];
+            if (ok) {
+                ++n_rebuilt;
+                if (STORE_MUT) atomicOr(&A.flags[pair], 4u << o);  // (bits 2-3: this kernel rebuilt the mate)
             }
-            // from step last + 1 on: token = step + (k - (last + 1)) until the next step with an event
-            if (rl == 0 && last + 1 < pitch) dsh[last + 1] = (int8_t)(k - (last + 1) - cur_shift);
-            cur_shift = k - (last + 1);
+            R[0] = pair;
+            R[1] = (uint32_t)t0pos;
+            // (a read that is not rebuilt here holds stale -- possibly never written -- event words: every field is masked)
+            R[2] = (uint32_t)o | ((n_runs & 15u) << 1) | ((n_let & 15u) << 5) | (((uint32_t)(!ok ? 0 : first_step) & 0x3ffu) << 9) |
+                   (ok ? 0x80000000u : 0u);
+            R[3] = (uint32_t)evmask;
+            R[4] = (uint32_t)(evmask >> 32);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- 4. the read: 8 positions per lane and pass.  (Every lane of the wavefront runs the pass loop -- the groups
-        //      without events with nothing to do: the candidate ring's head and tail stay wave-uniform.)
-        if (n_act && rl == 0) { ++n_reads; atomicOr(&A.flags[pair], 4u << o); }  // (bits 2-3: this kernel rebuilt the mate)
-        {
-            int carry = 0;  // (token - step) at the end of the previous pass
-            for (int b = rl, pass = 0; (b - rl) * 8 < pitch; b += GL, ++pass) {  // (every lane of the group takes part in the prefix sums)
-                const int j0 = b * 8;
-                const bool in = n_act && j0 < pitch;
-                uint2 q8 = pass == 0 ? q8_0 : (pass == 1 ? q8_1 : q8_2);
-                if (pass >= NP && in) q8 = *reinterpret_cast<const uint2 *>(out_qual + xp(j0));  // (32 lanes per read: read_length > 376)
-                uint2 e8w = {0u, 0u}, dw = {0u, 0u}, ov = {0u, 0u};
-                if (in) {
-                    e8w = *reinterpret_cast<const uint2 *>(dqm + j0);
-                    dw = *reinterpret_cast<const uint2 *>(dsh + j0);
-                    ov = *reinterpret_cast<const uint2 *>(ovr + j0);
-                }
-                // (token - step) in front of the lane's first position: prefix sum of the changes over the group's lanes
-                const int lane_sum = __builtin_amdgcn_sdot4((int)dw.x, 0x01010101, __builtin_amdgcn_sdot4((int)dw.y, 0x01010101, 0, false), false);
-                int incl = lane_sum;
+        // ================ phase 2: four lanes per read, 16 reads at a time
+        for (uint32_t sub = 0; sub < 4u; ++sub) {
+            const uint32_t slot = sub * 16u + (lane >> 2), j4 = lane & 3u;
+            const uint32_t *R = wave0 + slot * RW, *win = R + AP_HDR, *runs = win + WW;
+            const uint32_t pair = R[0], h2 = R[2];
+            const int t0pos = (int)R[1], o = (int)(h2 & 1u), n_runs = (int)((h2 >> 1) & 15u), first_step = (int)((h2 >> 9) & 0x3ffu);
+            const uint64_t evmask = (uint64_t)R[3] | ((uint64_t)R[4] << 32);
+            const bool valid = (h2 >> 31) != 0u;
+            if (!__ballot(valid)) continue;
+            uint8_t *rowp = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
+            int ri = 0, sh = 0, nstart = n_runs > 1 ? (int)(runs[1] & 0xffffu) : 0x7fffffff;
+            // A piece is rewritten WHOLE -- its 8 letters and, unchanged, its 8 phreds -- and the four lanes of a read store a
+            // full 64-byte sector together.  (Letters alone are half a sector, and so is a line whose pieces are written at
+            // different times: HBM with ECC turns every partial write into a read-modify-write -- measured: 1.7 GB written and
+            // 0.6 GB fetched for 0.45 GB of letters, the kernel bound by it.)  The pieces of AP_CH passes are requested
+            // together: a load behind the chip's write stream takes microseconds.
+            const uint32_t *evp = runs + AP_RUNS;  // the pieces with an explicit letter, in ascending order (phase 1)
+            for (int p0 = 0; p0 < n_pass; p0 += AP_CH) {
+                uint4 pv[AP_CH];
 #pragma unroll
-                for (int dd = 1; dd < GL; dd <<= 1) {
-                    const int t = __shfl_up(incl, dd, GL);
-                    if (rl >= dd) incl += t;
+                for (int q = 0; q < AP_CH; ++q) {
+                    const int piece = 4 * (p0 + q) + (int)j4, j0 = 8 * piece;
+                    pv[q] = make_uint4(0u, 0u, 0u, 0u);
+                    if (valid && p0 + q < n_pass && piece < S && j0 + 8 > first_step) pv[q] = *reinterpret_cast<const uint4 *>(rowp + xp(j0));
                 }
-                int shift = carry + incl - lane_sum;
-                carry += __shfl(incl, GL - 1, GL);
-                uint32_t ob0 = 0u, ob1 = 0u, cand = 0u;  // cand: bit 7 - c <=> the substitution test of position j0 + c fires or ties
-                if (in) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int j = j0 + c;
-                    shift += (int)(int8_t)(((c < 4 ? dw.x : dw.y) >> (8 * (c & 3))) & 0xffu);
-                    // (0 <= j + shift <= j + EV_K < TL: a step deletes at most one base; at a step with an explicit letter it
-                    //  is the previous run continued, and the letter read there is overridden below)
-                    const int base = (int)tmpl[j + shift];
-                    const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
-                    const uint32_t q = ((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu;
-                    cand = shift_in(cand, __builtin_amdgcn_ballot_w64(e8 >= mut8[q & 63u]));
-                    if (c < 4) ob0 |= (uint32_t)base << (8 * c); else ob1 |= (uint32_t)base << (8 * (c - 4));
-                }
-                {   // the explicit letters: byte-wise ov ? ov : ob
-                    auto nonzero_bytes = [](uint32_t v) { return (((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u; };  // 0x80 per non-zero byte
-                    const uint32_t m0 = (nonzero_bytes(ov.x) >> 7) * 0xffu, m1 = (nonzero_bytes(ov.y) >> 7) * 0xffu;
-                    ob0 = (ov.x & m0) | (ob0 & ~m0);
-                    ob1 = (ov.y & m1) | (ob1 & ~m1);
-                }
-                cand &= 0xffu & ~(0xffu >> min(max(RL - j0, 0), 8));  // positions inside the read
-                *reinterpret_cast<uint2 *>(out_base + xp(j0)) = make_uint2(ob0, ob1);
-                }
-                // the candidates of this piece, one ring entry each (after the store: they are settled by byte patches)
-                for (;;) {
-                    const unsigned long long pm = __ballot(cand != 0u);
-                    if (!pm) break;
-                    if (cand) {
-                        const int c = __clz(cand) - 24;
-                        cand &= ~(0x80u >> c);
-                        const int j = j0 + c;
-                        const uint32_t e8 = ((c < 4 ? e8w.x : e8w.y) >> (8 * (c & 3))) & 0xffu;
-                        const uint32_t q = ((c < 4 ? q8.x : q8.y) >> (8 * (c & 3))) & 0xffu;
-                        const uint32_t before = ((c < 4 ? ob0 : ob1) >> (8 * (c & 3))) & 0xffu;
-                        const uint32_t orig = STORE_MUT ? (uint32_t)tmpl[j] : 0u;
-                        uint32_t *e = cring + ((c_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))) & (APPLY_RING - 1)) * 3;
-                        e[0] = pair;
-                        e[1] = ((d.meta >> 16) << 16) | ((uint32_t)o << 15) | (j >= geo.t_len ? 1u << 14 : 0u) | (uint32_t)j;
-                        e[2] = (orig << 24) | (before << 16) | (q << 8) | e8;
+                for (int q = 0; q < AP_CH; ++q) {
+                    if (p0 + q >= n_pass) break;  // (uniform)
+                    const int piece = 4 * (p0 + q) + (int)j4, j0 = 8 * piece;
+                    const bool act = valid && piece < S && j0 + 8 > first_step;  // (pieces in front of the first event: k_main's stand)
+                    while (nstart <= j0) {  // the run position j0 lies in
+                        ++ri;
+                        sh = (int)runs[ri] >> 16;
+                        nstart = ri + 1 < n_runs ? (int)(runs[ri + 1] & 0xffffu) : 0x7fffffff;
                     }
-                    c_tail += (uint32_t)__popcll(pm);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    while (c_tail - c_head >= 64u) settle_candidates(64u);
+                    if (act) {
+                        uint2 nw;
+                        if ((evmask >> piece) & 1u) {
+                            const int i = __popcll(evmask & (((uint64_t)1 << piece) - 1u));
+                            nw = make_uint2(evp[2 * i], evp[2 * i + 1]);
+                        } else {  // the whole piece lies in one run: one funnel shift of the window
+                            nw = decode8(win, t0pos, o, j0 + sh);
+                        }
+                        *reinterpret_cast<uint4 *>(rowp + xp(j0)) = make_uint4(nw.x, nw.y, pv[q].z, pv[q].w);
+                    }
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (c_tail != c_head) settle_candidates(c_tail - c_head);
-    if (rl == 0 && n_reads) atomicAdd((unsigned long long *)stats, (unsigned long long)n_reads);
+    const unsigned long long any = __ballot(n_rebuilt != 0u);
+    if (any) {
+        uint32_t tot = n_rebuilt;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
+        if (lane == 0) atomicAdd((unsigned long long *)stats, (unsigned long long)tot);
+    }
+}
+
+// ================================================================== k_indel_resub
+// The substitutions of the reads k_indel_apply rebuilt, re-applied: one lane per entry of k_main's list.  The error test of
+// the position fired whatever its letter (__init__.py:94); the substitution choice is made for the letter that stands
+// there now (the shifted template letter or an inserted one).  Pieces in front of a read's first event were not rewritten:
+// k_main's letter stands.  --store_mutations: the rows of the mate's substitutions (k_main's are dropped by the host).
+template <bool STORE_MUT>
+__global__ __launch_bounds__(256) void k_indel_resub(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
+    const uint32_t n = min(A.sub_count[0], A.sub_cap);
+    if (A.sub_count[1]) return;  // (the list overflowed: k_indel_apply handed every listed read to k_indel_fixup)
+    const int RL = M.RL;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 e = A.sub_list[i];
+        if (e.x == 0xffffffffu) continue;
+        const uint32_t pair = e.x;
+        const int o = (int)((e.y >> 15) & 1u), j = (int)(e.y & 0x7fffu), orig = (int)((e.y >> 16) & 0xffu);
+        const uint32_t rd = 2u * pair + (uint32_t)o;
+        if (!A.ev_count[rd] || ((A.flags[pair] >> o) & 1u)) continue;  // no event: k_main's read stands; k_indel_fixup's mates are rebuilt there
+        const int lim = (int)(A.ev_list[(size_t)rd * EV_K] >> 8) & ~7;  // the first rewritten position
+        if (j < lim && !STORE_MUT) continue;
+        uint8_t *rowp = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
+        int before = rowp[xp(j)], base = before;
+        if (j >= lim) {
+            const int bi = base_index(before);
+            if (bi < 0) continue;  // nucl.upper() in "RYWSMKHBVDN": left alone
+            const Addr ca = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
+            const u32x4 sb = draw_block(ca, K_SUB, (uint32_t)j, (uint32_t)o);
+            base = substitute(M, sb, o, j, before);
+            rowp[xp(j)] = (uint8_t)base;
+        } else {
+            before = orig;  // (the letter k_main replaced; `base` is its substitute)
+        }
+        if (STORE_MUT) {  // only if the new letter differs from the ORIGINAL read at this index (__init__.py:98)
+            MutRecord sub;
+            sub.pair = (int32_t)(A.pair_base + pair); sub.mate = (int8_t)o; sub.type = (int8_t)32; sub.position = (int16_t)j;
+            sub.ref = (uint8_t)before; sub.alt = (uint8_t)base;
+            sub.quality = (int16_t)rowp[(row_array_off(1) - row_array_off(0)) + xp(j)];
+            if (base != orig) mut_emit1(A, sub);
+        }
+    }
 }
 
 // ================================================================== k_indel_fixup
@@ -1451,6 +1538,7 @@ __global__ __launch_bounds__(64 * APPLY_WAVES, ISS_APPLY_OCC) void k_indel_apply
 //            and for the steps that drain the insertion stack; "from step n0 on, source index =
 //            k0 + (n - n0)" records for everything in between.
 //   phase 3 (all lanes): token -> base -> mut_sequence -> store.
+constexpr int16_t FIX_NONE = 0x7fff;
 constexpr int FIX_MAX_RL = 1024;  // read_length limit (checked at model upload)
 constexpr int FIX_WAVES = 4;      // wavefronts (reads) per workgroup
 

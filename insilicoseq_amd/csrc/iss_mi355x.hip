@@ -93,6 +93,7 @@ struct PendingIndel {  // indel-stream work still in flight on output rows [row0
 };
 
 constexpr int FIX_SLOTS = 16;  // ring of fix-list counters (one per chunk in flight on the indel stream)
+constexpr size_t SUB_MARGIN = (size_t)1 << 20;  // entries a chunk's substitution list holds beyond its expectation (4096 wavefronts x SUB_CHUNK)
 
 // Device-formatted FASTQ on its way to the files: two slots of (device text, pinned host text) per mate; the
 // format kernel runs on the context's stream, the copy back on a copy stream, the file writes on a writer thread.
@@ -192,6 +193,12 @@ struct iss_ctx {
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
     uint32_t *ev_count = nullptr, *ev_list = nullptr, *read_list = nullptr;  // indel events (k_indel_scan -> k_indel_apply), per row
     uint32_t *read_count = nullptr;  // FIX_SLOTS counters of the read lists, like fix_count
+    // models with indels: the substitutions k_main applies (RunArgs::sub_list), sub_per_pair entries per output row + a
+    // margin per chunk in flight (every wavefront may leave most of a SUB_CHUNK unused); FIX_SLOTS x {reserved, overflow}
+    uint2 *sub_list = nullptr;
+    uint32_t *sub_count = nullptr;
+    int64_t sub_per_pair = 0;
+    bool light = false;  // reads with an indel are rare (< ISS_LIGHT_INDELS of the reads, default 2e-3): all of them take k_indel_fixup
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
     // custom fragment length on the Philox path
     bool has_frag = false;
@@ -281,6 +288,8 @@ void free_outputs(iss_ctx *ctx) {
     if (ctx->ev_count) (void)hipFree(ctx->ev_count);
     if (ctx->ev_list) (void)hipFree(ctx->ev_list);
     if (ctx->read_list) (void)hipFree(ctx->read_list);
+    if (ctx->sub_list) (void)hipFree(ctx->sub_list);
+    ctx->sub_list = nullptr;
     ctx->ev_count = ctx->ev_list = ctx->read_list = nullptr;
     ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
     ctx->capacity = 0;
@@ -711,8 +720,10 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, device_ordinal));
         ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        const void *mains[4] = {reinterpret_cast<const void *>(iss::k_main<false, false>), reinterpret_cast<const void *>(iss::k_main<false, true>),
-                                reinterpret_cast<const void *>(iss::k_main<true, false>), reinterpret_cast<const void *>(iss::k_main<true, true>)};
+        const void *mains[8] = {reinterpret_cast<const void *>(iss::k_main<false, false, false>), reinterpret_cast<const void *>(iss::k_main<false, true, false>),
+                                reinterpret_cast<const void *>(iss::k_main<true, false, false>), reinterpret_cast<const void *>(iss::k_main<true, true, false>),
+                                reinterpret_cast<const void *>(iss::k_main<false, false, true>), reinterpret_cast<const void *>(iss::k_main<false, true, true>),
+                                reinterpret_cast<const void *>(iss::k_main<true, false, true>), reinterpret_cast<const void *>(iss::k_main<true, true, true>)};
         for (const void *f : mains) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_mt_walk),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -720,9 +731,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        const void *applies[] = {reinterpret_cast<const void *>(iss::k_indel_apply<false, 8>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 8>),
-                                 reinterpret_cast<const void *>(iss::k_indel_apply<false, 16>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 16>),
-                                 reinterpret_cast<const void *>(iss::k_indel_apply<false, 32>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 32>)};
+        const void *applies[] = {reinterpret_cast<const void *>(iss::k_indel_apply<false>), reinterpret_cast<const void *>(iss::k_indel_apply<true>)};
         for (const void *f : applies) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
@@ -737,6 +746,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * FIX_SLOTS));
     ctx->read_count = static_cast<uint32_t *>(p);
     HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * FIX_SLOTS));
+    HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * 2 * FIX_SLOTS));
+    ctx->sub_count = static_cast<uint32_t *>(p);
+    HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * 2 * FIX_SLOTS));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
     *out = ctx;
     return 0;
@@ -755,6 +767,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
     if (ctx->read_count) (void)hipFree(ctx->read_count);
+    if (ctx->sub_count) (void)hipFree(ctx->sub_count);
     if (ctx->d_amb) (void)hipFree(ctx->d_amb);
     if (ctx->d_pmut) (void)hipFree(ctx->d_pmut);
     if (ctx->d_ov_pairs) (void)hipFree(ctx->d_ov_pairs);
@@ -1006,6 +1019,29 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     }
         M.alt_letters = (uint32_t)letters[0] | ((uint32_t)letters[1] << 8) | ((uint32_t)letters[2] << 16) | ((uint32_t)letters[3] << 24);
     }
+    {   // expected substitutions per pair (sizes the list of applied substitutions, RunArgs::sub_list): per mate and position the
+        // phred distribution of every bin (differences of the CDF thresholds) against the error probability of the phred
+        double exp_subs = 0;
+        const double inv = 1.0 / 9007199254740992.0;
+        for (int o = 0; o < 2; ++o) {
+            double bprev = 0;
+            for (int b = 0; b < 4; ++b) {
+                const double bcum = std::min(1.0, (double)t->bin_thr[o * 4 + b] * inv), pb = std::max(0.0, bcum - bprev);
+                bprev = bcum;
+                if (!t->bin_nonempty[o * 4 + b] || pb <= 0) continue;
+                for (int p = 0; p < RL; ++p) {
+                    const uint64_t *row = t->q_thr + ((size_t)(o * 4 + b) * RL + p) * nq;
+                    double prev = 0;
+                    for (int q = 0; q <= nq; ++q) {
+                        const double cum = q < nq ? std::min(1.0, (double)row[q] * inv) : 1.0;
+                        exp_subs += pb * std::max(0.0, cum - prev) * (1.0 - (double)t->mut_thr[q] * inv);
+                        prev = cum;
+                    }
+                }
+            }
+        }
+        M.exp_subs = (float)exp_subs;
+    }
     std::vector<uint64_t> del_max((size_t)2 * RL);
     for (int o = 0; o < 2; ++o)
         for (int n = 0; n < RL; ++n) {
@@ -1045,6 +1081,18 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     }
     M.ev_ns = ev_ns;
     M.n_scan = any_indel ? 1 : 0;
+    {   // how often a read has an event at all: models where that is rare (the shipped NovaSeq / HiSeq profiles: a few reads in
+        // 10^5) keep k_main free of the substitution list and hand those reads to the one-wavefront-per-read kernel
+        double p_any = 0;
+        for (int o = 0; o < 2; ++o) {
+            double none = 1.0;
+            for (int sl = 0; sl < ev_ns; ++sl) none *= 1.0 - (double)ev_T[(size_t)o * ev_ns + sl] / 9007199254740992.0;
+            p_any = std::max(p_any, 1.0 - none);
+        }
+        M.p_read_event = (float)p_any;
+        const char *e = getenv("ISS_LIGHT_INDELS");
+        ctx->light = p_any < (e ? atof(e) : 2e-3);
+    }
     // k_mt_resolve tables: un-merged 16-bit leading digits per (orientation, bin slot, position) -- a row of n_q
     // digits padded to an odd number of words -- and 27-bit leading parts of the indel thresholds
     M.mt_row_w = (nq + 2) / 2;  // >= one 0xffff padding digit after the n_q digits
@@ -1245,6 +1293,11 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     ctx->ev_list = static_cast<uint32_t *>(q);
     HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
     ctx->read_list = static_cast<uint32_t *>(q);
+    if (ctx->M.n_scan > 0 && !ctx->light) {
+        ctx->sub_per_pair = (int64_t)std::ceil(3.0 * (double)ctx->M.exp_subs) + 2;
+        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint2) * ((size_t)ctx->sub_per_pair * (size_t)capacity_pairs + (size_t)(FIX_SLOTS + 1) * SUB_MARGIN)));
+        ctx->sub_list = static_cast<uint2 *>(q);
+    }
     ctx->capacity = capacity_pairs;
     return 0;
 }
@@ -1360,12 +1413,15 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         const unsigned slot_i = (unsigned)(ctx->chunk_seq++ % FIX_SLOTS);
         uint32_t *counter = ctx->fix_count + slot_i;
         uint32_t *read_counter = ctx->read_count + slot_i;
+        uint32_t *sub_counter = ctx->sub_count + 2 * slot_i;
         if (ctx->overlap) {
             HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
             HIP_TRY(ctx, hipMemsetAsync(read_counter, 0, sizeof(uint32_t), s_main));
+            HIP_TRY(ctx, hipMemsetAsync(sub_counter, 0, 2 * sizeof(uint32_t), s_main));
         } else if (slot_i == 0) {
             HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
             HIP_TRY(ctx, hipMemsetAsync(ctx->read_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->sub_count, 0, sizeof(uint32_t) * 2 * FIX_SLOTS, s_main));
         }
         A.mut = ctx->d_pmut;
         A.mut_count = ctx->d_pmut_count;
@@ -1381,6 +1437,12 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.ev_list = ctx->ev_list + 2 * (size_t)iss::EV_K * row0;
         A.read_list = ctx->read_list + 2 * row0;
         A.read_count = read_counter;
+        A.light = ctx->light ? 1 : 0;
+        if (M.n_scan > 0 && ctx->sub_list && !ctx->light) {  // k_main lists the substitutions it applies: k_indel_resub re-applies those of shifted reads
+            A.sub_list = ctx->sub_list + (size_t)row0 * (size_t)ctx->sub_per_pair + (size_t)slot_i * SUB_MARGIN;
+            A.sub_count = sub_counter;
+            A.sub_cap = (uint32_t)std::min<uint64_t>((uint64_t)n * (uint64_t)ctx->sub_per_pair + SUB_MARGIN, 0xffffff00u);
+        }
         A.has_frag = ctx->has_frag ? 1 : 0;
         A.frag_mu = ctx->frag_mu;
         A.frag_sd = ctx->frag_sd;
@@ -1456,7 +1518,11 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             A.tile_wg0[M.n_tiles] = (uint16_t)total;
             const dim3 grid(total), block(iss::MAIN_THREADS);
             const bool plain = !any_exceptions && !ctx->has_frag;
-#define ISS_LAUNCH_MAIN(MUT, PLAIN) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN>), grid, block, lds_bytes, s_main, M, dg, A, desc)
+#define ISS_LAUNCH_MAIN(MUT, PLAIN)                                                                                         \
+    do {                                                                                                                    \
+        if (A.sub_list) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN, true>), grid, block, lds_bytes, s_main, M, dg, A, desc); \
+        else hipLaunchKernelGGL((iss::k_main<MUT, PLAIN, false>), grid, block, lds_bytes, s_main, M, dg, A, desc);           \
+    } while (0)
             if (A.mut) { if (plain) ISS_LAUNCH_MAIN(true, true); else ISS_LAUNCH_MAIN(true, false); }
             else { if (plain) ISS_LAUNCH_MAIN(false, true); else ISS_LAUNCH_MAIN(false, false); }
 #undef ISS_LAUNCH_MAIN
@@ -1478,19 +1544,19 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             HIP_TRY(ctx, mark(4, s_indel));
             if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
             HIP_TRY(ctx, mark(5, s_indel));
-            if (M.n_scan > 0) {  // reads with (few) events: replayed from their lists, 8 (16 / 32 for long reads) lanes per read
-                const int GL = iss::apply_gl(M.pitch);
-                const int64_t per_wg = (int64_t)iss::APPLY_WAVES * (64 / GL);  // reads per workgroup pass; at most 2 n reads
-                const size_t lds = iss::apply_lds_bytes(M.RL, M.pitch, GL);
-                // as many workgroups as are resident at once (4 wavefronts / SIMD, LDS permitting): the list is usually far
-                // shorter than 2 n, and a workgroup with this much LDS is not cheap to start only to find nothing to do
-                const int64_t resident = std::max<int64_t>(1, std::min<int64_t>(16 / iss::APPLY_WAVES, (int64_t)(160 * 1024) / (int64_t)lds));
-                const unsigned blocks = (unsigned)std::min<int64_t>(resident * ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
-                const dim3 grid(blocks), block(64 * iss::APPLY_WAVES);
-#define ISS_LAUNCH_APPLY(MUT, G) hipLaunchKernelGGL((iss::k_indel_apply<MUT, G>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats)
-                if (A.mut) { if (GL == 8) ISS_LAUNCH_APPLY(true, 8); else if (GL == 16) ISS_LAUNCH_APPLY(true, 16); else ISS_LAUNCH_APPLY(true, 32); }
-                else { if (GL == 8) ISS_LAUNCH_APPLY(false, 8); else if (GL == 16) ISS_LAUNCH_APPLY(false, 16); else ISS_LAUNCH_APPLY(false, 32); }
-#undef ISS_LAUNCH_APPLY
+            if (M.n_scan > 0 && !ctx->light) {  // reads with (few) events: rebuilt from their lists, 64 per wavefront block
+                const size_t lds = iss::apply_lds_bytes(M.RL, M.pitch);
+                const int waves = iss::apply_waves(M.RL, M.pitch);  // ONE workgroup per CU
+                const int64_t per_wg = (int64_t)waves * 64;  // reads per workgroup pass; at most 2 n reads (the list is usually far shorter)
+                const unsigned blocks = (unsigned)std::min<int64_t>(ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
+                const dim3 grid(blocks), block(64 * waves);
+                if (A.mut) hipLaunchKernelGGL((iss::k_indel_apply<true>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats);
+                else hipLaunchKernelGGL((iss::k_indel_apply<false>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats);
+                if (A.sub_list) {  // the listed substitutions of the reads just rebuilt, on the letters that stand there now
+                    const dim3 rgrid((unsigned)std::min<int64_t>(4 * ctx->n_cu, (2 * n + 255) / 256)), rblock(256);
+                    if (A.mut) hipLaunchKernelGGL((iss::k_indel_resub<true>), rgrid, rblock, 0, s_indel, M, A, desc);
+                    else hipLaunchKernelGGL((iss::k_indel_resub<false>), rgrid, rblock, 0, s_indel, M, A, desc);
+                }
             }
             {   // the rest (irregular pairs, reads with more events than a list holds): one wavefront per read
                 const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);

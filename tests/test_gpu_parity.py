@@ -81,6 +81,18 @@ def test_hip_matches_oracle(engine, case):
         assert stats["fixup_reads"] > 0  # the indel fix-up path really ran
 
 
+@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("case", [0, 5, 7, 9, 10, 11, 14, 15, 16])
+def test_both_indel_paths_match_oracle(engine, case, mode, monkeypatch):
+    """A model picks its indel path by how often a read has an event (DevModel::p_read_event against ISS_LIGHT_INDELS, 2e-3 by
+    default): rare -- every such read to the one-wavefront-per-read kernel, k_main without the substitution list; else
+    k_main lists its substitutions, k_indel_apply shifts letters, k_indel_resub re-applies the listed substitutions.  Both
+    paths for shipped and indel-heavy models alike ("0": never the light path, "2": always)."""
+    monkeypatch.setenv("ISS_LIGHT_INDELS", mode)
+    model, indel, mk_genome, n_pairs, seed, first, seq_type, gc_bias = CASES[case]
+    _compare(engine, dense_model(model, indel), mk_genome(), n_pairs, seed, first, seq_type, gc_bias)
+
+
 def test_rows_and_ordinals_compose(engine):
     """Two calls writing adjacent rows with consecutive ordinals == one call (work items of a worker)."""
     dense = dense_model("hiseq")
