@@ -94,18 +94,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it as `python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ...` (one rank per GPU)" % (
+                             args.gpus, world, args.gpus, args.gpus))
     if os.environ.get("ISS_BENCH_SHARE_GPU") == "1":  # dry runs only: every rank on GPU 0
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) are visible (one rank per GPU; ISS_BENCH_SHARE_GPU=1 puts "
+                         "every rank of a dry run on GPU 0)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL needs dmabuf IPC on this driver)
+        try:
+            if args.backend == "nccl":  # RCCL: the process group is bound to this rank's GPU (barriers and collectives run there)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
+        except Exception as e:
+            raise SystemExit("rank %d: torch.distributed.init_process_group(%r) failed: %r (MASTER_ADDR=%s MASTER_PORT=%s)" % (
+                rank, args.backend, e, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")))
+        if dist.get_world_size() != world:
+            raise SystemExit("rank %d: the process group has %d ranks, WORLD_SIZE says %d" % (rank, dist.get_world_size(), world))
 
     import __graft_entry__ as ge
 
@@ -247,6 +261,8 @@ def main():
             "model_broadcast_s": bcast_s,
             "parity_window": parity,
         }
+        out["n_ranks_seen"] = dist.get_world_size() if dist is not None else 1
+        out["backend"] = (args.backend if dist is not None else None)
         if world > 1:
             out["per_rank_pairs_per_sec"] = [n * args.steps / e if e > 0 else None for n, e in per_rank]
         if world == 1 and not args.no_other_workloads and not strong and args.model == "novaseq" and args.indel is None:
@@ -258,6 +274,14 @@ def main():
                     out["other_workloads"][name] = side_workload(local_rank, model, indel, genomes, records, abundance, args.reads)
                 except Exception as e:  # (never let a side leg take the line down)
                     out["other_workloads"][name] = {"error": repr(e)}
+            try:  # BASELINE configs[3] at its real shape on ONE GPU: 100 M HiSeq reads per step over 50 records of 5 Mbp
+                g50 = synthetic_genomes(50, GENOME_LEN, 123)
+                r50 = [Record(_SeqLen(len(g)), id="genome_%d" % i) for i, g in enumerate(g50)]
+                a50 = lognormal_abundance([r.id for r in r50], np.random.RandomState(123))
+                out["other_workloads"]["configs3_one_gpu"] = side_workload(local_rank, "hiseq", None, g50, r50, a50, 100_000_000, steps=3, warmup=1)
+                del g50
+            except Exception as e:
+                out["other_workloads"]["configs3_one_gpu"] = {"error": repr(e)}
         if world == 1 and not args.no_end_to_end:
             e2e_records = [Record(letters[id(r)], id=r.id) for r in records]
             out["end_to_end"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs)

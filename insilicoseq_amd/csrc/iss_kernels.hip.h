@@ -539,8 +539,11 @@ __global__ __launch_bounds__(256) void k_rows_to_arrays(const uint8_t *__restric
 
 // ================================================================== k_setup
 // `ov_frag` != NULL: second pass for the few pairs whose fragment length the host evaluated.
+// l_S / l_E (light models only, first pass): the indel event tables in LDS -- the pair's two reads are checked for an event
+// right here (a draw each, usually) and handed to k_indel_fixup if they have one; there is no k_indel_scan launch then.
 __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g, const RunArgs &A, PairDesc *desc,
-                                           const uint64_t *s_isize, int64_t i, const int64_t *ov_frag, int64_t coord_off = 0) {
+                                           const uint64_t *s_isize, int64_t i, const int64_t *ov_frag, int64_t coord_off = 0,
+                                           const uint64_t *l_S = nullptr, const uint16_t *l_E = nullptr) {
     const uint64_t ordinal = A.first_ordinal + (uint64_t)i;
     uint32_t attempt = 0;
     if (A.gc_bias) {  // generator.py:82-92 -- the 40<gc<60 window is dead, every candidate pair
@@ -625,14 +628,26 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
         for (int64_t w = (rs - 3) >> 5; w <= (re - 1) >> 5; ++w) any |= g.mask[w];
         exc |= any ? 32u : 0u;
     }
-    if (!ov_frag) A.flags[i] = 0u;  // first pass: the pair's indel / irregular flags start clean (no separate memset; the
-                                    // event counters are written by k_indel_scan, every one of them)
-    if (irregular && !(A.flags[i] & 3u)) {
-        A.flags[i] = 3u;
-        const uint32_t at = atomicAdd(A.fix_count, 2u);
-        A.fix_list[at] = (uint32_t)i * 2u;
-        A.fix_list[at + 1] = (uint32_t)i * 2u + 1u;
+    // first pass: the pair's indel / irregular flags start clean (no separate memset; the event counters are written by
+    // k_indel_scan, every one of them)
+    uint32_t fl = ov_frag ? A.flags[i] : 0u, fl_new = fl;
+    if (irregular) fl_new |= 3u;
+    if (l_S && !ov_frag) {  // light models: does a read of the pair have an indel event at all?
+        const int ns = M.ev_ns;
+        for (int o = 0; o < 2; ++o) {
+            if ((fl_new >> o) & 1u) continue;
+            int cur = -1, slot = -1;
+            for (uint32_t j = 0; cur < ns - 1 && slot < 0; ++j) {
+                const u32x4 w = draw_block(a, K_EV, j, (uint32_t)o);
+                uint32_t mask;
+                cur = ev_step(l_S + o * ns, l_E + o * ns, M.ev_T + (size_t)o * ns, M.del_thr + (size_t)o * RL * 4, cur, mk53(w.x, w.y), mk53(w.z, w.w), slot, mask);
+            }
+            if (slot >= 0) fl_new |= 1u << o;
+        }
     }
+    for (uint32_t o = 0; o < 2u; ++o)  // (one lane per pair: no atomics on the flags)
+        if (((fl_new & ~fl) >> o) & 1u) A.fix_list[atomicAdd(A.fix_count, 1u)] = (uint32_t)i * 2u + o;
+    if (fl_new != fl || !ov_frag) A.flags[i] = fl_new;
     PairDesc d;
     d.fs = (int32_t)(fs + coord_off);  // (batch calls: arena coordinates)
     d.re = (int32_t)(re + coord_off);
@@ -642,18 +657,34 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
     desc[i] = d;
 }
 
+__host__ __device__ inline size_t setup_lds_bytes(int n_isize, int ev_ns, bool light) {
+    return (size_t)n_isize * 8 + (light ? (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 7) & ~(size_t)7) : 0);
+}
+// (persistent workgroups: the tables are staged once per workgroup, not once per 256 pairs)
 __global__ __launch_bounds__(256) void k_setup(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_isize[];  // insert-size thresholds (binary-searched per pair)
+    const bool light = A.light && M.n_scan > 0;
+    const int ns = M.ev_ns;
+    // [2][ns] each (light models: the indel event tables; A.light == 2: too large for the LDS beside the insert sizes, read in place)
+    const uint64_t *l_S = M.ev_S;
+    const uint16_t *l_E = M.ev_E;
     for (int k = threadIdx.x; k < M.n_isize; k += blockDim.x) s_isize[k] = M.isize_thr[k];
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n_pairs) return;
-    if (A.items) {  // the record of this pair, then as for a single record
-        const BatchItem it = A.items[batch_item_of(A, A.pair_base + i)];
-        setup_pair(M, batch_genome(g, it), A, desc, s_isize, i, nullptr, it.off);
-        return;
+    if (light && A.light == 1) {
+        uint64_t *s_S = s_isize + M.n_isize;
+        uint16_t *s_E = reinterpret_cast<uint16_t *>(s_S + 2 * ns);
+        for (int k = threadIdx.x; k < 2 * ns; k += blockDim.x) { s_S[k] = M.ev_S[k]; s_E[k] = M.ev_E[k]; }
+        l_S = s_S;
+        l_E = s_E;
     }
-    setup_pair(M, g, A, desc, s_isize, i, nullptr);
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n_pairs; i += (int64_t)gridDim.x * blockDim.x) {
+        if (A.items) {  // the record of this pair, then as for a single record
+            const BatchItem it = A.items[batch_item_of(A, A.pair_base + i)];
+            setup_pair(M, batch_genome(g, it), A, desc, s_isize, i, nullptr, it.off, light ? l_S : nullptr, l_E);
+        } else {
+            setup_pair(M, g, A, desc, s_isize, i, nullptr, 0, light ? l_S : nullptr, l_E);
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_setup_override(DevModel M, DevGenome g, RunArgs A, PairDesc *desc) {
@@ -1550,8 +1581,12 @@ __host__ __device__ inline size_t fix_wave_bytes(int RL) {
            2 * rlp /* dqm: the mate's error-test digits, one Philox block per lane */ +
            (FIX_MAX_RL / 64) * 8 /* act: the steps with an event, one 64-bit mask per chunk (wave-uniform, out of the registers) */;
 }
+// (+ the indel event tables [2][ns] of 8 + 2 bytes when they fit beside the waves' rows: the binary search of a draw is a chain
+//  of dependent reads, microseconds each from global memory behind the chip's write stream)
+__host__ __device__ inline size_t fix_ev_bytes(int RL) { const size_t ns = (size_t)5 * (RL - 1); return 2 * ns * 8 + ((2 * ns * 2 + 7) & ~(size_t)7); }
+__host__ __device__ inline bool fix_ev_in_lds(int RL) { return 64 * 4 + FIX_WAVES * fix_wave_bytes(RL) + fix_ev_bytes(RL) <= (size_t)150 * 1024; }
 __host__ __device__ inline size_t fix_lds_bytes(int RL) {
-    return 64 * 4 + FIX_WAVES * fix_wave_bytes(RL);
+    return 64 * 4 + FIX_WAVES * fix_wave_bytes(RL) + (fix_ev_in_lds(RL) ? fix_ev_bytes(RL) : 0);
 }
 
 __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, DevGenome g, RunArgs A,
@@ -1567,6 +1602,15 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
     if (blockIdx.x * FIX_WAVES >= n_fix) return;                       // whole workgroup idle (uniform)
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)stats, (unsigned long long)n_fix);
     for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) mut8[i] = (uint32_t)(M.mut_thr[i] >> 45);
+    const uint64_t *ev_S = M.ev_S;
+    const uint16_t *ev_E = M.ev_E;
+    if (fix_ev_in_lds(RL)) {
+        uint64_t *s_S = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(mut8 + 64) + (size_t)FIX_WAVES * fix_wave_bytes(RL));
+        uint16_t *s_E = reinterpret_cast<uint16_t *>(s_S + 2 * M.ev_ns);
+        for (int i = threadIdx.x; i < 2 * M.ev_ns; i += blockDim.x) { s_S[i] = M.ev_S[i]; s_E[i] = M.ev_E[i]; }
+        ev_S = s_S;
+        ev_E = s_E;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint8_t *wbase = reinterpret_cast<uint8_t *>(mut8 + 64) + (size_t)wv * fix_wave_bytes(RL);
@@ -1609,7 +1653,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
         for (int n = lane; n < rlp; n += 64) ev[n] = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        indel_events(M.ev_S + (size_t)o * M.ev_ns, M.ev_E + (size_t)o * M.ev_ns, M.ev_T + (size_t)o * M.ev_ns, M.del_thr + (size_t)o * RL * 4,
+        indel_events(ev_S + (size_t)o * M.ev_ns, ev_E + (size_t)o * M.ev_ns, M.ev_T + (size_t)o * M.ev_ns, M.del_thr + (size_t)o * RL * 4,
                      M.ev_ns, a, o, [&](int n, uint32_t mask) { if (lane == 0) ev[n] |= (uint8_t)mask; });
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1620,7 +1664,23 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
             if (n < RL) { map[n] = FIX_NONE; qual[n] = out_qual[xp(n)]; }
             { const uint64_t am = __ballot(m8 != 0); if (lane == 0) act[c] = am; }
         }
-        for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)geom_base(gl, o, geo, k);
+        if (!gl.has_exceptions && geo.t_len == RL && (o == 0 ? geo.lo + n_pre <= gl.L : geo.hi - n_pre >= 0)) {
+            // the whole staged stretch lies inside a record of plain A/C/G/T: 16 letters per lane from one packed word
+            const int64_t g0 = o == 0 ? geo.lo : geo.hi - n_pre;  // lowest genome position of the stretch
+            for (int wi = lane; wi * 16 < n_pre + 16; wi += 64) {
+                const int64_t gp = ((g0 >> 4) + wi) << 4;  // genome position of the word's first base
+                const uint32_t w = gl.packed[(g0 >> 4) + wi];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int64_t pos = gp + c;
+                    const int64_t k = o == 0 ? pos - geo.lo : geo.hi - 1 - pos;
+                    const uint32_t code = (w >> (2 * c)) & 3u;
+                    if (k >= 0 && k < n_pre) tmpl[k] = code_to_ascii(o ? code ^ 1u : code);
+                }
+            }
+        } else {
+            for (int k = lane; k < n_pre; k += 64) tmpl[k] = (uint8_t)geom_base(gl, o, geo, k);
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase 2: every lane runs the same walk (wave-uniform values); lane 0 does the LDS writes

@@ -620,7 +620,7 @@ void fastq_writer_loop(iss_ctx *ctx) {
 }
 
 // all queued text is in the files; the descriptors stand at the end of what was written
-int fastq_flush(iss_ctx *ctx) {
+int fastq_flush(iss_ctx *ctx, bool keep_files = false) {
     FastqPipe &q = ctx->fq;
     if (!q.ready) return 0;
     std::string err;
@@ -639,19 +639,13 @@ int fastq_flush(iss_ctx *ctx) {
             err = "FASTQ pipeline: file shorter than the bytes written to it";
         (void)lseek(q.fd[m], (off_t)q.off[m], SEEK_SET);
     }
-    q.fd[0] = q.fd[1] = -1;
+    if (!keep_files) q.fd[0] = q.fd[1] = -1;
     if (!err.empty()) return fail(ctx, ISS_E_IO, err);
     return 0;
 }
 
 // the same, but the files stay attached (buffers are about to be reallocated in the middle of a run)
-int fastq_flush_keep(iss_ctx *ctx) {
-    FastqPipe &q = ctx->fq;
-    const int fd_keep[2] = {q.fd[0], q.fd[1]};
-    { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
-    q.fd[0] = fd_keep[0]; q.fd[1] = fd_keep[1];  // (q.off, attached_off and accounted stand as they were)
-    return 0;
-}
+int fastq_flush_keep(iss_ctx *ctx) { return fastq_flush(ctx, true); }
 
 void fastq_free_buffers(iss_ctx *ctx) {
     FastqPipe &q = ctx->fq;
@@ -728,6 +722,8 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_mt_walk),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_fixup),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_setup),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -1437,7 +1433,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.ev_list = ctx->ev_list + 2 * (size_t)iss::EV_K * row0;
         A.read_list = ctx->read_list + 2 * row0;
         A.read_count = read_counter;
-        A.light = ctx->light ? 1 : 0;
+        A.light = ctx->light ? (iss::setup_lds_bytes(M.n_isize, M.ev_ns, true) <= (size_t)150 * 1024 ? 1 : 2) : 0;
         if (M.n_scan > 0 && ctx->sub_list && !ctx->light) {  // k_main lists the substitutions it applies: k_indel_resub re-applies those of shifted reads
             A.sub_list = ctx->sub_list + (size_t)row0 * (size_t)ctx->sub_per_pair + (size_t)slot_i * SUB_MARGIN;
             A.sub_count = sub_counter;
@@ -1468,8 +1464,8 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         }
         HIP_TRY(ctx, mark(0, s_main));
         {
-            const unsigned blocks = (unsigned)((n + 255) / 256);
-            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), (size_t)M.n_isize * 8, s_main, M, dg, A, desc);
+            const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8 * (int64_t)ctx->n_cu);
+            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), iss::setup_lds_bytes(M.n_isize, M.ev_ns, A.light == 1 && M.n_scan > 0), s_main, M, dg, A, desc);
         }
         if (ctx->has_frag) {
             // fragment lengths the device could not decide (|x - round(x)| < guard): libm on the host, then redo those pairs
@@ -1536,7 +1532,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                 HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_setup, 0));  // the scan needs the pair descriptors only
             }
             HIP_TRY(ctx, mark(3, s_indel));
-            if (M.n_scan > 0) {  // one lane per read
+            if (M.n_scan > 0 && !ctx->light) {  // one lane per read (light models: k_setup has checked the pair's reads already)
                 const uint64_t reads = 2 * (uint64_t)n;
                 const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 8, (reads + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
                 hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), s_indel, M, A, desc);

@@ -93,3 +93,43 @@ def test_two_ranks_through_the_device(tmp_path):
     import torch.multiprocessing as mp
 
     mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_multirank_dry_run(world):
+    """bench.py's own N > 1 code -- torch.distributed.run rendezvous on 127.0.0.1, the process group, the one broadcast of
+    tables + packed genomes, chunk r of the reference's divider per rank (iss/app.py:81-83), the barrier-bracketed timed
+    region, the all_gather of every rank's (pairs, seconds), elapsed = max over ranks -- as a dry run on ONE GPU (gloo;
+    ISS_BENCH_SHARE_GPU=1).  The driver's 8-GPU run differs in the backend name ("nccl" = RCCL) and the device per rank."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    reads = 300000
+    env = dict(os.environ, ISS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world),
+                          "--backend", "gloo", "--reads", str(reads), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-end-to-end", "--no-other-workloads"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["n_ranks_seen"] == world and d["scaling"] == "weak" and d["steps"] == 3
+    pairs = d["config"]["pairs_per_step_per_gpu"]
+    # (the divider rounds every record's share and drops a surplus chunk like the reference: iss/app.py:104)
+    assert len(pairs) == world and abs(sum(pairs) - reads * world // 2) <= 64 and min(pairs) > 0 and max(pairs) <= -(-reads * world // 2 // world)
+    assert len(d["per_rank_pairs_per_sec"]) == world and all(v > 0 for v in d["per_rank_pairs_per_sec"])
+    assert abs(d["value"] - sum(pairs) * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]  # whole-job pairs / the slowest rank's time
+    assert str(d["parity_window"]).startswith("ok")
+
+
+def test_bench_refuses_a_mismatched_launch():
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)
