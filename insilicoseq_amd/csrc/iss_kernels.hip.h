@@ -733,9 +733,12 @@ __device__ __forceinline__ uint64_t error_test_draw(uint32_t e8, const u32x4 &su
 constexpr int MAIN_THREADS = 1024;
 constexpr int MAIN_PAIRS = MAIN_THREADS / 4;  // pairs of one workgroup pass: four lanes per pair
 constexpr int MAIN_MUT_WORDS = 128;  // LDS words of the substitution-test thresholds (n_q <= 60)
-constexpr int SLOW_RING = 128;  // entries (two words) of a wavefront's private ring of deferred lane-items (LDS): a
-                                // wavefront pushes <= 64 per half iteration and drains a round of 64 as soon as it has one
-// Dynamic LDS of k_main (32-bit words):
+constexpr int SLOW_RING = 128;  // entries (three words) of a wavefront's private ring of deferred lane-items (LDS): a
+                                // wavefront pushes <= 64 per iteration and drains a round of 64 as soon as it has one
+constexpr int MAIN_LUT_WORDS = 512;  // LDS words [0, 512): 4 two-bit codes (a byte of the packed genome) -> 4 letters, for the forward mate
+                                     // and -- complemented, in reverse order -- for the reverse mate (at LDS offset 0: the lookups'
+                                     // addresses are one SDWA shift of the window byte, the table base an immediate offset)
+// Dynamic LDS of k_main (32-bit words), after the MAIN_LUT_WORDS of the letter tables:
 //   [0, tile_words)           compressed quality rows of the position tile: per (mate, bin slot, group)
 //                             GS words = 4 rows of stride_w words + 1 pad word; a row = guide bytes
 //                             (1 << GB of them, each the BYTE offset 4 * j of an entry) then packed entries
@@ -744,7 +747,7 @@ constexpr int SLOW_RING = 128;  // entries (two words) of a wavefront's private 
 //   [mut, +128)               the substitution-test thresholds (u64) of phreds 0 .. n_q (exact path)
 //   [subst, +2 * TP * 4)      per (mate, position of the tile, template base): leading 13 bits of the two substitution
 //                             thresholds | alternatives (2 bits each, indices into DevModel::alt_letters) << 26
-//   [rings]                   MAIN_THREADS / 64 private rings of SLOW_RING deferred lane-items, two words each
+//   [rings]                   MAIN_THREADS / 64 private rings of SLOW_RING deferred lane-items, three words each
 struct MainTile {  // per-workgroup constants of k_main
     int s0;        // first superitem (8 positions) of the tile
     uint32_t ts;   // superitems in the tile
@@ -840,6 +843,17 @@ __device__ __forceinline__ uint32_t hot_lookup(const uint8_t *ldsb, uint32_t row
     return sel;
 }
 
+// word (byte BYTE of w) of the letter table at byte offset OFF of the LDS: the address is ONE instruction (byte select and
+// "* 4" in an SDWA multiply), the table base the load's immediate offset
+template <int BYTE, int OFF>
+__device__ __forceinline__ uint32_t lut_at(const uint32_t *lds0, uint32_t w) {
+    uint32_t a;
+    const uint32_t four = 4u;
+    if (BYTE == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(a) : "v"(w), "v"(four));
+    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(w), "v"(four));
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds0) + OFF + a);
+}
+
 // r = r << 1 | flag in one instruction: the flag's lane mask is the carry-in of v_addc
 __device__ __forceinline__ uint32_t shift_in(uint32_t r, unsigned long long flag_mask) {
     asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(r) : "s"(flag_mask) : "vcc");
@@ -862,7 +876,8 @@ __device__ __forceinline__ uint32_t shift_in(uint32_t r, unsigned long long flag
 template <bool STORE_MUT, bool PLAIN, bool SUBLIST>
 __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    uint32_t *const lds = lds_all + MAIN_LUT_WORDS;  // (the tables; the letter tables stand in front of them)
     // workgroups are dealt to the position tiles in proportion to the tiles' sizes (the last tile may be short)
     int tile = 0;
     while (tile + 1 < M.n_tiles && blockIdx.x >= A.tile_wg0[tile + 1]) ++tile;
@@ -871,10 +886,11 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     T.s0 = tile * M.TS;
     T.ts = (uint32_t)min(M.TS, M.S - T.s0);
     // Deferred lane-items (a base needs the exact path): a private ring per wavefront -- no atomics, no barriers.
-    // Entry = {(pass << it_bits | iteration) << 19 | lane << 13 | half << 12 | bin slots << 8 | base mask,
-    //          forward window | complemented reverse window << 16 (2-bit codes of the lane-item's 8 + 8 template bases)};
+    // Entry = {(pass << it_bits | iteration) << 19 | lane << 13 | bin slots << 8,
+    //          forward window | complemented reverse window << 16 (2-bit codes of the lane-item's 8 + 8 template bases),
+    //          base mask: bit 15 - (8 * half + s) <=> base s = mate * 4 + cc of that half of the superitem};
     // head / tail are wave-uniform.
-    uint2 *ring = reinterpret_cast<uint2 *>(lds + M.tile_words + MAIN_MUT_WORDS + 2 * M.TP * 4) + (threadIdx.x >> 6) * SLOW_RING;
+    uint32_t *ring = lds + M.tile_words + MAIN_MUT_WORDS + 2 * M.TP * 4 + (threadIdx.x >> 6) * (SLOW_RING * 3);
     uint32_t q_head = 0, q_tail = 0;
     const uint32_t lane = threadIdx.x & 63u;
     {   // stage this tile's tables in LDS (once per workgroup)
@@ -884,9 +900,18 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) reinterpret_cast<uint64_t *>(lds + M.tile_words)[i] = M.mut_thr[i];
         const uint32_t *ssrc = M.subst13 + (size_t)tile * 2 * M.TP * 4;
         for (int i = threadIdx.x; i < 2 * M.TP * 4; i += blockDim.x) lds[M.tile_words + MAIN_MUT_WORDS + i] = ssrc[i];
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) {  // the letter tables: byte k of entry i = the letter of code k of byte i
+            uint32_t f = 0, r = 0;
+            for (int k = 0; k < 4; ++k) {
+                f |= (uint32_t)code_to_ascii(((uint32_t)i >> (2 * k)) & 3u) << (8 * k);
+                r |= (uint32_t)code_to_ascii((((uint32_t)i >> (2 * (3 - k))) & 3u) ^ 1u) << (8 * k);  // complement: code ^ 1
+            }
+            lds_all[i] = f;
+            lds_all[256 + i] = r;
+        }
     }
     __syncthreads();
-    const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds);
+    const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds_all);  // (row offsets below count from the start of LDS: ds_read2's offsets are too narrow to skip the letter tables)
     auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     const uint32_t n_iter = sgpr((T.ts + 3u) >> 2);
     const uint32_t it_max = ((uint32_t)M.TS + 3u) / 4u - 1u;  // largest iteration number of a pass
@@ -910,42 +935,45 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     auto drain_round = [&](uint32_t n) {
         // (the byte patches below follow this wavefront's own stores of the same lines: vector memory instructions of
         //  one wavefront reach a given address in issue order, no wait is needed)
-        uint2 rest = {0u, 0u};
+        uint32_t rest_m = 0u, ent_x = 0u, ent_y = 0u;
         int subst = 0;
         uint32_t sub_pair = 0;
         MutRecord rec;
         rec.position = 0; rec.mate = 0; rec.ref = 0;
         if (lane < n) {
-            const uint2 ent = ring[(q_head + lane) & (SLOW_RING - 1)];
-            const uint32_t e_pass = ent.x >> (19u + it_bits), e_it = (ent.x >> 19) & ((1u << it_bits) - 1u), e_lane = (ent.x >> 13) & 63u;
+            const uint32_t *ep = ring + ((q_head + lane) & (SLOW_RING - 1)) * 3;
+            ent_x = ep[0]; ent_y = ep[1];
+            const uint32_t e_pass = ent_x >> (19u + it_bits), e_it = (ent_x >> 19) & ((1u << it_bits) - 1u), e_lane = (ent_x >> 13) & 63u;
             const uint32_t e_pair = __umul24(wg + __umul24(e_pass, n_wg), (uint32_t)MAIN_PAIRS) + wave_pair0 + (e_lane >> 2);
-            const uint32_t mask = ent.x & 0xffu;  // never empty
+            const uint32_t mask = ep[2];  // never empty
             const int bit = 31 - __clz(mask);
-            if (mask & (mask - 1u)) rest = make_uint2(ent.x & ~(1u << bit), ent.y);
-            subst = main_slow_base<PLAIN>(M, g, A, desc, lds, T, e_pair, 4u * e_it + (e_lane & 3u), (int)((ent.x >> 12) & 1u),
-                                                    7 - bit, (ent.x >> 8) & 15u, ent.y, rec);
+            rest_m = mask & ~(1u << bit);
+            subst = main_slow_base<PLAIN>(M, g, A, desc, lds, T, e_pair, 4u * e_it + (e_lane & 3u), (15 - bit) >> 3,
+                                                    (15 - bit) & 7, (ent_x >> 8) & 15u, ent_y, rec);
             if (STORE_MUT) mut_emit(A, mchunk, subst == 3, rec);
             sub_pair = e_pair;
         }
         // (models with indels: the reads k_indel_apply shifts have their substitutions re-applied from this list)
         if (SUBLIST) sub_emit(A, schunk, subst != 0, sub_pair, (uint32_t)rec.position | ((uint32_t)rec.mate << 15) | ((uint32_t)rec.ref << 16));
         q_head += n;
-        const unsigned long long again = __ballot(rest.x != 0u);
+        const unsigned long long again = __ballot(rest_m != 0u);
         if (again) {
-            if (rest.x) {
+            if (rest_m) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
-                ring[(q_tail + rank) & (SLOW_RING - 1)] = rest;
+                uint32_t *ep = ring + ((q_tail + rank) & (SLOW_RING - 1)) * 3;
+                ep[0] = ent_x; ep[1] = ent_y; ep[2] = rest_m;
             }
             q_tail += (uint32_t)__popcll(again);
         }
     };
-    // tag: (pass << it_bits | iteration) << 19 | lane << 13 | half << 12 | bin slots << 8
+    // tag: (pass << it_bits | iteration) << 19 | lane << 13 | bin slots << 8; rare: the base mask of the lane-item's 16 bases
     auto push = [&](uint32_t rare, uint32_t tag, uint32_t windows) {
         const unsigned long long rm = __ballot(rare != 0u);
         if (rm) {
             if (rare) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
-                ring[(q_tail + rank) & (SLOW_RING - 1)] = make_uint2(tag | rare, windows);
+                uint32_t *ep = ring + ((q_tail + rank) & (SLOW_RING - 1)) * 3;
+                ep[0] = tag; ep[1] = windows; ep[2] = rare;
             }
             q_tail += (uint32_t)__popcll(rm);
             while (q_tail - q_head >= 64u) drain_round(64u);
@@ -968,7 +996,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         }
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
         // LDS byte offsets of the pair's rows (its bin slots) at this lane's first superitem; one iteration = 8 groups on
-        const uint32_t lane_row = j4 * 2u * gs_b;
+        const uint32_t lane_row = j4 * 2u * gs_b + (uint32_t)MAIN_LUT_WORDS * 4u;
         uint32_t rowf = __umul24(d.meta & 3u, slot_b) + lane_row, rowf_e = rowf + gbytes;
         uint32_t rowr = __umul24((uint32_t)M.NB + ((d.meta >> 2) & 3u), slot_b) + lane_row, rowr_e = rowr + gbytes;
         const uint32_t s_lane = (uint32_t)T.s0 + j4;
@@ -978,7 +1006,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         const bool regular = PLAIN || !(A.has_frag && (d.meta & 64u));  // irregular pairs are built by the fix-up kernel
         const uint32_t tag0 = (pass << (19u + it_bits)) | (lane << 13) | ((d.meta & 15u) << 8);
         for (uint32_t it = 0; it < n_iter; ++it) {
-            uint32_t rare0 = 0, rare1 = 0, windows = 0;
+            uint32_t rare0 = 0, windows = 0;
             if (valid && 4u * it + j4 < T.ts) {
                 const uint32_t s_abs = s_lane + 4u * it;
                 // ---- the two 8-base windows of the 2-bit genome: forward g[pf .. pf+7]; reverse comp(g[pr+7 .. pr]); loaded
@@ -999,7 +1027,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
 #define ISS_LOOKUP(K, ROW, C, HI, BYTE, WQ, WE, RARE)                                                                \
                 sel[K] = hot_lookup<HI, BYTE>(ldsb, ROW, ROW##_e, off_g[C], WQ, WE, gsh, gb, fl);                      \
                 RARE = shift_in(RARE, fl);
-                // half 0: positions 0-3; bit (7 - s) of rare0 <=> base s = mate * 4 + cc
+                // half 0: positions 0-3; bit 15 - (8 * half + s) of rare0 <=> base s = mate * 4 + cc of that half
                 ISS_LOOKUP(0, rowf, 0, 0, 0, q0.x, ee.x, rare0)
                 ISS_LOOKUP(1, rowf, 1, 1, 1, q0.x, ee.x, rare0)
                 ISS_LOOKUP(2, rowf, 2, 0, 2, q0.y, ee.x, rare0)
@@ -1009,14 +1037,14 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 ISS_LOOKUP(6, rowr, 2, 0, 2, q0.w, ee.y, rare0)
                 ISS_LOOKUP(7, rowr, 3, 1, 3, q0.w, ee.y, rare0)
                 // half 1: positions 4-7
-                ISS_LOOKUP(8, rowf, 4, 0, 0, q1.x, ee.z, rare1)
-                ISS_LOOKUP(9, rowf, 5, 1, 1, q1.x, ee.z, rare1)
-                ISS_LOOKUP(10, rowf, 6, 0, 2, q1.y, ee.z, rare1)
-                ISS_LOOKUP(11, rowf, 7, 1, 3, q1.y, ee.z, rare1)
-                ISS_LOOKUP(12, rowr, 4, 0, 0, q1.z, ee.w, rare1)
-                ISS_LOOKUP(13, rowr, 5, 1, 1, q1.z, ee.w, rare1)
-                ISS_LOOKUP(14, rowr, 6, 0, 2, q1.w, ee.w, rare1)
-                ISS_LOOKUP(15, rowr, 7, 1, 3, q1.w, ee.w, rare1)
+                ISS_LOOKUP(8, rowf, 4, 0, 0, q1.x, ee.z, rare0)
+                ISS_LOOKUP(9, rowf, 5, 1, 1, q1.x, ee.z, rare0)
+                ISS_LOOKUP(10, rowf, 6, 0, 2, q1.y, ee.z, rare0)
+                ISS_LOOKUP(11, rowf, 7, 1, 3, q1.y, ee.z, rare0)
+                ISS_LOOKUP(12, rowr, 4, 0, 0, q1.z, ee.w, rare0)
+                ISS_LOOKUP(13, rowr, 5, 1, 1, q1.z, ee.w, rare0)
+                ISS_LOOKUP(14, rowr, 6, 0, 2, q1.w, ee.w, rare0)
+                ISS_LOOKUP(15, rowr, 7, 1, 3, q1.w, ee.w, rare0)
 #undef ISS_LOOKUP
                 // phred bytes: byte 1 of each selected entry
                 auto quals = [&](int k) {
@@ -1026,18 +1054,18 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 // ---- template bases
                 uint32_t fm = 0, rm = 0;
                 const uint32_t fb = funnel_r(gf.x, gf.y, (uint32_t)(pf & 15) * 2);
-                const uint32_t rb = funnel_r(gr.x, gr.y, (uint32_t)(pr & 15) * 2) ^ 0x5555u;  // complement: code ^ 1
-                windows = __builtin_amdgcn_perm(rb, fb, 0x05040100u);  // fb[15:0] | rb[15:0] << 16
+                const uint32_t rbr = funnel_r(gr.x, gr.y, (uint32_t)(pr & 15) * 2);
+                windows = __builtin_amdgcn_perm(rbr ^ 0x5555u, fb, 0x05040100u);  // fb[15:0] | complemented (code ^ 1) rb[15:0] << 16
                 if (!PLAIN && regular && (d.meta & 0x30u)) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
                     const uint32_t *mw = g.mask + (pf >> 5);
                     fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xffu;
                     const uint32_t *nw = g.mask + (pr >> 5);
                     rm = funnel_r(nw[0], nw[1], (uint32_t)(pr & 31)) & 0xffu;
                 }
-                uint2 base_f = {codes_to_ascii4(fb & 0xffu), codes_to_ascii4((fb >> 8) & 0xffu)};
-                // reverse mate: read position c <-> genome position pr + 7 - c
-                uint2 base_r = {__builtin_amdgcn_perm(0u, codes_to_ascii4((rb >> 8) & 0xffu), 0x00010203u),
-                                __builtin_amdgcn_perm(0u, codes_to_ascii4(rb & 0xffu), 0x00010203u)};
+                // (letters from the LDS tables: forward a byte of codes as it stands; reverse mate: read position c <-> genome
+                //  position pr + 7 - c, complemented)
+                uint2 base_f = {lut_at<0, 0>(lds_all, fb), lut_at<1, 0>(lds_all, fb)};
+                uint2 base_r = {lut_at<1, 1024>(lds_all, rbr), lut_at<0, 1024>(lds_all, rbr)};
                 if (!PLAIN && (fm | rm)) {  // IUPAC / lower-case letters: patch from the ASCII copy
                     for (int c = 0; c < 8; ++c) {
                         if ((fm >> c) & 1u) {
@@ -1057,9 +1085,8 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 dst[0] = make_uint4(base_f.x, base_f.y, qual_f.x, qual_f.y);
                 dst[4] = make_uint4(base_r.x, base_r.y, qual_r.x, qual_r.y);
             }
-            // bit (7 - s) <=> base s of the half needs the exact path (~1.7 % of bases: mostly substitution events)
+            // bit 15 - (8 * half + s) <=> base s of that half needs the exact path (~0.9 % of bases: mostly substitution tests that tie)
             push(rare0, tag0 | (it << 19), windows);
-            push(rare1, tag0 | (it << 19) | 4096u, windows);
             rowf += 8u * gs_b; rowf_e += 8u * gs_b;
             rowr += 8u * gs_b; rowr_e += 8u * gs_b;
             pf += 32;

@@ -461,7 +461,7 @@ int mt_prefetch_commit(iss_ctx *ctx, const MtPrefetch &pf) {
 
 // dynamic LDS of k_main: quality rows + deferred-work queues
 size_t main_lds_bytes(const iss::DevModel &M) {
-    return ((size_t)M.tile_words + iss::MAIN_MUT_WORDS + (size_t)2 * M.TP * 4 + (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 2) * 4;
+    return ((size_t)iss::MAIN_LUT_WORDS + M.tile_words + iss::MAIN_MUT_WORDS + (size_t)2 * M.TP * 4 + (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 3) * 4;
 }
 
 int settle_timing(iss_ctx *ctx) {
@@ -903,8 +903,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         for (int nt = 1; nt <= M.S; ++nt) {
             const int ts = nt > 1 ? ((M.S + nt - 1) / nt + 3) / 4 * 4 : M.S;
             const size_t tg = 2 * (size_t)ts;
-            const size_t words = (2 * (size_t)M.NB * tg * gs + 3) / 4 * 4 + iss::MAIN_MUT_WORDS + 2 * tg * 4 * 4 +
-                                 (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 2;
+            const size_t words = (size_t)iss::MAIN_LUT_WORDS + (2 * (size_t)M.NB * tg * gs + 3) / 4 * 4 + iss::MAIN_MUT_WORDS + 2 * tg * 4 * 4 +
+                                 (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 3;
             if (words * 4 <= 158 * 1024) { *ts_out = ts; return (M.S + ts - 1) / ts; }
         }
         *ts_out = 0;
