@@ -1338,8 +1338,10 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
                 rec_lo = it.off; rec_hi = it.off + it.L; plain = !it.has_exceptions;
             }
             // window: tokens 0 .. WIN - 1 = genome positions fs .. fs + WIN - 1 (forward) / re - 1 down to re - WIN (reverse)
+            // (beyond the record's ends the reference pads with 'A', uncomplemented -- __init__.py:141-155: code 0 in a forward
+            //  window, code 1 in a reverse one, whose letters are complemented)
             const int64_t w_lo = o ? (int64_t)d.re - WIN : (int64_t)d.fs;
-            const bool simple = plain && !all_to_fixup && w_lo >= rec_lo && w_lo + WIN <= rec_hi;
+            const bool simple = plain && !all_to_fixup;
             auto to_fixup = [&]() {
                 if (!(atomicOr(&A.flags[pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
             };
@@ -1347,9 +1349,21 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
             uint32_t *R = wave0 + lane * RW, *win = R + AP_HDR, *runs = win + WW, *let = runs + AP_RUNS;
             const int64_t wpos = (w_lo >> 4) << 4;  // genome position of bit 0 of the window
             const int t0pos = (int)((o ? (int64_t)d.re - 1 : (int64_t)d.fs) - wpos);  // window position of token 0 (token t: t0pos +/- t)
-            if (ok) {
+            if (ok && w_lo >= rec_lo && w_lo + WIN <= rec_hi) {  // the window lies inside the record (all but a few reads in 10^5)
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(((wpos >> 4) + 1) << 2));
                 for (int k = 0; k < WW; ++k) win[k] = src[k];
+            } else if (ok) {
+                const uint32_t pad = o ? 0x55555555u : 0u;
+                for (int k = 0; k < WW; ++k) {
+                    const int64_t g0 = wpos + 16 * k;  // genome position of the word's first base
+                    uint32_t w = pad;
+                    if (g0 + 16 > rec_lo && g0 < rec_hi) {  // (the arena holds other records' letters beyond this one's ends)
+                        w = *reinterpret_cast<const uint32_t *>(packed_b + (size_t)(((g0 >> 4) + 1) << 2));
+                        if (g0 < rec_lo) { const uint32_t m = 0xffffffffu << (2 * (int)(rec_lo - g0)); w = (w & m) | (pad & ~m); }
+                        if (g0 + 16 > rec_hi) { const uint32_t m = 0xffffffffu >> (2 * (int)(g0 + 16 - rec_hi)); w = (w & m) | (pad & ~m); }
+                    }
+                    win[k] = w;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             // the walk over the steps with an event (k_indel_scan lists them in step order, one entry per step)

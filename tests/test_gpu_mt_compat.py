@@ -267,15 +267,15 @@ def test_resolver_equals_walker(engine, monkeypatch, case):
 
 
 def test_config1_scale_short_genomes_miseq(engine):
-    """BASELINE configs[1] flavour: data/genomes.fasta (records shorter than the MiSeq fragment: fallback
-    branches everywhere), --model miseq, seed-fixed, GPU (MT mode) vs CPU (oracle with the reference's MT
-    streams) bit-exact -- 60 k pairs spread over the records like a worker's work list."""
+    """BASELINE configs[1] at its full size: data/genomes.fasta (records shorter than the MiSeq fragment: fallback
+    branches everywhere), --model miseq, 1 M reads, seed-fixed, GPU (MT mode) vs CPU (oracle with the reference's MT
+    streams) bit-exact -- 500 k pairs spread over the records like a worker's work list."""
     from insilicoseq_amd.generator import parse_fasta
     from oracle import oracle as O
 
     dense = dense_model("miseq")
     records = list(parse_fasta(os.path.join(GOLDEN, "genomes.fasta")))
-    counts = [24000, 9000, 12000, 15000, 100]
+    counts = [200000, 75000, 100000, 124900, 100]
     engine.load_model(dense)
     engine.clear_genomes()
     engine.seed_mt(42)
@@ -297,6 +297,36 @@ def test_config1_scale_short_genomes_miseq(engine):
     py, npw = engine.mt_peek(8)
     assert list(_res53(py)) == [rng.py_random() for _ in range(4)]
     assert list(_res53(npw)) == [rng.np_random() for _ in range(4)]
+
+
+def test_config1_full_size_philox_windows(engine):
+    """The same work list (BASELINE configs[1]: 1 M reads, data/genomes.fasta, --model miseq) on the parallel path: ONE
+    iss_generate_batch call, windows of every work item (its first and last 1500 pairs: ordinals run across the items)
+    recomputed by the oracle's Philox provider."""
+    from insilicoseq_amd.generator import parse_fasta
+    from oracle import oracle as O
+
+    dense = dense_model("miseq")
+    records = [r for r in parse_fasta(os.path.join(GOLDEN, "genomes.fasta")) if len(r.seq) > dense.read_length]
+    counts = [200000, 75000, 100000, 124900, 100][:len(records)]
+    counts[-1] += 500000 - sum(counts)
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gids = [engine.add_genome(r.seq) for r in records]
+    engine.reserve(sum(counts))
+    engine.generate_batch(gids, counts, first_ordinal=7, seed=42, out_first_pair=0)
+    engine.synchronize()
+    orc = O.Oracle(dense)
+    first = 0
+    for rec, n in zip(records, counts):
+        for w0 in sorted({0, max(0, n - 1500)}):
+            m = min(1500, n - w0)
+            got = engine.download(first + w0, m)
+            exp = orc.simulate(O.Rng().seed_philox(42), rec.seq, m, first_ordinal=7 + first + w0)
+            assert exp["status"] == 0
+            for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+                assert np.array_equal(got[k], exp[k]), (rec.id, w0, k)
+        first += n
 
 
 @pytest.mark.parametrize("case", ["syn_novaseq_vcf", "genomes_basic_cpu2"])
