@@ -253,9 +253,12 @@ struct RunArgs {
     const int64_t *ov_frags;      // ... with these host-evaluated fragment lengths
     uint32_t n_ov;
     uint32_t *flags, *fix_list, *fix_count;  // irregular pairs (template shorter than the read, ...) go straight to the fix-up
-    // indel events (k_indel_scan -> k_indel_apply): per read a counter and EV_K event words (step << 8 | event mask); reads
-    // (2 * pair + mate) with an event are listed once in read_list
-    uint32_t *ev_count, *ev_list, *read_list, *read_count;
+    // indel events (k_indel_scan -> k_indel_apply): reads (2 * pair + mate) with an event are listed once in read_list as
+    // {read, first event, second event, number of steps with an event}, an event = step << 8 | event mask; a read with
+    // more than two such steps keeps all of them in its EV_K words of ev_list.  ev_count[read] = min(steps with an
+    // event, 15) | first such step << 4 (0: none) for every read of the launch.
+    uint32_t *ev_count, *ev_list, *read_count;
+    uint4 *read_list;
     // substitutions k_main applied (models with indels only): {pair, position | mate << 15 | template letter << 16}, appended in
     // chunks of SUB_CHUNK entries per wavefront (unused entries: pair == 0xffffffff); sub_count[0] = entries reserved,
     // sub_count[1] != 0: the list overflowed (k_indel_apply then hands every listed read to k_indel_fixup)
@@ -1113,7 +1116,7 @@ constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to 
                                        // bits 4-5 mate is in read_list
 constexpr int SCAN_RANGE = 2048;  // reads of a wavefront's range whose event counts are staged in LDS (written out in whole lines)
 __host__ __device__ inline size_t scan_lds_bytes(int ev_ns) {
-    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 7) & ~(size_t)7) + (size_t)(SCAN_THREADS / 64) * (SCAN_LIST * 4 + SCAN_RANGE);
+    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 15) & ~(size_t)15) + (size_t)(SCAN_THREADS / 64) * (SCAN_LIST * 16 + SCAN_RANGE * 2);
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
@@ -1121,10 +1124,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     const int ns = M.ev_ns;
     uint64_t *l_S = scan_lds;                                         // [2][ns]
     uint16_t *l_E = reinterpret_cast<uint16_t *>(l_S + 2 * ns);       // [2][ns]
-    uint32_t *l_list = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(scan_lds) + (size_t)2 * ns * 8 + (((size_t)2 * ns * 2 + 7) & ~(size_t)7)) +
-                       (threadIdx.x >> 6) * SCAN_LIST;                // this wavefront's listed reads
-    uint8_t *l_cnt = reinterpret_cast<uint8_t *>(scan_lds) + (size_t)2 * ns * 8 + (((size_t)2 * ns * 2 + 7) & ~(size_t)7) +
-                     (size_t)(SCAN_THREADS / 64) * SCAN_LIST * 4 + (threadIdx.x >> 6) * SCAN_RANGE;  // this wavefront's event counts
+    uint8_t *l_rest = reinterpret_cast<uint8_t *>(scan_lds) + (size_t)2 * ns * 8 + (((size_t)2 * ns * 2 + 15) & ~(size_t)15);
+    uint4 *l_list = reinterpret_cast<uint4 *>(l_rest) + (threadIdx.x >> 6) * SCAN_LIST;  // this wavefront's listed reads
+    uint16_t *l_cnt = reinterpret_cast<uint16_t *>(l_rest + (size_t)(SCAN_THREADS / 64) * SCAN_LIST * 16) + (threadIdx.x >> 6) * SCAN_RANGE;  // ... event counts
     for (int i = threadIdx.x; i < 2 * ns; i += blockDim.x) { l_S[i] = M.ev_S[i]; l_E[i] = M.ev_E[i]; }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -1145,7 +1147,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
     // of every lane's current read; a lane whose read is finished takes the next read of the wavefront's range.
     uint32_t next = w_first;  // wave-uniform
     bool busy = false;
-    uint32_t rd = 0, cnt = 0, prev = 0, j = 0;
+    uint32_t rd = 0, cnt = 0, prev = 0, j = 0, e0 = 0, e1 = 0;  // (e0, e1: the read's first two events; prev: its last)
     int cur = -1, o = 0;
     Addr a = make_addr(A.seed, A.first_ordinal, 0u);
     for (;;) {
@@ -1153,7 +1155,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
         if (need && next < w_last) {
             const uint32_t cand = next + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (!busy && cand < w_last) {
-                rd = cand; cnt = 0; prev = 0; j = 0; cur = -1; busy = true;
+                rd = cand; cnt = 0; prev = 0; j = 0; cur = -1; busy = true; e0 = 0; e1 = 0;
                 o = (int)(rd & 1u);
                 // the attempt number is 0 unless gc_bias re-drew the pair: no descriptor load in the common case
                 a = make_addr(A.seed, A.first_ordinal + (rd >> 1), A.gc_bias ? desc[rd >> 1].meta >> 16 : 0u);
@@ -1170,17 +1172,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
                 int slot;
                 uint32_t mask;
                 cur = ev_step(l_S + o * ns, l_E + o * ns, M.ev_T + (size_t)o * ns, M.del_thr + (size_t)o * M.RL * 4, cur, mk53(w.x, w.y), mk53(w.z, w.w), slot, mask);
-                if (slot >= 0) {  // (one list entry per step: a step's tests come one after the other)
-                    uint32_t *list = A.ev_list + (size_t)rd * EV_K;
+                if (slot >= 0) {  // (one event per step: a step's tests come one after the other)
+                    uint32_t *list = A.ev_list + (size_t)rd * EV_K;  // (written only for reads with more than two events)
                     const int n = slot / 5;
                     if (cnt && (int)(prev >> 8) == n) {
                         prev |= mask;
-                        if (cnt <= (uint32_t)EV_K) list[cnt - 1] = prev;
                     } else {
                         prev = ((uint32_t)n << 8) | mask;
-                        if (cnt < (uint32_t)EV_K) list[cnt] = prev;
                         ++cnt;
+                        if (cnt == 3u) { list[0] = e0; list[1] = e1; }
                     }
+                    if (cnt == 1u) e0 = prev; else if (cnt == 2u) e1 = prev; else if (cnt <= (uint32_t)EV_K) list[cnt - 1] = prev;
                 }
             }
             if (cur >= ns - 1) {  // the read is done
@@ -1189,14 +1191,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
                     cnt = 0;
                 }
                 // (every read's counter is written: nothing else initialises them -- staged, so that they leave in whole lines)
-                if (rd - w_first < (uint32_t)SCAN_RANGE) l_cnt[rd - w_first] = (uint8_t)cnt; else A.ev_count[rd] = cnt;
+                const uint32_t evc = cnt ? min(cnt, 15u) | ((e0 >> 8) << 4) : 0u;  // steps with an event (capped) | the first of them << 4
+                if (rd - w_first < (uint32_t)SCAN_RANGE) l_cnt[rd - w_first] = (uint16_t)evc; else A.ev_count[rd] = evc;
                 fin = true;
                 busy = false;
             }
         }
         const unsigned long long m = __ballot(fin && cnt != 0u);
         if (m) {
-            if (fin && cnt) l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rd;
+            if (fin && cnt) l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = make_uint4(rd, e0, e1, cnt);
             n_listed += (uint32_t)__popcll(m);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             if (n_listed >= (uint32_t)SCAN_LIST - 64u) flush_list();  // (room for the next 64)
@@ -1256,7 +1259,8 @@ __host__ __device__ inline int apply_waves(int RL, int pitch) {
 }
 __host__ __device__ inline size_t apply_lds_bytes(int RL, int pitch) { return ap_tab_bytes(RL) + (size_t)apply_waves(RL, pitch) * ap_wave_bytes(pitch); }
 
-template <bool STORE_MUT>
+// WWM: window words a lane keeps in registers for the NEXT block's read (>= ap_ww(pitch): 12 for read lengths up to 168, else 26)
+template <bool STORE_MUT, int WWM>
 __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(DevModel M, DevGenome g, RunArgs A,
                                                                               const PairDesc *__restrict__ desc, uint64_t *stats) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ap_lds[];
@@ -1295,33 +1299,52 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
     // (descriptor, flags, events) one block ahead -- a chain of dependent loads behind the chip's write stream
     const uint32_t NO_READ = 0xffffffffu, stride = gridDim.x * n_waves;
     const uint32_t blk0 = blockIdx.x * n_waves + wv;
-    auto list_entry = [&](uint32_t b) { return b < n_blocks && b * 64u + lane < n_list ? A.read_list[b * 64u + lane] : NO_READ; };
-    uint32_t rd_a = list_entry(blk0), rd_b = list_entry(blk0 + stride);
-    uint32_t ra = rd_a == NO_READ ? 0u : rd_a;
+    auto list_entry = [&](uint32_t b) { return b < n_blocks && b * 64u + lane < n_list ? A.read_list[b * 64u + lane] : make_uint4(NO_READ, 0u, 0u, 0u); };
+    uint4 rec_a = list_entry(blk0), rec_b = list_entry(blk0 + stride);
+    uint32_t ra = rec_a.x == NO_READ ? 0u : rec_a.x;
     PairDesc d_a = desc[ra >> 1];
-    uint32_t fl_a = A.flags[ra >> 1], cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
-    uint4 ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0], eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
+    uint4 ea_a = make_uint4(0u, 0u, 0u, 0u), eb_a = ea_a;  // (the events of a read with more than two)
+    if (rec_a.x != NO_READ && rec_a.w > 2u) {
+        ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
+        eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
+    }
+    // ... and its window of the packed genome, requested once the descriptor has arrived (at the start of phase 2 of the block
+    // before): the walk of a block starts with everything it reads at hand
+    uint32_t wn[WWM];
+    auto request_window = [&]() {
+        const int64_t wl = (ra & 1u) ? (int64_t)d_a.re - WIN : (int64_t)d_a.fs;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(packed_b + (size_t)((((wl >> 4) << 4 >> 4) + 1) << 2));
+#pragma unroll
+        for (int k = 0; k < WWM; ++k) wn[k] = k < WW ? src[k] : 0u;
+    };
+    request_window();
     for (uint32_t blk = blk0; blk < n_blocks; blk += stride) {
+        uint32_t wc[WWM];  // this block's windows
+#pragma unroll
+        for (int k = 0; k < WWM; ++k) wc[k] = wn[k];
         // ================ phase 1: one lane per read
         {
             const uint32_t rd = ra;
             const uint32_t pair = rd >> 1;
             const int o = (int)(rd & 1u);
             const PairDesc d = d_a;
-            const uint32_t fl = fl_a, cnt = cnt_a;
+            const uint32_t cnt = rec_a.x == NO_READ ? 0u : rec_a.w;
             uint32_t e[EV_K];
             e[0] = ea_a.x; e[1] = ea_a.y; e[2] = ea_a.z; e[3] = ea_a.w; e[4] = eb_a.x; e[5] = eb_a.y; e[6] = eb_a.z; e[7] = eb_a.w;
+            if (cnt <= 2u) { e[0] = rec_a.y; e[1] = rec_a.z; }
             {   // requests for the next two blocks
-                rd_a = rd_b;
-                ra = rd_a == NO_READ ? 0u : rd_a;
+                rec_a = rec_b;
+                ra = rec_a.x == NO_READ ? 0u : rec_a.x;
                 d_a = desc[ra >> 1];
-                fl_a = A.flags[ra >> 1];
-                cnt_a = rd_a == NO_READ ? 0u : A.ev_count[ra];
-                ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
-                eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
-                rd_b = list_entry(blk + 2u * stride);
+                if (rec_a.x != NO_READ && rec_a.w > 2u) {
+                    ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
+                    eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
+                }
+                rec_b = list_entry(blk + 2u * stride);
             }
-            bool ok = cnt > 0u && cnt <= (uint32_t)EV_K && !((fl >> o) & 1u);  // (else: no event, or the mate is k_indel_fixup's already)
+            // (a listed read is never k_indel_fixup's already: the scan lists neither the mates of irregular pairs nor reads
+            //  with more events than a list holds)
+            bool ok = cnt > 0u && cnt <= (uint32_t)EV_K;
             // the record of the pair: the launch's genome, or its slice of the arena (batch calls); descriptors hold arena coordinates
             int64_t rec_lo = 0, rec_hi = g.L;
             bool plain = !g.has_exceptions;
@@ -1350,8 +1373,8 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
             const int64_t wpos = (w_lo >> 4) << 4;  // genome position of bit 0 of the window
             const int t0pos = (int)((o ? (int64_t)d.re - 1 : (int64_t)d.fs) - wpos);  // window position of token 0 (token t: t0pos +/- t)
             if (ok && w_lo >= rec_lo && w_lo + WIN <= rec_hi) {  // the window lies inside the record (all but a few reads in 10^5)
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(((wpos >> 4) + 1) << 2));
-                for (int k = 0; k < WW; ++k) win[k] = src[k];
+#pragma unroll
+                for (int k = 0; k < WWM; ++k) if (k < WW) win[k] = wc[k];  // (requested a block ago)
             } else if (ok) {
                 const uint32_t pad = o ? 0x55555555u : 0u;
                 for (int k = 0; k < WW; ++k) {
@@ -1499,30 +1522,45 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ================ phase 2: four lanes per read, 16 reads at a time
-        for (uint32_t sub = 0; sub < 4u; ++sub) {
-            const uint32_t slot = sub * 16u + (lane >> 2), j4 = lane & 3u;
-            const uint32_t *R = wave0 + slot * RW, *win = R + AP_HDR, *runs = win + WW;
-            const uint32_t pair = R[0], h2 = R[2];
-            const int t0pos = (int)R[1], o = (int)(h2 & 1u), n_runs = (int)((h2 >> 1) & 15u), first_step = (int)((h2 >> 9) & 0x3ffu);
-            const uint64_t evmask = (uint64_t)R[3] | ((uint64_t)R[4] << 32);
-            const bool valid = (h2 >> 31) != 0u;
-            if (!__ballot(valid)) continue;
-            uint8_t *rowp = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
-            int ri = 0, sh = 0, nstart = n_runs > 1 ? (int)(runs[1] & 0xffffu) : 0x7fffffff;
-            // A piece is rewritten WHOLE -- its 8 letters and, unchanged, its 8 phreds -- and the four lanes of a read store a
-            // full 64-byte sector together.  (Letters alone are half a sector, and so is a line whose pieces are written at
-            // different times: HBM with ECC turns every partial write into a read-modify-write -- measured: 1.7 GB written and
-            // 0.6 GB fetched for 0.45 GB of letters, the kernel bound by it.)  The pieces of AP_CH passes are requested
-            // together: a load behind the chip's write stream takes microseconds.
-            const uint32_t *evp = runs + AP_RUNS;  // the pieces with an explicit letter, in ascending order (phase 1)
-            for (int p0 = 0; p0 < n_pass; p0 += AP_CH) {
-                uint4 pv[AP_CH];
+        // A piece is rewritten WHOLE -- its 8 letters and, unchanged, its 8 phreds -- and the four lanes of a read store a full
+        // 64-byte sector together.  (Letters alone are half a sector, and so is a line whose pieces are written at different
+        // times: HBM with ECC turns every partial write into a read-modify-write -- measured: 1.7 GB written and 0.6 GB
+        // fetched for 0.45 GB of letters, the kernel bound by it.)  A load behind the chip's write stream takes
+        // microseconds: the pieces of AP_CH passes are requested together, one step (16 reads x AP_CH passes) ahead of their use.
+        request_window();  // (the next block's: its descriptor was requested at the top of this block)
+        {
+            const int n_chunks = (n_pass + AP_CH - 1) / AP_CH, n_steps = 4 * n_chunks;
+            auto request = [&](int t, uint4 (&dst)[AP_CH]) {  // the pieces of step t: sub-round t / n_chunks, passes (t % n_chunks) * AP_CH ...
+                const uint32_t *R = wave0 + ((uint32_t)(t / n_chunks) * 16u + (lane >> 2)) * RW;
+                const uint32_t h2 = R[2];
+                const uint8_t *rowp = A.out[0] + (size_t)R[0] * M.row + row_array_off(2 * (int)(h2 & 1u));
+                const int first_step = (int)((h2 >> 9) & 0x3ffu), p0 = (t % n_chunks) * AP_CH;
 #pragma unroll
                 for (int q = 0; q < AP_CH; ++q) {
-                    const int piece = 4 * (p0 + q) + (int)j4, j0 = 8 * piece;
-                    pv[q] = make_uint4(0u, 0u, 0u, 0u);
-                    if (valid && p0 + q < n_pass && piece < S && j0 + 8 > first_step) pv[q] = *reinterpret_cast<const uint4 *>(rowp + xp(j0));
+                    const int piece = 4 * (p0 + q) + (int)(lane & 3u), j0 = 8 * piece;
+                    dst[q] = make_uint4(0u, 0u, 0u, 0u);
+                    if ((h2 >> 31) && p0 + q < n_pass && piece < S && j0 + 8 > first_step) dst[q] = *reinterpret_cast<const uint4 *>(rowp + xp(j0));
                 }
+            };
+            uint4 pn[AP_CH];
+            request(0, pn);
+            int ri = 0, sh = 0, nstart = 0;
+            for (int t = 0; t < n_steps; ++t) {
+                uint4 pv[AP_CH];
+#pragma unroll
+                for (int q = 0; q < AP_CH; ++q) pv[q] = pn[q];
+                if (t + 1 < n_steps) request(t + 1, pn);
+                const uint32_t slot = (uint32_t)(t / n_chunks) * 16u + (lane >> 2), j4 = lane & 3u;
+                const int p0 = (t % n_chunks) * AP_CH;
+                const uint32_t *R = wave0 + slot * RW, *win = R + AP_HDR, *runs = win + WW;
+                const uint32_t *evp = runs + AP_RUNS;  // the pieces with an explicit letter, in ascending order (phase 1)
+                const uint32_t pair = R[0], h2 = R[2];
+                const int t0pos = (int)R[1], o = (int)(h2 & 1u), n_runs = (int)((h2 >> 1) & 15u), first_step = (int)((h2 >> 9) & 0x3ffu);
+                const uint64_t evmask = (uint64_t)R[3] | ((uint64_t)R[4] << 32);
+                const bool valid = (h2 >> 31) != 0u;
+                if (!__ballot(valid)) continue;
+                uint8_t *rowp = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
+                if (p0 == 0) { ri = 0; sh = 0; nstart = n_runs > 1 ? (int)(runs[1] & 0xffffu) : 0x7fffffff; }
 #pragma unroll
                 for (int q = 0; q < AP_CH; ++q) {
                     if (p0 + q >= n_pass) break;  // (uniform)
@@ -1574,8 +1612,9 @@ __global__ __launch_bounds__(256) void k_indel_resub(DevModel M, RunArgs A, cons
         const uint32_t pair = e.x;
         const int o = (int)((e.y >> 15) & 1u), j = (int)(e.y & 0x7fffu), orig = (int)((e.y >> 16) & 0xffu);
         const uint32_t rd = 2u * pair + (uint32_t)o;
-        if (!A.ev_count[rd] || ((A.flags[pair] >> o) & 1u)) continue;  // no event: k_main's read stands; k_indel_fixup's mates are rebuilt there
-        const int lim = (int)(A.ev_list[(size_t)rd * EV_K] >> 8) & ~7;  // the first rewritten position
+        const uint32_t evc = A.ev_count[rd];
+        if (!evc || ((A.flags[pair] >> o) & 1u)) continue;  // no event: k_main's read stands; k_indel_fixup's mates are rebuilt there
+        const int lim = (int)(evc >> 4) & ~7;  // the first rewritten position
         if (j < lim && !STORE_MUT) continue;
         uint8_t *rowp = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
         int before = rowp[xp(j)], base = before;

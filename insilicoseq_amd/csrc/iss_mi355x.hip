@@ -191,7 +191,8 @@ struct iss_ctx {
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
-    uint32_t *ev_count = nullptr, *ev_list = nullptr, *read_list = nullptr;  // indel events (k_indel_scan -> k_indel_apply), per row
+    uint32_t *ev_count = nullptr, *ev_list = nullptr;  // indel events (k_indel_scan -> k_indel_apply), per row
+    uint4 *read_list = nullptr;
     uint32_t *read_count = nullptr;  // FIX_SLOTS counters of the read lists, like fix_count
     // models with indels: the substitutions k_main applies (RunArgs::sub_list), sub_per_pair entries per output row + a
     // margin per chunk in flight (every wavefront may leave most of a SUB_CHUNK unused); FIX_SLOTS x {reserved, overflow}
@@ -290,7 +291,8 @@ void free_outputs(iss_ctx *ctx) {
     if (ctx->read_list) (void)hipFree(ctx->read_list);
     if (ctx->sub_list) (void)hipFree(ctx->sub_list);
     ctx->sub_list = nullptr;
-    ctx->ev_count = ctx->ev_list = ctx->read_list = nullptr;
+    ctx->ev_count = ctx->ev_list = nullptr;
+    ctx->read_list = nullptr;
     ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
     ctx->capacity = 0;
 }
@@ -727,7 +729,8 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        const void *applies[] = {reinterpret_cast<const void *>(iss::k_indel_apply<false>), reinterpret_cast<const void *>(iss::k_indel_apply<true>)};
+        const void *applies[] = {reinterpret_cast<const void *>(iss::k_indel_apply<false, 12>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 12>),
+                                 reinterpret_cast<const void *>(iss::k_indel_apply<false, 26>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 26>)};
         for (const void *f : applies) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
@@ -1287,8 +1290,8 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     ctx->ev_count = static_cast<uint32_t *>(q);
     HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * iss::EV_K * (size_t)capacity_pairs));
     ctx->ev_list = static_cast<uint32_t *>(q);
-    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
-    ctx->read_list = static_cast<uint32_t *>(q);
+    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint4) * 2 * (size_t)capacity_pairs));
+    ctx->read_list = static_cast<uint4 *>(q);
     if (ctx->M.n_scan > 0 && !ctx->light) {
         ctx->sub_per_pair = (int64_t)std::ceil(3.0 * (double)ctx->M.exp_subs) + 2;
         HIP_TRY(ctx, hipMalloc(&q, sizeof(uint2) * ((size_t)ctx->sub_per_pair * (size_t)capacity_pairs + (size_t)(FIX_SLOTS + 1) * SUB_MARGIN)));
@@ -1546,8 +1549,11 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                 const int64_t per_wg = (int64_t)waves * 64;  // reads per workgroup pass; at most 2 n reads (the list is usually far shorter)
                 const unsigned blocks = (unsigned)std::min<int64_t>(ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
                 const dim3 grid(blocks), block(64 * waves);
-                if (A.mut) hipLaunchKernelGGL((iss::k_indel_apply<true>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats);
-                else hipLaunchKernelGGL((iss::k_indel_apply<false>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats);
+                const bool narrow = iss::ap_ww(M.pitch) <= 12;  // (window words a lane prefetches in registers)
+                if (A.mut) { if (narrow) hipLaunchKernelGGL((iss::k_indel_apply<true, 12>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats);
+                             else hipLaunchKernelGGL((iss::k_indel_apply<true, 26>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats); }
+                else { if (narrow) hipLaunchKernelGGL((iss::k_indel_apply<false, 12>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats);
+                       else hipLaunchKernelGGL((iss::k_indel_apply<false, 26>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats); }
                 if (A.sub_list) {  // the listed substitutions of the reads just rebuilt, on the letters that stand there now
                     const dim3 rgrid((unsigned)std::min<int64_t>(4 * ctx->n_cu, (2 * n + 255) / 256)), rblock(256);
                     if (A.mut) hipLaunchKernelGGL((iss::k_indel_resub<true>), rgrid, rblock, 0, s_indel, M, A, desc);
