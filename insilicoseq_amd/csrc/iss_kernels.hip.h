@@ -265,6 +265,8 @@ struct RunArgs {
     uint2 *sub_list;
     uint32_t *sub_count;
     uint32_t sub_cap;
+    PairDesc *desc_out;  // k_main copies the descriptors it works from here (the call's own set is double-buffered: k_setup of the
+                         // next call may be rewriting it while the host asks for this call's coordinates)
     int32_t light;  // 1: reads with an indel are rare (DevModel::p_read_event): k_indel_scan hands every one of them to k_indel_fixup
                     // (no substitution list, no k_indel_apply / k_indel_resub launches)
     uint16_t tile_wg0[MAX_TILES + 2];  // k_main: workgroups [tile_wg0[t], tile_wg0[t + 1]) work on position tile t
@@ -993,6 +995,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         const uint32_t pair = blk * MAIN_PAIRS + wave_pair0 + (lane >> 2);
         const bool valid = pair < (uint32_t)A.n_pairs;
         const PairDesc d = d_next;
+        if (tile == 0 && j4 == 0u && valid) A.desc_out[pair] = d;
         {
             const uint32_t pair_n = pair + n_wg * MAIN_PAIRS;
             if (blk + n_wg < n_pass && pair_n < (uint32_t)A.n_pairs) d_next = desc[pair_n];

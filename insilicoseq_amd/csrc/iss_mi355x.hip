@@ -81,9 +81,11 @@ inline int letter_class(uint8_t c) {
     return ok ? 2 : 0;
 }
 
+constexpr int FIX_SLOTS_C = 16;  // (= FIX_SLOTS below)
 struct TimedLaunch {
-    // main stream: ev0 setup ev1 main ev2;  indel stream: ev3 scan ev4 ... ev5 fixup ev6
-    hipEvent_t ev[7];
+    // main stream: ev0 setup ev1 main ev2;  indel stream: ev3 scan ev4 ... ev5 fixup ev6;  ev7: the end of k_setup when it
+    // runs on the setup stream (beside the previous call's kernels)
+    hipEvent_t ev[8];
     bool has_scan;
 };
 
@@ -92,7 +94,7 @@ struct PendingIndel {  // indel-stream work still in flight on output rows [row0
     hipEvent_t done;
 };
 
-constexpr int FIX_SLOTS = 16;  // ring of fix-list counters (one per chunk in flight on the indel stream)
+constexpr int FIX_SLOTS = FIX_SLOTS_C;  // ring of fix-list counters (one per chunk in flight on the indel stream)
 constexpr size_t SUB_MARGIN = (size_t)1 << 20;  // entries a chunk's substitution list holds beyond its expectation (4096 wavefronts x SUB_CHUNK)
 
 // Device-formatted FASTQ on its way to the files: two slots of (device text, pinned host text) per mate; the
@@ -159,6 +161,20 @@ struct iss_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // setup + main kernels
     hipStream_t indel_stream = nullptr;  // indel scan + fix-up of a chunk run beside the next chunk's main kernel
+    // k_setup of a call runs on its own stream, beside the kernels of the call (or chunk) before: it reads nothing they
+    // write, and what it writes -- descriptors, flags, the fix-up list -- is double-buffered by call parity (`desc`, `flags`,
+    // `fix_list` below point at the current call's set).  ISS_SETUP_AHEAD=0: everything in order on one stream.
+    hipStream_t setup_stream = nullptr;
+    bool setup_ahead = true;
+    iss::PairDesc *desc_buf[2] = {nullptr, nullptr};
+    uint32_t *flags_buf[2] = {nullptr, nullptr}, *fixl_buf[2] = {nullptr, nullptr};
+    hipEvent_t ev_call_done[2] = {nullptr, nullptr};  // the last kernel of the last call that used the set
+    bool ev_call_valid[2] = {false, false};
+    hipEvent_t ev_setup_done[FIX_SLOTS_C] = {};         // k_setup of a chunk -> its k_main (ring, like the counters)
+    hipEvent_t ev_inputs = nullptr;                     // tables / arena copies queued on the main stream for this call's k_setup
+    uint64_t call_seq = 0;
+    bool inputs_pending = false;  // copies for this call's k_setup were queued on the main stream (ev_inputs)
+    bool timing_all = false;      // HIP events around every kernel: one stream
     bool overlap = false;  // ISS_OVERLAP=1: run the indel passes beside the next chunk (measured: no gain, k_main is VALU-bound)
     std::vector<PendingIndel> pending;
     GenomeArena arena;
@@ -284,8 +300,13 @@ void free_outputs(iss_ctx *ctx) {
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     ctx->d_stage = nullptr; ctx->stage_cap = 0;
     if (ctx->desc) (void)hipFree(ctx->desc);
-    if (ctx->flags) (void)hipFree(ctx->flags);
-    if (ctx->fix_list) (void)hipFree(ctx->fix_list);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->desc_buf[k]) (void)hipFree(ctx->desc_buf[k]);
+        if (ctx->flags_buf[k]) (void)hipFree(ctx->flags_buf[k]);
+        if (ctx->fixl_buf[k]) (void)hipFree(ctx->fixl_buf[k]);
+        ctx->desc_buf[k] = nullptr; ctx->flags_buf[k] = nullptr; ctx->fixl_buf[k] = nullptr;
+        ctx->ev_call_valid[k] = false;
+    }
     if (ctx->ev_count) (void)hipFree(ctx->ev_count);
     if (ctx->ev_list) (void)hipFree(ctx->ev_list);
     if (ctx->read_list) (void)hipFree(ctx->read_list);
@@ -473,9 +494,11 @@ int settle_timing(iss_ctx *ctx) {
         if (t.has_scan && t.ev[6]) HIP_TRY(ctx, hipEventSynchronize(t.ev[6]));
         for (int k = 0; k < 4; ++k) {
             if (k >= 2 && !t.has_scan) continue;
-            if (!t.ev[first[k]] || !t.ev[first[k] + 1]) continue;  // k_main-only timing
+            hipEvent_t e_end = t.ev[first[k] + 1];
+            if (k == 0 && t.ev[7]) e_end = t.ev[7];
+            if (!t.ev[first[k]] || !e_end) continue;  // k_main-only timing
             float ms = 0.f;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, t.ev[first[k]], t.ev[first[k] + 1]));
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, t.ev[first[k]], e_end));
             ctx->ms_acc[k] += ms;
         }
         for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
@@ -486,6 +509,7 @@ int settle_timing(iss_ctx *ctx) {
 
 // everything queued on both streams has finished
 int sync_all(iss_ctx *ctx) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->setup_stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->indel_stream));
     for (auto &pi : ctx->pending) (void)hipEventDestroy(pi.done);
@@ -736,7 +760,12 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->indel_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->setup_stream, hipStreamNonBlocking));
+    for (auto &e : ctx->ev_call_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : ctx->ev_setup_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inputs, hipEventDisableTiming));
     if (const char *e = getenv("ISS_OVERLAP")) ctx->overlap = atoi(e) != 0;
+    if (const char *e = getenv("ISS_SETUP_AHEAD")) ctx->setup_ahead = atoi(e) != 0;
     void *p = nullptr;
     HIP_TRY(ctx, hipMalloc(&p, 256));
     ctx->fix_count = static_cast<uint32_t *>(p);  // FIX_SLOTS counters; +128 B stats; +192 B genome-pack status
@@ -759,6 +788,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     fastq_shutdown(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->indel_stream) (void)hipStreamSynchronize(ctx->indel_stream);
+    if (ctx->setup_stream) (void)hipStreamSynchronize(ctx->setup_stream);
     for (auto &pi : ctx->pending) (void)hipEventDestroy(pi.done);
     for (auto &t : ctx->timed) for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
     free_model(ctx);
@@ -774,6 +804,10 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     free_mt(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->indel_stream) (void)hipStreamDestroy(ctx->indel_stream);
+    if (ctx->setup_stream) (void)hipStreamDestroy(ctx->setup_stream);
+    for (auto &e : ctx->ev_call_done) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_setup_done) if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_inputs) (void)hipEventDestroy(ctx->ev_inputs);
     delete ctx;
 }
 
@@ -1213,6 +1247,9 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     }
     G.packed = G.packed_alloc + 1;
     G.mask = G.mask_alloc + 1;
+    // (the packing kernel / copies of this record may still run on the main stream: k_setup, on the setup stream, waits for them)
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_inputs, ctx->stream));
+    ctx->inputs_pending = true;
     ctx->genomes.push_back(G);
     *genome_id = (int32_t)ctx->genomes.size() - 1;
     return 0;
@@ -1249,6 +1286,9 @@ int iss_genome_upload_packed(iss_ctx *ctx, const uint32_t *codes, int64_t length
     G.has_exceptions = false;
     G.packed = G.packed_alloc + 1;
     G.mask = G.mask_alloc + 1;
+    // (the packing kernel / copies of this record may still run on the main stream: k_setup, on the setup stream, waits for them)
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_inputs, ctx->stream));
+    ctx->inputs_pending = true;
     ctx->genomes.push_back(G);
     *genome_id = (int32_t)ctx->genomes.size() - 1;
     return 0;
@@ -1280,12 +1320,17 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     void *q = nullptr;
     HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.row * (size_t)capacity_pairs));
     for (int k = 0; k < 4; ++k) ctx->out[k] = static_cast<uint8_t *>(q) + iss::row_array_off(k);
+    for (int k = 0; k < 2; ++k) {  // (two sets: k_setup of a call runs beside the kernels of the call before)
+        HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));
+        ctx->desc_buf[k] = static_cast<iss::PairDesc *>(q);
+        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * (size_t)capacity_pairs));
+        ctx->flags_buf[k] = static_cast<uint32_t *>(q);
+        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
+        ctx->fixl_buf[k] = static_cast<uint32_t *>(q);
+    }
     HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));
-    ctx->desc = static_cast<iss::PairDesc *>(q);
-    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * (size_t)capacity_pairs));
-    ctx->flags = static_cast<uint32_t *>(q);
-    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
-    ctx->fix_list = static_cast<uint32_t *>(q);
+    ctx->desc = static_cast<iss::PairDesc *>(q);  // what the host reads (iss_output_download_coords) and the MT kernels write
+    ctx->flags = ctx->flags_buf[0]; ctx->fix_list = ctx->fixl_buf[0];
     HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
     ctx->ev_count = static_cast<uint32_t *>(q);
     HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * iss::EV_K * (size_t)capacity_pairs));
@@ -1370,6 +1415,18 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
     ctx->last_row0 = out_first_pair;
     ctx->last_n = n_pairs;
     if (!items) { ctx->last_first.clear(); ctx->last_off.clear(); }
+    // this call's set of descriptors / flags / fix-up list; k_setup on the setup stream once the call before last -- the last
+    // user of the set -- is done (custom fragment lengths: the host reads k_setup's results back: everything on one stream)
+    const int par = (int)(ctx->call_seq++ & 1u);
+    ctx->flags = ctx->flags_buf[par];
+    ctx->fix_list = ctx->fixl_buf[par];
+    const bool ahead = ctx->setup_ahead && !ctx->has_frag && !ctx->overlap && !ctx->timing_all;
+    hipStream_t s_setup = ahead ? ctx->setup_stream : ctx->stream;
+    if (ahead) {
+        if (ctx->ev_call_valid[par]) HIP_TRY(ctx, hipStreamWaitEvent(s_setup, ctx->ev_call_done[par], 0));
+        if (ctx->inputs_pending) HIP_TRY(ctx, hipStreamWaitEvent(s_setup, ctx->ev_inputs, 0));  // (arena / table copies of this call)
+    }
+    ctx->inputs_pending = false;
     for (int64_t done = 0; done < n_pairs;) {
         const int64_t n = std::min(max_chunk, n_pairs - done);
         const int64_t row0 = out_first_pair + done;
@@ -1381,7 +1438,8 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.gc_bias = gc_bias ? 1 : 0;
         A.gc_thr = 8106479329266893ull;  // ceil(0.90 * 2^53), 0.90 being the f64 nearest to 0.9
         for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.row;
-        iss::PairDesc *desc = ctx->desc + row0;
+        iss::PairDesc *desc = ctx->desc_buf[par] + row0;
+        A.desc_out = ctx->desc + row0;
         uint32_t *flags = ctx->flags + row0;
         uint32_t *fix_list = ctx->fix_list + 2 * row0;
         TimedLaunch tl{};
@@ -1413,10 +1471,10 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         uint32_t *counter = ctx->fix_count + slot_i;
         uint32_t *read_counter = ctx->read_count + slot_i;
         uint32_t *sub_counter = ctx->sub_count + 2 * slot_i;
-        if (ctx->overlap) {
-            HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_main));
-            HIP_TRY(ctx, hipMemsetAsync(read_counter, 0, sizeof(uint32_t), s_main));
-            HIP_TRY(ctx, hipMemsetAsync(sub_counter, 0, 2 * sizeof(uint32_t), s_main));
+        if (ctx->overlap || ahead) {  // (the counters of the chunk before may still be in use: only this chunk's own are cleared)
+            HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_setup));
+            HIP_TRY(ctx, hipMemsetAsync(read_counter, 0, sizeof(uint32_t), s_setup));
+            HIP_TRY(ctx, hipMemsetAsync(sub_counter, 0, 2 * sizeof(uint32_t), s_setup));
         } else if (slot_i == 0) {
             HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
             HIP_TRY(ctx, hipMemsetAsync(ctx->read_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
@@ -1441,6 +1499,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             A.sub_list = ctx->sub_list + (size_t)row0 * (size_t)ctx->sub_per_pair + (size_t)slot_i * SUB_MARGIN;
             A.sub_count = sub_counter;
             A.sub_cap = (uint32_t)std::min<uint64_t>((uint64_t)n * (uint64_t)ctx->sub_per_pair + SUB_MARGIN, 0xffffff00u);
+            if (const char *e = getenv("ISS_SUB_CAP")) A.sub_cap = std::min<uint32_t>(A.sub_cap, (uint32_t)std::max(0, atoi(e)));  // (tests: force the overflow path)
         }
         A.has_frag = ctx->has_frag ? 1 : 0;
         A.frag_mu = ctx->frag_mu;
@@ -1465,10 +1524,17 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             A.amb_list = ctx->d_amb;
             A.amb_count = ctx->d_amb_count;
         }
-        HIP_TRY(ctx, mark(0, s_main));
+        HIP_TRY(ctx, mark(0, s_setup));
+        if (ahead && A.light == 1 && main_lds_bytes(M) + iss::setup_lds_bytes(M.n_isize, M.ev_ns, true) > (size_t)158 * 1024)
+            A.light = 2;  // (k_main's tables leave no room for the event tables beside them: read in place, off the critical path)
         {
             const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8 * (int64_t)ctx->n_cu);
-            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), iss::setup_lds_bytes(M.n_isize, M.ev_ns, A.light == 1 && M.n_scan > 0), s_main, M, dg, A, desc);
+            hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), iss::setup_lds_bytes(M.n_isize, M.ev_ns, A.light == 1 && M.n_scan > 0), s_setup, M, dg, A, desc);
+            if (ahead) {  // k_main (and what follows it) waits for this chunk's k_setup
+                if (ctx->timing && !ctx->timing_main_only) { HIP_TRY(ctx, hipEventCreate(&tl.ev[7])); HIP_TRY(ctx, hipEventRecord(tl.ev[7], s_setup)); }
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_setup_done[slot_i], s_setup));
+                HIP_TRY(ctx, hipStreamWaitEvent(s_main, ctx->ev_setup_done[slot_i], 0));
+            }
         }
         if (ctx->has_frag) {
             // fragment lengths the device could not decide (|x - round(x)| < guard): libm on the host, then redo those pairs
@@ -1580,6 +1646,8 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         done += n;
     }
     ctx->n_launches += 1;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_call_done[par], ctx->overlap ? ctx->indel_stream : ctx->stream));
+    ctx->ev_call_valid[par] = true;
     return 0;
 }
 
@@ -1731,6 +1799,8 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
             ctx->comm_ids = ids;
             ctx->comm_items = items;
             ctx->comm_exceptions = exceptions;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_inputs, ctx->stream));  // (k_setup may run on the setup stream: it waits for the arena)
+            ctx->inputs_pending = true;
         }
         call_items = ctx->comm_items;
         dg = iss::DevGenome{ctx->comm_packed + 2, ctx->comm_mask + 2, ctx->comm_ascii, 0, ctx->comm_exceptions ? 1 : 0};
@@ -1759,8 +1829,10 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
     if (ctx->batch_seq >= 2) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_items[set]));  // the call before last is done with this set
     memcpy(ctx->h_items[set], call_items.data(), (size_t)n_items * sizeof(iss::BatchItem));
     memcpy(ctx->h_item_first[set], first.data(), ((size_t)n_items + 1) * sizeof(int64_t));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_items[set], ctx->h_items[set], (size_t)n_items * sizeof(iss::BatchItem), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_item_first[set], ctx->h_item_first[set], ((size_t)n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    // (on the stream k_setup runs on: beside the previous call's kernels, not behind them)
+    hipStream_t s_in = ctx->setup_ahead && !ctx->has_frag && !ctx->overlap && !ctx->timing_all ? ctx->setup_stream : ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_items[set], ctx->h_items[set], (size_t)n_items * sizeof(iss::BatchItem), hipMemcpyHostToDevice, s_in));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_item_first[set], ctx->h_item_first[set], ((size_t)n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s_in));
     const int rc = generate_core(ctx, dg, any_exceptions, ctx->d_items[set], ctx->d_item_first[set], n_items, total, first_ordinal,
                                  seed, sequence_type, gc_bias, out_first_pair);
     if (rc) return rc;
@@ -1938,6 +2010,7 @@ int iss_timing_enable(iss_ctx *ctx, int enable) {
     int rc = settle_timing(ctx);
     ctx->timing = enable != 0;
     ctx->timing_main_only = enable == 2;
+    ctx->timing_all = enable == 1;  // (a split by kernel needs the kernels one after the other)
     return rc;
 }
 

@@ -93,6 +93,58 @@ def test_both_indel_paths_match_oracle(engine, case, mode, monkeypatch):
     _compare(engine, dense_model(model, indel), mk_genome(), n_pairs, seed, first, seq_type, gc_bias)
 
 
+@pytest.mark.parametrize("case", [14, 15])
+def test_substitution_list_overflow_is_exact(engine, case, monkeypatch):
+    """The list of substitutions k_main applies is sized from the model's expected error rate; a launch that overflows it
+    (here: a cap of one chunk) raises a flag and k_indel_apply hands every read with an event to the one-wavefront-per-read
+    kernel instead -- slower, the same bytes."""
+    monkeypatch.setenv("ISS_SUB_CAP", "256")
+    monkeypatch.setenv("ISS_LIGHT_INDELS", "0")
+    model, indel, mk_genome, n_pairs, seed, first, seq_type, gc_bias = CASES[case]
+    _, stats = _compare(engine, dense_model(model, indel), mk_genome(), n_pairs, seed, first, seq_type, gc_bias)
+    assert stats["fixup_reads"] > n_pairs // 4
+
+
+@pytest.mark.parametrize("ahead", ["1", "0"])
+@pytest.mark.parametrize("model,indel", [("novaseq", None), ("novaseq", (0.001, 0.003)), ("hiseq", None)])
+def test_back_to_back_calls_pipeline(model, indel, ahead, monkeypatch):
+    """k_setup of a call runs on its own stream beside the kernels of the call before (double-buffered descriptors, flags and
+    fix-up lists; ISS_SETUP_AHEAD=0: one stream).  Forty calls into the SAME rows without a host synchronisation in
+    between, alternating between two work lists and two genomes: the rows, coordinates (the copy k_main leaves for the
+    host) of the last call and of a call in the middle (synchronised there) equal the oracle's."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    monkeypatch.setenv("ISS_SETUP_AHEAD", ahead)
+    dense = dense_model(model, indel)
+    genomes = [random_genome(41, 60000), random_genome(42, 45000)]
+    orc = O.Oracle(dense)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gids = [eng.add_genome(g) for g in genomes]
+        lists = [([0, 1], [9000, 7000]), ([1, 0, 1], [4000, 8000, 3000])]
+        eng.reserve(16000)
+
+        def check(call):
+            ids, counts = lists[call % 2]
+            eng.synchronize()
+            row, ordinal = 0, 1000 * call
+            for g, n in zip(ids, counts):
+                exp = orc.simulate(O.Rng().seed_philox(5 + call), genomes[g], n, first_ordinal=ordinal, want_coords=True)
+                got, cg = eng.download(row, n), eng.coords(row, n)
+                for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                    assert np.array_equal(got[key], exp[key]), (call, g, key)
+                assert np.array_equal(np.asarray(cg), exp["coords"]), (call, g)
+                row += n
+                ordinal += n
+
+        for call in range(40):
+            ids, counts = lists[call % 2]
+            eng.generate_batch([gids[g] for g in ids], counts, first_ordinal=1000 * call, seed=5 + call, out_first_pair=0)
+            if call in (17, 39):
+                check(call)
+
+
 def test_rows_and_ordinals_compose(engine):
     """Two calls writing adjacent rows with consecutive ordinals == one call (work items of a worker)."""
     dense = dense_model("hiseq")
