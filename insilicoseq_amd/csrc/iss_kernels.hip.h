@@ -259,7 +259,8 @@ struct RunArgs {
     // event, 15) | first such step << 4 (0: none) for every read of the launch.
     uint32_t *ev_count, *ev_list, *read_count;
     uint4 *read_list;
-    // substitutions k_main applied (models with indels only): {pair, position | mate << 15 | template letter << 16}, appended in
+    // substitutions k_main applied to reads with an indel event (models whose reads often have one; k_indel_scan runs in front of
+    // k_main then): {pair, position | mate << 15 | template letter << 16}, appended in
     // chunks of SUB_CHUNK entries per wavefront (unused entries: pair == 0xffffffff); sub_count[0] = entries reserved,
     // sub_count[1] != 0: the list overflowed (k_indel_apply then hands every listed read to k_indel_fixup)
     uint2 *sub_list;
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     T.s0 = tile * M.TS;
     T.ts = (uint32_t)min(M.TS, M.S - T.s0);
     // Deferred lane-items (a base needs the exact path): a private ring per wavefront -- no atomics, no barriers.
-    // Entry = {(pass << it_bits | iteration) << 19 | lane << 13 | bin slots << 8,
+    // Entry = {(pass << it_bits | iteration) << 19 | lane << 13 | bin slots << 8 | (SUBLIST) "mate has an indel event" bits 0-1,
     //          forward window | complemented reverse window << 16 (2-bit codes of the lane-item's 8 + 8 template bases),
     //          base mask: bit 15 - (8 * half + s) <=> base s = mate * 4 + cc of that half of the superitem};
     // head / tail are wave-uniform.
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
             sub_pair = e_pair;
         }
         // (models with indels: the reads k_indel_apply shifts have their substitutions re-applied from this list)
-        if (SUBLIST) sub_emit(A, schunk, subst != 0, sub_pair, (uint32_t)rec.position | ((uint32_t)rec.mate << 15) | ((uint32_t)rec.ref << 16));
+        if (SUBLIST) sub_emit(A, schunk, subst != 0 && ((ent_x >> rec.mate) & 1u), sub_pair, (uint32_t)rec.position | ((uint32_t)rec.mate << 15) | ((uint32_t)rec.ref << 16));
         q_head += n;
         const unsigned long long again = __ballot(rest_m != 0u);
         if (again) {
@@ -987,18 +988,26 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     const uint32_t j4 = lane & 3u;
     // (the descriptor of the NEXT pass is requested at the start of a pass: its latency hides behind the pass)
     PairDesc d_next = {0, 0, 0u, 0};
+    uint2 ec_next = {0u, 0u};  // SUBLIST: the event counters of the pair's two reads (k_indel_scan ran in front of this kernel)
     {
         const uint32_t pair0 = wg * MAIN_PAIRS + wave_pair0 + (lane >> 2);
-        if (wg < n_pass && pair0 < (uint32_t)A.n_pairs) d_next = desc[pair0];
+        if (wg < n_pass && pair0 < (uint32_t)A.n_pairs) {
+            d_next = desc[pair0];
+            if (SUBLIST) ec_next = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair0);
+        }
     }
     for (uint32_t pass = 0, blk = wg; blk < n_pass; ++pass, blk += n_wg) {
         const uint32_t pair = blk * MAIN_PAIRS + wave_pair0 + (lane >> 2);
         const bool valid = pair < (uint32_t)A.n_pairs;
         const PairDesc d = d_next;
+        const uint32_t has_ev = SUBLIST ? (ec_next.x ? 1u : 0u) | (ec_next.y ? 2u : 0u) : 0u;  // bit mate: that read has an indel event
         if (tile == 0 && j4 == 0u && valid) A.desc_out[pair] = d;
         {
             const uint32_t pair_n = pair + n_wg * MAIN_PAIRS;
-            if (blk + n_wg < n_pass && pair_n < (uint32_t)A.n_pairs) d_next = desc[pair_n];
+            if (blk + n_wg < n_pass && pair_n < (uint32_t)A.n_pairs) {
+                d_next = desc[pair_n];
+                if (SUBLIST) ec_next = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair_n);
+            }
         }
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
         // LDS byte offsets of the pair's rows (its bin slots) at this lane's first superitem; one iteration = 8 groups on
@@ -1010,7 +1019,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         int32_t pr = d.re - 8 - (int32_t)(s_lane * 8u);       // lowest genome position of its 8 reverse bases
         uint32_t out_b = pair * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u;  // (tiles start at multiples of 4 superitems: whole lines)
         const bool regular = PLAIN || !(A.has_frag && (d.meta & 64u));  // irregular pairs are built by the fix-up kernel
-        const uint32_t tag0 = (pass << (19u + it_bits)) | (lane << 13) | ((d.meta & 15u) << 8);
+        const uint32_t tag0 = (pass << (19u + it_bits)) | (lane << 13) | ((d.meta & 15u) << 8) | has_ev;
         for (uint32_t it = 0; it < n_iter; ++it) {
             uint32_t rare0 = 0, windows = 0;
             if (valid && 4u * it + j4 < T.ts) {

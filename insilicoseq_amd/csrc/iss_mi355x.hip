@@ -1464,22 +1464,16 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             if (pi.row0 < row0 + n && row0 < pi.row0 + pi.n) HIP_TRY(ctx, hipStreamWaitEvent(s_main, pi.done, 0));
             ++i;
         }
-        // fix-list counter of this chunk: a ring of FIX_SLOTS counters.  Everything in order on one stream: the whole
-        // ring is cleared once per FIX_SLOTS chunks; with the indel stream running beside, per chunk.  (The flags
-        // are cleared by k_setup itself.)
+        // fix-list / read-list / substitution-list counters of this chunk: rings of FIX_SLOTS counters (k_setup runs at most two
+        // calls ahead of the other kernels: a slot's previous user is long done).  (The flags are cleared by k_setup itself.)
         const unsigned slot_i = (unsigned)(ctx->chunk_seq++ % FIX_SLOTS);
         uint32_t *counter = ctx->fix_count + slot_i;
         uint32_t *read_counter = ctx->read_count + slot_i;
         uint32_t *sub_counter = ctx->sub_count + 2 * slot_i;
-        if (ctx->overlap || ahead) {  // (the counters of the chunk before may still be in use: only this chunk's own are cleared)
-            HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_setup));
-            HIP_TRY(ctx, hipMemsetAsync(read_counter, 0, sizeof(uint32_t), s_setup));
-            HIP_TRY(ctx, hipMemsetAsync(sub_counter, 0, 2 * sizeof(uint32_t), s_setup));
-        } else if (slot_i == 0) {
-            HIP_TRY(ctx, hipMemsetAsync(ctx->fix_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->read_count, 0, sizeof(uint32_t) * FIX_SLOTS, s_main));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->sub_count, 0, sizeof(uint32_t) * 2 * FIX_SLOTS, s_main));
-        }
+        // (the counters of the chunk before may still be in use: only this chunk's own are cleared -- on the stream k_setup runs on)
+        HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_setup));
+        HIP_TRY(ctx, hipMemsetAsync(read_counter, 0, sizeof(uint32_t), s_setup));
+        HIP_TRY(ctx, hipMemsetAsync(sub_counter, 0, 2 * sizeof(uint32_t), s_setup));
         A.mut = ctx->d_pmut;
         A.mut_count = ctx->d_pmut_count;
         A.mut_cap = (uint32_t)ctx->pmut_cap;
@@ -1563,6 +1557,19 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             HIP_TRY(ctx, hipEventCreateWithFlags(&ev_setup, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventRecord(ev_setup, s_main));
         }
+        // Models whose reads often have indels: the scan runs IN FRONT of k_main (it needs the descriptors only), so that
+        // k_main lists the substitutions of the reads with an event only -- the others are never shifted
+        const bool scan_first = A.sub_list != nullptr;
+        auto launch_scan = [&](hipStream_t st) {
+            const uint64_t reads = 2 * (uint64_t)n;
+            const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 8, (reads + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
+            hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), st, M, A, desc);
+        };
+        if (scan_first) {
+            HIP_TRY(ctx, mark(3, s_main));
+            launch_scan(s_main);
+            HIP_TRY(ctx, mark(4, s_main));
+        }
         HIP_TRY(ctx, mark(1, s_main));
         {
             const uint64_t passes = ((uint64_t)n + iss::MAIN_PAIRS - 1) / iss::MAIN_PAIRS;  // a workgroup pass = 256 pairs
@@ -1600,13 +1607,12 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                 HIP_TRY(ctx, hipEventRecord(ev_main, s_main));
                 HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_setup, 0));  // the scan needs the pair descriptors only
             }
-            HIP_TRY(ctx, mark(3, s_indel));
-            if (M.n_scan > 0 && !ctx->light) {  // one lane per read (light models: k_setup has checked the pair's reads already)
-                const uint64_t reads = 2 * (uint64_t)n;
-                const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 8, (reads + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
-                hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), s_indel, M, A, desc);
+            if (!scan_first) {
+                HIP_TRY(ctx, mark(3, s_indel));
+                // one lane per read (light models: k_setup has checked the pair's reads already)
+                if (M.n_scan > 0 && !ctx->light) launch_scan(s_indel);
+                HIP_TRY(ctx, mark(4, s_indel));
             }
-            HIP_TRY(ctx, mark(4, s_indel));
             if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
             HIP_TRY(ctx, mark(5, s_indel));
             if (M.n_scan > 0 && !ctx->light) {  // reads with (few) events: rebuilt from their lists, 64 per wavefront block

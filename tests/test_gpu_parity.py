@@ -145,6 +145,33 @@ def test_back_to_back_calls_pipeline(model, indel, ahead, monkeypatch):
                 check(call)
 
 
+def test_calls_with_and_without_setup_stream_share_the_counter_rings(monkeypatch):
+    """Regression (round 3): calls whose k_setup runs on the setup stream and calls that keep everything on one stream
+    (custom fragment lengths: the host reads k_setup's results back) take their fix-up / read-list / substitution-list
+    counters from the same rings -- every chunk clears its own.  Twenty calls of the first kind, then one of the second
+    on a slot in the middle of the ring, compared with the oracle incl. its --store_mutations rows."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    dense = dense_model("novaseq", (0.001, 0.003))
+    genome = random_genome(55, 2000)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        for call in range(21):
+            eng.generate(gid, 3000, first_ordinal=call, seed=7)
+        eng.mutations_reserve(1_000_000)
+        eng.set_fragment(200, 60)
+        eng.generate(gid, 3000, first_ordinal=11, seed=7)
+        eng.synchronize()
+        rows, got = eng.mutations(), eng.download(0, 3000)
+    exp = O.Oracle(dense).simulate(O.Rng().seed_philox(7), genome, 3000, first_ordinal=11, store_mutations=True,
+                                   fragment_length=200, fragment_sd=60)
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert len(rows) == len(exp["mutations"]) and all(np.array_equal(rows[f], exp["mutations"][f]) for f in ("pair", "mate", "type", "position", "ref", "alt"))
+
+
 def test_rows_and_ordinals_compose(engine):
     """Two calls writing adjacent rows with consecutive ordinals == one call (work items of a worker)."""
     dense = dense_model("hiseq")
