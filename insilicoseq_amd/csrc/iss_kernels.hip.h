@@ -257,8 +257,9 @@ struct RunArgs {
     // {read, first event, second event, number of steps with an event}, an event = step << 8 | event mask; a read with
     // more than two such steps keeps all of them in its EV_K words of ev_list.  ev_count[read] = min(steps with an
     // event, 15) | first such step << 4 (0: none) for every read of the launch.
-    uint32_t *ev_count, *ev_list, *read_count;
+    uint32_t *ev_count, *ev_list, *read_count;  // read_count[w]: listed reads of scan workgroup w
     uint4 *read_list;
+    uint32_t scan_wgs;  // workgroups of k_indel_scan: the read list is one segment per workgroup (no global counter)
     // substitutions k_main applied to reads with an indel event (models whose reads often have one; k_indel_scan runs in front of
     // k_main then): {pair, position | mate << 15 | template letter << 16}, appended in
     // chunks of SUB_CHUNK entries per wavefront (unused entries: pair == 0xffffffff); sub_count[0] = entries reserved,
@@ -1118,53 +1119,79 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
 // survival table, i.e. one for a read without events) in step order into its event list (EV_K words, step << 8 | event
 // mask); no event => provably no indel, k_main's output stands.  k_indel_apply replays the lists.  A read with more than
 // EV_K events goes to the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  The reads with events
-// are collected per wavefront in LDS and reach the global read list with one atomic per >= 128 reads (a counter
-// everybody adds to takes ~10 ns per add).  Consecutive lanes take consecutive reads, so the list is in pair order,
-// more or less, and k_indel_apply's wavefronts share cache lines, DRAM pages and TLB entries.
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_LIST = 256;    // listed reads a wavefront collects before they go to the global list
+// are collected per wavefront in LDS and reach the read list >= 64 at a time.  The list is SEGMENTED: a workgroup's
+// reads go to read_list[first read of its range ...], the place reserved by an LDS atomic of the workgroup -- a global
+// counter everybody adds to takes ~10 ns per add, 0.2-0.5 ms per 5 M pairs of configs[4] -- and the segments' lengths
+// to read_count[workgroup]; k_indel_apply walks the segments through a prefix sum of their 64-read blocks.  Consecutive
+// lanes take consecutive reads, so the list is in pair order, more or less, and k_indel_apply's wavefronts share cache
+// lines, DRAM pages and TLB entries.
+constexpr int SCAN_THREADS = 1024;  // two workgroups per CU: 8 wavefronts / SIMD (the kernel is bound by the latency of its dependent LDS reads)
+constexpr int SCAN_LIST = 128;    // listed reads a wavefront collects before they go to the global list
 constexpr int EV_K = 8;           // events kept per read
 constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
                                        // bits 4-5 mate is in read_list
-constexpr int SCAN_RANGE = 2048;  // reads of a wavefront's range whose event counts are staged in LDS (written out in whole lines)
+constexpr int SCAN_MAX_WGS = 512; // (k_indel_apply keeps the segment table in LDS)
+__host__ __device__ inline uint32_t scan_per_wg(uint32_t n_reads, uint32_t wgs) {  // reads of a workgroup's contiguous range
+    return ((n_reads + wgs - 1) / wgs + SCAN_THREADS - 1) / SCAN_THREADS * SCAN_THREADS;
+}
+constexpr int SCAN_WIN = 512;     // window of a wavefront's range whose event counts are staged in LDS: they leave in whole lines, half a window at a time
 __host__ __device__ inline size_t scan_lds_bytes(int ev_ns) {
-    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 15) & ~(size_t)15) + (size_t)(SCAN_THREADS / 64) * (SCAN_LIST * 16 + SCAN_RANGE * 2);
+    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 15) & ~(size_t)15) + (size_t)(SCAN_THREADS / 64) * (SCAN_LIST * 16 + SCAN_WIN * 2);
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
+__global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint64_t scan_lds[];
     const int ns = M.ev_ns;
     uint64_t *l_S = scan_lds;                                         // [2][ns]
     uint16_t *l_E = reinterpret_cast<uint16_t *>(l_S + 2 * ns);       // [2][ns]
     uint8_t *l_rest = reinterpret_cast<uint8_t *>(scan_lds) + (size_t)2 * ns * 8 + (((size_t)2 * ns * 2 + 15) & ~(size_t)15);
     uint4 *l_list = reinterpret_cast<uint4 *>(l_rest) + (threadIdx.x >> 6) * SCAN_LIST;  // this wavefront's listed reads
-    uint16_t *l_cnt = reinterpret_cast<uint16_t *>(l_rest + (size_t)(SCAN_THREADS / 64) * SCAN_LIST * 16) + (threadIdx.x >> 6) * SCAN_RANGE;  // ... event counts
+    uint16_t *l_cnt = reinterpret_cast<uint16_t *>(l_rest + (size_t)(SCAN_THREADS / 64) * SCAN_LIST * 16) + (threadIdx.x >> 6) * SCAN_WIN;  // ... event counts
+    __shared__ uint32_t l_seg;  // listed reads of this workgroup so far
     for (int i = threadIdx.x; i < 2 * ns; i += blockDim.x) { l_S[i] = M.ev_S[i]; l_E[i] = M.ev_E[i]; }
+    if (threadIdx.x == 0) l_seg = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_reads = 2u * (uint32_t)A.n_pairs;
+    const uint32_t per_wg = scan_per_wg(n_reads, gridDim.x);  // contiguous ranges (a wavefront's: a multiple of 64 reads)
+    uint4 *const seg_list = A.read_list + (size_t)blockIdx.x * per_wg;  // (a range lists at most its own reads)
     uint32_t n_listed = 0;  // wave-uniform
-    auto flush_list = [&]() {  // this wavefront's listed reads -> the global list: one atomic
+    auto flush_list = [&]() {  // this wavefront's listed reads -> the workgroup's segment of the list
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(A.read_count, n_listed);
+        if (lane == 0) base = atomicAdd(&l_seg, n_listed);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        for (uint32_t i = lane; i < n_listed; i += 64u) A.read_list[base + i] = l_list[i];
+        for (uint32_t i = lane; i < n_listed; i += 64u) seg_list[base + i] = l_list[i];
         n_listed = 0;
     };
-    const uint32_t n_reads = 2u * (uint32_t)A.n_pairs;
-    const uint32_t per_wg = ((n_reads + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;  // contiguous ranges
     const uint32_t per_wave = per_wg / (blockDim.x >> 6);
     const uint32_t w_first = min(n_reads, blockIdx.x * per_wg + (threadIdx.x >> 6) * per_wave), w_last = min(n_reads, w_first + per_wave);
     // A read needs one draw per event and per segment of the survival table -- one for most reads, half a dozen for the
     // unluckiest of 64: the lanes of a wavefront therefore do not walk the range in lockstep.  Every iteration is ONE draw
     // of every lane's current read; a lane whose read is finished takes the next read of the wavefront's range.
-    uint32_t next = w_first;  // wave-uniform
+    // The event counts of reads [wb, wb + SCAN_WIN) are staged (ring l_cnt, index = read - w_first mod SCAN_WIN): reads are
+    // handed out in order, so a window's first half is complete once no lane still holds one of its reads.
+    uint32_t next = w_first, wb = w_first;  // wave-uniform
+    auto flush_counts = [&](uint32_t n) {  // counts of reads [wb, wb + n) -> global memory, whole lines
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (uint32_t i = lane; i < n; i += 64u) A.ev_count[wb + i] = l_cnt[(wb - w_first + i) & (uint32_t)(SCAN_WIN - 1)];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the slots are reused)
+    };
     bool busy = false;
     uint32_t rd = 0, cnt = 0, prev = 0, j = 0, e0 = 0, e1 = 0;  // (e0, e1: the read's first two events; prev: its last)
     int cur = -1, o = 0;
     Addr a = make_addr(A.seed, A.first_ordinal, 0u);
     for (;;) {
         const unsigned long long need = __ballot(!busy);
-        if (need && next < w_last) {
+        bool room = true;
+        if (need && next < w_last && next + 64u > wb + (uint32_t)SCAN_WIN) {  // the window is full: retire its first half ...
+            if (!__ballot(busy && rd - wb < (uint32_t)(SCAN_WIN / 2))) {
+                flush_counts((uint32_t)(SCAN_WIN / 2));
+                wb += (uint32_t)(SCAN_WIN / 2);
+            } else {
+                room = false;  // ... once the lanes still working on it are done (no new reads until then)
+            }
+        }
+        if (need && next < w_last && room) {
             const uint32_t cand = next + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             if (!busy && cand < w_last) {
                 rd = cand; cnt = 0; prev = 0; j = 0; cur = -1; busy = true; e0 = 0; e1 = 0;
@@ -1204,7 +1231,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
                 }
                 // (every read's counter is written: nothing else initialises them -- staged, so that they leave in whole lines)
                 const uint32_t evc = cnt ? min(cnt, 15u) | ((e0 >> 8) << 4) : 0u;  // steps with an event (capped) | the first of them << 4
-                if (rd - w_first < (uint32_t)SCAN_RANGE) l_cnt[rd - w_first] = (uint16_t)evc; else A.ev_count[rd] = evc;
+                l_cnt[(rd - w_first) & (uint32_t)(SCAN_WIN - 1)] = (uint16_t)evc;
                 fin = true;
                 busy = false;
             }
@@ -1218,8 +1245,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_indel_scan(DevModel M, RunArgs
         }
     }
     if (n_listed) flush_list();
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    for (uint32_t i = lane; i < min(w_last - w_first, (uint32_t)SCAN_RANGE); i += 64u) A.ev_count[w_first + i] = l_cnt[i];
+    flush_counts(w_last - wb);
+    __syncthreads();
+    if (threadIdx.x == 0) A.read_count[blockIdx.x] = l_seg;
 }
 
 // ================================================================== k_indel_apply
@@ -1261,8 +1289,9 @@ __host__ __device__ inline int ap_win(int pitch) { return ap_pitch(pitch) + 8; }
 __host__ __device__ inline int ap_ww(int pitch) { return (ap_win(pitch) + 15) / 16 + 1; }  // window words (16 bases each)
 __host__ __device__ inline int ap_rec_words(int pitch) { return (AP_HDR + ap_ww(pitch) + AP_RUNS + 2 * AP_EVP) | 1; }  // odd: no bank conflicts between lanes
 __host__ __device__ inline size_t ap_items_bytes() { return (AP_ITEMS + 2) * 4 + AP_ITEMS * sizeof(BatchItem); }
-// [ins_letter 2*RL*4 u8, padded][item_first AP_ITEMS+2 u32][items AP_ITEMS][per wave: 64 records]
-__host__ __device__ inline size_t ap_tab_bytes(int RL) { return (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + ap_items_bytes(); }
+__host__ __device__ inline size_t ap_seg_bytes() { return (size_t)(2 * SCAN_MAX_WGS + 4) * 4; }  // the read list's segments: 64-read blocks in front of each, lengths
+// [ins_letter 2*RL*4 u8, padded][segments][item_first AP_ITEMS+2 u32][items AP_ITEMS][per wave: 64 records]
+__host__ __device__ inline size_t ap_tab_bytes(int RL) { return (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + ap_seg_bytes() + ap_items_bytes(); }
 __host__ __device__ inline size_t ap_wave_bytes(int pitch) { return (size_t)64 * ap_rec_words(pitch) * 4; }
 __host__ __device__ inline int apply_waves(int RL, int pitch) {
     const size_t room = (size_t)160 * 1024 - 512 - ap_tab_bytes(RL);
@@ -1280,10 +1309,32 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
     uint8_t *insl = reinterpret_cast<uint8_t *>(ap_lds);                  // [2][RL][4]
     uint32_t *ifirst = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ap_lds) + ap_tab_bytes(RL) - ap_items_bytes());  // (a call holds < 2^31 pairs)
     BatchItem *l_items = reinterpret_cast<BatchItem *>(ifirst + AP_ITEMS + 2);
-    const uint32_t n_list = *A.read_count;
-    const uint32_t n_blocks = (n_list + 63u) / 64u;
+    // the read list's segments (one per workgroup of k_indel_scan): seg_blk[s] = 64-read blocks in front of segment s
+    uint32_t *seg_blk = ifirst - (2 * SCAN_MAX_WGS + 4), *seg_len = seg_blk + SCAN_MAX_WGS + 2;
     const uint32_t n_waves = blockDim.x >> 6;
-    if (blockIdx.x * n_waves >= n_blocks) return;  // whole workgroup idle (uniform)
+    if (threadIdx.x < 64u) {
+        constexpr uint32_t PER = SCAN_MAX_WGS / 64;
+        uint32_t len[PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t sg = threadIdx.x * PER + k;
+            len[k] = sg < A.scan_wgs ? A.read_count[sg] : 0u;
+            sum += (len[k] + 63u) / 64u;
+        }
+        uint32_t inc = sum;
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, dlt);
+            if ((int)threadIdx.x >= dlt) inc += t;
+        }
+        uint32_t run = inc - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            seg_blk[threadIdx.x * PER + k] = run;
+            seg_len[threadIdx.x * PER + k] = len[k];
+            run += (len[k] + 63u) / 64u;
+        }
+        if (threadIdx.x == 63u) seg_blk[SCAN_MAX_WGS] = run;
+    }
     for (int i = threadIdx.x; i < 2 * RL * 4; i += blockDim.x) insl[i] = M.ins_letter[i];
     const bool items_cached = A.items && A.n_items <= AP_ITEMS;
     if (items_cached) {
@@ -1291,6 +1342,9 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
         for (int i = threadIdx.x; i < A.n_items; i += blockDim.x) l_items[i] = A.items[i];
     }
     __syncthreads();
+    const uint32_t n_blocks = seg_blk[SCAN_MAX_WGS];
+    if (blockIdx.x * n_waves >= n_blocks) return;  // whole workgroup idle (uniform)
+    const uint32_t seg_stride = scan_per_wg(2u * (uint32_t)A.n_pairs, A.scan_wgs);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t *wave0 = ap_lds + ap_tab_bytes(RL) / 4 + (size_t)wv * (ap_wave_bytes(pitch) / 4);
     // (then every listed read is k_indel_fixup's: the substitutions of a shifted read cannot be re-applied without their list)
@@ -1311,7 +1365,16 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
     // (descriptor, flags, events) one block ahead -- a chain of dependent loads behind the chip's write stream
     const uint32_t NO_READ = 0xffffffffu, stride = gridDim.x * n_waves;
     const uint32_t blk0 = blockIdx.x * n_waves + wv;
-    auto list_entry = [&](uint32_t b) { return b < n_blocks && b * 64u + lane < n_list ? A.read_list[b * 64u + lane] : make_uint4(NO_READ, 0u, 0u, 0u); };
+    auto list_entry = [&](uint32_t b) {  // lane `lane` of block b of the segmented list
+        if (b >= n_blocks) return make_uint4(NO_READ, 0u, 0u, 0u);
+        uint32_t lo = 0, hi = SCAN_MAX_WGS;  // the segment: seg_blk[lo] <= b < seg_blk[lo + 1]
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (seg_blk[mid] <= b) lo = mid; else hi = mid;
+        }
+        const uint32_t off = (b - seg_blk[lo]) * 64u + lane;
+        return off < seg_len[lo] ? A.read_list[(size_t)lo * seg_stride + off] : make_uint4(NO_READ, 0u, 0u, 0u);
+    };
     uint4 rec_a = list_entry(blk0), rec_b = list_entry(blk0 + stride);
     uint32_t ra = rec_a.x == NO_READ ? 0u : rec_a.x;
     PairDesc d_a = desc[ra >> 1];

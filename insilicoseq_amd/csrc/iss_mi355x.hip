@@ -87,6 +87,7 @@ struct TimedLaunch {
     // runs on the setup stream (beside the previous call's kernels)
     hipEvent_t ev[8];
     bool has_scan;
+    bool scan_first;  // the scan stands between k_setup and k_main (ev0 setup ev3 scan ev4 = ev1 main ev2)
 };
 
 struct PendingIndel {  // indel-stream work still in flight on output rows [row0, row0 + n)
@@ -207,8 +208,10 @@ struct iss_ctx {
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
-    uint32_t *ev_count = nullptr, *ev_list = nullptr;  // indel events (k_indel_scan -> k_indel_apply), per row
-    uint4 *read_list = nullptr;
+    // indel events (k_indel_scan -> k_main / k_indel_apply / k_indel_resub), per row; two sets for the models whose scan runs
+    // on the setup stream, beside the kernels of the call before (otherwise [1] aliases [0])
+    uint32_t *ev_count[2] = {nullptr, nullptr}, *ev_list[2] = {nullptr, nullptr};
+    uint4 *read_list[2] = {nullptr, nullptr};
     uint32_t *read_count = nullptr;  // FIX_SLOTS counters of the read lists, like fix_count
     // models with indels: the substitutions k_main applies (RunArgs::sub_list), sub_per_pair entries per output row + a
     // margin per chunk in flight (every wavefront may leave most of a SUB_CHUNK unused); FIX_SLOTS x {reserved, overflow}
@@ -307,13 +310,14 @@ void free_outputs(iss_ctx *ctx) {
         ctx->desc_buf[k] = nullptr; ctx->flags_buf[k] = nullptr; ctx->fixl_buf[k] = nullptr;
         ctx->ev_call_valid[k] = false;
     }
-    if (ctx->ev_count) (void)hipFree(ctx->ev_count);
-    if (ctx->ev_list) (void)hipFree(ctx->ev_list);
-    if (ctx->read_list) (void)hipFree(ctx->read_list);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->ev_count[k] && (k == 0 || ctx->ev_count[k] != ctx->ev_count[0])) (void)hipFree(ctx->ev_count[k]);
+        if (ctx->ev_list[k] && (k == 0 || ctx->ev_list[k] != ctx->ev_list[0])) (void)hipFree(ctx->ev_list[k]);
+        if (ctx->read_list[k] && (k == 0 || ctx->read_list[k] != ctx->read_list[0])) (void)hipFree(ctx->read_list[k]);
+    }
     if (ctx->sub_list) (void)hipFree(ctx->sub_list);
     ctx->sub_list = nullptr;
-    ctx->ev_count = ctx->ev_list = nullptr;
-    ctx->read_list = nullptr;
+    for (int k = 0; k < 2; ++k) { ctx->ev_count[k] = ctx->ev_list[k] = nullptr; ctx->read_list[k] = nullptr; }
     ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
     ctx->capacity = 0;
 }
@@ -495,6 +499,7 @@ int settle_timing(iss_ctx *ctx) {
         for (int k = 0; k < 4; ++k) {
             if (k >= 2 && !t.has_scan) continue;
             hipEvent_t e_end = t.ev[first[k] + 1];
+            if (k == 0 && t.scan_first && t.ev[3]) e_end = t.ev[3];
             if (k == 0 && t.ev[7]) e_end = t.ev[7];
             if (!t.ev[first[k]] || !e_end) continue;  // k_main-only timing
             float ms = 0.f;
@@ -771,9 +776,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->fix_count = static_cast<uint32_t *>(p);  // FIX_SLOTS counters; +128 B stats; +192 B genome-pack status
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
-    HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * FIX_SLOTS));
+    HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * FIX_SLOTS * iss::SCAN_MAX_WGS));
     ctx->read_count = static_cast<uint32_t *>(p);
-    HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * FIX_SLOTS));
+    HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * FIX_SLOTS * iss::SCAN_MAX_WGS));
     HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * 2 * FIX_SLOTS));
     ctx->sub_count = static_cast<uint32_t *>(p);
     HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * 2 * FIX_SLOTS));
@@ -1331,13 +1336,17 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));
     ctx->desc = static_cast<iss::PairDesc *>(q);  // what the host reads (iss_output_download_coords) and the MT kernels write
     ctx->flags = ctx->flags_buf[0]; ctx->fix_list = ctx->fixl_buf[0];
-    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
-    ctx->ev_count = static_cast<uint32_t *>(q);
-    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * iss::EV_K * (size_t)capacity_pairs));
-    ctx->ev_list = static_cast<uint32_t *>(q);
-    HIP_TRY(ctx, hipMalloc(&q, sizeof(uint4) * 2 * (size_t)capacity_pairs));
-    ctx->read_list = static_cast<uint4 *>(q);
-    if (ctx->M.n_scan > 0 && !ctx->light) {
+    const bool heavy = ctx->M.n_scan > 0 && !ctx->light;
+    for (int k = 0; k < (heavy ? 2 : 1); ++k) {
+        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
+        ctx->ev_count[k] = static_cast<uint32_t *>(q);
+        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * iss::EV_K * (size_t)capacity_pairs));
+        ctx->ev_list[k] = static_cast<uint32_t *>(q);
+        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint4) * 2 * (size_t)capacity_pairs));
+        ctx->read_list[k] = static_cast<uint4 *>(q);
+    }
+    if (!heavy) { ctx->ev_count[1] = ctx->ev_count[0]; ctx->ev_list[1] = ctx->ev_list[0]; ctx->read_list[1] = ctx->read_list[0]; }
+    if (heavy) {
         ctx->sub_per_pair = (int64_t)std::ceil(3.0 * (double)ctx->M.exp_subs) + 2;
         HIP_TRY(ctx, hipMalloc(&q, sizeof(uint2) * ((size_t)ctx->sub_per_pair * (size_t)capacity_pairs + (size_t)(FIX_SLOTS + 1) * SUB_MARGIN)));
         ctx->sub_list = static_cast<uint2 *>(q);
@@ -1468,11 +1477,10 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         // calls ahead of the other kernels: a slot's previous user is long done).  (The flags are cleared by k_setup itself.)
         const unsigned slot_i = (unsigned)(ctx->chunk_seq++ % FIX_SLOTS);
         uint32_t *counter = ctx->fix_count + slot_i;
-        uint32_t *read_counter = ctx->read_count + slot_i;
+        uint32_t *read_counter = ctx->read_count + (size_t)slot_i * iss::SCAN_MAX_WGS;  // (one per workgroup of k_indel_scan, all of them written by it)
         uint32_t *sub_counter = ctx->sub_count + 2 * slot_i;
         // (the counters of the chunk before may still be in use: only this chunk's own are cleared -- on the stream k_setup runs on)
         HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_setup));
-        HIP_TRY(ctx, hipMemsetAsync(read_counter, 0, sizeof(uint32_t), s_setup));
         HIP_TRY(ctx, hipMemsetAsync(sub_counter, 0, 2 * sizeof(uint32_t), s_setup));
         A.mut = ctx->d_pmut;
         A.mut_count = ctx->d_pmut_count;
@@ -1484,10 +1492,11 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.flags = flags;
         A.fix_list = fix_list;
         A.fix_count = counter;
-        A.ev_count = M.n_scan > 0 ? ctx->ev_count + 2 * row0 : nullptr;
-        A.ev_list = ctx->ev_list + 2 * (size_t)iss::EV_K * row0;
-        A.read_list = ctx->read_list + 2 * row0;
+        A.ev_count = M.n_scan > 0 ? ctx->ev_count[par] + 2 * row0 : nullptr;
+        A.ev_list = ctx->ev_list[par] + 2 * (size_t)iss::EV_K * row0;
+        A.read_list = ctx->read_list[par] + 2 * row0;
         A.read_count = read_counter;
+        A.scan_wgs = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)ctx->n_cu * 2, iss::SCAN_MAX_WGS), (2 * (uint64_t)n + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
         A.light = ctx->light ? (iss::setup_lds_bytes(M.n_isize, M.ev_ns, true) <= (size_t)150 * 1024 ? 1 : 2) : 0;
         if (M.n_scan > 0 && ctx->sub_list && !ctx->light) {  // k_main lists the substitutions it applies: k_indel_resub re-applies those of shifted reads
             A.sub_list = ctx->sub_list + (size_t)row0 * (size_t)ctx->sub_per_pair + (size_t)slot_i * SUB_MARGIN;
@@ -1518,12 +1527,23 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             A.amb_list = ctx->d_amb;
             A.amb_count = ctx->d_amb_count;
         }
+        // Models whose reads often have indels: the scan runs IN FRONT of k_main (it needs the descriptors only), so that
+        // k_main lists the substitutions of the reads with an event only -- the others are never shifted; with k_setup on
+        // the setup stream, right behind it there (its lists are double-buffered like the descriptors)
+        const bool scan_first = A.sub_list != nullptr;
+        const bool scan_ahead = scan_first && ahead;
+        auto launch_scan = [&](hipStream_t st) {
+            const uint64_t reads = 2 * (uint64_t)n;
+            hipLaunchKernelGGL(iss::k_indel_scan, dim3(A.scan_wgs), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), st, M, A, desc);
+        };
+        tl.scan_first = scan_first && !scan_ahead;
         HIP_TRY(ctx, mark(0, s_setup));
         if (ahead && A.light == 1 && main_lds_bytes(M) + iss::setup_lds_bytes(M.n_isize, M.ev_ns, true) > (size_t)158 * 1024)
             A.light = 2;  // (k_main's tables leave no room for the event tables beside them: read in place, off the critical path)
         {
             const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8 * (int64_t)ctx->n_cu);
             hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), iss::setup_lds_bytes(M.n_isize, M.ev_ns, A.light == 1 && M.n_scan > 0), s_setup, M, dg, A, desc);
+            if (scan_ahead) launch_scan(s_setup);
             if (ahead) {  // k_main (and what follows it) waits for this chunk's k_setup
                 if (ctx->timing && !ctx->timing_main_only) { HIP_TRY(ctx, hipEventCreate(&tl.ev[7])); HIP_TRY(ctx, hipEventRecord(tl.ev[7], s_setup)); }
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_setup_done[slot_i], s_setup));
@@ -1557,15 +1577,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             HIP_TRY(ctx, hipEventCreateWithFlags(&ev_setup, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventRecord(ev_setup, s_main));
         }
-        // Models whose reads often have indels: the scan runs IN FRONT of k_main (it needs the descriptors only), so that
-        // k_main lists the substitutions of the reads with an event only -- the others are never shifted
-        const bool scan_first = A.sub_list != nullptr;
-        auto launch_scan = [&](hipStream_t st) {
-            const uint64_t reads = 2 * (uint64_t)n;
-            const unsigned blocks = (unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu * 8, (reads + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
-            hipLaunchKernelGGL(iss::k_indel_scan, dim3(blocks), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), st, M, A, desc);
-        };
-        if (scan_first) {
+        if (scan_first && !scan_ahead) {
             HIP_TRY(ctx, mark(3, s_main));
             launch_scan(s_main);
             HIP_TRY(ctx, mark(4, s_main));
