@@ -765,7 +765,16 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->indel_stream, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->setup_stream, hipStreamNonBlocking));
+    {   // The setup stream gets the highest priority: its hardware queue then comes from another pool than the main stream's
+        // (streams of one priority share a few queues), and its small kernels are dispatched as soon as a CU has room.  Measured
+        // with engines created one after the other in one process (tools/placement_probe.py, default bench's step): 1.25-1.26 ms
+        // per step for every engine, against 1.24-1.29 (one box) and 1.28 / 1.41 alternating (another) at the default priority.
+        int prio_least = 0, prio_greatest = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        int prio = prio_greatest;
+        if (const char *e = getenv("ISS_SETUP_PRIO")) prio = atoi(e);
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->setup_stream, hipStreamNonBlocking, prio));
+    }
     for (auto &e : ctx->ev_call_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ctx->ev_setup_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inputs, hipEventDisableTiming));
