@@ -105,8 +105,13 @@ def main():
                          "every rank of a dry run on GPU 0)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # ISS_BENCH_FORCE_DIST=1: the multi-rank code path (process group bound to the GPU, barriers, the broadcast, the
+    # all_gather) with however many ranks there are -- ONE rank on a single-GPU box runs every RCCL call of an 8-GPU run
+    force_dist = os.environ.get("ISS_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_PORT", "29511")
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL needs dmabuf IPC on this driver)
@@ -144,7 +149,8 @@ def main():
             dense.dele[:] = args.indel[1]
         genomes = synthetic_genomes(args.n_genomes, GENOME_LEN, 123)
     t_b = time.time()
-    dense, grefs = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank), as_refs=True)
+    dense, grefs = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank), as_refs=True,
+                                               force=force_dist)
     torch.cuda.synchronize()
     bcast_s = time.time() - t_b if dist is not None else 0.0
 
@@ -263,7 +269,7 @@ def main():
         }
         out["n_ranks_seen"] = dist.get_world_size() if dist is not None else 1
         out["backend"] = (args.backend if dist is not None else None)
-        if world > 1:
+        if dist is not None:
             out["per_rank_pairs_per_sec"] = [n * args.steps / e if e > 0 else None for n, e in per_rank]
         if world == 1 and not args.no_other_workloads and not strong and args.model == "novaseq" and args.indel is None:
             # the same work list on the other models of the parity suite (a few steps each; BASELINE's metric stays the line above)

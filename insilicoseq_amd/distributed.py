@@ -86,9 +86,10 @@ def _align16(n):
     return (n + 15) & ~15
 
 
-def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, as_refs=False):
+def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, as_refs=False, force=False):
     """Rank ``src`` passes (DenseModel, list of uint8 arrays / bytes); other ranks pass (None, None).
-    Returns (DenseModel, genomes) on every rank; no-op when ``dist`` is None / world == 1.
+    Returns (DenseModel, genomes) on every rank; no-op when ``dist`` is None / world == 1 (``force``: go through the
+    collectives even then -- a one-rank RCCL group on a single-GPU box runs the very calls of an 8-GPU run).
 
     ONE payload: [header][model tables][genomes], the genomes as 2-bit codes (plain A/C/G/T records: a quarter of the
     letters -- 62.5 MB for BASELINE configs[3]'s 250 Mbp) or ASCII (records with IUPAC / lower-case letters), sent by one
@@ -98,7 +99,7 @@ def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, 
     def as_u8(g):
         return np.frombuffer(g, dtype=np.uint8) if isinstance(g, (bytes, bytearray)) else np.ascontiguousarray(g, dtype=np.uint8)
 
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None or (dist.get_world_size() == 1 and not force):
         glist = [as_u8(g) for g in genomes]
         return dense, ([BroadcastGenome(g.size, False, g) for g in glist] if as_refs else glist)
     import json

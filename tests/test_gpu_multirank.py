@@ -133,3 +133,62 @@ def test_bench_refuses_a_mismatched_launch():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)
+
+
+def test_bench_rccl_calls_with_one_rank():
+    """Every RCCL call of bench.py's N > 1 path -- init_process_group("nccl", device_id=...), the barriers, the two broadcasts
+    of CUDA tensors (size announcement, payload), uploads straight from the received device buffer, the all_gather of the
+    ranks' (pairs, seconds) -- executed for real on the one GPU of this box by a ONE-rank group (ISS_BENCH_FORCE_DIST=1
+    under torch.distributed.run).  An 8-GPU run differs by the number of ranks."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ISS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1",
+                          "--reads", "400000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end",
+                          "--no-other-workloads"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["n_ranks_seen"] == 1 and d["n_gpus"] == 1
+    assert d["model_broadcast_s"] > 0 and str(d["parity_window"]).startswith("ok")
+    assert len(d["per_rank_pairs_per_sec"]) == 1 and d["per_rank_pairs_per_sec"][0] > 0
+
+
+def test_rccl_broadcast_payload_equals_the_local_one():
+    """The same through the library call alone: a one-rank RCCL group, force=True -- the tables and the 2-bit genomes that
+    come back from the device buffer equal what went in, and an engine fed from the buffer generates the reads of one fed
+    from the host arrays."""
+    import torch
+    import torch.distributed as dist
+
+    from insilicoseq_amd.distributed import broadcast_model_and_genomes
+    from insilicoseq_amd.engine import ReadEngine
+    from insilicoseq_amd.model import DenseModel
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dense = DenseModel.load(os.path.join(root, "insilicoseq_amd", "profiles", "novaseq.dense.npz"))
+    rng = np.random.RandomState(5)
+    genomes = [np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, size=n)] for n in (30000, 4097)]
+    genomes.append(np.frombuffer(b"ACGTNacgtRY", dtype=np.uint8)[rng.randint(0, 11, size=5000)])  # (travels as ASCII)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got_dense, refs = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", 0), as_refs=True, force=True)
+        for k in DenseModel.FIELDS:
+            assert np.array_equal(getattr(got_dense, k), getattr(dense, k)), k
+        assert [r.length for r in refs] == [g.size for g in genomes]
+        outs = []
+        for feed in ("buffer", "host"):
+            with ReadEngine(0) as eng:
+                eng.load_model(dense)
+                gids = [r.upload(eng) for r in refs] if feed == "buffer" else [eng.add_genome(g) for g in genomes]
+                eng.generate_batch(gids, [700, 300, 200], first_ordinal=0, seed=3)
+                outs.append(eng.download(0, 1200))
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], outs[1][k]), k
+    finally:
+        dist.destroy_process_group()
