@@ -259,6 +259,7 @@ struct RunArgs {
     // event, 15) | first such step << 4 (0: none) for every read of the launch.
     uint32_t *ev_count, *ev_list, *read_count;  // read_count[w]: listed reads of scan workgroup w
     uint4 *read_list;
+    uint32_t main_blocked;  // k_main: a workgroup takes a contiguous range of 256-pair blocks instead of every n_wg-th
     uint32_t scan_wgs;  // workgroups of k_indel_scan: the read list is one segment per workgroup (no global counter)
     // substitutions k_main applied to reads with an indel event (models whose reads often have one; k_indel_scan runs in front of
     // k_main then): {pair, position | mate << 15 | template letter << 16}, appended in
@@ -924,6 +925,10 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     const uint32_t it_max = ((uint32_t)M.TS + 3u) / 4u - 1u;  // largest iteration number of a pass
     const uint32_t it_bits = sgpr(it_max ? 32u - (uint32_t)__clz(it_max) : 0u);  // (13 bits hold pass and iteration)
     const uint32_t n_pass = sgpr(((uint32_t)A.n_pairs + MAIN_PAIRS - 1) / MAIN_PAIRS);
+    // a workgroup's passes (256 pairs each): every n_wg-th block of the launch, or (A.main_blocked) a contiguous range of blocks
+    const uint32_t per_wg_blk = (n_pass + n_wg - 1) / n_wg;
+    const uint32_t blk_first = sgpr(A.main_blocked ? wg * per_wg_blk : wg), blk_step = sgpr(A.main_blocked ? 1u : n_wg);
+    const uint32_t blk_end = sgpr(A.main_blocked ? min(n_pass, blk_first + per_wg_blk) : n_pass);
     const uint32_t gsh = 16u - (uint32_t)M.GB, gb = (uint32_t)M.GB;
     const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
     const uint32_t gs_b = (uint32_t)M.GS * 4u;
@@ -951,7 +956,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
             const uint32_t *ep = ring + ((q_head + lane) & (SLOW_RING - 1)) * 3;
             ent_x = ep[0]; ent_y = ep[1];
             const uint32_t e_pass = ent_x >> (19u + it_bits), e_it = (ent_x >> 19) & ((1u << it_bits) - 1u), e_lane = (ent_x >> 13) & 63u;
-            const uint32_t e_pair = __umul24(wg + __umul24(e_pass, n_wg), (uint32_t)MAIN_PAIRS) + wave_pair0 + (e_lane >> 2);
+            const uint32_t e_pair = __umul24(blk_first + __umul24(e_pass, blk_step), (uint32_t)MAIN_PAIRS) + wave_pair0 + (e_lane >> 2);
             const uint32_t mask = ep[2];  // never empty
             const int bit = 31 - __clz(mask);
             rest_m = mask & ~(1u << bit);
@@ -991,21 +996,21 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     PairDesc d_next = {0, 0, 0u, 0};
     uint2 ec_next = {0u, 0u};  // SUBLIST: the event counters of the pair's two reads (k_indel_scan ran in front of this kernel)
     {
-        const uint32_t pair0 = wg * MAIN_PAIRS + wave_pair0 + (lane >> 2);
-        if (wg < n_pass && pair0 < (uint32_t)A.n_pairs) {
+        const uint32_t pair0 = blk_first * MAIN_PAIRS + wave_pair0 + (lane >> 2);
+        if (blk_first < blk_end && pair0 < (uint32_t)A.n_pairs) {
             d_next = desc[pair0];
             if (SUBLIST) ec_next = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair0);
         }
     }
-    for (uint32_t pass = 0, blk = wg; blk < n_pass; ++pass, blk += n_wg) {
+    for (uint32_t pass = 0, blk = blk_first; blk < blk_end; ++pass, blk += blk_step) {
         const uint32_t pair = blk * MAIN_PAIRS + wave_pair0 + (lane >> 2);
         const bool valid = pair < (uint32_t)A.n_pairs;
         const PairDesc d = d_next;
         const uint32_t has_ev = SUBLIST ? (ec_next.x ? 1u : 0u) | (ec_next.y ? 2u : 0u) : 0u;  // bit mate: that read has an indel event
         if (tile == 0 && j4 == 0u && valid) A.desc_out[pair] = d;
         {
-            const uint32_t pair_n = pair + n_wg * MAIN_PAIRS;
-            if (blk + n_wg < n_pass && pair_n < (uint32_t)A.n_pairs) {
+            const uint32_t pair_n = pair + blk_step * MAIN_PAIRS;
+            if (blk + blk_step < blk_end && pair_n < (uint32_t)A.n_pairs) {
                 d_next = desc[pair_n];
                 if (SUBLIST) ec_next = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair_n);
             }

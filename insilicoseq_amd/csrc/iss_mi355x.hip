@@ -792,6 +792,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->sub_count = static_cast<uint32_t *>(p);
     HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * 2 * FIX_SLOTS));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
+    if (const char *e = getenv("ISS_MAIN_GRID")) ctx->max_main_grid = (unsigned)std::max(1, atoi(e));  // tuning aid
     *out = ctx;
     return 0;
 }
@@ -1332,6 +1333,8 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     free_outputs(ctx);
     void *q = nullptr;
+    // (plain hipMalloc: physically contiguous rows -- hipExtMallocWithFlags(hipDeviceMallocContiguous) -- were measured at 1.82-1.88
+    //  instead of 1.25-1.34 ms per step of the default bench, whatever the grid)
     HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.row * (size_t)capacity_pairs));
     for (int k = 0; k < 4; ++k) ctx->out[k] = static_cast<uint8_t *>(q) + iss::row_array_off(k);
     for (int k = 0; k < 2; ++k) {  // (two sets: k_setup of a call runs beside the kernels of the call before)
@@ -1505,6 +1508,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.ev_list = ctx->ev_list[par] + 2 * (size_t)iss::EV_K * row0;
         A.read_list = ctx->read_list[par] + 2 * row0;
         A.read_count = read_counter;
+        A.main_blocked = getenv("ISS_MAIN_BLOCKED") ? (uint32_t)atoi(getenv("ISS_MAIN_BLOCKED")) : 0u;
         A.scan_wgs = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)ctx->n_cu * 2, iss::SCAN_MAX_WGS), (2 * (uint64_t)n + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
         A.light = ctx->light ? (iss::setup_lds_bytes(M.n_isize, M.ev_ns, true) <= (size_t)150 * 1024 ? 1 : 2) : 0;
         if (M.n_scan > 0 && ctx->sub_list && !ctx->light) {  // k_main lists the substitutions it applies: k_indel_resub re-applies those of shifted reads

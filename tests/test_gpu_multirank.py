@@ -157,10 +157,11 @@ def test_bench_rccl_calls_with_one_rank():
     assert len(d["per_rank_pairs_per_sec"]) == 1 and d["per_rank_pairs_per_sec"][0] > 0
 
 
-def test_rccl_broadcast_payload_equals_the_local_one():
-    """The same through the library call alone: a one-rank RCCL group, force=True -- the tables and the 2-bit genomes that
-    come back from the device buffer equal what went in, and an engine fed from the buffer generates the reads of one fed
-    from the host arrays."""
+def _rccl_one_rank_main(rank, port):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
     import torch
     import torch.distributed as dist
 
@@ -168,13 +169,14 @@ def test_rccl_broadcast_payload_equals_the_local_one():
     from insilicoseq_amd.engine import ReadEngine
     from insilicoseq_amd.model import DenseModel
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dense = DenseModel.load(os.path.join(root, "insilicoseq_amd", "profiles", "novaseq.dense.npz"))
     rng = np.random.RandomState(5)
     genomes = [np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, size=n)] for n in (30000, 4097)]
     genomes.append(np.frombuffer(b"ACGTNacgtRY", dtype=np.uint8)[rng.randint(0, 11, size=5000)])  # (travels as ASCII)
+    torch.cuda.set_device(0)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         got_dense, refs = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", 0), as_refs=True, force=True)
@@ -192,3 +194,12 @@ def test_rccl_broadcast_payload_equals_the_local_one():
             assert np.array_equal(outs[0][k], outs[1][k]), k
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_broadcast_payload_equals_the_local_one():
+    """The same through the library call alone: a one-rank RCCL group (in a process of its own), force=True -- the tables
+    and the 2-bit genomes that come back from the device buffer equal what went in, and an engine fed from the buffer
+    generates the reads of one fed from the host arrays."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rccl_one_rank_main, args=(_free_port(),), nprocs=1, join=True)
