@@ -202,6 +202,8 @@ struct iss_ctx {
     // outputs
     int64_t capacity = 0;
     uint8_t *out[4] = {nullptr, nullptr, nullptr, nullptr};  // ONE allocation of interleaved rows (iss::xp): out[k] = out[0] + iss::row_array_off(k)
+    std::vector<hipMemGenericAllocationHandle_t> rows_handles;  // ISS_ROWS_CHUNK_MB: the rows' physical chunks
+    size_t rows_va_bytes = 0;
     uint8_t *d_stage = nullptr;  // iss_output_download: the four plain arrays of the rows being copied
     size_t stage_cap = 0;
     iss::PairDesc *desc = nullptr;
@@ -298,6 +300,13 @@ void free_model(iss_ctx *ctx) {
 }
 
 void free_outputs(iss_ctx *ctx) {
+    if (ctx->out[0] && !ctx->rows_handles.empty()) {  // (rows mapped chunk by chunk: ISS_ROWS_CHUNK_MB)
+        (void)hipMemUnmap(ctx->out[0], ctx->rows_va_bytes);
+        for (auto &h : ctx->rows_handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(ctx->out[0], ctx->rows_va_bytes);
+        ctx->rows_handles.clear();
+        ctx->out[0] = nullptr;
+    }
     if (ctx->out[0]) (void)hipFree(ctx->out[0]);
     for (auto &p : ctx->out) p = nullptr;
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -1335,7 +1344,38 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     void *q = nullptr;
     // (plain hipMalloc: physically contiguous rows -- hipExtMallocWithFlags(hipDeviceMallocContiguous) -- were measured at 1.82-1.88
     //  instead of 1.25-1.34 ms per step of the default bench, whatever the grid)
+    if (const char *e = getenv("ISS_ROWS_CHUNK_MB")) {
+        // experiment: the rows as separately created physical chunks of this size mapped into one address range, in order
+        // (ISS_ROWS_SHUFFLE=0) or shuffled -- what the step time owes to the physical layout
+        const size_t bytes = (size_t)ctx->M.row * (size_t)capacity_pairs;
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = ctx->device;
+        size_t gran = 0;
+        HIP_TRY(ctx, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        size_t chunk = std::max<size_t>((size_t)(atof(e) * 1048576.0), gran);
+        chunk = (chunk + gran - 1) / gran * gran;
+        const size_t n_chunks = (bytes + chunk - 1) / chunk, va = n_chunks * chunk;
+        HIP_TRY(ctx, hipMemAddressReserve(&q, va, chunk, nullptr, 0));
+        std::vector<size_t> order(n_chunks);
+        for (size_t i = 0; i < n_chunks; ++i) order[i] = i;
+        if (!getenv("ISS_ROWS_SHUFFLE") || atoi(getenv("ISS_ROWS_SHUFFLE"))) {
+            uint64_t st = 0x9e3779b97f4a7c15ull;
+            for (size_t i = n_chunks; i > 1; --i) { st = st * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[i - 1], order[(st >> 33) % i]); }
+        }
+        ctx->rows_handles.resize(n_chunks);
+        for (size_t i = 0; i < n_chunks; ++i) HIP_TRY(ctx, hipMemCreate(&ctx->rows_handles[i], chunk, &prop, 0));
+        for (size_t i = 0; i < n_chunks; ++i) HIP_TRY(ctx, hipMemMap(static_cast<uint8_t *>(q) + order[i] * chunk, chunk, 0, ctx->rows_handles[i], 0));
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        HIP_TRY(ctx, hipMemSetAccess(q, va, &acc, 1));
+        ctx->rows_va_bytes = va;
+        if (getenv("ISS_DEBUG_MODEL")) fprintf(stderr, "rows: %zu chunks of %zu bytes (granularity %zu)\n", n_chunks, chunk, gran);
+    } else {
     HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.row * (size_t)capacity_pairs));
+    }
     for (int k = 0; k < 4; ++k) ctx->out[k] = static_cast<uint8_t *>(q) + iss::row_array_off(k);
     for (int k = 0; k < 2; ++k) {  // (two sets: k_setup of a call runs beside the kernels of the call before)
         HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));

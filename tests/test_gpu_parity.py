@@ -145,6 +145,31 @@ def test_back_to_back_calls_pipeline(model, indel, ahead, monkeypatch):
                 check(call)
 
 
+@pytest.mark.parametrize("switches", [{"ISS_ROWS_CHUNK_MB": "2"}, {"ISS_ROWS_CHUNK_MB": "0.25", "ISS_ROWS_SHUFFLE": "0"},
+                                      {"ISS_MAIN_BLOCKED": "1"}, {"ISS_MAIN_GRID": "100", "ISS_SETUP_PRIO": "0"}])
+def test_tuning_switches_do_not_change_results(switches, monkeypatch):
+    """The measurement switches of INTEGRATION.md 7 (rows mapped from separately created physical chunks, k_main's pass
+    distribution and grid, the setup stream's priority) leave the reads alone -- also across a re-allocation of the rows."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    dense = dense_model("novaseq", (0.001, 0.003))
+    genome = random_genome(77, 50000)
+    orc = O.Oracle(dense)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        for n in (70000, 150000):  # (the second reserve frees the first rows)
+            eng.reserve(n)
+            eng.generate(gid, n, first_ordinal=n, seed=9)
+            got = eng.download(n - 3000, 3000)
+            exp = orc.simulate(O.Rng().seed_philox(9), genome, 3000, first_ordinal=2 * n - 3000)
+            for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                assert np.array_equal(got[key], exp[key]), (n, key)
+
+
 def test_calls_with_and_without_setup_stream_share_the_counter_rings(monkeypatch):
     """Regression (round 3): calls whose k_setup runs on the setup stream and calls that keep everything on one stream
     (custom fragment lengths: the host reads k_setup's results back) take their fix-up / read-list / substitution-list
