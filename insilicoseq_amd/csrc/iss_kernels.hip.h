@@ -1824,8 +1824,10 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
             if (n < RL) { map[n] = FIX_NONE; qual[n] = out_qual[xp(n)]; }
             { const uint64_t am = __ballot(m8 != 0); if (lane == 0) act[c] = am; }
         }
-        if (!gl.has_exceptions && geo.t_len == RL && (o == 0 ? geo.lo + n_pre <= gl.L : geo.hi - n_pre >= 0)) {
+        if (!gl.has_exceptions && geo.t_len == RL && (o == 0 ? geo.lo + n_pre <= gl.L : geo.hi - n_pre >= 0 && geo.rs == geo.lo)) {
             // the whole staged stretch lies inside a record of plain A/C/G/T: 16 letters per lane from one packed word
+            // (not for a reverse mate whose slice Python wrapped around -- custom fragment lengths, negative bounds: its
+            //  tokens behind the template follow the UN-normalised start, 'A' below zero: geom_base)
             const int64_t g0 = o == 0 ? geo.lo : geo.hi - n_pre;  // lowest genome position of the stretch
             for (int wi = lane; wi * 16 < n_pre + 16; wi += 64) {
                 const int64_t gp = ((g0 >> 4) + wi) << 4;  // genome position of the word's first base
