@@ -94,3 +94,37 @@ def test_single_rank_is_a_noop_broadcast():
     dense = DenseModel.load(os.path.join(GOLDEN, "..", "..", "insilicoseq_amd", "profiles", "ecoli.dense.npz"))
     d2, g2 = D.broadcast_model_and_genomes(dense, [b"ACGT" * 10], None)
     assert d2 is dense and g2[0].tobytes() == b"ACGT" * 10
+
+
+def _forced_one_rank_main(rank, port):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+
+    from insilicoseq_amd import distributed as D
+    from insilicoseq_amd.model import DenseModel
+
+    dense = DenseModel.load(os.path.join(GOLDEN, "..", "..", "insilicoseq_amd", "profiles", "ecoli.dense.npz"))
+    rng = np.random.RandomState(3)
+    genomes = [np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, size=n)] for n in (1, 15, 16, 17, 4099)]
+    genomes.append(np.frombuffer(b"ACGTNacgtRYKM", dtype=np.uint8)[rng.randint(0, 13, size=333)])  # (travels as ASCII)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        for as_refs in (False, True):
+            d2, g2 = D.broadcast_model_and_genomes(dense, genomes, dist, device="cpu", as_refs=as_refs, force=True)
+            for k in DenseModel.FIELDS:
+                assert np.array_equal(getattr(d2, k), getattr(dense, k)), k
+            got = [g.ascii() for g in g2] if as_refs else g2
+            assert len(got) == len(genomes) and all(np.array_equal(np.asarray(a), b) for a, b in zip(got, genomes))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_one_rank_broadcast_roundtrips_the_payload():
+    """force=True sends the payload through the collectives even with one rank (the switch behind bench.py's
+    ISS_BENCH_FORCE_DIST and the one-rank RCCL tests on the GPU box): header, tables, 2-bit packed and ASCII genomes -- incl. lengths
+    around a 16-base word -- come back as they went in."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_forced_one_rank_main, args=(_free_port(),), nprocs=1, join=True)
