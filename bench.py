@@ -390,7 +390,7 @@ def side_workload(device, model, indel, genomes, records, abundance, reads, step
             "value": total * steps / elapsed, "unit": "read-pairs/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
             "model": model, "read_length": dense.read_length, "indel_override": indel, "pairs_per_step": total,
             "kernel_ms_per_step": {"main_ms": main_ms, "setup_ms": tm["setup_ms"] / 3, "indel_scan_ms": tm["indel_scan_ms"] / 3,
-                                   "indel_apply_fixup_ms": tm["indel_fixup_ms"] / 3,
+                                   "indel_fixup_ms": tm["indel_fixup_ms"] / 3,
                                    "note": "main_ms: HIP events over the timed steps; the others: events around every kernel over three further steps"},
             "k_main_frac_of_hbm_peak": (total * algorithmic_bytes_per_pair(dense.read_length)) / (main_ms / 1e3) / 1e9 / HBM_PEAK_GBPS
             if main_ms > 0 else None,

@@ -28,11 +28,13 @@
 extern "C" {
 #endif
 
-/* 4: device rows interleaved per pair (whole 128-byte lines per store, see iss_output_reserve), iss_output_row;
+/* 6: indels inside k_main (edit scripts): iss_stats_read reports the scripted reads too; iss_build_id.
+ * 5: the ErrorModel methods as batched entries (iss_gen_phred_scores, ...), iss_ev_step.
+ * 4: device rows interleaved per pair (whole 128-byte lines per store, see iss_output_reserve), iss_output_row;
  *    Philox address map of the hot draws: three blocks per 16 bases.
  * 3: iss_fastq_compress / iss_deflate_code_build (gzip members built on the device), iss_generate_batch,
  *    iss_fastq_emit_batch (a whole work list per call).  2: iss_fastq_emit / iss_fastq_flush, MT-mode path counters. */
-#define ISS_ABI_VERSION 5
+#define ISS_ABI_VERSION 6
 
 #define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
 #define ISS_E_HIP (-2)         /* HIP runtime failure (message has the hip error)  */
@@ -47,6 +49,9 @@ extern "C" {
 typedef struct iss_ctx iss_ctx;
 
 int iss_abi_version(void);
+/* A hash of the kernel sources this library was compiled from (hex string; "unknown" for a build that did not pass
+ * -DISS_BUILD_ID).  bench.py ties committed PMC traffic figures (profiles/ *_traffic.json) to the binary that runs. */
+const char *iss_build_id(void);
 
 /* One context = one GPU = one reference worker (`cpu_number`), iss/generator.py:223. */
 int iss_ctx_create(int device_ordinal, iss_ctx **out);
@@ -222,8 +227,9 @@ int iss_output_download_coords(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs
 int iss_timing_enable(iss_ctx *ctx, int enable);
 int iss_timing_read(iss_ctx *ctx, double ms[4], int64_t *n_launches);
 
-/* Counters of the last iss_generate call(s): reads re-done by the indel fix-up kernel. */
-int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads);
+/* Counters since the last read: reads rebuilt by the indel fix-up kernel (one wavefront per read), reads k_main built from an
+ * edit script (models whose reads often have indels).  Either pointer may be NULL. */
+int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads, int64_t *n_scripted_reads);
 
 /*
  * Reference-compatible RNG mode (sequential; for bit-identity with the reference, not throughput).

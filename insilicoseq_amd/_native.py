@@ -17,7 +17,7 @@ EXPORTS = (
     "iss_abi_version", "iss_ctx_create", "iss_ctx_destroy", "iss_last_error", "iss_ctx_set_stream",
     "iss_model_upload", "iss_genome_upload", "iss_genome_upload_packed", "iss_genome_clear", "iss_output_reserve", "iss_output_pitch",
     "iss_output_device_ptrs", "iss_output_row", "iss_generate", "iss_synchronize", "iss_output_download",
-    "iss_output_download_coords", "iss_timing_enable", "iss_timing_read", "iss_stats_read", "iss_fastq_write",
+    "iss_output_download_coords", "iss_timing_enable", "iss_timing_read", "iss_stats_read", "iss_build_id", "iss_fastq_write",
     "iss_mt_seed", "iss_generate_mt", "iss_mt_peek", "iss_mt_mutations_reserve", "iss_mt_mutations_download",
     "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
     "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush", "iss_fastq_compress", "iss_deflate_code_build",
@@ -85,7 +85,9 @@ def lib():
     L.iss_output_download_coords.argtypes = [vp, i64, i64, vp]
     L.iss_timing_enable.argtypes = [vp, C.c_int]
     L.iss_timing_read.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(i64)]
-    L.iss_stats_read.argtypes = [vp, C.POINTER(i64)]
+    L.iss_stats_read.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.iss_build_id.restype = C.c_char_p
+    L.iss_build_id.argtypes = []
     L.iss_mt_seed.argtypes = [vp, u64]
     L.iss_generate_mt.argtypes = [vp, i32, i64, i32, i32, i64, C.POINTER(i64)]
     L.iss_mt_peek.argtypes = [vp, vp, vp, i32]

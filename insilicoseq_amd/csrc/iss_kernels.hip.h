@@ -169,7 +169,10 @@ struct DevModel {
     const uint32_t *subst13;    // [n_tiles][2][TP][4]: t0_13 | t1_13 << 13 | (alt0 | alt1 << 2 | alt2 << 4) << 26: leading 13 bits of
                                 // subst_thr, alternatives as indices into alt_letters
     uint32_t alt_letters;       // the (<= 4) distinct letters of subst_alt
-    float exp_subs;             // expected substitutions per pair (sizes RunArgs::sub_list)
+    // edit scripts of reads with indel events (k_indel_script -> k_main<.., INDEL>; see SC_* below)
+    int32_t sc_gpt;             // groups of 8 iterations per position tile of k_main: ceil(ceil(TS / 4) / 8)
+    int32_t sc_stride;          // bytes per read: n_tiles * sc_gpt * 64
+    int32_t ins_plain;          // every insertion letter of the model is one of A/C/G/T (else reads with events take k_indel_fixup)
     float p_read_event;         // probability that a read has an indel event (the larger of the two mates')
     const uint64_t *subst_thr;  // [2][RL][4][3]
     const uint8_t *subst_alt;   // [2][RL][4][3]
@@ -259,15 +262,10 @@ struct RunArgs {
     // event, 15) | first such step << 4 (0: none) for every read of the launch.
     uint32_t *ev_count, *ev_list, *read_count;  // read_count[w]: listed reads of scan workgroup w
     uint4 *read_list;
-    uint32_t main_blocked;  // k_main: a workgroup takes a contiguous range of 256-pair blocks instead of every n_wg-th
     uint32_t scan_wgs;  // workgroups of k_indel_scan: the read list is one segment per workgroup (no global counter)
-    // substitutions k_main applied to reads with an indel event (models whose reads often have one; k_indel_scan runs in front of
-    // k_main then): {pair, position | mate << 15 | template letter << 16}, appended in
-    // chunks of SUB_CHUNK entries per wavefront (unused entries: pair == 0xffffffff); sub_count[0] = entries reserved,
-    // sub_count[1] != 0: the list overflowed (k_indel_apply then hands every listed read to k_indel_fixup)
-    uint2 *sub_list;
-    uint32_t *sub_count;
-    uint32_t sub_cap;
+    // Models whose reads often have indels: the edit scripts k_indel_script leaves for k_main (see SC_* below): M.sc_stride bytes
+    // per READ (2 * pair + mate), valid iff ev_count[read] != 0 once k_indel_script has run
+    uint8_t *script;
     PairDesc *desc_out;  // k_main copies the descriptors it works from here (the call's own set is double-buffered: k_setup of the
                          // next call may be rewriting it while the host asks for this call's coordinates)
     int32_t light;  // 1: reads with an indel are rare (DevModel::p_read_event): k_indel_scan hands every one of them to k_indel_fixup
@@ -328,32 +326,7 @@ __device__ __forceinline__ void mut_emit(const RunArgs &A, MutChunk &c, bool hav
     if (have && at != 0xffffffffu) A.mut[at + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = r;
 }
 
-// The list of applied substitutions (RunArgs::sub_list): ALL 64 lanes of the wavefront call this; lanes with `have` append
-// their entry.  A chunk that cannot take a round's entries is closed (its unused entries marked) and a new one reserved.
-constexpr uint32_t SUB_CHUNK = 256;
-__device__ __forceinline__ void sub_close(const RunArgs &A, const MutChunk &c) {
-    if (c.base + SUB_CHUNK <= A.sub_cap)
-        for (uint32_t i = c.used + (threadIdx.x & 63u); i < SUB_CHUNK; i += 64u) A.sub_list[c.base + i] = make_uint2(0xffffffffu, 0u);
-}
-__device__ __forceinline__ void sub_emit(const RunArgs &A, MutChunk &c, bool have, uint32_t pair, uint32_t word) {
-    const unsigned long long m = __ballot(have);
-    if (!m) return;
-    const uint32_t n = (uint32_t)__popcll(m);
-    if (c.used + n > SUB_CHUNK) {
-        sub_close(A, c);
-        uint32_t b = 0;
-        if ((threadIdx.x & 63u) == 0u) b = atomicAdd(A.sub_count, SUB_CHUNK);
-        c.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        c.used = 0;
-        if (c.base + SUB_CHUNK > A.sub_cap && (threadIdx.x & 63u) == 0u) A.sub_count[1] = 1u;
-    }
-    const uint32_t at = c.base + c.used;
-    c.used += n;
-    if (have && c.base + SUB_CHUNK <= A.sub_cap)
-        A.sub_list[at + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = make_uint2(pair, word);
-}
-
-// one row from one lane (the groups of a k_indel_apply wavefront walk different reads: no wave-uniform chunk there)
+// one row from one lane (the lanes of a k_indel_script wavefront walk different reads: no wave-uniform chunk there)
 __device__ __forceinline__ void mut_emit1(const RunArgs &A, const MutRecord &r) {
     const uint32_t at = atomicAdd(A.mut_count, 1u);
     if (at < A.mut_cap) A.mut[at] = r;
@@ -738,6 +711,18 @@ __device__ __forceinline__ uint64_t error_test_draw(uint32_t e8, const u32x4 &su
     return ((uint64_t)e8 << 45) | ((uint64_t)(sub_blk.z & 0x1fffu) << 32) | sub_blk.w;
 }
 
+// ---- edit scripts (k_indel_script -> k_main<.., INDEL>)
+// Per READ with an indel event DevModel::sc_stride bytes: for every position tile of k_main and every group of 8 of the tile's
+// iterations four 16-byte rows, one per lane j4 of the pair.  Bytes 0-7 of a row: one byte per iteration `it` of the group, for
+// the piece (8 read positions) s = tile * TS + 4 * it + j4:
+//   64 + sh (0..127): the piece is the template shifted by sh tokens (read position j <-> template token j + sh);
+//   128 + 16 k      : the piece holds inserted letters or a run boundary: its 8 letters are the k-th 16-bit word (k < SC_ROW_CODES)
+//                     of bytes 8-15 -- 2-bit codes in the format of k_main's genome windows (forward: bit pair c = read
+//                     position c; reverse: bit pair c = read position 7 - c, complemented, i.e. genome orientation).
+// A read without a script is all SC_IDLE bytes (shift 0).  The four lanes of a pair load 64 contiguous bytes per mate and pass.
+constexpr uint32_t SC_IDLE = 0x40404040u;
+constexpr int SC_ROW_CODES = 4;
+
 constexpr int MAIN_THREADS = 1024;
 constexpr int MAIN_PAIRS = MAIN_THREADS / 4;  // pairs of one workgroup pass: four lanes per pair
 constexpr int MAIN_MUT_WORDS = 128;  // LDS words of the substitution-test thresholds (n_q <= 60)
@@ -769,13 +754,16 @@ struct MainTile {  // per-workgroup constants of k_main
 // stream takes microseconds: so the common case touches NO global memory except for the two byte stores -- the queue
 // entry carries the lane-item's two 8-base genome windows and the pair's bin slots, the thresholds sit in LDS.
 // (Records with IUPAC / lower-case letters, gc_bias and digit ties do load: descriptor, ASCII genome, full thresholds.)
-// Returns 0 (no substitution), 1 (substituted, by the letter it had) or 3 (by a different letter: a --store_mutations row);
-// `rec` is filled whenever a substitution was applied.
-template <bool PLAIN>
+// Returns 0 (no substitution), 1 (substituted, by the letter the ORIGINAL read had there) or 3 (by a different letter: a
+// --store_mutations row); `rec` is filled whenever a substitution was applied.
+// INDEL: `scripted` != 0 <=> the mate was built from an edit script (k_indel_script): its windows hold the FINAL letters
+// (shifted template / inserted letters, all of them plain A/C/G/T), which is what mut_sequence sees (generator.py:152-154:
+// indels first, then the phreds, then the substitutions).
+template <bool PLAIN, bool INDEL, bool STORE_MUT>
 __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome &g, const RunArgs &A,
                                                const PairDesc *__restrict__ desc, const uint32_t *lds, const MainTile &T,
                                                uint32_t pair, uint32_t sl, int half, int s, uint32_t slots, uint32_t windows,
-                                               MutRecord &rec) {
+                                               uint32_t scripted, MutRecord &rec) {
     const int o = s >> 2, cc = s & 3, c = half * 4 + cc;
     const uint32_t s_abs = (uint32_t)T.s0 + sl;
     const int p = (int)s_abs * 8 + c;
@@ -810,7 +798,7 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
     // the template base: forward window bit pair c; reverse window (already complemented) bit pair 7 - c
     const uint32_t code = o ? ((windows >> (16 + 2 * (7 - c))) & 3u) : ((windows >> (2 * c)) & 3u);
     int base = code_to_ascii(code), bi = (int)code;
-    if (!PLAIN) {  // the letter may be IUPAC / lower case, the pair irregular (custom fragment lengths)
+    if (!PLAIN && !(INDEL && scripted)) {  // the letter may be IUPAC / lower case, the pair irregular (custom fragment lengths)
         const PairDesc d = desc[pair];
         if (A.has_frag && (d.meta & 64u)) return 0;  // irregular pair: the fix-up kernel builds its bases
         base = fetch_ascii(g, o ? (int64_t)d.re - 1 - p : (int64_t)d.fs + p);
@@ -829,10 +817,17 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
     }
     const uint32_t nb = (M.alt_letters >> (8 * ((sd >> (26 + 2 * k)) & 3u))) & 0xffu;
     A.out[2 * o][byte_off] = (uint8_t)nb;
-    // without indels the original read equals the template, i.e. the base just replaced (__init__.py:98)
+    // without indels the original read equals the template, i.e. the base just replaced (__init__.py:98); a scripted
+    // mate's original letter at this index is the UN-shifted template's
+    int orig = base;
+    if (INDEL && STORE_MUT && scripted) {
+        const PairDesc d = desc[pair];
+        orig = fetch_ascii(g, o ? (int64_t)d.re - 1 - p : (int64_t)d.fs + p);
+        if (o) orig = complement_ascii(orig);
+    }
     rec.pair = (int32_t)(A.pair_base + pair); rec.mate = (int8_t)o; rec.type = 0; rec.position = (int16_t)p;
     rec.ref = (uint8_t)base; rec.alt = (uint8_t)nb; rec.quality = (int16_t)q;
-    return (int)nb != base ? 3 : 1;
+    return (int)nb != orig ? 3 : 1;
 }
 
 // One CDF inversion + substitution test of the hot loop, loop-free: guide byte -> two consecutive entries -> select.
@@ -884,8 +879,12 @@ __device__ __forceinline__ uint32_t shift_in(uint32_t r, unsigned long long flag
 #ifndef ISS_MAIN_OCC
 #define ISS_MAIN_OCC 4   // wavefronts per SIMD the register budget is cut for: one 1024-lane workgroup per CU, 128 VGPRs (measured against 8 / 64: -12 % time)
 #endif
-// SUBLIST: the launch lists the substitutions it applies (RunArgs::sub_list: models whose reads often have indels).
-template <bool STORE_MUT, bool PLAIN, bool SUBLIST>
+// INDEL: models whose reads often have indels (k_indel_scan and k_indel_script ran in front of this launch).  A read with an
+// event has an edit script (SC_* below): per 8-position piece either "the template, shifted by sh tokens" -- the lane then
+// takes its 8-base window from the shifted genome position, the same funnel shift as ever -- or 8 explicit letters as
+// 2-bit codes in the window's own format.  The letters mut_sequence tests are the final ones (generator.py:152-154), so no
+// piece is written twice and nothing is listed for later.
+template <bool STORE_MUT, bool PLAIN, bool INDEL>
 __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M, DevGenome g, RunArgs A,
                                                        const PairDesc *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
@@ -898,7 +897,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     T.s0 = tile * M.TS;
     T.ts = (uint32_t)min(M.TS, M.S - T.s0);
     // Deferred lane-items (a base needs the exact path): a private ring per wavefront -- no atomics, no barriers.
-    // Entry = {(pass << it_bits | iteration) << 19 | lane << 13 | bin slots << 8 | (SUBLIST) "mate has an indel event" bits 0-1,
+    // Entry = {(pass << it_bits | iteration) << 19 | lane << 13 | bin slots << 8 | (INDEL) "mate was built from an edit script" bits 0-1,
     //          forward window | complemented reverse window << 16 (2-bit codes of the lane-item's 8 + 8 template bases),
     //          base mask: bit 15 - (8 * half + s) <=> base s = mate * 4 + cc of that half of the superitem};
     // head / tail are wave-uniform.
@@ -929,10 +928,9 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     const uint32_t it_max = ((uint32_t)M.TS + 3u) / 4u - 1u;  // largest iteration number of a pass
     const uint32_t it_bits = sgpr(it_max ? 32u - (uint32_t)__clz(it_max) : 0u);  // (13 bits hold pass and iteration)
     const uint32_t n_pass = sgpr(((uint32_t)A.n_pairs + MAIN_PAIRS - 1) / MAIN_PAIRS);
-    // a workgroup's passes (256 pairs each): every n_wg-th block of the launch, or (A.main_blocked) a contiguous range of blocks
-    const uint32_t per_wg_blk = (n_pass + n_wg - 1) / n_wg;
-    const uint32_t blk_first = sgpr(A.main_blocked ? wg * per_wg_blk : wg), blk_step = sgpr(A.main_blocked ? 1u : n_wg);
-    const uint32_t blk_end = sgpr(A.main_blocked ? min(n_pass, blk_first + per_wg_blk) : n_pass);
+    // a workgroup's passes (256 pairs each): every n_wg-th block of the launch (the chip's concurrent writes stay in one moving
+    // window of rows; contiguous ranges per workgroup were measured 15 % slower)
+    const uint32_t blk_first = sgpr(wg), blk_step = sgpr(n_wg), blk_end = n_pass;
     const uint32_t gsh = 16u - (uint32_t)M.GB, gb = (uint32_t)M.GB;
     const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
     const uint32_t gs_b = (uint32_t)M.GS * 4u;
@@ -943,7 +941,6 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     for (int c = 0; c < 8; ++c) off_g[c] = sgpr((uint32_t)(c >> 2) * gs_b + (uint32_t)(c & 3) * stride_b);
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // the leading padding word: offsets >= 0
     MutChunk mchunk = {0u, MUT_CHUNK};  // --store_mutations: forces a reservation at first use
-    MutChunk schunk = {0xffffffffu - SUB_CHUNK, SUB_CHUNK};  // the list of applied substitutions, likewise
     const uint32_t wave_pair0 = (threadIdx.x >> 6) * 16u;
     // one round of the exact path: lane k takes ONE base of the k-th pending entry of this wavefront (n <= 64 of them);
     // an entry with more bases (noisy models: NextSeq, MiSeq) goes back into the ring, so every round runs full
@@ -953,7 +950,6 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         //  one wavefront reach a given address in issue order, no wait is needed)
         uint32_t rest_m = 0u, ent_x = 0u, ent_y = 0u;
         int subst = 0;
-        uint32_t sub_pair = 0;
         MutRecord rec;
         rec.position = 0; rec.mate = 0; rec.ref = 0;
         if (lane < n) {
@@ -964,13 +960,11 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
             const uint32_t mask = ep[2];  // never empty
             const int bit = 31 - __clz(mask);
             rest_m = mask & ~(1u << bit);
-            subst = main_slow_base<PLAIN>(M, g, A, desc, lds, T, e_pair, 4u * e_it + (e_lane & 3u), (15 - bit) >> 3,
-                                                    (15 - bit) & 7, (ent_x >> 8) & 15u, ent_y, rec);
+            subst = main_slow_base<PLAIN, INDEL, STORE_MUT>(M, g, A, desc, lds, T, e_pair, 4u * e_it + (e_lane & 3u), (15 - bit) >> 3,
+                                                             (15 - bit) & 7, (ent_x >> 8) & 15u, ent_y,
+                                                             INDEL ? (ent_x >> (((15 - bit) & 7) >> 2)) & 1u : 0u, rec);
             if (STORE_MUT) mut_emit(A, mchunk, subst == 3, rec);
-            sub_pair = e_pair;
         }
-        // (models with indels: the reads k_indel_apply shifts have their substitutions re-applied from this list)
-        if (SUBLIST) sub_emit(A, schunk, subst != 0 && ((ent_x >> rec.mate) & 1u), sub_pair, (uint32_t)rec.position | ((uint32_t)rec.mate << 15) | ((uint32_t)rec.ref << 16));
         q_head += n;
         const unsigned long long again = __ballot(rest_m != 0u);
         if (again) {
@@ -998,25 +992,50 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     const uint32_t j4 = lane & 3u;
     // (the descriptor of the NEXT pass is requested at the start of a pass: its latency hides behind the pass)
     PairDesc d_next = {0, 0, 0u, 0};
-    uint2 ec_next = {0u, 0u};  // SUBLIST: the event counters of the pair's two reads (k_indel_scan ran in front of this kernel)
+    // INDEL: the event counters of a pair's two reads (!= 0 <=> the read has an edit script) are requested two passes ahead,
+    // this lane's script rows one pass ahead: both have a whole pass to arrive
+    uint2 ec_ahead = {0u, 0u};
+    uint4 scn_f = make_uint4(SC_IDLE, SC_IDLE, 0u, 0u), scn_r = scn_f;
+    uint32_t hv_next = 0u;  // bit mate: that read of the next pass has a script
+    auto sc_rows = [&](uint32_t pair_x, uint2 ec, uint32_t grp, uint4 &rf, uint4 &rr) {
+        const uint8_t *row = A.script + (size_t)(2u * pair_x) * (size_t)(uint32_t)M.sc_stride +
+                             (((uint32_t)tile * (uint32_t)M.sc_gpt + grp) * 4u + j4) * 16u;
+        if (ec.x) rf = *reinterpret_cast<const uint4 *>(row);
+        if (ec.y) rr = *reinterpret_cast<const uint4 *>(row + M.sc_stride);
+    };
     {
         const uint32_t pair0 = blk_first * MAIN_PAIRS + wave_pair0 + (lane >> 2);
         if (blk_first < blk_end && pair0 < (uint32_t)A.n_pairs) {
             d_next = desc[pair0];
-            if (SUBLIST) ec_next = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair0);
+            if (INDEL) {  // (the first pass of a workgroup waits for this chain once)
+                const uint2 ec0 = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair0);
+                const uint32_t pair1 = pair0 + blk_step * MAIN_PAIRS;
+                if (blk_first + blk_step < blk_end && pair1 < (uint32_t)A.n_pairs) ec_ahead = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair1);
+                hv_next = (ec0.x ? 1u : 0u) | (ec0.y ? 2u : 0u);
+                sc_rows(pair0, ec0, 0u, scn_f, scn_r);
+            }
         }
     }
     for (uint32_t pass = 0, blk = blk_first; blk < blk_end; ++pass, blk += blk_step) {
         const uint32_t pair = blk * MAIN_PAIRS + wave_pair0 + (lane >> 2);
         const bool valid = pair < (uint32_t)A.n_pairs;
         const PairDesc d = d_next;
-        const uint32_t has_ev = SUBLIST ? (ec_next.x ? 1u : 0u) | (ec_next.y ? 2u : 0u) : 0u;  // bit mate: that read has an indel event
+        const uint32_t has_ev = INDEL ? hv_next : 0u;  // bit mate: that read is built from its edit script
+        uint4 sc_f = scn_f, sc_r = scn_r;
         if (tile == 0 && j4 == 0u && valid) A.desc_out[pair] = d;
         {
             const uint32_t pair_n = pair + blk_step * MAIN_PAIRS;
-            if (blk + blk_step < blk_end && pair_n < (uint32_t)A.n_pairs) {
-                d_next = desc[pair_n];
-                if (SUBLIST) ec_next = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair_n);
+            const bool valid_n = blk + blk_step < blk_end && pair_n < (uint32_t)A.n_pairs;
+            if (valid_n) d_next = desc[pair_n];
+            if (INDEL) {
+                const uint2 ec = ec_ahead;  // the next pass's counters (zero beyond the launch's pairs)
+                ec_ahead = make_uint2(0u, 0u);
+                const uint32_t pair_nn = pair_n + blk_step * MAIN_PAIRS;
+                if (blk + 2u * blk_step < blk_end && pair_nn < (uint32_t)A.n_pairs) ec_ahead = *reinterpret_cast<const uint2 *>(A.ev_count + 2u * pair_nn);
+                hv_next = (ec.x ? 1u : 0u) | (ec.y ? 2u : 0u);
+                scn_f = make_uint4(SC_IDLE, SC_IDLE, 0u, 0u);
+                scn_r = scn_f;
+                if (valid_n) sc_rows(pair_n, ec, 0u, scn_f, scn_r);
             }
         }
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
@@ -1037,9 +1056,29 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 // ---- the two 8-base windows of the 2-bit genome: forward g[pf .. pf+7]; reverse comp(g[pr+7 .. pr]); loaded
                 //      first, used last (the wait for them would otherwise also be a wait for the previous stores)
                 uint2 gf = {0u, 0u}, gr = {0u, 0u};
+                // INDEL: this piece of each mate per its script row -- shifted template (the window moves) or explicit codes
+                int32_t pf_e = pf, pr_e = pr;
+                uint32_t code_f = 0u, code_r = 0u;
+                bool ex_f = false, ex_r = false;
+                if (INDEL) {
+                    if ((it & 7u) == 0u && it != 0u) {  // long tiles: the rows of the next 8 iterations (a wait; no shipped model)
+                        sc_f = make_uint4(SC_IDLE, SC_IDLE, 0u, 0u);
+                        sc_r = sc_f;
+                        sc_rows(pair, make_uint2(has_ev & 1u, has_ev & 2u), it >> 3, sc_f, sc_r);
+                    }
+                    const uint32_t bf = sc_f.x & 0xffu, br = sc_r.x & 0xffu;
+                    ex_f = bf >= 128u;
+                    ex_r = br >= 128u;
+                    pf_e = pf + (ex_f ? 0 : (int32_t)bf - 64);
+                    pr_e = pr - (ex_r ? 0 : (int32_t)br - 64);
+                    code_f = (uint32_t)((((uint64_t)sc_f.w << 32) | sc_f.z) >> (bf & 63u));  // (128 + 16 k) & 63 = 16 k
+                    code_r = (uint32_t)((((uint64_t)sc_r.w << 32) | sc_r.z) >> (br & 63u));
+                    sc_f.x = __builtin_amdgcn_alignbit(sc_f.y, sc_f.x, 8u); sc_f.y >>= 8;
+                    sc_r.x = __builtin_amdgcn_alignbit(sc_r.y, sc_r.x, 8u); sc_r.y >>= 8;
+                }
                 if (regular) {
-                    gf = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pf >> 4) + 1) << 2));
-                    gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pr >> 4) + 1) << 2));
+                    gf = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pf_e >> 4) + 1) << 2));
+                    gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pr_e >> 4) + 1) << 2));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- hot digits: 16 quality digits (16 bits) + 16 error-test digits (8 bits)
@@ -1078,14 +1117,17 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 uint2 qual_f = {quals(0), quals(8)}, qual_r = {quals(4), quals(12)};
                 // ---- template bases
                 uint32_t fm = 0, rm = 0;
-                const uint32_t fb = funnel_r(gf.x, gf.y, (uint32_t)(pf & 15) * 2);
-                const uint32_t rbr = funnel_r(gr.x, gr.y, (uint32_t)(pr & 15) * 2);
+                uint32_t fb = funnel_r(gf.x, gf.y, (uint32_t)(pf_e & 15) * 2);
+                uint32_t rbr = funnel_r(gr.x, gr.y, (uint32_t)(pr_e & 15) * 2);
+                if (INDEL) { fb = ex_f ? code_f : fb; rbr = ex_r ? code_r : rbr; }
                 windows = __builtin_amdgcn_perm(rbr ^ 0x5555u, fb, 0x05040100u);  // fb[15:0] | complemented (code ^ 1) rb[15:0] << 16
                 if (!PLAIN && regular && (d.meta & 0x30u)) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
-                    const uint32_t *mw = g.mask + (pf >> 5);
-                    fm = funnel_r(mw[0], mw[1], (uint32_t)(pf & 31)) & 0xffu;
-                    const uint32_t *nw = g.mask + (pr >> 5);
-                    rm = funnel_r(nw[0], nw[1], (uint32_t)(pr & 31)) & 0xffu;
+                    // (a scripted mate lies in a record of plain A/C/G/T -- k_indel_script -- so pf_e / pr_e differ from pf / pr
+                    //  only where the mask is clear)
+                    const uint32_t *mw = g.mask + (pf_e >> 5);
+                    fm = funnel_r(mw[0], mw[1], (uint32_t)(pf_e & 31)) & 0xffu;
+                    const uint32_t *nw = g.mask + (pr_e >> 5);
+                    rm = funnel_r(nw[0], nw[1], (uint32_t)(pr_e & 31)) & 0xffu;
                 }
                 // (letters from the LDS tables: forward a byte of codes as it stands; reverse mate: read position c <-> genome
                 //  position pr + 7 - c, complemented)
@@ -1094,12 +1136,12 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 if (!PLAIN && (fm | rm)) {  // IUPAC / lower-case letters: patch from the ASCII copy
                     for (int c = 0; c < 8; ++c) {
                         if ((fm >> c) & 1u) {
-                            const uint32_t ch = g.ascii[(int64_t)pf + c];
+                            const uint32_t ch = g.ascii[(int64_t)pf_e + c];
                             uint32_t &w = c < 4 ? base_f.x : base_f.y;
                             w = (w & ~(0xffu << (8 * (c & 3)))) | (ch << (8 * (c & 3)));
                         }
                         if ((rm >> (7 - c)) & 1u) {
-                            const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)pr + 7 - c]);
+                            const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)pr_e + 7 - c]);
                             uint32_t &w = c < 4 ? base_r.x : base_r.y;
                             w = (w & ~(0xffu << (8 * (c & 3)))) | (ch << (8 * (c & 3)));
                         }
@@ -1120,7 +1162,6 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         }
     }
     while (q_tail != q_head) drain_round(min(64u, q_tail - q_head));
-    if (SUBLIST) sub_close(A, schunk);  // the rest of this wavefront's last chunk: unused
 }
 
 // ================================================================== k_indel_scan
@@ -1259,62 +1300,57 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
     if (threadIdx.x == 0) A.read_count[blockIdx.x] = l_seg;
 }
 
-// ================================================================== k_indel_apply
-// The reads k_indel_scan listed (a mate with at least one event), 64 per wavefront block.  introduce_indels +
-// adjust_seq_length from the read's event list, exactly, as the token transducer of k_indel_fixup (below): the list
-// prefix [0, n) is final when step n starts; the not-yet-visited suffix is (stack of freshly inserted letters, LIFO)
-// ++ E(k), E(k+1), ...  Round 3 design -- the kernel does only what an indel changes, the letters:
-//   * mut_sequence's error test of a position (__init__.py:94) depends on the position's phred and uniform, not on its
-//     letter.  k_main lists the substitutions it applies (RunArgs::sub_list); this kernel writes template letters only
-//     and k_indel_resub re-applies the listed substitutions of the rebuilt reads to the letters that stand there now.
-//     No digit is redrawn, no phred and no old letter is read here.
-//   * phase 1, ONE LANE PER READ: descriptor, events (registers), the read's window of the 2-bit genome into LDS, the
-//     walk over the steps with an event.  It leaves an edit script in LDS: runs (from step s on, token = step + shift),
-//     explicit letters (event steps, stack drains), a bitmap of the 8-position pieces that hold an explicit letter.
-//   * phase 2, FOUR LANES PER READ (the four 16-byte pieces of a 64-byte half line), 16 reads at a time: a piece
-//     without explicit letter lies inside one run -- its 8 letters are one funnel shift of the window, like in k_main;
-//     pieces in front of the first event are k_main's already and are skipped.  The ~2 pieces per read with an explicit
-//     letter go to a ring of the wavefront and are built 64 at a time (run merges + letter inserts).
-// Reads this cannot take -- records with IUPAC / lower-case letters, a window that leaves the record, more explicit
-// letters or stacked insertions than the script holds, read lengths beyond AP_MAX_PITCH, an overflowed substitution
-// list -- join the irregular pairs and the reads with more than EV_K events in k_indel_fixup's list (one wavefront per
-// read, exact, slow).
-constexpr int AP_WAVES = 16;            // wavefronts per workgroup at most (ONE workgroup per CU: the tables are staged once; fewer when
-                                        // the records of long reads need the LDS)
-#ifndef ISS_APPLY_OCC
-#define ISS_APPLY_OCC 4                 // wavefronts per SIMD the register budget is cut for
+// ================================================================== k_indel_script
+// The reads k_indel_scan listed (a mate with at least one event), 64 per wavefront block, one lane per read:
+// introduce_indels + adjust_seq_length (__init__.py:158-228, 114-156) from the read's event list, exactly, as the token
+// transducer of k_indel_fixup (below) -- the list prefix [0, n) is final when step n starts; the not-yet-visited suffix is
+// (stack of freshly inserted letters, LIFO) ++ E(k), E(k+1), ... -- but instead of rebuilding the read it leaves the EDIT
+// SCRIPT k_main<.., INDEL> builds the read from (SC_* above).  Round 4: round 3 rewrote the letters behind k_main
+// (k_indel_apply: every rewritten piece crossed HBM twice more, 3.1 GB per 5 M pairs of BASELINE configs[4], and the
+// substitutions k_main had applied were listed and re-applied to the letters standing there afterwards); now the walk runs in
+// FRONT of k_main, which takes a piece's window from the shifted genome position, and nothing is written twice.
+//   * descriptor, events (registers), the read's window of the 2-bit genome (LDS), the walk over the steps with an event:
+//     runs (from step s on, token = step + shift) and explicit letters (event steps, stack drains), as 2-bit codes;
+//   * per piece of 8 positions one byte: the run's shift, or -- a piece with an explicit letter or a run boundary -- the index
+//     of its 8 letters, merged here from the runs it touches and the explicit letters, in k_main's window format;
+//   * the rows go out as whole 64-byte sectors (four 16-byte rows of a tile's group of 8 iterations).
+// Reads this cannot take -- records with IUPAC / lower-case letters, a window that leaves the record (the reference pads with
+// 'A' there), more explicit letters or stacked insertions than the script holds, more than SC_ROW_CODES explicit pieces in one
+// row, read lengths beyond AP_MAX_PITCH, insertion letters outside A/C/G/T -- join the irregular pairs and the reads with more
+// than EV_K events in k_indel_fixup's list (one wavefront per read, exact, slow) and have their event counter cleared:
+// ev_count[read] != 0 <=> the read has a valid script.
+constexpr int SC_WAVES = 8;             // wavefronts per workgroup
+constexpr int SC_WGS_PER_CU = 2;        // workgroups per CU (the lanes' records: 2 x 8 x 7.4 KB of LDS for read lengths up to 168)
+#ifndef ISS_SCRIPT_OCC
+#define ISS_SCRIPT_OCC 4                // wavefronts per SIMD the register budget is cut for
 #endif
 constexpr int AP_RUNS = EV_K + 1;       // runs of a read: the initial one + one per step with an event
-constexpr int AP_LETTERS = 12;          // explicit letters kept per read
-constexpr int AP_EVP = 8;               // pieces with an explicit letter kept per read (their 8 letters take the letters' place in the record)
-constexpr int AP_HDR = 5;               // header words of a read's record
+constexpr int AP_LETTERS = 12;          // explicit letters kept per read (16 bits each: position << 2 | code)
 constexpr int AP_ITEMS = 128;           // batch calls: the table of up to this many work items is cached in LDS (beyond: global loads)
 constexpr int AP_MAX_PITCH = 384;       // longer reads: k_indel_fixup
 constexpr int AP_STACK = 8;             // inserted letters waiting to surface (a 64-bit register)
-constexpr int AP_CH = 5;                // passes whose pieces are requested together
 
 __host__ __device__ inline int ap_pitch(int pitch) { return pitch < AP_MAX_PITCH ? pitch : AP_MAX_PITCH; }
 __host__ __device__ inline int ap_win(int pitch) { return ap_pitch(pitch) + 8; }  // template positions a read of <= EV_K events reaches
 __host__ __device__ inline int ap_ww(int pitch) { return (ap_win(pitch) + 15) / 16 + 1; }  // window words (16 bases each)
-__host__ __device__ inline int ap_rec_words(int pitch) { return (AP_HDR + ap_ww(pitch) + AP_RUNS + 2 * AP_EVP) | 1; }  // odd: no bank conflicts between lanes
+// a lane's LDS record: [runs AP_RUNS][window words][letters AP_LETTERS / 2][pad][header SC_HDR, at the END of the record] (odd:
+// no bank conflicts between lanes; the window's neighbours are the lane's own words: the piece builder may look one word
+// past either end, masked out afterwards)
+constexpr int SC_HDR = 5;               // read, geometry, piece mask (2), explicit pieces of the block in front of this read's
+__host__ __device__ inline int sc_rec_words(int pitch) { return (AP_RUNS + ap_ww(pitch) + AP_LETTERS / 2 + 1 + SC_HDR) | 1; }
 __host__ __device__ inline size_t ap_items_bytes() { return (AP_ITEMS + 2) * 4 + AP_ITEMS * sizeof(BatchItem); }
 __host__ __device__ inline size_t ap_seg_bytes() { return (size_t)(2 * SCAN_MAX_WGS + 4) * 4; }  // the read list's segments: 64-read blocks in front of each, lengths
 // [ins_letter 2*RL*4 u8, padded][segments][item_first AP_ITEMS+2 u32][items AP_ITEMS][per wave: 64 records]
 __host__ __device__ inline size_t ap_tab_bytes(int RL) { return (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + ap_seg_bytes() + ap_items_bytes(); }
-__host__ __device__ inline size_t ap_wave_bytes(int pitch) { return (size_t)64 * ap_rec_words(pitch) * 4; }
-__host__ __device__ inline int apply_waves(int RL, int pitch) {
-    const size_t room = (size_t)160 * 1024 - 512 - ap_tab_bytes(RL);
-    const int w = (int)(room / ap_wave_bytes(pitch));
-    return w < 1 ? 1 : (w > AP_WAVES ? AP_WAVES : w);
-}
-__host__ __device__ inline size_t apply_lds_bytes(int RL, int pitch) { return ap_tab_bytes(RL) + (size_t)apply_waves(RL, pitch) * ap_wave_bytes(pitch); }
+__host__ __device__ inline size_t sc_wave_bytes(int pitch) { return (size_t)64 * sc_rec_words(pitch) * 4; }
+__host__ __device__ inline size_t script_lds_bytes(int RL, int pitch) { return ap_tab_bytes(RL) + (size_t)SC_WAVES * sc_wave_bytes(pitch); }
 
 // WWM: window words a lane keeps in registers for the NEXT block's read (>= ap_ww(pitch): 12 for read lengths up to 168, else 26)
 template <bool STORE_MUT, int WWM>
-__global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(DevModel M, DevGenome g, RunArgs A,
-                                                                              const PairDesc *__restrict__ desc, uint64_t *stats) {
+__global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(DevModel M, DevGenome g, RunArgs A,
+                                                                               const PairDesc *__restrict__ desc, uint64_t *stats) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ap_lds[];
-    const int RL = M.RL, pitch = M.pitch, S = M.S, WW = ap_ww(pitch), RW = ap_rec_words(pitch), WIN = ap_win(pitch);
+    const int RL = M.RL, pitch = M.pitch, S = M.S, WW = ap_ww(pitch), RW = sc_rec_words(pitch), WIN = ap_win(pitch);
     uint8_t *insl = reinterpret_cast<uint8_t *>(ap_lds);                  // [2][RL][4]
     uint32_t *ifirst = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ap_lds) + ap_tab_bytes(RL) - ap_items_bytes());  // (a call holds < 2^31 pairs)
     BatchItem *l_items = reinterpret_cast<BatchItem *>(ifirst + AP_ITEMS + 2);
@@ -1355,23 +1391,13 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
     if (blockIdx.x * n_waves >= n_blocks) return;  // whole workgroup idle (uniform)
     const uint32_t seg_stride = scan_per_wg(2u * (uint32_t)A.n_pairs, A.scan_wgs);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t *wave0 = ap_lds + ap_tab_bytes(RL) / 4 + (size_t)wv * (ap_wave_bytes(pitch) / 4);
-    // (then every listed read is k_indel_fixup's: the substitutions of a shifted read cannot be re-applied without their list)
-    const bool all_to_fixup = pitch > AP_MAX_PITCH || !A.sub_list || A.sub_count[1] != 0u;
-    const int n_pass = (S + 3) >> 2;
-    auto rank_of = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-    // the 8 template letters of tokens t .. t + 7 in read direction, from a read's window (branch-free in the mate)
-    auto decode8 = [&](const uint32_t *win, int t0pos, int o, int t) {
-        const int b = 2 * (o ? t0pos - t - 7 : t0pos + t);
-        uint32_t w16 = funnel_r(win[b >> 5], win[(b >> 5) + 1], (uint32_t)b) ^ (o ? 0x5555u : 0u);  // complement: code ^ 1
-        const uint32_t lo = codes_to_ascii4(w16 & 0xffu), hi = codes_to_ascii4((w16 >> 8) & 0xffu);
-        const uint32_t sel = o ? 0x00010203u : 0x03020100u;  // reverse mate: read position c <-> window position 7 - c
-        return make_uint2(__builtin_amdgcn_perm(0u, o ? hi : lo, sel), __builtin_amdgcn_perm(0u, o ? lo : hi, sel));
-    };
+    uint32_t *wave0 = ap_lds + ap_tab_bytes(RL) / 4 + (size_t)wv * (sc_wave_bytes(pitch) / 4);
+    // (then every listed read is k_indel_fixup's)
+    const bool all_to_fixup = pitch > AP_MAX_PITCH || !M.ins_plain;
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // (the leading padding word: offsets >= 0)
-    uint32_t n_rebuilt = 0;
+    uint32_t n_scripted = 0;
     // software pipeline of the block loop: the list entry is requested two blocks ahead, what hangs on the read number
-    // (descriptor, flags, events) one block ahead -- a chain of dependent loads behind the chip's write stream
+    // (descriptor, events) one block ahead, the window once the descriptor is there -- a chain of dependent loads
     const uint32_t NO_READ = 0xffffffffu, stride = gridDim.x * n_waves;
     const uint32_t blk0 = blockIdx.x * n_waves + wv;
     auto list_entry = [&](uint32_t b) {  // lane `lane` of block b of the segmented list
@@ -1392,12 +1418,10 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
         ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
         eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
     }
-    // ... and its window of the packed genome, requested once the descriptor has arrived (at the start of phase 2 of the block
-    // before): the walk of a block starts with everything it reads at hand
     uint32_t wn[WWM];
     auto request_window = [&]() {
         const int64_t wl = (ra & 1u) ? (int64_t)d_a.re - WIN : (int64_t)d_a.fs;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(packed_b + (size_t)((((wl >> 4) << 4 >> 4) + 1) << 2));
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(((wl >> 4) + 1) << 2));
 #pragma unroll
         for (int k = 0; k < WWM; ++k) wn[k] = k < WW ? src[k] : 0u;
     };
@@ -1406,319 +1430,258 @@ __global__ __launch_bounds__(64 * AP_WAVES, ISS_APPLY_OCC) void k_indel_apply(De
         uint32_t wc[WWM];  // this block's windows
 #pragma unroll
         for (int k = 0; k < WWM; ++k) wc[k] = wn[k];
-        // ================ phase 1: one lane per read
-        {
-            const uint32_t rd = ra;
-            const uint32_t pair = rd >> 1;
-            const int o = (int)(rd & 1u);
-            const PairDesc d = d_a;
-            const uint32_t cnt = rec_a.x == NO_READ ? 0u : rec_a.w;
-            uint32_t e[EV_K];
-            e[0] = ea_a.x; e[1] = ea_a.y; e[2] = ea_a.z; e[3] = ea_a.w; e[4] = eb_a.x; e[5] = eb_a.y; e[6] = eb_a.z; e[7] = eb_a.w;
-            if (cnt <= 2u) { e[0] = rec_a.y; e[1] = rec_a.z; }
-            {   // requests for the next two blocks
-                rec_a = rec_b;
-                ra = rec_a.x == NO_READ ? 0u : rec_a.x;
-                d_a = desc[ra >> 1];
-                if (rec_a.x != NO_READ && rec_a.w > 2u) {
-                    ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
-                    eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
-                }
-                rec_b = list_entry(blk + 2u * stride);
+        const uint32_t rd = ra;
+        const uint32_t pair = rd >> 1;
+        const int o = (int)(rd & 1u);
+        const PairDesc d = d_a;
+        const bool listed = rec_a.x != NO_READ;
+        const uint32_t cnt = listed ? rec_a.w : 0u;
+        uint32_t e[EV_K];
+        e[0] = ea_a.x; e[1] = ea_a.y; e[2] = ea_a.z; e[3] = ea_a.w; e[4] = eb_a.x; e[5] = eb_a.y; e[6] = eb_a.z; e[7] = eb_a.w;
+        if (cnt <= 2u) { e[0] = rec_a.y; e[1] = rec_a.z; }
+        {   // requests for the next two blocks
+            rec_a = rec_b;
+            ra = rec_a.x == NO_READ ? 0u : rec_a.x;
+            d_a = desc[ra >> 1];
+            if (rec_a.x != NO_READ && rec_a.w > 2u) {
+                ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
+                eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
             }
-            // (a listed read is never k_indel_fixup's already: the scan lists neither the mates of irregular pairs nor reads
-            //  with more events than a list holds)
-            bool ok = cnt > 0u && cnt <= (uint32_t)EV_K;
-            // the record of the pair: the launch's genome, or its slice of the arena (batch calls); descriptors hold arena coordinates
-            int64_t rec_lo = 0, rec_hi = g.L;
-            bool plain = !g.has_exceptions;
-            if (A.items) {
-                BatchItem it;
-                if (items_cached) {
-                    const uint32_t p = (uint32_t)(A.pair_base + pair);
-                    int lo = 0, hi = A.n_items;  // largest k with item_first[k] <= p
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ifirst[mid] <= p) lo = mid; else hi = mid; }
-                    it = l_items[lo];
-                } else {
-                    it = A.items[batch_item_of(A, A.pair_base + pair)];
-                }
-                rec_lo = it.off; rec_hi = it.off + it.L; plain = !it.has_exceptions;
+            rec_b = list_entry(blk + 2u * stride);
+        }
+        // (a listed read is never k_indel_fixup's already: the scan lists neither the mates of irregular pairs nor reads
+        //  with more events than a list holds)
+        bool ok = cnt > 0u && cnt <= (uint32_t)EV_K;
+        // the record of the pair: the launch's genome, or its slice of the arena (batch calls); descriptors hold arena coordinates
+        int64_t rec_lo = 0, rec_hi = g.L;
+        bool plain = !g.has_exceptions;
+        if (A.items) {
+            BatchItem it;
+            if (items_cached) {
+                const uint32_t p = (uint32_t)(A.pair_base + pair);
+                int lo = 0, hi = A.n_items;  // largest k with item_first[k] <= p
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ifirst[mid] <= p) lo = mid; else hi = mid; }
+                it = l_items[lo];
+            } else {
+                it = A.items[batch_item_of(A, A.pair_base + pair)];
             }
-            // window: tokens 0 .. WIN - 1 = genome positions fs .. fs + WIN - 1 (forward) / re - 1 down to re - WIN (reverse)
-            // (beyond the record's ends the reference pads with 'A', uncomplemented -- __init__.py:141-155: code 0 in a forward
-            //  window, code 1 in a reverse one, whose letters are complemented)
-            const int64_t w_lo = o ? (int64_t)d.re - WIN : (int64_t)d.fs;
-            const bool simple = plain && !all_to_fixup;
-            auto to_fixup = [&]() {
-                if (!(atomicOr(&A.flags[pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
-            };
-            if (ok && !simple) { to_fixup(); ok = false; }
-            uint32_t *R = wave0 + lane * RW, *win = R + AP_HDR, *runs = win + WW, *let = runs + AP_RUNS;
-            const int64_t wpos = (w_lo >> 4) << 4;  // genome position of bit 0 of the window
-            const int t0pos = (int)((o ? (int64_t)d.re - 1 : (int64_t)d.fs) - wpos);  // window position of token 0 (token t: t0pos +/- t)
-            if (ok && w_lo >= rec_lo && w_lo + WIN <= rec_hi) {  // the window lies inside the record (all but a few reads in 10^5)
+            rec_lo = it.off; rec_hi = it.off + it.L; plain = !it.has_exceptions;
+        }
+        // window: tokens 0 .. WIN - 1 = genome positions fs .. fs + WIN - 1 (forward) / re - 1 down to re - WIN (reverse).  Beyond
+        // the record's ends the reference pads with 'A' (__init__.py:141-155), which k_main's windows cannot: such reads -- a few
+        // in 10^5 -- are the fix-up kernel's
+        const int64_t w_lo = o ? (int64_t)d.re - WIN : (int64_t)d.fs;
+        auto to_fixup = [&]() {
+            if (!(atomicOr(&A.flags[pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
+            A.ev_count[rd] = 0u;  // no script
+        };
+        if (ok && !(plain && !all_to_fixup && w_lo >= rec_lo && w_lo + WIN <= rec_hi)) { to_fixup(); ok = false; }
+        uint32_t *R = wave0 + lane * RW, *runs = R, *win = R + AP_RUNS;
+        uint16_t *let = reinterpret_cast<uint16_t *>(win + WW);
+        const int64_t wpos = (w_lo >> 4) << 4;  // genome position of bit 0 of the window
+        const int t0pos = (int)((o ? (int64_t)d.re - 1 : (int64_t)d.fs) - wpos);  // window position of token 0 (token t: t0pos +/- t)
+        if (ok) {
 #pragma unroll
-                for (int k = 0; k < WWM; ++k) if (k < WW) win[k] = wc[k];  // (requested a block ago)
-            } else if (ok) {
-                const uint32_t pad = o ? 0x55555555u : 0u;
-                for (int k = 0; k < WW; ++k) {
-                    const int64_t g0 = wpos + 16 * k;  // genome position of the word's first base
-                    uint32_t w = pad;
-                    if (g0 + 16 > rec_lo && g0 < rec_hi) {  // (the arena holds other records' letters beyond this one's ends)
-                        w = *reinterpret_cast<const uint32_t *>(packed_b + (size_t)(((g0 >> 4) + 1) << 2));
-                        if (g0 < rec_lo) { const uint32_t m = 0xffffffffu << (2 * (int)(rec_lo - g0)); w = (w & m) | (pad & ~m); }
-                        if (g0 + 16 > rec_hi) { const uint32_t m = 0xffffffffu >> (2 * (int)(g0 + 16 - rec_hi)); w = (w & m) | (pad & ~m); }
-                    }
-                    win[k] = w;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            // the walk over the steps with an event (k_indel_scan lists them in step order, one entry per step)
-            auto letter_at = [&](int tk) {
-                const int b = 2 * (o ? t0pos - tk : t0pos + tk);
-                const uint32_t c = (win[b >> 5] >> (b & 31)) & 3u;
-                return (int)code_to_ascii(o ? c ^ 1u : c);
-            };
-            uint64_t evmask = 0;  // pieces with an explicit letter
-            uint32_t n_runs = 1, n_let = 0;
-            bool bad = false;
-            const int first_step = (int)(e[0] >> 8);
-            // (--store_mutations: a dry walk first -- a read whose script overflows goes to k_indel_fixup, which writes ALL of its
-            //  rows: none may come from here)
-            auto walk = [&](bool emit_rows) {
-                uint32_t ev[EV_K];
-#pragma unroll
-                for (int z = 0; z < EV_K; ++z) ev[z] = e[z];
-                uint64_t stk = 0;  // inserted letters waiting to surface (LIFO, a byte each)
-                int sp = 0, k = 0, last = -1;
-                evmask = 0; n_runs = 1; n_let = 0; bad = false;
-                if (ok) runs[0] = 0u;
-                MutRecord row;  // --store_mutations row being built
-                row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
-                auto put_letter = [&](int pos, int ch) {
-                    if (n_let < (uint32_t)AP_LETTERS) let[n_let] = ((uint32_t)pos << 8) | (uint32_t)ch; else bad = true;
-                    ++n_let;
-                    evmask |= (uint64_t)1 << (pos >> 3);
-                };
-                for (uint32_t left = ok ? cnt : 0u; left > 0u; --left) {
-                    const int n = (int)(ev[0] >> 8);
-                    const uint32_t m8 = ev[0] & 0xffu;
-#pragma unroll
-                    for (int z = 0; z + 1 < EV_K; ++z) ev[z] = ev[z + 1];
-                    const int next_n = left > 1u ? (int)(ev[0] >> 8) : RL;
-                    k += n - (last + 1);  // the settled run covers steps last+1 .. n-1 from the template
-                    int ch;
-                    bool visit;  // tok < len(template): else n >= len(seq), IndexError swallowed (:223): emitted unvisited
-                    if (sp > 0) { ch = (int)(stk & 0xffu); stk >>= 8; --sp; visit = true; }
-                    else { visit = k < RL; ch = letter_at(k); ++k; }
-                    if (visit) {
-                        const int bi = base_index(ch);
-                        if (bi >= 0) {  // else ambiguous: skipped (:190-192)
-                            for (int x = 0; x < 4; ++x)
-                                if ((m8 >> x) & 1u) {
-                                    const int letter = insl[((size_t)o * RL + n) * 4 + x];
-                                    if (sp < AP_STACK) stk = (stk << 8) | (uint64_t)letter; else bad = true;
-                                    ++sp;
-                                    if (STORE_MUT && emit_rows) {  // ref = mutable_seq[position], alt = ref + letter (__init__.py:197-207)
-                                        row.type = (int8_t)(1 | (x << 2) | 32); row.position = (int16_t)n;
-                                        row.ref = (uint8_t)ch; row.alt = (uint8_t)letter;
-                                        mut_emit1(A, row);
-                                    }
-                                }
-                            if (bad) break;
-                            if ((m8 >> (4 + bi)) & 1u) {  // deleted: the next token slides in
-                                const bool exists = sp > 0 || k < RL;  // else mutable_seq[position] raises IndexError: no row
-                                if (sp > 0) { ch = (int)(stk & 0xffu); stk >>= 8; --sp; }
-                                else { ch = letter_at(k); ++k; }
-                                if (STORE_MUT && emit_rows && exists) {  // ref = mutable_seq[position] after the pop (__init__.py:211-221)
-                                    row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
-                                    row.ref = (uint8_t)ch; row.alt = '.';
-                                    mut_emit1(A, row);
-                                }
-                            }
-                        }
-                    }
-                    put_letter(n, ch);
-                    last = n;
-                    // steps after n drain the insertion stack until it is empty or the next step with an event
-                    while (sp > 0 && last + 1 < RL && last + 1 != next_n) {
-                        ++last;
-                        put_letter(last, (int)(stk & 0xffu));
-                        stk >>= 8; --sp;
-                    }
-                    // from step last + 1 on: token = step + (k - (last + 1)) until the next step with an event
-                    if (last + 1 < pitch) { runs[n_runs] = (uint32_t)(last + 1) | ((uint32_t)(k - (last + 1)) << 16); ++n_runs; }
-                }
-            };
-            if (STORE_MUT) { walk(false); if (ok && (bad || __popcll(evmask) > AP_EVP)) { to_fixup(); ok = false; } }
-            walk(true);
-            if (ok && __popcll(evmask) > AP_EVP) bad = true;
-            if (ok && bad) { to_fixup(); ok = false; }
-            // the pieces with an explicit letter, built here by the read's own lane (the run the piece starts in, the runs that
-            // start inside it merged from their first position on, the explicit letters) and left in the record in the
-            // letters' place: in phase 2 the four lanes of a read then store WHOLE 64-byte sectors together
-            {
-                uint2 evp[AP_EVP];
-                uint64_t todo = ok ? evmask : 0;
-#pragma unroll
-                for (int i = 0; i < AP_EVP; ++i) {
-                    evp[i] = make_uint2(0u, 0u);
-                    if (!__ballot(todo != 0)) continue;  // (uniform)
-                    if (todo) {
-                        const int j0 = 8 * (__ffsll((unsigned long long)todo) - 1);
-                        todo &= todo - 1;
-                        int k0 = 0;
-                        while (k0 + 1 < (int)n_runs && (int)(runs[k0 + 1] & 0xffffu) <= j0) ++k0;
-                        uint2 nw = decode8(win, t0pos, o, j0 + ((int)runs[k0] >> 16));
-                        for (int k = k0 + 1; k < (int)n_runs && (int)(runs[k] & 0xffffu) < j0 + 8; ++k) {
-                            const int c = (int)(runs[k] & 0xffffu) - j0;
-                            const uint2 v = decode8(win, t0pos, o, j0 + ((int)runs[k] >> 16));
-                            const uint32_t mx = c < 4 ? 0xffffffffu << (8 * c) : 0u, my = c < 4 ? 0xffffffffu : 0xffffffffu << (8 * (c - 4));
-                            nw.x = (v.x & mx) | (nw.x & ~mx);
-                            nw.y = (v.y & my) | (nw.y & ~my);
-                        }
-                        for (uint32_t z = 0; z < n_let; ++z) {
-                            const int c = (int)(let[z] >> 8) - j0;
-                            if (c >= 0 && c < 8) {
-                                const uint32_t sh8 = 8u * (uint32_t)(c & 3), ins = (let[z] & 0xffu) << sh8, keep = ~(0xffu << sh8);
-                                if (c < 4) nw.x = (nw.x & keep) | ins; else nw.y = (nw.y & keep) | ins;
-                            }
-                        }
-                        evp[i] = nw;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the letters are read above, their place is written below)
-#pragma unroll
-                for (int i = 0; i < AP_EVP; ++i) { let[2 * i] = evp[i].x; let[2 * i + 1] = evp[i].y; }
-            }
-            if (ok) {
-                ++n_rebuilt;
-                if (STORE_MUT) atomicOr(&A.flags[pair], 4u << o);  // (bits 2-3: this kernel rebuilt the mate)
-            }
-            R[0] = pair;
-            R[1] = (uint32_t)t0pos;
-            // (a read that is not rebuilt here holds stale -- possibly never written -- event words: every field is masked)
-            R[2] = (uint32_t)o | ((n_runs & 15u) << 1) | ((n_let & 15u) << 5) | (((uint32_t)(!ok ? 0 : first_step) & 0x3ffu) << 9) |
-                   (ok ? 0x80000000u : 0u);
-            R[3] = (uint32_t)evmask;
-            R[4] = (uint32_t)(evmask >> 32);
+            for (int k = 0; k < WWM; ++k) if (k < WW) win[k] = wc[k];  // (requested a block ago)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ================ phase 2: four lanes per read, 16 reads at a time
-        // A piece is rewritten WHOLE -- its 8 letters and, unchanged, its 8 phreds -- and the four lanes of a read store a full
-        // 64-byte sector together.  (Letters alone are half a sector, and so is a line whose pieces are written at different
-        // times: HBM with ECC turns every partial write into a read-modify-write -- measured: 1.7 GB written and 0.6 GB
-        // fetched for 0.45 GB of letters, the kernel bound by it.)  A load behind the chip's write stream takes
-        // microseconds: the pieces of AP_CH passes are requested together, one step (16 reads x AP_CH passes) ahead of their use.
         request_window();  // (the next block's: its descriptor was requested at the top of this block)
-        {
-            const int n_chunks = (n_pass + AP_CH - 1) / AP_CH, n_steps = 4 * n_chunks;
-            auto request = [&](int t, uint4 (&dst)[AP_CH]) {  // the pieces of step t: sub-round t / n_chunks, passes (t % n_chunks) * AP_CH ...
-                const uint32_t *R = wave0 + ((uint32_t)(t / n_chunks) * 16u + (lane >> 2)) * RW;
-                const uint32_t h2 = R[2];
-                const uint8_t *rowp = A.out[0] + (size_t)R[0] * M.row + row_array_off(2 * (int)(h2 & 1u));
-                const int first_step = (int)((h2 >> 9) & 0x3ffu), p0 = (t % n_chunks) * AP_CH;
+        // the walk over the steps with an event (k_indel_scan lists them in step order, one entry per step)
+        auto code_at = [&](int tk) {  // 2-bit code of template token tk in read direction
+            const int b = 2 * (o ? t0pos - tk : t0pos + tk);
+            const uint32_t c = (win[b >> 5] >> (b & 31)) & 3u;
+            return o ? c ^ 1u : c;  // complement: code ^ 1
+        };
+        uint64_t evmask = 0;  // pieces with an explicit letter
+        uint32_t n_runs = 1, n_let = 0;
+        bool bad = false;
+        // (--store_mutations: a dry walk first -- a read whose script overflows goes to k_indel_fixup, which writes ALL of its
+        //  rows: none may come from here)
+        auto walk = [&](bool emit_rows) {
+            uint32_t ev[EV_K];
 #pragma unroll
-                for (int q = 0; q < AP_CH; ++q) {
-                    const int piece = 4 * (p0 + q) + (int)(lane & 3u), j0 = 8 * piece;
-                    dst[q] = make_uint4(0u, 0u, 0u, 0u);
-                    if ((h2 >> 31) && p0 + q < n_pass && piece < S && j0 + 8 > first_step) dst[q] = *reinterpret_cast<const uint4 *>(rowp + xp(j0));
-                }
+            for (int z = 0; z < EV_K; ++z) ev[z] = e[z];
+            uint64_t stk = 0;  // inserted letters waiting to surface (LIFO, a byte each: their 2-bit codes)
+            int sp = 0, k = 0, last = -1;
+            evmask = 0; n_runs = 1; n_let = 0; bad = false;
+            if (ok) runs[0] = 0u;
+            MutRecord row;  // --store_mutations row being built
+            row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
+            auto put_letter = [&](int pos, uint32_t code) {
+                if (n_let < (uint32_t)AP_LETTERS) let[n_let] = (uint16_t)(((uint32_t)pos << 2) | code); else bad = true;
+                ++n_let;
+                evmask |= (uint64_t)1 << (pos >> 3);
             };
-            uint4 pn[AP_CH];
-            request(0, pn);
-            int ri = 0, sh = 0, nstart = 0;
-            for (int t = 0; t < n_steps; ++t) {
-                uint4 pv[AP_CH];
+            for (uint32_t left = ok ? cnt : 0u; left > 0u; --left) {
+                const int n = (int)(ev[0] >> 8);
+                const uint32_t m8 = ev[0] & 0xffu;
 #pragma unroll
-                for (int q = 0; q < AP_CH; ++q) pv[q] = pn[q];
-                if (t + 1 < n_steps) request(t + 1, pn);
-                const uint32_t slot = (uint32_t)(t / n_chunks) * 16u + (lane >> 2), j4 = lane & 3u;
-                const int p0 = (t % n_chunks) * AP_CH;
-                const uint32_t *R = wave0 + slot * RW, *win = R + AP_HDR, *runs = win + WW;
-                const uint32_t *evp = runs + AP_RUNS;  // the pieces with an explicit letter, in ascending order (phase 1)
-                const uint32_t pair = R[0], h2 = R[2];
-                const int t0pos = (int)R[1], o = (int)(h2 & 1u), n_runs = (int)((h2 >> 1) & 15u), first_step = (int)((h2 >> 9) & 0x3ffu);
-                const uint64_t evmask = (uint64_t)R[3] | ((uint64_t)R[4] << 32);
-                const bool valid = (h2 >> 31) != 0u;
-                if (!__ballot(valid)) continue;
-                uint8_t *rowp = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
-                if (p0 == 0) { ri = 0; sh = 0; nstart = n_runs > 1 ? (int)(runs[1] & 0xffffu) : 0x7fffffff; }
-#pragma unroll
-                for (int q = 0; q < AP_CH; ++q) {
-                    if (p0 + q >= n_pass) break;  // (uniform)
-                    const int piece = 4 * (p0 + q) + (int)j4, j0 = 8 * piece;
-                    const bool act = valid && piece < S && j0 + 8 > first_step;  // (pieces in front of the first event: k_main's stand)
-                    while (nstart <= j0) {  // the run position j0 lies in
-                        ++ri;
-                        sh = (int)runs[ri] >> 16;
-                        nstart = ri + 1 < n_runs ? (int)(runs[ri + 1] & 0xffffu) : 0x7fffffff;
-                    }
-                    if (act) {
-                        uint2 nw;
-                        if ((evmask >> piece) & 1u) {
-                            const int i = __popcll(evmask & (((uint64_t)1 << piece) - 1u));
-                            nw = make_uint2(evp[2 * i], evp[2 * i + 1]);
-                        } else {  // the whole piece lies in one run: one funnel shift of the window
-                            nw = decode8(win, t0pos, o, j0 + sh);
+                for (int z = 0; z + 1 < EV_K; ++z) ev[z] = ev[z + 1];
+                const int next_n = left > 1u ? (int)(ev[0] >> 8) : RL;
+                k += n - (last + 1);  // the settled run covers steps last+1 .. n-1 from the template
+                uint32_t ch;  // 2-bit code (the record is plain A/C/G/T and so are the insertion letters: no ambiguous token, :190-192)
+                bool visit;  // tok < len(template): else n >= len(seq), IndexError swallowed (:223): emitted unvisited
+                if (sp > 0) { ch = (uint32_t)(stk & 0xffu); stk >>= 8; --sp; visit = true; }
+                else { visit = k < RL; ch = code_at(k); ++k; }
+                if (visit) {
+                    for (int x = 0; x < 4; ++x)
+                        if ((m8 >> x) & 1u) {
+                            const int letter = insl[((size_t)o * RL + n) * 4 + x];
+                            if (sp < AP_STACK) stk = (stk << 8) | (uint64_t)(uint32_t)base_index(letter); else bad = true;
+                            ++sp;
+                            if (STORE_MUT && emit_rows) {  // ref = mutable_seq[position], alt = ref + letter (__init__.py:197-207)
+                                row.type = (int8_t)(1 | (x << 2) | 32); row.position = (int16_t)n;
+                                row.ref = code_to_ascii(ch); row.alt = (uint8_t)letter;
+                                mut_emit1(A, row);
+                            }
                         }
-                        *reinterpret_cast<uint4 *>(rowp + xp(j0)) = make_uint4(nw.x, nw.y, pv[q].z, pv[q].w);
+                    if (bad) break;
+                    if ((m8 >> (4 + ch)) & 1u) {  // deleted: the next token slides in
+                        const bool exists = sp > 0 || k < RL;  // else mutable_seq[position] raises IndexError: no row
+                        if (sp > 0) { ch = (uint32_t)(stk & 0xffu); stk >>= 8; --sp; }
+                        else { ch = code_at(k); ++k; }
+                        if (STORE_MUT && emit_rows && exists) {  // ref = mutable_seq[position] after the pop (__init__.py:211-221)
+                            row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
+                            row.ref = code_to_ascii(ch); row.alt = '.';
+                            mut_emit1(A, row);
+                        }
                     }
+                }
+                put_letter(n, ch);
+                last = n;
+                // steps after n drain the insertion stack until it is empty or the next step with an event
+                while (sp > 0 && last + 1 < RL && last + 1 != next_n) {
+                    ++last;
+                    put_letter(last, (uint32_t)(stk & 0xffu));
+                    stk >>= 8; --sp;
+                }
+                // from step last + 1 on: token = step + (k - (last + 1)) until the next step with an event
+                if (last + 1 < pitch) { runs[n_runs] = (uint32_t)(last + 1) | ((uint32_t)(k - (last + 1)) << 16); ++n_runs; }
+            }
+        };
+        if (STORE_MUT) { walk(false); if (ok && bad) { to_fixup(); ok = false; } }
+        walk(true);
+        if (ok && bad) { to_fixup(); ok = false; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // ---- the rows, one lane per read: per tile and group of 8 iterations one byte per piece, in ascending order (the run
+        //      pointer only moves forward) -- the run's shift, or the place of the piece's explicit codes in its row.  The four
+        //      rows of a group leave as one whole 64-byte sector, the code halves still empty.
+        if (__ballot(ok)) {
+            int ri = 0, sh = 0, nstart = n_runs > 1 ? (int)(runs[1] & 0xffffu) : 0x7fffffff;
+            uint8_t *out = A.script + (size_t)rd * (size_t)(uint32_t)M.sc_stride;
+            const int n_grp = M.n_tiles * M.sc_gpt;
+            bool over = false;
+            for (int gq = 0; gq < n_grp; ++gq) {
+                const int tile = gq / M.sc_gpt, s_first = tile * M.TS + 32 * (gq - tile * M.sc_gpt), s_end = min(S, (tile + 1) * M.TS);
+                uint32_t rx[4], ry[4], ne[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { rx[j] = SC_IDLE; ry[j] = SC_IDLE; ne[j] = 0; }
+                for (int it8 = 0; it8 < 8; ++it8) {
+                    if (!__ballot(ok && s_first + 4 * it8 < s_end)) break;  // (uniform)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int s = s_first + 4 * it8 + j, j0 = 8 * s;
+                        if (!ok || s >= s_end) continue;
+                        while (nstart <= j0) {  // the run position j0 lies in
+                            ++ri;
+                            sh = (int)runs[ri] >> 16;
+                            nstart = ri + 1 < (int)n_runs ? (int)(runs[ri + 1] & 0xffffu) : 0x7fffffff;
+                        }
+                        uint32_t byte = (uint32_t)(64 + sh);
+                        if ((evmask >> s) & 1u) {
+                            if (ne[j] >= (uint32_t)SC_ROW_CODES) over = true;
+                            byte = 128u + 16u * (ne[j] & 3u);
+                            ++ne[j];
+                        }
+                        const uint32_t ins = (byte ^ 0x40u) << (8u * (uint32_t)(it8 & 3));  // (the rows start as SC_IDLE)
+                        if (it8 < 4) rx[j] ^= ins; else ry[j] ^= ins;
+                    }
+                }
+                if (ok)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) reinterpret_cast<uint4 *>(out + (size_t)gq * 64)[j] = make_uint4(rx[j], ry[j], 0u, 0u);
+            }
+            if (ok && over) { to_fixup(); ok = false; }
+        }
+        // ---- the explicit pieces, DENSELY: a read has one or two of them among its pitch / 8 pieces, so a lane-per-read loop
+        //      over the pieces would run the (long) merge below with a tenth of its lanes.  The block's explicit pieces are
+        //      numbered through (prefix sum of the reads' counts) and dealt out 64 at a time, one per lane: the lane finds the
+        //      piece's read (bisection of the prefix sums), builds the piece's 8 codes from that read's record in LDS -- the run
+        //      the piece starts in, the runs that start inside it merged from their first position on, the explicit letters --
+        //      and stores them behind the row's bytes (two bytes into the sector the read's own lane has just written: the
+        //      line is still in the L2).
+        {
+            const uint32_t n_exp = ok ? (uint32_t)__popcll(evmask) : 0u;
+            uint32_t incl = n_exp;
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, dlt);
+                if ((int)lane >= dlt) incl += t;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            R[RW - SC_HDR + 0] = rd;
+            R[RW - SC_HDR + 1] = (uint32_t)t0pos | ((uint32_t)o << 16) | (n_runs << 20) | (n_let << 24);
+            R[RW - SC_HDR + 2] = (uint32_t)evmask;
+            R[RW - SC_HDR + 3] = (uint32_t)(evmask >> 32);
+            R[RW - SC_HDR + 4] = incl - n_exp;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t item = base + lane;
+                if (item < total) {
+                    uint32_t lo = 0, hi = 64;  // the read of this piece: the largest l with (pieces in front of l) <= item
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (wave0[mid * RW + RW - SC_HDR + 4] <= item) lo = mid; else hi = mid;
+                    }
+                    const uint32_t *Ro = wave0 + lo * RW, *o_runs = Ro, *o_win = Ro + AP_RUNS, *H = Ro + RW - SC_HDR;
+                    const uint16_t *o_let = reinterpret_cast<const uint16_t *>(o_win + WW);
+                    const uint64_t em = (uint64_t)H[2] | ((uint64_t)H[3] << 32);
+                    uint64_t m = em;
+                    for (uint32_t i = item - H[4]; i > 0u; --i) m &= m - 1;
+                    const int s = __ffsll((unsigned long long)m) - 1, j0 = 8 * s;
+                    const uint32_t h1 = H[1];
+                    const int p_t0 = (int)(h1 & 0xffffu), p_o = (int)((h1 >> 16) & 1u), p_runs = (int)((h1 >> 20) & 15u);
+                    const uint32_t p_let = h1 >> 24;
+                    // raw window bits of tokens t .. t + 7, the format of k_main's fb / rbr (reverse: genome orientation, uncomplemented)
+                    auto raw16 = [&](int t) {
+                        const int b = 2 * (p_o ? p_t0 - t - 7 : p_t0 + t);
+                        return funnel_r(o_win[b >> 5], o_win[(b >> 5) + 1], (uint32_t)b) & 0xffffu;
+                    };
+                    int k0 = 0;
+                    while (k0 + 1 < p_runs && (int)(o_runs[k0 + 1] & 0xffffu) <= j0) ++k0;
+                    uint32_t nw = raw16(j0 + ((int)o_runs[k0] >> 16));
+                    for (int k = k0 + 1; k < p_runs && (int)(o_runs[k] & 0xffffu) < j0 + 8; ++k) {
+                        const int c = (int)(o_runs[k] & 0xffffu) - j0;
+                        const uint32_t v = raw16(j0 + ((int)o_runs[k] >> 16));
+                        const uint32_t mk = p_o ? 0xffffu >> (2 * c) : (0xffffu << (2 * c)) & 0xffffu;  // read positions c .. 7
+                        nw = (v & mk) | (nw & ~mk);
+                    }
+                    for (uint32_t z = 0; z < p_let; ++z) {
+                        const int c = (int)(o_let[z] >> 2) - j0;
+                        if (c >= 0 && c < 8) {
+                            const uint32_t code = o_let[z] & 3u, at = 2u * (uint32_t)(p_o ? 7 - c : c);
+                            nw = (nw & ~(3u << at)) | ((p_o ? code ^ 1u : code) << at);
+                        }
+                    }
+                    // its place: tile, group of 8 iterations, row j4, and the number of explicit pieces of the row in front of it
+                    const int tile = s / M.TS, it = (s - tile * M.TS) >> 2, grp = it >> 3, it8 = it & 7;
+                    const uint64_t row_before = (0x1111111111111111ull << (s - 4 * it8)) & (((uint64_t)1 << s) - 1u) & em;
+                    uint8_t *dst = A.script + (size_t)H[0] * (size_t)(uint32_t)M.sc_stride +
+                                   (size_t)((((tile * M.sc_gpt + grp) * 4 + (s & 3)) * 16) + 8 + 2 * __popcll(row_before));
+                    *reinterpret_cast<uint16_t *>(dst) = (uint16_t)nw;
                 }
             }
         }
+        if (ok) ++n_scripted;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    const unsigned long long any = __ballot(n_rebuilt != 0u);
+    const unsigned long long any = __ballot(n_scripted != 0u);
     if (any) {
-        uint32_t tot = n_rebuilt;
+        uint32_t tot = n_scripted;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
-        if (lane == 0) atomicAdd((unsigned long long *)stats, (unsigned long long)tot);
-    }
-}
-
-// ================================================================== k_indel_resub
-// The substitutions of the reads k_indel_apply rebuilt, re-applied: one lane per entry of k_main's list.  The error test of
-// the position fired whatever its letter (__init__.py:94); the substitution choice is made for the letter that stands
-// there now (the shifted template letter or an inserted one).  Pieces in front of a read's first event were not rewritten:
-// k_main's letter stands.  --store_mutations: the rows of the mate's substitutions (k_main's are dropped by the host).
-template <bool STORE_MUT>
-__global__ __launch_bounds__(256) void k_indel_resub(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
-    const uint32_t n = min(A.sub_count[0], A.sub_cap);
-    if (A.sub_count[1]) return;  // (the list overflowed: k_indel_apply handed every listed read to k_indel_fixup)
-    const int RL = M.RL;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint2 e = A.sub_list[i];
-        if (e.x == 0xffffffffu) continue;
-        const uint32_t pair = e.x;
-        const int o = (int)((e.y >> 15) & 1u), j = (int)(e.y & 0x7fffu), orig = (int)((e.y >> 16) & 0xffu);
-        const uint32_t rd = 2u * pair + (uint32_t)o;
-        const uint32_t evc = A.ev_count[rd];
-        if (!evc || ((A.flags[pair] >> o) & 1u)) continue;  // no event: k_main's read stands; k_indel_fixup's mates are rebuilt there
-        const int lim = (int)(evc >> 4) & ~7;  // the first rewritten position
-        if (j < lim && !STORE_MUT) continue;
-        uint8_t *rowp = A.out[0] + (size_t)pair * M.row + row_array_off(2 * o);
-        int before = rowp[xp(j)], base = before;
-        if (j >= lim) {
-            const int bi = base_index(before);
-            if (bi < 0) continue;  // nucl.upper() in "RYWSMKHBVDN": left alone
-            const Addr ca = make_addr(A.seed, A.first_ordinal + pair, A.gc_bias ? desc[pair].meta >> 16 : 0u);
-            const u32x4 sb = draw_block(ca, K_SUB, (uint32_t)j, (uint32_t)o);
-            base = substitute(M, sb, o, j, before);
-            rowp[xp(j)] = (uint8_t)base;
-        } else {
-            before = orig;  // (the letter k_main replaced; `base` is its substitute)
-        }
-        if (STORE_MUT) {  // only if the new letter differs from the ORIGINAL read at this index (__init__.py:98)
-            MutRecord sub;
-            sub.pair = (int32_t)(A.pair_base + pair); sub.mate = (int8_t)o; sub.type = (int8_t)32; sub.position = (int16_t)j;
-            sub.ref = (uint8_t)before; sub.alt = (uint8_t)base;
-            sub.quality = (int16_t)rowp[(row_array_off(1) - row_array_off(0)) + xp(j)];
-            if (base != orig) mut_emit1(A, sub);
-        }
+        if (lane == 0) atomicAdd((unsigned long long *)stats + 1, (unsigned long long)tot);
     }
 }
 

@@ -83,20 +83,14 @@ inline int letter_class(uint8_t c) {
 
 constexpr int FIX_SLOTS_C = 16;  // (= FIX_SLOTS below)
 struct TimedLaunch {
-    // main stream: ev0 setup ev1 main ev2;  indel stream: ev3 scan ev4 ... ev5 fixup ev6;  ev7: the end of k_setup when it
-    // runs on the setup stream (beside the previous call's kernels)
+    // ev0 setup [ev3 scan + script ev4] ev1 main ev2 ev5 fixup ev6;  ev7: the end of the setup-stream kernels (k_setup, and for
+    // models with frequent indels k_indel_scan + k_indel_script) when they run beside the previous call's kernels
     hipEvent_t ev[8];
     bool has_scan;
-    bool scan_first;  // the scan stands between k_setup and k_main (ev0 setup ev3 scan ev4 = ev1 main ev2)
+    bool scan_first;  // the scan stands between k_setup and k_main on one stream (ev0 setup ev3 scan ev4 = ev1 main ev2)
 };
 
-struct PendingIndel {  // indel-stream work still in flight on output rows [row0, row0 + n)
-    int64_t row0, n;
-    hipEvent_t done;
-};
-
-constexpr int FIX_SLOTS = FIX_SLOTS_C;  // ring of fix-list counters (one per chunk in flight on the indel stream)
-constexpr size_t SUB_MARGIN = (size_t)1 << 20;  // entries a chunk's substitution list holds beyond its expectation (4096 wavefronts x SUB_CHUNK)
+constexpr int FIX_SLOTS = FIX_SLOTS_C;  // ring of fix-list / read-list counters (one per chunk in flight)
 
 // Device-formatted FASTQ on its way to the files: two slots of (device text, pinned host text) per mate; the
 // format kernel runs on the context's stream, the copy back on a copy stream, the file writes on a writer thread.
@@ -161,7 +155,7 @@ struct iss_ctx {
     int n_cu = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // setup + main kernels
-    hipStream_t indel_stream = nullptr;  // indel scan + fix-up of a chunk run beside the next chunk's main kernel
+    hipStream_t indel_stream = nullptr;  // MT mode: the stream words are produced here, one chunk ahead of their consumption
     // k_setup of a call runs on its own stream, beside the kernels of the call (or chunk) before: it reads nothing they
     // write, and what it writes -- descriptors, flags, the fix-up list -- is double-buffered by call parity (`desc`, `flags`,
     // `fix_list` below point at the current call's set).  ISS_SETUP_AHEAD=0: everything in order on one stream.
@@ -172,12 +166,12 @@ struct iss_ctx {
     hipEvent_t ev_call_done[2] = {nullptr, nullptr};  // the last kernel of the last call that used the set
     bool ev_call_valid[2] = {false, false};
     hipEvent_t ev_setup_done[FIX_SLOTS_C] = {};         // k_setup of a chunk -> its k_main (ring, like the counters)
+    hipEvent_t ev_slot_done[FIX_SLOTS_C] = {};          // the last kernel of the chunk that used a counter slot: the setup stream waits
+    bool ev_slot_valid[FIX_SLOTS_C] = {};               //   for it before the slot's next user clears the counters
     hipEvent_t ev_inputs = nullptr;                     // tables / arena copies queued on the main stream for this call's k_setup
     uint64_t call_seq = 0;
     bool inputs_pending = false;  // copies for this call's k_setup were queued on the main stream (ev_inputs)
     bool timing_all = false;      // HIP events around every kernel: one stream
-    bool overlap = false;  // ISS_OVERLAP=1: run the indel passes beside the next chunk (measured: no gain, k_main is VALU-bound)
-    std::vector<PendingIndel> pending;
     GenomeArena arena;
     // iss_generate_batch: the records of the last batch copied side by side into one arena (ids + items cached)
     std::vector<int32_t> comm_ids;
@@ -202,24 +196,24 @@ struct iss_ctx {
     // outputs
     int64_t capacity = 0;
     uint8_t *out[4] = {nullptr, nullptr, nullptr, nullptr};  // ONE allocation of interleaved rows (iss::xp): out[k] = out[0] + iss::row_array_off(k)
-    std::vector<hipMemGenericAllocationHandle_t> rows_handles;  // ISS_ROWS_CHUNK_MB: the rows' physical chunks
-    size_t rows_va_bytes = 0;
     uint8_t *d_stage = nullptr;  // iss_output_download: the four plain arrays of the rows being copied
     size_t stage_cap = 0;
     iss::PairDesc *desc = nullptr;
     uint32_t *flags = nullptr;
     uint32_t *fix_list = nullptr;
     uint32_t *fix_count = nullptr;  // one counter per launch chunk is reset in-stream
-    // indel events (k_indel_scan -> k_main / k_indel_apply / k_indel_resub), per row; two sets for the models whose scan runs
+    // indel events (k_indel_scan -> k_indel_script -> k_main), per row; two sets for the models whose scan runs
     // on the setup stream, beside the kernels of the call before (otherwise [1] aliases [0])
     uint32_t *ev_count[2] = {nullptr, nullptr}, *ev_list[2] = {nullptr, nullptr};
     uint4 *read_list[2] = {nullptr, nullptr};
     uint32_t *read_count = nullptr;  // FIX_SLOTS counters of the read lists, like fix_count
-    // models with indels: the substitutions k_main applies (RunArgs::sub_list), sub_per_pair entries per output row + a
-    // margin per chunk in flight (every wavefront may leave most of a SUB_CHUNK unused); FIX_SLOTS x {reserved, overflow}
-    uint2 *sub_list = nullptr;
-    uint32_t *sub_count = nullptr;
-    int64_t sub_per_pair = 0;
+    // models with frequent indels: the edit scripts of the reads with an event (k_indel_script -> k_main), DevModel::sc_stride
+    // bytes per read, two sets like the event lists
+    uint8_t *script[2] = {nullptr, nullptr};
+    double light_below = 2e-3;  // ISS_LIGHT_INDELS (read once, at iss_ctx_create): models whose reads have an event less often are "light"
+    int env_tiles = 0, env_guide_bits = 0;  // ISS_TILES / ISS_GUIDE_BITS: tuning aids of the tile sweeps (0: the cost model decides)
+    bool debug_model = false;               // ISS_DEBUG_MODEL
+    double mt_guard = 1e-6;                 // ISS_MT_GUARD: how close to a rounding boundary the device still decides (tests widen it)
     bool light = false;  // reads with an indel are rare (< ISS_LIGHT_INDELS of the reads, default 2e-3): all of them take k_indel_fixup
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
     // custom fragment length on the Philox path
@@ -293,6 +287,18 @@ int upload(iss_ctx *ctx, const T *host, size_t n, T **dev, std::vector<void *> *
     return 0;
 }
 
+// The switches of the library -- each selects a code path the tests force: which indel path a model
+// takes, the tile / guide-bit sweeps, the rounding guard of MT mode.  Read at iss_ctx_create, at every model upload and once
+// per generate call (never per launch).
+void read_switches(iss_ctx *ctx) {
+    const char *e;
+    ctx->light_below = (e = getenv("ISS_LIGHT_INDELS")) ? atof(e) : 2e-3;
+    ctx->env_tiles = (e = getenv("ISS_TILES")) ? atoi(e) : 0;
+    ctx->env_guide_bits = (e = getenv("ISS_GUIDE_BITS")) ? std::min(8, std::max(6, atoi(e))) : 0;
+    ctx->mt_guard = (e = getenv("ISS_MT_GUARD")) ? atof(e) : 1e-6;
+    ctx->debug_model = getenv("ISS_DEBUG_MODEL") != nullptr;
+}
+
 void free_model(iss_ctx *ctx) {
     for (void *p : ctx->model_allocs) (void)hipFree(p);
     ctx->model_allocs.clear();
@@ -300,13 +306,6 @@ void free_model(iss_ctx *ctx) {
 }
 
 void free_outputs(iss_ctx *ctx) {
-    if (ctx->out[0] && !ctx->rows_handles.empty()) {  // (rows mapped chunk by chunk: ISS_ROWS_CHUNK_MB)
-        (void)hipMemUnmap(ctx->out[0], ctx->rows_va_bytes);
-        for (auto &h : ctx->rows_handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(ctx->out[0], ctx->rows_va_bytes);
-        ctx->rows_handles.clear();
-        ctx->out[0] = nullptr;
-    }
     if (ctx->out[0]) (void)hipFree(ctx->out[0]);
     for (auto &p : ctx->out) p = nullptr;
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -324,8 +323,11 @@ void free_outputs(iss_ctx *ctx) {
         if (ctx->ev_list[k] && (k == 0 || ctx->ev_list[k] != ctx->ev_list[0])) (void)hipFree(ctx->ev_list[k]);
         if (ctx->read_list[k] && (k == 0 || ctx->read_list[k] != ctx->read_list[0])) (void)hipFree(ctx->read_list[k]);
     }
-    if (ctx->sub_list) (void)hipFree(ctx->sub_list);
-    ctx->sub_list = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->script[k]) (void)hipFree(ctx->script[k]);
+        ctx->script[k] = nullptr;
+    }
+    for (auto &v : ctx->ev_slot_valid) v = false;  // (free_outputs follows a sync_all: nothing of the old buffers is in flight)
     for (int k = 0; k < 2; ++k) { ctx->ev_count[k] = ctx->ev_list[k] = nullptr; ctx->read_list[k] = nullptr; }
     ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
     ctx->capacity = 0;
@@ -526,8 +528,6 @@ int sync_all(iss_ctx *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->setup_stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->indel_stream));
-    for (auto &pi : ctx->pending) (void)hipEventDestroy(pi.done);
-    ctx->pending.clear();
     return 0;
 }
 
@@ -737,6 +737,11 @@ extern "C" {
 
 int iss_abi_version(void) { return ISS_ABI_VERSION; }
 
+#ifndef ISS_BUILD_ID
+#define ISS_BUILD_ID "unknown"
+#endif
+const char *iss_build_id(void) { return ISS_BUILD_ID; }
+
 const char *iss_last_error(const iss_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
 
 int iss_ctx_create(int device_ordinal, iss_ctx **out) {
@@ -767,9 +772,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        const void *applies[] = {reinterpret_cast<const void *>(iss::k_indel_apply<false, 12>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 12>),
-                                 reinterpret_cast<const void *>(iss::k_indel_apply<false, 26>), reinterpret_cast<const void *>(iss::k_indel_apply<true, 26>)};
-        for (const void *f : applies) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        const void *scripts[] = {reinterpret_cast<const void *>(iss::k_indel_script<false, 12>), reinterpret_cast<const void *>(iss::k_indel_script<true, 12>),
+                                 reinterpret_cast<const void *>(iss::k_indel_script<false, 26>), reinterpret_cast<const void *>(iss::k_indel_script<true, 26>)};
+        for (const void *f : scripts) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
@@ -780,15 +785,14 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         // per step for every engine, against 1.24-1.29 (one box) and 1.28 / 1.41 alternating (another) at the default priority.
         int prio_least = 0, prio_greatest = 0;
         HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        int prio = prio_greatest;
-        if (const char *e = getenv("ISS_SETUP_PRIO")) prio = atoi(e);
-        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->setup_stream, hipStreamNonBlocking, prio));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->setup_stream, hipStreamNonBlocking, prio_greatest));
     }
     for (auto &e : ctx->ev_call_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ctx->ev_setup_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : ctx->ev_slot_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inputs, hipEventDisableTiming));
-    if (const char *e = getenv("ISS_OVERLAP")) ctx->overlap = atoi(e) != 0;
-    if (const char *e = getenv("ISS_SETUP_AHEAD")) ctx->setup_ahead = atoi(e) != 0;
+    if (const char *e = getenv("ISS_SETUP_AHEAD")) ctx->setup_ahead = atoi(e) != 0;  // 0: everything in order on one stream
+    read_switches(ctx);
     void *p = nullptr;
     HIP_TRY(ctx, hipMalloc(&p, 256));
     ctx->fix_count = static_cast<uint32_t *>(p);  // FIX_SLOTS counters; +128 B stats; +192 B genome-pack status
@@ -797,11 +801,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * FIX_SLOTS * iss::SCAN_MAX_WGS));
     ctx->read_count = static_cast<uint32_t *>(p);
     HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * FIX_SLOTS * iss::SCAN_MAX_WGS));
-    HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * 2 * FIX_SLOTS));
-    ctx->sub_count = static_cast<uint32_t *>(p);
-    HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * 2 * FIX_SLOTS));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
-    if (const char *e = getenv("ISS_MAIN_GRID")) ctx->max_main_grid = (unsigned)std::max(1, atoi(e));  // tuning aid
     *out = ctx;
     return 0;
 }
@@ -813,14 +813,12 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->indel_stream) (void)hipStreamSynchronize(ctx->indel_stream);
     if (ctx->setup_stream) (void)hipStreamSynchronize(ctx->setup_stream);
-    for (auto &pi : ctx->pending) (void)hipEventDestroy(pi.done);
     for (auto &t : ctx->timed) for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
     free_model(ctx);
     free_outputs(ctx);
     iss_genome_clear(ctx);
     if (ctx->fix_count) (void)hipFree(ctx->fix_count);
     if (ctx->read_count) (void)hipFree(ctx->read_count);
-    if (ctx->sub_count) (void)hipFree(ctx->sub_count);
     if (ctx->d_amb) (void)hipFree(ctx->d_amb);
     if (ctx->d_pmut) (void)hipFree(ctx->d_pmut);
     if (ctx->d_ov_pairs) (void)hipFree(ctx->d_ov_pairs);
@@ -831,6 +829,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     if (ctx->setup_stream) (void)hipStreamDestroy(ctx->setup_stream);
     for (auto &e : ctx->ev_call_done) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_setup_done) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_slot_done) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_inputs) (void)hipEventDestroy(ctx->ev_inputs);
     delete ctx;
 }
@@ -852,6 +851,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     free_model(ctx);
+    read_switches(ctx);
     const int RL = t->read_length, nq = t->n_q;
     const uint64_t two53 = 1ull << 53;
     auto check = [&](const uint64_t *p, size_t n) { for (size_t i = 0; i < n; ++i) if (p[i] > two53) return false; return true; };
@@ -972,7 +972,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         return 0;
     };
     M.GB = 6;
-    if (const char *e = getenv("ISS_GUIDE_BITS")) M.GB = std::min(8, std::max(6, atoi(e)));
+    if (ctx->env_guide_bits) M.GB = ctx->env_guide_bits;
     else {
         double best = 1e30;
         for (int gb = 6; gb <= 8; ++gb) {
@@ -982,7 +982,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             if (cost < best - 1e-9) { best = cost; M.GB = gb; }
         }
     }
-    if (getenv("ISS_DEBUG_MODEL")) {  // expected share of bases that leave the hot loop
+    if (ctx->debug_model) {  // expected share of bases that leave the hot loop
         double err = 0;
         size_t rows = 0;
         for (int o = 0; o < 2; ++o)
@@ -1014,7 +1014,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         return main_lds_bytes(M) <= budget;
     };
     const size_t two_per_cu = 79 * 1024, one_per_cu = 158 * 1024;
-    const int env_tiles = getenv("ISS_TILES") ? atoi(getenv("ISS_TILES")) : 0;  // tuning aid
+    const int env_tiles = ctx->env_tiles;  // tuning aid
     M.n_tiles = 0;
     if (env_tiles > 0 && fits(env_tiles, one_per_cu)) M.n_tiles = env_tiles;
     (void)two_per_cu;
@@ -1024,7 +1024,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     if ((M.S + M.TS - 1) / M.TS > iss::MAX_TILES) return fail(ctx, ISS_E_INVALID, "quality tables need more position tiles than the engine supports");
     (void)fits(M.n_tiles, one_per_cu);
     M.n_tiles = (M.S + M.TS - 1) / M.TS;
-    if (getenv("ISS_DEBUG_MODEL"))
+    if (ctx->debug_model)
         fprintf(stderr, "[model] RL %d G %d NB %d GB %d stride_w %d GS %d TG %d n_tiles %d tile %.1f KB (k_main LDS %.1f KB)\n",
                 M.RL, M.G, M.NB, M.GB, M.stride_w, M.GS, M.TG, M.n_tiles, M.tile_words * 4 / 1024.0,
                 main_lds_bytes(M) / 1024.0);
@@ -1076,28 +1076,14 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     }
         M.alt_letters = (uint32_t)letters[0] | ((uint32_t)letters[1] << 8) | ((uint32_t)letters[2] << 16) | ((uint32_t)letters[3] << 24);
     }
-    {   // expected substitutions per pair (sizes the list of applied substitutions, RunArgs::sub_list): per mate and position the
-        // phred distribution of every bin (differences of the CDF thresholds) against the error probability of the phred
-        double exp_subs = 0;
-        const double inv = 1.0 / 9007199254740992.0;
-        for (int o = 0; o < 2; ++o) {
-            double bprev = 0;
-            for (int b = 0; b < 4; ++b) {
-                const double bcum = std::min(1.0, (double)t->bin_thr[o * 4 + b] * inv), pb = std::max(0.0, bcum - bprev);
-                bprev = bcum;
-                if (!t->bin_nonempty[o * 4 + b] || pb <= 0) continue;
-                for (int p = 0; p < RL; ++p) {
-                    const uint64_t *row = t->q_thr + ((size_t)(o * 4 + b) * RL + p) * nq;
-                    double prev = 0;
-                    for (int q = 0; q <= nq; ++q) {
-                        const double cum = q < nq ? std::min(1.0, (double)row[q] * inv) : 1.0;
-                        exp_subs += pb * std::max(0.0, cum - prev) * (1.0 - (double)t->mut_thr[q] * inv);
-                        prev = cum;
-                    }
-                }
-            }
+    {   // edit scripts (k_indel_script -> k_main): four 16-byte rows per tile and group of 8 iterations
+        M.sc_gpt = ((M.TS + 3) / 4 + 7) / 8;
+        M.sc_stride = M.n_tiles * M.sc_gpt * 64;
+        M.ins_plain = 1;
+        for (size_t i = 0; i < (size_t)2 * RL * 4; ++i) {
+            const uint8_t c = t->ins_letter[i];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') M.ins_plain = 0;
         }
-        M.exp_subs = (float)exp_subs;
     }
     std::vector<uint64_t> del_max((size_t)2 * RL);
     for (int o = 0; o < 2; ++o)
@@ -1147,8 +1133,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             p_any = std::max(p_any, 1.0 - none);
         }
         M.p_read_event = (float)p_any;
-        const char *e = getenv("ISS_LIGHT_INDELS");
-        ctx->light = p_any < (e ? atof(e) : 2e-3);
+        ctx->light = p_any < ctx->light_below;
     }
     // k_mt_resolve tables: un-merged 16-bit leading digits per (orientation, bin slot, position) -- a row of n_q
     // digits padded to an odd number of words -- and 27-bit leading parts of the indel thresholds
@@ -1344,38 +1329,9 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     void *q = nullptr;
     // (plain hipMalloc: physically contiguous rows -- hipExtMallocWithFlags(hipDeviceMallocContiguous) -- were measured at 1.82-1.88
     //  instead of 1.25-1.34 ms per step of the default bench, whatever the grid)
-    if (const char *e = getenv("ISS_ROWS_CHUNK_MB")) {
-        // experiment: the rows as separately created physical chunks of this size mapped into one address range, in order
-        // (ISS_ROWS_SHUFFLE=0) or shuffled -- what the step time owes to the physical layout
-        const size_t bytes = (size_t)ctx->M.row * (size_t)capacity_pairs;
-        hipMemAllocationProp prop{};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = ctx->device;
-        size_t gran = 0;
-        HIP_TRY(ctx, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-        size_t chunk = std::max<size_t>((size_t)(atof(e) * 1048576.0), gran);
-        chunk = (chunk + gran - 1) / gran * gran;
-        const size_t n_chunks = (bytes + chunk - 1) / chunk, va = n_chunks * chunk;
-        HIP_TRY(ctx, hipMemAddressReserve(&q, va, chunk, nullptr, 0));
-        std::vector<size_t> order(n_chunks);
-        for (size_t i = 0; i < n_chunks; ++i) order[i] = i;
-        if (!getenv("ISS_ROWS_SHUFFLE") || atoi(getenv("ISS_ROWS_SHUFFLE"))) {
-            uint64_t st = 0x9e3779b97f4a7c15ull;
-            for (size_t i = n_chunks; i > 1; --i) { st = st * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[i - 1], order[(st >> 33) % i]); }
-        }
-        ctx->rows_handles.resize(n_chunks);
-        for (size_t i = 0; i < n_chunks; ++i) HIP_TRY(ctx, hipMemCreate(&ctx->rows_handles[i], chunk, &prop, 0));
-        for (size_t i = 0; i < n_chunks; ++i) HIP_TRY(ctx, hipMemMap(static_cast<uint8_t *>(q) + order[i] * chunk, chunk, 0, ctx->rows_handles[i], 0));
-        hipMemAccessDesc acc{};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        HIP_TRY(ctx, hipMemSetAccess(q, va, &acc, 1));
-        ctx->rows_va_bytes = va;
-        if (getenv("ISS_DEBUG_MODEL")) fprintf(stderr, "rows: %zu chunks of %zu bytes (granularity %zu)\n", n_chunks, chunk, gran);
-    } else {
+    //  instead of 1.25-1.34 ms per step of the default bench, whatever the grid; rows mapped from separately created physical
+    //  chunks -- hipMemCreate / hipMemMap, 64 KB to 16 MB, in order or shuffled -- at 1.23-1.9: no layout helped on every box)
     HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.row * (size_t)capacity_pairs));
-    }
     for (int k = 0; k < 4; ++k) ctx->out[k] = static_cast<uint8_t *>(q) + iss::row_array_off(k);
     for (int k = 0; k < 2; ++k) {  // (two sets: k_setup of a call runs beside the kernels of the call before)
         HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));
@@ -1398,11 +1354,11 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
         ctx->read_list[k] = static_cast<uint4 *>(q);
     }
     if (!heavy) { ctx->ev_count[1] = ctx->ev_count[0]; ctx->ev_list[1] = ctx->ev_list[0]; ctx->read_list[1] = ctx->read_list[0]; }
-    if (heavy) {
-        ctx->sub_per_pair = (int64_t)std::ceil(3.0 * (double)ctx->M.exp_subs) + 2;
-        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint2) * ((size_t)ctx->sub_per_pair * (size_t)capacity_pairs + (size_t)(FIX_SLOTS + 1) * SUB_MARGIN)));
-        ctx->sub_list = static_cast<uint2 *>(q);
-    }
+    if (heavy)  // the edit scripts of the reads with an event (sparse: a read's slot is written only if it has one)
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.sc_stride * 2 * (size_t)capacity_pairs));
+            ctx->script[k] = static_cast<uint8_t *>(q);
+        }
     ctx->capacity = capacity_pairs;
     return 0;
 }
@@ -1423,6 +1379,14 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                          const int64_t *item_first, int32_t n_items, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                          int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair);
 
+// Do the kernels in front of k_main (k_setup, k_indel_scan, k_indel_script) of a call run on the setup stream, beside the kernels
+// of the call before?  Not with custom fragment lengths (the host reads k_setup's results back), not while every kernel is
+// timed, and not when k_indel_script appends --store_mutations rows (the call clears the row buffer on the main stream).
+static bool setup_runs_ahead(const iss_ctx *ctx) {
+    const bool heavy = ctx->M.n_scan > 0 && !ctx->light;
+    return ctx->setup_ahead && !ctx->has_frag && !ctx->timing_all && !(heavy && ctx->d_pmut);
+}
+
 int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                  int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
     if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_generate: upload a model first");
@@ -1442,29 +1406,29 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
 }
 
 // The launches of one generate call: `dg` is the record, or (items != NULL) the arena holding the records of a batch.
+// Per chunk: k_setup [k_indel_scan, k_indel_script: models whose reads often have indels] -> k_main -> k_indel_fixup.  The
+// kernels in front of k_main read nothing the call before writes and write double-buffered sets (descriptors, flags, fix-up
+// lists, event lists, scripts): they run on the setup stream, beside the kernels of the call (or chunk) before.
 static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_exceptions, const iss::BatchItem *items,
                          const int64_t *item_first, int32_t n_items, int64_t n_pairs, uint64_t first_ordinal, uint64_t seed,
                          int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair) {
     const iss::DevModel &M = ctx->M;
-    // k_indel_scan counts lane-items in 32 bits (keep them below 2^31)
+    read_switches(ctx);
     const size_t lds_bytes = main_lds_bytes(M);
-    (void)lds_bytes;
-    unsigned per_cu = 1u;  // ONE 1024-lane workgroup per CU: k_main is compiled for 128 VGPRs (4 wavefronts / SIMD)
-    if (const char *e = getenv("ISS_MAIN_PER_CU")) per_cu = std::min(per_cu, (unsigned)std::max(1, atoi(e)));  // tuning aid
-    const unsigned wg_per_tile = std::max(1u, std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid) / (unsigned)M.n_tiles);
-    const unsigned wg_per_tile_cap = 8192;  // (tile_wg0 is 16 bits wide)
+    const bool heavy = M.n_scan > 0 && !ctx->light;  // reads with an indel event are common: scan + edit scripts + k_main<.., INDEL>
     // k_main's deferred queue: 13 bits for (pass of a workgroup, iteration of the pass); the tile with the fewest
     // workgroups (a short last tile) makes the most passes
     const unsigned it_max = ((unsigned)M.TS + 3u) / 4u - 1u;
     unsigned it_bits = 0;
     while ((1u << it_bits) <= it_max && it_max) ++it_bits;
     const int64_t max_passes = ((int64_t)1 << (13 - it_bits)) - 1;
-    const unsigned budget_all = std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid);
+    const unsigned budget_all = std::min((unsigned)ctx->n_cu, ctx->max_main_grid);  // ONE 1024-lane workgroup per CU (k_main: 4 wavefronts / SIMD)
     unsigned weight_all = 0;
     for (int t = 0; t < M.n_tiles; ++t) weight_all += 1u + (unsigned)(std::min(M.TS, M.S - t * M.TS) + 3) / 4u;
     const unsigned last_weight = 1u + (unsigned)(M.S - (M.n_tiles - 1) * M.TS + 3) / 4u;
     const unsigned min_tile_wg = std::max(1u, (unsigned)((uint64_t)budget_all * last_weight / weight_all));
-    // the pass number of a workgroup (>= 1 workgroup per tile, 256 pairs per pass), and 32 bits for a row's byte offset
+    // the pass number of a workgroup (>= 1 workgroup per tile, 256 pairs per pass); 32 bits for a row's byte offset and for the
+    // read numbers of k_indel_scan
     const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)1 << 31) / std::max(M.n_scan, 1),
                                                                                       (((int64_t)1 << 32) - 1) / M.row),
                                                                     max_passes * iss::MAIN_PAIRS * min_tile_wg));
@@ -1476,13 +1440,15 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
     ctx->last_row0 = out_first_pair;
     ctx->last_n = n_pairs;
     if (!items) { ctx->last_first.clear(); ctx->last_off.clear(); }
-    // this call's set of descriptors / flags / fix-up list; k_setup on the setup stream once the call before last -- the last
-    // user of the set -- is done (custom fragment lengths: the host reads k_setup's results back: everything on one stream)
+    // this call's set of descriptors / flags / lists; the setup-stream kernels start once the call before last -- the last
+    // user of the set -- is done (custom fragment lengths: the host reads k_setup's results back: everything on one stream;
+    // --store_mutations: the rows are cleared on the main stream above)
     const int par = (int)(ctx->call_seq++ & 1u);
     ctx->flags = ctx->flags_buf[par];
     ctx->fix_list = ctx->fixl_buf[par];
-    const bool ahead = ctx->setup_ahead && !ctx->has_frag && !ctx->overlap && !ctx->timing_all;
+    const bool ahead = setup_runs_ahead(ctx);
     hipStream_t s_setup = ahead ? ctx->setup_stream : ctx->stream;
+    hipStream_t s_main = ctx->stream;
     if (ahead) {
         if (ctx->ev_call_valid[par]) HIP_TRY(ctx, hipStreamWaitEvent(s_setup, ctx->ev_call_done[par], 0));
         if (ctx->inputs_pending) HIP_TRY(ctx, hipStreamWaitEvent(s_setup, ctx->ev_inputs, 0));  // (arena / table copies of this call)
@@ -1505,8 +1471,6 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         uint32_t *fix_list = ctx->fix_list + 2 * row0;
         TimedLaunch tl{};
         tl.has_scan = M.n_scan > 0 || ctx->has_frag;
-        hipStream_t s_main = ctx->stream;
-        hipStream_t s_indel = ctx->overlap ? ctx->indel_stream : ctx->stream;
         auto mark = [&](int k, hipStream_t st) -> hipError_t {
             if (!ctx->timing) return hipSuccess;
             if (ctx->timing_main_only && k != 1 && k != 2) return hipSuccess;  // (every event costs a bubble in the stream)
@@ -1514,26 +1478,14 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             if (e != hipSuccess) return e;
             return hipEventRecord(tl.ev[k], st);
         };
-        // rows about to be rewritten may still be in use by an earlier chunk's indel pass
-        for (size_t i = 0; i < ctx->pending.size();) {
-            PendingIndel &pi = ctx->pending[i];
-            if (hipEventQuery(pi.done) == hipSuccess) {
-                (void)hipEventDestroy(pi.done);
-                ctx->pending.erase(ctx->pending.begin() + (long)i);
-                continue;
-            }
-            if (pi.row0 < row0 + n && row0 < pi.row0 + pi.n) HIP_TRY(ctx, hipStreamWaitEvent(s_main, pi.done, 0));
-            ++i;
-        }
-        // fix-list / read-list / substitution-list counters of this chunk: rings of FIX_SLOTS counters (k_setup runs at most two
-        // calls ahead of the other kernels: a slot's previous user is long done).  (The flags are cleared by k_setup itself.)
+        // fix-list / read-list counters of this chunk: rings of FIX_SLOTS counters.  The setup stream runs ahead of the main
+        // stream: before a slot's counters are cleared for its next user, the chunk that used it last must be done with them
+        // (its k_indel_fixup reads the fix-list counter on the main stream).  (The flags are cleared by k_setup itself.)
         const unsigned slot_i = (unsigned)(ctx->chunk_seq++ % FIX_SLOTS);
         uint32_t *counter = ctx->fix_count + slot_i;
         uint32_t *read_counter = ctx->read_count + (size_t)slot_i * iss::SCAN_MAX_WGS;  // (one per workgroup of k_indel_scan, all of them written by it)
-        uint32_t *sub_counter = ctx->sub_count + 2 * slot_i;
-        // (the counters of the chunk before may still be in use: only this chunk's own are cleared -- on the stream k_setup runs on)
+        if (ahead && ctx->ev_slot_valid[slot_i]) HIP_TRY(ctx, hipStreamWaitEvent(s_setup, ctx->ev_slot_done[slot_i], 0));
         HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_setup));
-        HIP_TRY(ctx, hipMemsetAsync(sub_counter, 0, 2 * sizeof(uint32_t), s_setup));
         A.mut = ctx->d_pmut;
         A.mut_count = ctx->d_pmut_count;
         A.mut_cap = (uint32_t)ctx->pmut_cap;
@@ -1548,19 +1500,13 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.ev_list = ctx->ev_list[par] + 2 * (size_t)iss::EV_K * row0;
         A.read_list = ctx->read_list[par] + 2 * row0;
         A.read_count = read_counter;
-        A.main_blocked = getenv("ISS_MAIN_BLOCKED") ? (uint32_t)atoi(getenv("ISS_MAIN_BLOCKED")) : 0u;
         A.scan_wgs = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)ctx->n_cu * 2, iss::SCAN_MAX_WGS), (2 * (uint64_t)n + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
         A.light = ctx->light ? (iss::setup_lds_bytes(M.n_isize, M.ev_ns, true) <= (size_t)150 * 1024 ? 1 : 2) : 0;
-        if (M.n_scan > 0 && ctx->sub_list && !ctx->light) {  // k_main lists the substitutions it applies: k_indel_resub re-applies those of shifted reads
-            A.sub_list = ctx->sub_list + (size_t)row0 * (size_t)ctx->sub_per_pair + (size_t)slot_i * SUB_MARGIN;
-            A.sub_count = sub_counter;
-            A.sub_cap = (uint32_t)std::min<uint64_t>((uint64_t)n * (uint64_t)ctx->sub_per_pair + SUB_MARGIN, 0xffffff00u);
-            if (const char *e = getenv("ISS_SUB_CAP")) A.sub_cap = std::min<uint32_t>(A.sub_cap, (uint32_t)std::max(0, atoi(e)));  // (tests: force the overflow path)
-        }
+        A.script = heavy ? ctx->script[par] + (size_t)2 * (size_t)row0 * (size_t)M.sc_stride : nullptr;
         A.has_frag = ctx->has_frag ? 1 : 0;
         A.frag_mu = ctx->frag_mu;
         A.frag_sd = ctx->frag_sd;
-        A.frag_guard = getenv("ISS_MT_GUARD") ? atof(getenv("ISS_MT_GUARD")) : 1e-6;
+        A.frag_guard = ctx->mt_guard;
         if (ctx->has_frag) {
             if (ctx->amb_cap < n) {
                 if (ctx->d_amb) (void)hipFree(ctx->d_amb);
@@ -1580,30 +1526,15 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             A.amb_list = ctx->d_amb;
             A.amb_count = ctx->d_amb_count;
         }
-        // Models whose reads often have indels: the scan runs IN FRONT of k_main (it needs the descriptors only), so that
-        // k_main lists the substitutions of the reads with an event only -- the others are never shifted; with k_setup on
-        // the setup stream, right behind it there (its lists are double-buffered like the descriptors)
-        const bool scan_first = A.sub_list != nullptr;
-        const bool scan_ahead = scan_first && ahead;
-        auto launch_scan = [&](hipStream_t st) {
-            const uint64_t reads = 2 * (uint64_t)n;
-            hipLaunchKernelGGL(iss::k_indel_scan, dim3(A.scan_wgs), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), st, M, A, desc);
-        };
-        tl.scan_first = scan_first && !scan_ahead;
+        tl.scan_first = heavy && !ahead;
         HIP_TRY(ctx, mark(0, s_setup));
         if (ahead && A.light == 1 && main_lds_bytes(M) + iss::setup_lds_bytes(M.n_isize, M.ev_ns, true) > (size_t)158 * 1024)
             A.light = 2;  // (k_main's tables leave no room for the event tables beside them: read in place, off the critical path)
         {
             const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8 * (int64_t)ctx->n_cu);
             hipLaunchKernelGGL(iss::k_setup, dim3(blocks), dim3(256), iss::setup_lds_bytes(M.n_isize, M.ev_ns, A.light == 1 && M.n_scan > 0), s_setup, M, dg, A, desc);
-            if (scan_ahead) launch_scan(s_setup);
-            if (ahead) {  // k_main (and what follows it) waits for this chunk's k_setup
-                if (ctx->timing && !ctx->timing_main_only) { HIP_TRY(ctx, hipEventCreate(&tl.ev[7])); HIP_TRY(ctx, hipEventRecord(tl.ev[7], s_setup)); }
-                HIP_TRY(ctx, hipEventRecord(ctx->ev_setup_done[slot_i], s_setup));
-                HIP_TRY(ctx, hipStreamWaitEvent(s_main, ctx->ev_setup_done[slot_i], 0));
-            }
         }
-        if (ctx->has_frag) {
+        if (ctx->has_frag) {  // (one stream: s_setup == s_main)
             // fragment lengths the device could not decide (|x - round(x)| < guard): libm on the host, then redo those pairs
             uint32_t n_amb = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&n_amb, ctx->d_amb_count, sizeof n_amb, hipMemcpyDeviceToHost, s_main));
@@ -1625,29 +1556,39 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
                 hipLaunchKernelGGL(iss::k_setup_override, dim3((n_amb + 63) / 64), dim3(64), 0, s_main, M, dg, A, desc);
             }
         }
-        hipEvent_t ev_setup = nullptr, ev_main = nullptr;
-        if ((M.n_scan > 0 || ctx->has_frag) && ctx->overlap) {
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ev_setup, hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventRecord(ev_setup, s_main));
+        if (heavy) {
+            // the event lists of all reads, one lane per read, then the edit scripts of the reads that have an event
+            if (!ahead) HIP_TRY(ctx, mark(3, s_setup));
+            hipLaunchKernelGGL(iss::k_indel_scan, dim3(A.scan_wgs), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), s_setup, M, A, desc);
+            {
+                const size_t lds = iss::script_lds_bytes(M.RL, M.pitch);
+                const int64_t per_wg = (int64_t)iss::SC_WAVES * 64;  // reads per workgroup pass; at most 2 n reads (the list is usually shorter)
+                const unsigned blocks = (unsigned)std::min<int64_t>((int64_t)iss::SC_WGS_PER_CU * ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
+                const dim3 grid(blocks), block(64 * iss::SC_WAVES);
+                const bool narrow = iss::ap_ww(M.pitch) <= 12;  // (window words a lane prefetches in registers)
+                if (A.mut) { if (narrow) hipLaunchKernelGGL((iss::k_indel_script<true, 12>), grid, block, lds, s_setup, M, dg, A, desc, ctx->stats);
+                             else hipLaunchKernelGGL((iss::k_indel_script<true, 26>), grid, block, lds, s_setup, M, dg, A, desc, ctx->stats); }
+                else { if (narrow) hipLaunchKernelGGL((iss::k_indel_script<false, 12>), grid, block, lds, s_setup, M, dg, A, desc, ctx->stats);
+                       else hipLaunchKernelGGL((iss::k_indel_script<false, 26>), grid, block, lds, s_setup, M, dg, A, desc, ctx->stats); }
+            }
+            if (!ahead) HIP_TRY(ctx, mark(4, s_setup));
         }
-        if (scan_first && !scan_ahead) {
-            HIP_TRY(ctx, mark(3, s_main));
-            launch_scan(s_main);
-            HIP_TRY(ctx, mark(4, s_main));
+        if (ahead) {  // k_main (and what follows it) waits for this chunk's setup-stream kernels
+            if (ctx->timing && !ctx->timing_main_only) { HIP_TRY(ctx, hipEventCreate(&tl.ev[7])); HIP_TRY(ctx, hipEventRecord(tl.ev[7], s_setup)); }
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_setup_done[slot_i], s_setup));
+            HIP_TRY(ctx, hipStreamWaitEvent(s_main, ctx->ev_setup_done[slot_i], 0));
         }
         HIP_TRY(ctx, mark(1, s_main));
         {
             const uint64_t passes = ((uint64_t)n + iss::MAIN_PAIRS - 1) / iss::MAIN_PAIRS;  // a workgroup pass = 256 pairs
-            // persistent grid (8 waves / SIMD when two workgroups share a CU), split evenly over the position tiles
-            // ... in proportion to the tiles' work per pass -- a fixed part (descriptor, addresses) + one part per iteration
-            // of 4 superitems, whether or not all four lanes of a pair have one (the last tile may be short) -- at most one
-            // workgroup per pass of a tile
-            const unsigned budget = std::min(per_cu * (unsigned)ctx->n_cu, ctx->max_main_grid);
-            unsigned total = 0, weight_sum = 0;
-            for (int t = 0; t < M.n_tiles; ++t) weight_sum += 1u + (unsigned)(std::min(M.TS, M.S - t * M.TS) + 3) / 4u;
+            // persistent grid, split over the position tiles in proportion to the tiles' work per pass -- a fixed part
+            // (descriptor, addresses) + one part per iteration of 4 superitems, whether or not all four lanes of a pair have one
+            // (the last tile may be short) -- at most one workgroup per pass of a tile
+            const unsigned wg_per_tile_cap = 8192;  // (tile_wg0 is 16 bits wide)
+            unsigned total = 0;
             for (int t = 0; t < M.n_tiles; ++t) {
                 const unsigned weight = 1u + (unsigned)(std::min(M.TS, M.S - t * M.TS) + 3) / 4u;
-                unsigned w = std::max(1u, (unsigned)((uint64_t)budget * weight / weight_sum));
+                unsigned w = std::max(1u, (unsigned)((uint64_t)budget_all * weight / weight_all));
                 w = (unsigned)std::min<uint64_t>(std::min<uint64_t>(w, wg_per_tile_cap), passes);
                 A.tile_wg0[t] = (uint16_t)total;
                 total += w;
@@ -1655,69 +1596,33 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             A.tile_wg0[M.n_tiles] = (uint16_t)total;
             const dim3 grid(total), block(iss::MAIN_THREADS);
             const bool plain = !any_exceptions && !ctx->has_frag;
-#define ISS_LAUNCH_MAIN(MUT, PLAIN)                                                                                         \
-    do {                                                                                                                    \
-        if (A.sub_list) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN, true>), grid, block, lds_bytes, s_main, M, dg, A, desc); \
-        else hipLaunchKernelGGL((iss::k_main<MUT, PLAIN, false>), grid, block, lds_bytes, s_main, M, dg, A, desc);           \
+#define ISS_LAUNCH_MAIN(MUT, PLAIN)                                                                                      \
+    do {                                                                                                                 \
+        if (heavy) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN, true>), grid, block, lds_bytes, s_main, M, dg, A, desc);   \
+        else hipLaunchKernelGGL((iss::k_main<MUT, PLAIN, false>), grid, block, lds_bytes, s_main, M, dg, A, desc);        \
     } while (0)
             if (A.mut) { if (plain) ISS_LAUNCH_MAIN(true, true); else ISS_LAUNCH_MAIN(true, false); }
             else { if (plain) ISS_LAUNCH_MAIN(false, true); else ISS_LAUNCH_MAIN(false, false); }
 #undef ISS_LAUNCH_MAIN
         }
         HIP_TRY(ctx, mark(2, s_main));
-        const bool indel_pass = M.n_scan > 0 || ctx->has_frag;
-        if (indel_pass) {
-            if (ctx->overlap) {
-                HIP_TRY(ctx, hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
-                HIP_TRY(ctx, hipEventRecord(ev_main, s_main));
-                HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_setup, 0));  // the scan needs the pair descriptors only
-            }
-            if (!scan_first) {
-                HIP_TRY(ctx, mark(3, s_indel));
-                // one lane per read (light models: k_setup has checked the pair's reads already)
-                if (M.n_scan > 0 && !ctx->light) launch_scan(s_indel);
-                HIP_TRY(ctx, mark(4, s_indel));
-            }
-            if (ctx->overlap) HIP_TRY(ctx, hipStreamWaitEvent(s_indel, ev_main, 0));  // the fix-up patches k_main's rows
-            HIP_TRY(ctx, mark(5, s_indel));
-            if (M.n_scan > 0 && !ctx->light) {  // reads with (few) events: rebuilt from their lists, 64 per wavefront block
-                const size_t lds = iss::apply_lds_bytes(M.RL, M.pitch);
-                const int waves = iss::apply_waves(M.RL, M.pitch);  // ONE workgroup per CU
-                const int64_t per_wg = (int64_t)waves * 64;  // reads per workgroup pass; at most 2 n reads (the list is usually far shorter)
-                const unsigned blocks = (unsigned)std::min<int64_t>(ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
-                const dim3 grid(blocks), block(64 * waves);
-                const bool narrow = iss::ap_ww(M.pitch) <= 12;  // (window words a lane prefetches in registers)
-                if (A.mut) { if (narrow) hipLaunchKernelGGL((iss::k_indel_apply<true, 12>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats);
-                             else hipLaunchKernelGGL((iss::k_indel_apply<true, 26>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats); }
-                else { if (narrow) hipLaunchKernelGGL((iss::k_indel_apply<false, 12>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats);
-                       else hipLaunchKernelGGL((iss::k_indel_apply<false, 26>), grid, block, lds, s_indel, M, dg, A, desc, ctx->stats); }
-                if (A.sub_list) {  // the listed substitutions of the reads just rebuilt, on the letters that stand there now
-                    const dim3 rgrid((unsigned)std::min<int64_t>(4 * ctx->n_cu, (2 * n + 255) / 256)), rblock(256);
-                    if (A.mut) hipLaunchKernelGGL((iss::k_indel_resub<true>), rgrid, rblock, 0, s_indel, M, A, desc);
-                    else hipLaunchKernelGGL((iss::k_indel_resub<false>), rgrid, rblock, 0, s_indel, M, A, desc);
-                }
-            }
-            {   // the rest (irregular pairs, reads with more events than a list holds): one wavefront per read
-                const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
-                hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), iss::fix_lds_bytes(M.RL), s_indel, M, dg, A, desc,
-                                   fix_list, counter, ctx->stats);
-            }
-            HIP_TRY(ctx, mark(6, s_indel));
-            if (ctx->overlap) {
-                PendingIndel pi{row0, n, nullptr};
-                HIP_TRY(ctx, hipEventCreateWithFlags(&pi.done, hipEventDisableTiming));
-                HIP_TRY(ctx, hipEventRecord(pi.done, s_indel));
-                ctx->pending.push_back(pi);
-                (void)hipEventDestroy(ev_setup);  // destruction is deferred by the runtime until the waits completed
-                (void)hipEventDestroy(ev_main);
-            }
+        if (M.n_scan > 0 || ctx->has_frag) {
+            // the rest (irregular pairs, reads whose script does not fit, every read with an event of a light model): one
+            // wavefront per read, behind k_main (it takes the read's phreds from the row and rewrites its letters)
+            HIP_TRY(ctx, mark(5, s_main));
+            const unsigned blocks = (unsigned)std::min<int64_t>(8 * ctx->n_cu, (2 * n + iss::FIX_WAVES - 1) / iss::FIX_WAVES);
+            hipLaunchKernelGGL(iss::k_indel_fixup, dim3(blocks), dim3(64 * iss::FIX_WAVES), iss::fix_lds_bytes(M.RL), s_main, M, dg, A, desc,
+                               fix_list, counter, ctx->stats);
+            HIP_TRY(ctx, mark(6, s_main));
         }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_slot_done[slot_i], s_main));
+        ctx->ev_slot_valid[slot_i] = true;
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->timing) ctx->timed.push_back(tl);
         done += n;
     }
     ctx->n_launches += 1;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_call_done[par], ctx->overlap ? ctx->indel_stream : ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_call_done[par], ctx->stream));
     ctx->ev_call_valid[par] = true;
     return 0;
 }
@@ -1771,12 +1676,6 @@ static void free_item_tables(iss_ctx *ctx) {
         ctx->ev_items[k] = nullptr;
     }
     ctx->d_items_cap = 0;
-}
-
-// with ISS_OVERLAP the indel passes of a call run on their own stream: the main stream waits for them here
-static int sync_indel_into_main(iss_ctx *ctx) {
-    if (!ctx->overlap) return 0;
-    return sync_all(ctx);
 }
 
 static void free_community(iss_ctx *ctx) {
@@ -1841,7 +1740,6 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
                 exceptions |= G.has_exceptions;
             }
             if (coord >= ((int64_t)1 << 31) - 4096) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: the records of one call must stay below 2^31 bases");
-            if (ctx->overlap) { int rc_ = sync_all(ctx); if (rc_) return rc_; }  // (readers on the indel stream)
             if (coord > ctx->comm_cap) {
                 { int rc_ = sync_all(ctx); if (rc_) return rc_; }
                 free_community(ctx);
@@ -1901,13 +1799,12 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
     memcpy(ctx->h_items[set], call_items.data(), (size_t)n_items * sizeof(iss::BatchItem));
     memcpy(ctx->h_item_first[set], first.data(), ((size_t)n_items + 1) * sizeof(int64_t));
     // (on the stream k_setup runs on: beside the previous call's kernels, not behind them)
-    hipStream_t s_in = ctx->setup_ahead && !ctx->has_frag && !ctx->overlap && !ctx->timing_all ? ctx->setup_stream : ctx->stream;
+    hipStream_t s_in = setup_runs_ahead(ctx) ? ctx->setup_stream : ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_items[set], ctx->h_items[set], (size_t)n_items * sizeof(iss::BatchItem), hipMemcpyHostToDevice, s_in));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_item_first[set], ctx->h_item_first[set], ((size_t)n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s_in));
     const int rc = generate_core(ctx, dg, any_exceptions, ctx->d_items[set], ctx->d_item_first[set], n_items, total, first_ordinal,
                                  seed, sequence_type, gc_bias, out_first_pair);
     if (rc) return rc;
-    { int rc_ = sync_indel_into_main(ctx); if (rc_) return rc_; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_items[set], ctx->stream));
     ++ctx->batch_seq;
     ctx->last_first.assign(first.begin(), first.end());
@@ -2096,13 +1993,14 @@ int iss_timing_read(iss_ctx *ctx, double ms[4], int64_t *n_launches) {
     return 0;
 }
 
-int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads) {
+int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads, int64_t *n_scripted_reads) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
-    uint64_t v = 0;
-    HIP_TRY(ctx, hipMemcpy(&v, ctx->stats, sizeof v, hipMemcpyDeviceToHost));
+    uint64_t v[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(v, ctx->stats, sizeof v, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof v));
-    if (n_fixup_reads) *n_fixup_reads = (int64_t)v;
+    if (n_fixup_reads) *n_fixup_reads = (int64_t)v[0];
+    if (n_scripted_reads) *n_scripted_reads = (int64_t)v[1];
     return 0;
 }
 
@@ -2616,7 +2514,6 @@ static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, 
         q.writer = std::thread(fastq_writer_loop, ctx);
         q.ready = true;
     }
-    if (ctx->overlap) { int rc_ = sync_all(ctx); if (rc_) return rc_; }  // fix-ups may still run on the indel stream
     if (q.fd[0] != fd_r1 || q.fd[1] != fd_r2) {
         { int rc_ = fastq_flush(ctx); if (rc_) return rc_; }
         q.fd[0] = fd_r1; q.fd[1] = fd_r2;

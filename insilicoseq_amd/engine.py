@@ -334,9 +334,9 @@ class ReadEngine(object):
                 "launches": n.value}
 
     def stats_read(self):
-        n = C.c_int64(0)
-        self._check(self._lib.iss_stats_read(self._ctx, C.byref(n)))
-        return {"fixup_reads": n.value}
+        n, m = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.iss_stats_read(self._ctx, C.byref(n), C.byref(m)))
+        return {"fixup_reads": n.value, "scripted_reads": m.value}
 
 
 def fastq_write(fd_r1, fd_r2, record_id, first_i, cpu_number, n_pairs, read_length, pitch, r1_base, r1_qual, r2_base,

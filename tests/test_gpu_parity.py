@@ -85,24 +85,49 @@ def test_hip_matches_oracle(engine, case):
 @pytest.mark.parametrize("case", [0, 5, 7, 9, 10, 11, 14, 15, 16])
 def test_both_indel_paths_match_oracle(engine, case, mode, monkeypatch):
     """A model picks its indel path by how often a read has an event (DevModel::p_read_event against ISS_LIGHT_INDELS, 2e-3 by
-    default): rare -- every such read to the one-wavefront-per-read kernel, k_main without the substitution list; else
-    k_main lists its substitutions, k_indel_apply shifts letters, k_indel_resub re-applies the listed substitutions.  Both
-    paths for shipped and indel-heavy models alike ("0": never the light path, "2": always)."""
+    default): rare -- every such read to the one-wavefront-per-read kernel, k_main as it is; else k_indel_scan lists the
+    events, k_indel_script turns them into edit scripts and k_main builds the reads from shifted windows / explicit letters.
+    Both paths for shipped and indel-heavy models alike ("0": never the light path, "2": always)."""
     monkeypatch.setenv("ISS_LIGHT_INDELS", mode)
     model, indel, mk_genome, n_pairs, seed, first, seq_type, gc_bias = CASES[case]
     _compare(engine, dense_model(model, indel), mk_genome(), n_pairs, seed, first, seq_type, gc_bias)
 
 
-@pytest.mark.parametrize("case", [14, 15])
-def test_substitution_list_overflow_is_exact(engine, case, monkeypatch):
-    """The list of substitutions k_main applies is sized from the model's expected error rate; a launch that overflows it
-    (here: a cap of one chunk) raises a flag and k_indel_apply hands every read with an event to the one-wavefront-per-read
-    kernel instead -- slower, the same bytes."""
-    monkeypatch.setenv("ISS_SUB_CAP", "256")
+@pytest.mark.parametrize("model,indel,min_share", [("novaseq", (0.001, 0.003), 0.95), ("miseq-legacy", None, 0.9), ("novaseq", (0.01, 0.03), 0.0)])
+def test_scripted_reads_are_built_by_k_main(engine, model, indel, min_share, monkeypatch):
+    """Round 4: the reads with (few) indel events of a heavy model are built by k_main itself from their edit scripts -- no
+    second pass over their letters.  BASELINE configs[4]'s rates (0.001 / 0.003) and MiSeq-legacy (five position tiles):
+    nearly every read with an event is scripted, the one-wavefront-per-read kernel takes the rest (more than EV_K events,
+    windows leaving the record).  Ten times configs[4]'s rates: most reads have more events than a script holds, more explicit
+    letters or more explicit pieces than a row does -- the overflow exits, exact as well."""
     monkeypatch.setenv("ISS_LIGHT_INDELS", "0")
-    model, indel, mk_genome, n_pairs, seed, first, seq_type, gc_bias = CASES[case]
-    _, stats = _compare(engine, dense_model(model, indel), mk_genome(), n_pairs, seed, first, seq_type, gc_bias)
-    assert stats["fixup_reads"] > n_pairs // 4
+    engine.stats_read()
+    n_pairs = 4000
+    _, stats = _compare(engine, dense_model(model, indel), random_genome(61, 120000), n_pairs, 77)
+    assert stats["scripted_reads"] > 0
+    assert stats["scripted_reads"] >= min_share * (stats["scripted_reads"] + stats["fixup_reads"])
+    if min_share == 0.0:
+        assert stats["fixup_reads"] > n_pairs // 4
+
+
+@pytest.mark.parametrize("entries", ["nan", "inf", "mixed"])
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_bam_built_indel_tables_nan_inf_zero_one(engine, entries, mode, monkeypatch):
+    """A model built by `iss model` from a BAM file divides indel counts by match counts (iss/modeller.py:338-349): positions
+    nobody covered give 0/0 = NaN and n/0 = inf, others 0 or values >= 1.  `random() < NaN` never fires, `random() < inf`
+    and >= 1 always do (__init__.py:194, :209); both indel paths (scripts / one wavefront per read) against the oracle, which
+    compares IEEE doubles on the raw tables."""
+    monkeypatch.setenv("ISS_LIGHT_INDELS", mode)
+    dense = dense_model("novaseq", (0.0005, 0.002))
+    r = np.random.RandomState(5)
+    for tab in (dense.ins, dense.dele):
+        for o in range(2):
+            pos = r.choice(dense.read_length - 1, size=6, replace=False)
+            vals = {"nan": [np.nan] * 6, "inf": [np.inf, np.nan, np.inf, 0.0, np.nan, 0.0],
+                    "mixed": [np.nan, np.inf, 0.0, 1.0, 1.5, 0.9999999]}[entries]
+            for p_, v in zip(pos, vals):
+                tab[o, p_, r.randint(0, 4)] = v
+    _compare(engine, dense, random_genome(91, 80000), 4000, 31)
 
 
 @pytest.mark.parametrize("ahead", ["1", "0"])
@@ -145,11 +170,12 @@ def test_back_to_back_calls_pipeline(model, indel, ahead, monkeypatch):
                 check(call)
 
 
-@pytest.mark.parametrize("switches", [{"ISS_ROWS_CHUNK_MB": "2"}, {"ISS_ROWS_CHUNK_MB": "0.25", "ISS_ROWS_SHUFFLE": "0"},
-                                      {"ISS_MAIN_BLOCKED": "1"}, {"ISS_MAIN_GRID": "100", "ISS_SETUP_PRIO": "0"}])
+@pytest.mark.parametrize("switches", [{"ISS_TILES": "3"}, {"ISS_TILES": "2", "ISS_GUIDE_BITS": "8"}, {"ISS_GUIDE_BITS": "6"},
+                                      {"ISS_SETUP_AHEAD": "0"}])
 def test_tuning_switches_do_not_change_results(switches, monkeypatch):
-    """The measurement switches of INTEGRATION.md 7 (rows mapped from separately created physical chunks, k_main's pass
-    distribution and grid, the setup stream's priority) leave the reads alone -- also across a re-allocation of the rows."""
+    """The switches the library still reads (k_main's position tiles and guide bits -- an indel-heavy model
+    cut into several tiles also exercises the edit scripts' rows per tile --, everything on one stream) leave the reads alone,
+    also across a re-allocation of the rows."""
     from insilicoseq_amd.engine import ReadEngine
     from oracle import oracle as O
 
@@ -689,11 +715,13 @@ def test_fastq_pipeline_many_tiny_jobs(compress, tmp_path):
     assert rd(paths[1]) == open(paths[3], "rb").read()
 
 
-@pytest.mark.parametrize("model,n_genomes,pairs_total,batch", [("novaseq", 5, 5_000_000, True), ("hiseq", 50, 6_250_000, True),
-                                                               ("novaseq", 5, 5_000_000, False)])
-def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total, batch):
+@pytest.mark.parametrize("model,indel,n_genomes,pairs_total,batch", [("novaseq", None, 5, 5_000_000, True), ("hiseq", None, 50, 6_250_000, True),
+                                                                     ("novaseq", None, 5, 5_000_000, False),
+                                                                     ("novaseq", (0.001, 0.003), 1, 5_000_000, True)])
+def test_baseline_sizes_sampled_against_oracle(model, indel, n_genomes, pairs_total, batch):
     """BASELINE.json's full sizes (configs[2]: 10 M NovaSeq reads over 5 x 5 Mbp; one rank's 6.25 M-pair share of
-    configs[3]: HiSeq, 50 x 5 Mbp genomes): the whole work list is generated on the GPU exactly as bench.py times it
+    configs[3]: HiSeq, 50 x 5 Mbp genomes; configs[4]: 10 M reads of an indel-heavy NovaSeq-shaped model over ONE 5 Mbp
+    genome -- two reads in three carry an indel and are built from edit scripts): the whole work list is generated on the GPU exactly as bench.py times it
     (ONE iss_generate_batch call; `batch` False: one iss_generate call per record), and -- every pair being a pure
     function of (seed, ordinal, genome) -- windows of consecutive ordinals are recomputed by the CPU oracle and compared
     byte for byte, coordinates included: the first and last pairs of every work item (the item boundaries of the batch),
@@ -702,7 +730,7 @@ def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total, ba
     from insilicoseq_amd.generator import lognormal_abundance
     from oracle import oracle as O
 
-    dense = dense_model(model)
+    dense = dense_model(model, indel)
     rng = np.random.RandomState(123)
     letters = np.frombuffer(b"ACGT", dtype=np.uint8)
     genomes = [letters[rng.randint(0, 4, size=5_000_000)].tobytes().decode() for _ in range(n_genomes)]
@@ -728,7 +756,7 @@ def test_baseline_sizes_sampled_against_oracle(model, n_genomes, pairs_total, ba
         # pairs around multiples of 2^20 (any launch-chunk edge of the engine is one) fall into some item's window list
         edges = [e for e in range(1 << 20, total, 1 << 20)][:: max(1, (total >> 20) // 6)]
         for k, (gid, n, row0, ord0) in enumerate(items):
-            inner = 6 if n_genomes <= 8 else 1
+            inner = (24 if n_genomes == 1 else 6) if n_genomes <= 8 else 1
             starts = set([0, max(n - 64, 0)] + list(pick.randint(0, max(n - 64, 1), size=inner)))
             starts.update(min(max(e - row0 - 32, 0), max(n - 64, 0)) for e in edges if row0 <= e < row0 + n)
             for start in sorted(starts):
@@ -1245,3 +1273,56 @@ def test_generate_batch_equals_consecutive_calls(case, monkeypatch):
         assert np.array_equal(ra[0][k], rb[0][k]), k
     assert np.array_equal(ca, cb)
     assert ma == mb
+
+
+def test_exact_path_store_order_stress():
+    """k_main's exact path patches single bytes of rows the same wavefront stored a few iterations earlier and relies on a
+    wavefront's vector memory operations reaching an address in issue order (iss_kernels.hip.h, drain_round).  Stress: a
+    NovaSeq-shaped model whose rows put half of the mass on Q2, so that more than 30 % of all bases take the exact path (the
+    substitution test of a Q2 base fires with probability 0.63) at full occupancy, 10^9 bases in one call.  EVERY base and
+    phred is then cross-checked on the device by the one-lane-per-read unit kernels (iss_gen_phred_scores / iss_mut_sequence:
+    other kernels, no deferred stores, exact 53-bit compares) on templates rebuilt from the coordinates, and windows of pairs
+    are recomputed by the CPU oracle."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    dense = dense_model("novaseq", (0.0, 0.0))
+    q = dense.qcdf.copy()
+    q[..., :2] *= 0.5
+    q[..., 2:] = 0.5 + 0.5 * q[..., 2:]
+    q[..., -1] = 1.0
+    dense.qcdf[:] = q
+    dense.validate()
+    RL = dense.read_length
+    genome = random_genome(99, 2_000_000)
+    g = np.frombuffer(genome.encode(), dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    n = (10**9 + 2 * RL - 1) // (2 * RL)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        eng.generate(gid, n, first_ordinal=5, seed=77)
+        eng.synchronize()
+        substituted = 0
+        step = 250_000
+        for at in range(0, n, step):
+            m = min(step, n - at)
+            got, co = eng.download(at, m), eng.coords(at, m)
+            fwd = g[co[:, 0:1] + np.arange(RL)[None, :]]
+            rev = comp[g[co[:, 2:3] - 1 - np.arange(RL)[None, :]]]
+            for o, tmpl, kb, kq in ((0, fwd, "r1_base", "r1_qual"), (1, rev, "r2_base", "r2_qual")):
+                ph = eng.gen_phred_scores(o, m, first_ordinal=5 + at, seed=77)
+                assert np.array_equal(ph, got[kq]), (at, kq)
+                mut, st = eng.mut_sequence(o, tmpl, ph, first_ordinal=5 + at, seed=77)
+                assert not st.any()
+                assert np.array_equal(mut, got[kb]), (at, kb)
+                substituted += int((got[kb] != tmpl).sum())
+        assert substituted >= 0.3 * 2 * RL * n  # (every one of them a late byte patch of the exact path)
+        orc = O.Oracle(dense)
+        for start in np.random.RandomState(3).randint(0, n - 64, size=24):
+            got = eng.download(int(start), 64)
+            exp = orc.simulate(O.Rng().seed_philox(77), genome, 64, first_ordinal=5 + int(start))
+            for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                assert np.array_equal(got[key], exp[key]), (int(start), key)
