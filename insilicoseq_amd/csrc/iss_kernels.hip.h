@@ -260,8 +260,10 @@ struct RunArgs {
     // {read, first event, second event, number of steps with an event}, an event = step << 8 | event mask; a read with
     // more than two such steps keeps all of them in its EV_K words of ev_list.  ev_count[read] = min(steps with an
     // event, 15) | first such step << 4 (0: none) for every read of the launch.
-    uint32_t *ev_count, *ev_list, *read_count;  // read_count[w]: listed reads of scan workgroup w
-    uint4 *read_list;
+    uint32_t *ev_count, *ev_list, *read_count;  // read_count[w] / [SCAN_MAX_WGS + w]: reads scan workgroup w listed in read_list / read_list1
+    uint4 *read_list;    // reads with two or more steps with an event
+    uint2 *read_list1;   // reads with ONE such step: {read, event} -- more than half of the listed reads of BASELINE configs[4]; their
+                         // edit scripts are straight-line code (k_indel_script<.., SINGLE>), and no lane of a block waits for a longer walk
     uint32_t scan_wgs;  // workgroups of k_indel_scan: the read list is one segment per workgroup (no global counter)
     // Models whose reads often have indels: the edit scripts k_indel_script leaves for k_main (see SC_* below): M.sc_stride bytes
     // per READ (2 * pair + mate), valid iff ev_count[read] != 0 once k_indel_script has run
@@ -1023,7 +1025,10 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         const uint32_t has_ev = INDEL ? hv_next : 0u;  // bit mate: that read is built from its edit script
         uint4 sc_f = scn_f, sc_r = scn_r;
         if (tile == 0 && j4 == 0u && valid) A.desc_out[pair] = d;
-        {
+        // The requests for the NEXT pass (descriptor; INDEL: counters two passes ahead, script rows).  They are issued in the
+        // pass's first iteration BEHIND its genome windows: vmcnt counts in issue order, so the wait for the windows -- hits of
+        // the L2 -- at the end of that iteration would otherwise also be a wait for these cold lines from HBM.
+        auto request_next = [&]() {
             const uint32_t pair_n = pair + blk_step * MAIN_PAIRS;
             const bool valid_n = blk + blk_step < blk_end && pair_n < (uint32_t)A.n_pairs;
             if (valid_n) d_next = desc[pair_n];
@@ -1037,7 +1042,10 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 scn_r = scn_f;
                 if (valid_n) sc_rows(pair_n, ec, 0u, scn_f, scn_r);
             }
-        }
+        };
+#ifdef ISS_REQUEST_AT_TOP
+        request_next();
+#endif
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
         // LDS byte offsets of the pair's rows (its bin slots) at this lane's first superitem; one iteration = 8 groups on
         const uint32_t lane_row = j4 * 2u * gs_b + (uint32_t)MAIN_LUT_WORDS * 4u;
@@ -1081,6 +1089,12 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                     gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pr_e >> 4) + 1) << 2));
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef ISS_REQUEST_AT_TOP
+                if (it == 0u) {  // (every lane with work in this tile has an iteration 0; the others need no descriptor)
+                    request_next();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
                 // ---- hot digits: 16 quality digits (16 bits) + 16 error-test digits (8 bits)
                 const u32x4 q0 = draw_block(a, K_QM, s_abs, 0);
                 const u32x4 ee = draw_block(a, K_QM, s_abs, 1);
@@ -1176,7 +1190,8 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
 // lanes take consecutive reads, so the list is in pair order, more or less, and k_indel_apply's wavefronts share cache
 // lines, DRAM pages and TLB entries.
 constexpr int SCAN_THREADS = 1024;  // two workgroups per CU: 8 wavefronts / SIMD (the kernel is bound by the latency of its dependent LDS reads)
-constexpr int SCAN_LIST = 128;    // listed reads a wavefront collects before they go to the global list
+constexpr int SCAN_LISTN = 96;    // listed reads (two or more event steps) a wavefront collects before they go to the global list
+constexpr int SCAN_LIST1 = 128;   // ... reads with one event step
 constexpr int EV_K = 8;           // events kept per read
 constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
                                        // bits 4-5 mate is in read_list
@@ -1186,7 +1201,7 @@ __host__ __device__ inline uint32_t scan_per_wg(uint32_t n_reads, uint32_t wgs) 
 }
 constexpr int SCAN_WIN = 512;     // window of a wavefront's range whose event counts are staged in LDS: they leave in whole lines, half a window at a time
 __host__ __device__ inline size_t scan_lds_bytes(int ev_ns) {
-    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 15) & ~(size_t)15) + (size_t)(SCAN_THREADS / 64) * (SCAN_LIST * 16 + SCAN_WIN * 2);
+    return (size_t)2 * ev_ns * 8 + (((size_t)2 * ev_ns * 2 + 15) & ~(size_t)15) + (size_t)(SCAN_THREADS / 64) * (SCAN_LISTN * 16 + SCAN_LIST1 * 8 + SCAN_WIN * 2);
 }
 
 __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunArgs A, const PairDesc *__restrict__ desc) {
@@ -1195,23 +1210,32 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
     uint64_t *l_S = scan_lds;                                         // [2][ns]
     uint16_t *l_E = reinterpret_cast<uint16_t *>(l_S + 2 * ns);       // [2][ns]
     uint8_t *l_rest = reinterpret_cast<uint8_t *>(scan_lds) + (size_t)2 * ns * 8 + (((size_t)2 * ns * 2 + 15) & ~(size_t)15);
-    uint4 *l_list = reinterpret_cast<uint4 *>(l_rest) + (threadIdx.x >> 6) * SCAN_LIST;  // this wavefront's listed reads
-    uint16_t *l_cnt = reinterpret_cast<uint16_t *>(l_rest + (size_t)(SCAN_THREADS / 64) * SCAN_LIST * 16) + (threadIdx.x >> 6) * SCAN_WIN;  // ... event counts
-    __shared__ uint32_t l_seg;  // listed reads of this workgroup so far
+    uint4 *l_list = reinterpret_cast<uint4 *>(l_rest) + (threadIdx.x >> 6) * SCAN_LISTN;  // this wavefront's listed reads (>= 2 event steps)
+    uint2 *l_list1 = reinterpret_cast<uint2 *>(l_rest + (size_t)(SCAN_THREADS / 64) * SCAN_LISTN * 16) + (threadIdx.x >> 6) * SCAN_LIST1;  // ... (one)
+    uint16_t *l_cnt = reinterpret_cast<uint16_t *>(l_rest + (size_t)(SCAN_THREADS / 64) * (SCAN_LISTN * 16 + SCAN_LIST1 * 8)) + (threadIdx.x >> 6) * SCAN_WIN;  // ... event counts
+    __shared__ uint32_t l_seg[2];  // reads of this workgroup listed so far
     for (int i = threadIdx.x; i < 2 * ns; i += blockDim.x) { l_S[i] = M.ev_S[i]; l_E[i] = M.ev_E[i]; }
-    if (threadIdx.x == 0) l_seg = 0u;
+    if (threadIdx.x < 2) l_seg[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_reads = 2u * (uint32_t)A.n_pairs;
     const uint32_t per_wg = scan_per_wg(n_reads, gridDim.x);  // contiguous ranges (a wavefront's: a multiple of 64 reads)
     uint4 *const seg_list = A.read_list + (size_t)blockIdx.x * per_wg;  // (a range lists at most its own reads)
-    uint32_t n_listed = 0;  // wave-uniform
+    uint2 *const seg_list1 = A.read_list1 + (size_t)blockIdx.x * per_wg;
+    uint32_t n_listed = 0, n_listed1 = 0;  // wave-uniform
     auto flush_list = [&]() {  // this wavefront's listed reads -> the workgroup's segment of the list
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&l_seg, n_listed);
+        if (lane == 0) base = atomicAdd(&l_seg[0], n_listed);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         for (uint32_t i = lane; i < n_listed; i += 64u) seg_list[base + i] = l_list[i];
         n_listed = 0;
+    };
+    auto flush_list1 = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&l_seg[1], n_listed1);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < n_listed1; i += 64u) seg_list1[base + i] = l_list1[i];
+        n_listed1 = 0;
     };
     const uint32_t per_wave = per_wg / (blockDim.x >> 6);
     const uint32_t w_first = min(n_reads, blockIdx.x * per_wg + (threadIdx.x >> 6) * per_wave), w_last = min(n_reads, w_first + per_wave);
@@ -1286,18 +1310,25 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
                 busy = false;
             }
         }
-        const unsigned long long m = __ballot(fin && cnt != 0u);
+        const unsigned long long m = __ballot(fin && cnt > 1u), m1 = __ballot(fin && cnt == 1u);
         if (m) {
-            if (fin && cnt) l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = make_uint4(rd, e0, e1, cnt);
+            if (fin && cnt > 1u) l_list[n_listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = make_uint4(rd, e0, e1, cnt);
             n_listed += (uint32_t)__popcll(m);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (n_listed >= (uint32_t)SCAN_LIST - 64u) flush_list();  // (room for the next 64)
+            if (n_listed > (uint32_t)SCAN_LISTN - 64u) flush_list();  // (room for the next 64)
+        }
+        if (m1) {
+            if (fin && cnt == 1u) l_list1[n_listed1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = make_uint2(rd, e0);
+            n_listed1 += (uint32_t)__popcll(m1);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (n_listed1 > (uint32_t)SCAN_LIST1 - 64u) flush_list1();
         }
     }
     if (n_listed) flush_list();
+    if (n_listed1) flush_list1();
     flush_counts(w_last - wb);
     __syncthreads();
-    if (threadIdx.x == 0) A.read_count[blockIdx.x] = l_seg;
+    if (threadIdx.x < 2) A.read_count[threadIdx.x * SCAN_MAX_WGS + blockIdx.x] = l_seg[threadIdx.x];
 }
 
 // ================================================================== k_indel_script
@@ -1320,7 +1351,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
 // than EV_K events in k_indel_fixup's list (one wavefront per read, exact, slow) and have their event counter cleared:
 // ev_count[read] != 0 <=> the read has a valid script.
 constexpr int SC_WAVES = 8;             // wavefronts per workgroup
-constexpr int SC_WGS_PER_CU = 2;        // workgroups per CU (the lanes' records: 2 x 8 x 7.4 KB of LDS for read lengths up to 168)
+constexpr int SC_WAVES1 = 16;           // ... of the SINGLE launch (a lane's record is its window: 8 wavefronts / SIMD hide the loads' latency)
+constexpr int SC_WGS_PER_CU = 2;        // workgroups per CU (the lanes' records: 2 x 8 x 8.4 KB of LDS for read lengths up to 168)
 #ifndef ISS_SCRIPT_OCC
 #define ISS_SCRIPT_OCC 4                // wavefronts per SIMD the register budget is cut for
 #endif
@@ -1342,15 +1374,21 @@ __host__ __device__ inline size_t ap_items_bytes() { return (AP_ITEMS + 2) * 4 +
 __host__ __device__ inline size_t ap_seg_bytes() { return (size_t)(2 * SCAN_MAX_WGS + 4) * 4; }  // the read list's segments: 64-read blocks in front of each, lengths
 // [ins_letter 2*RL*4 u8, padded][segments][item_first AP_ITEMS+2 u32][items AP_ITEMS][per wave: 64 records]
 __host__ __device__ inline size_t ap_tab_bytes(int RL) { return (((size_t)2 * RL * 4 + 15) & ~(size_t)15) + ap_seg_bytes() + ap_items_bytes(); }
-__host__ __device__ inline size_t sc_wave_bytes(int pitch) { return (size_t)64 * sc_rec_words(pitch) * 4; }
-__host__ __device__ inline size_t script_lds_bytes(int RL, int pitch) { return ap_tab_bytes(RL) + (size_t)SC_WAVES * sc_wave_bytes(pitch); }
+__host__ __device__ inline int sc_rec_words1(int pitch) { return (1 + ap_ww(pitch) + 2) | 1; }  // SINGLE: [pad][window][pad]
+__host__ __device__ inline size_t sc_wave_bytes(int pitch, bool single) { return (size_t)64 * (single ? sc_rec_words1(pitch) : sc_rec_words(pitch)) * 4; }
+__host__ __device__ inline size_t script_lds_bytes(int RL, int pitch, bool single) {
+    return ap_tab_bytes(RL) + (size_t)(single ? SC_WAVES1 : SC_WAVES) * sc_wave_bytes(pitch, single);
+}
 
 // WWM: window words a lane keeps in registers for the NEXT block's read (>= ap_ww(pitch): 12 for read lengths up to 168, else 26)
-template <bool STORE_MUT, int WWM>
-__global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(DevModel M, DevGenome g, RunArgs A,
+// SINGLE: the launch takes the reads with ONE step with an event (RunArgs::read_list1; more than half of the listed reads of
+// BASELINE configs[4]) -- no walk, no lists: the event's effect is a closed form (at most five explicit letters in at most two
+// pieces, one run behind them) and the rows follow from three numbers; the other launch takes read_list with the general code.
+template <bool STORE_MUT, int WWM, bool SINGLE>
+__global__ __launch_bounds__(SINGLE ? 64 * SC_WAVES1 : 64 * SC_WAVES, SINGLE ? 8 : ISS_SCRIPT_OCC) void k_indel_script(DevModel M, DevGenome g, RunArgs A,
                                                                                const PairDesc *__restrict__ desc, uint64_t *stats) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ap_lds[];
-    const int RL = M.RL, pitch = M.pitch, S = M.S, WW = ap_ww(pitch), RW = sc_rec_words(pitch), WIN = ap_win(pitch);
+    const int RL = M.RL, pitch = M.pitch, S = M.S, WW = ap_ww(pitch), RW = SINGLE ? sc_rec_words1(pitch) : sc_rec_words(pitch), WIN = ap_win(pitch);
     uint8_t *insl = reinterpret_cast<uint8_t *>(ap_lds);                  // [2][RL][4]
     uint32_t *ifirst = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ap_lds) + ap_tab_bytes(RL) - ap_items_bytes());  // (a call holds < 2^31 pairs)
     BatchItem *l_items = reinterpret_cast<BatchItem *>(ifirst + AP_ITEMS + 2);
@@ -1363,7 +1401,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t sg = threadIdx.x * PER + k;
-            len[k] = sg < A.scan_wgs ? A.read_count[sg] : 0u;
+            len[k] = sg < A.scan_wgs ? A.read_count[(SINGLE ? SCAN_MAX_WGS : 0) + sg] : 0u;
             sum += (len[k] + 63u) / 64u;
         }
         uint32_t inc = sum;
@@ -1391,13 +1429,12 @@ __global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(
     if (blockIdx.x * n_waves >= n_blocks) return;  // whole workgroup idle (uniform)
     const uint32_t seg_stride = scan_per_wg(2u * (uint32_t)A.n_pairs, A.scan_wgs);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t *wave0 = ap_lds + ap_tab_bytes(RL) / 4 + (size_t)wv * (sc_wave_bytes(pitch) / 4);
+    uint32_t *wave0 = ap_lds + ap_tab_bytes(RL) / 4 + (size_t)wv * (sc_wave_bytes(pitch, SINGLE) / 4);
     // (then every listed read is k_indel_fixup's)
     const bool all_to_fixup = pitch > AP_MAX_PITCH || !M.ins_plain;
+    const uint32_t inv_ts = (65536u + (uint32_t)M.TS - 1u) / (uint32_t)M.TS;  // s / TS == (s * inv_ts) >> 16 for the s < 128 of a read
     const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);  // (the leading padding word: offsets >= 0)
     uint32_t n_scripted = 0;
-    // software pipeline of the block loop: the list entry is requested two blocks ahead, what hangs on the read number
-    // (descriptor, events) one block ahead, the window once the descriptor is there -- a chain of dependent loads
     const uint32_t NO_READ = 0xffffffffu, stride = gridDim.x * n_waves;
     const uint32_t blk0 = blockIdx.x * n_waves + wv;
     auto list_entry = [&](uint32_t b) {  // lane `lane` of block b of the segmented list
@@ -1408,46 +1445,68 @@ __global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(
             if (seg_blk[mid] <= b) lo = mid; else hi = mid;
         }
         const uint32_t off = (b - seg_blk[lo]) * 64u + lane;
-        return off < seg_len[lo] ? A.read_list[(size_t)lo * seg_stride + off] : make_uint4(NO_READ, 0u, 0u, 0u);
+        if (off >= seg_len[lo]) return make_uint4(NO_READ, 0u, 0u, 0u);
+        if (SINGLE) { const uint2 v = A.read_list1[(size_t)lo * seg_stride + off]; return make_uint4(v.x, v.y, 0u, 1u); }
+        return A.read_list[(size_t)lo * seg_stride + off];
     };
-    uint4 rec_a = list_entry(blk0), rec_b = list_entry(blk0 + stride);
-    uint32_t ra = rec_a.x == NO_READ ? 0u : rec_a.x;
-    PairDesc d_a = desc[ra >> 1];
-    uint4 ea_a = make_uint4(0u, 0u, 0u, 0u), eb_a = ea_a;  // (the events of a read with more than two)
-    if (rec_a.x != NO_READ && rec_a.w > 2u) {
-        ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
-        eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
-    }
+    // software pipeline of the block loop, three deep: the list entry is requested three blocks ahead, what hangs on the read
+    // number (the descriptor's two coordinates, the events of a read with more than two) two blocks ahead, the window of the
+    // packed genome -- it hangs on the descriptor -- one block ahead: every load of the chain has a whole block to arrive
+    struct Coords { int32_t fs, re; };
+    auto coords_of = [&](const uint4 &rec) {
+        const PairDesc *dp = desc + ((rec.x == NO_READ ? 0u : rec.x) >> 1);
+        return Coords{dp->fs, dp->re};
+    };
+    auto events_of = [&](const uint4 &rec, uint4 &ea, uint4 &eb) {
+        ea = make_uint4(0u, 0u, 0u, 0u); eb = ea;
+        if (!SINGLE && rec.x != NO_READ && rec.w > 2u) {
+            ea = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)rec.x * EV_K)[0];
+            eb = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)rec.x * EV_K)[1];
+        }
+    };
     uint32_t wn[WWM];
-    auto request_window = [&]() {
-        const int64_t wl = (ra & 1u) ? (int64_t)d_a.re - WIN : (int64_t)d_a.fs;
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(packed_b + (size_t)(((wl >> 4) + 1) << 2));
+    auto request_window = [&](const uint4 &rec, const Coords &c) {
+        const int64_t wl = (rec.x != NO_READ && (rec.x & 1u)) ? (int64_t)c.re - WIN : (int64_t)c.fs;
+        // (16 bytes per load instruction, 4-byte aligned: a lane's window is 1-2 cache lines and every instruction brings 64
+        //  lanes' lines through the L1 -- twelve single words per lane were measured at twice the kernel's time)
+        const uint4 *src = reinterpret_cast<const uint4 *>(packed_b + (size_t)(((wl >> 4) + 1) << 2));
 #pragma unroll
-        for (int k = 0; k < WWM; ++k) wn[k] = k < WW ? src[k] : 0u;
+        for (int k = 0; k < WWM; k += 4) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (k < WW) v = src[k >> 2];
+            wn[k] = v.x;
+            if (k + 1 < WWM) wn[k + 1] = v.y;
+            if (k + 2 < WWM) wn[k + 2] = v.z;
+            if (k + 3 < WWM) wn[k + 3] = v.w;
+        }
     };
-    request_window();
+    uint4 rec0 = list_entry(blk0), rec1 = list_entry(blk0 + stride), rec2 = list_entry(blk0 + 2u * stride);
+    Coords c0 = coords_of(rec0), c1 = coords_of(rec1);
+    uint4 ea0, eb0, ea1, eb1;
+    events_of(rec0, ea0, eb0);
+    events_of(rec1, ea1, eb1);
+    request_window(rec0, c0);
     for (uint32_t blk = blk0; blk < n_blocks; blk += stride) {
         uint32_t wc[WWM];  // this block's windows
 #pragma unroll
         for (int k = 0; k < WWM; ++k) wc[k] = wn[k];
-        const uint32_t rd = ra;
+        const bool listed = rec0.x != NO_READ;
+        const uint32_t rd = listed ? rec0.x : 0u;
         const uint32_t pair = rd >> 1;
         const int o = (int)(rd & 1u);
-        const PairDesc d = d_a;
-        const bool listed = rec_a.x != NO_READ;
-        const uint32_t cnt = listed ? rec_a.w : 0u;
+        PairDesc d;
+        d.fs = c0.fs; d.re = c0.re;
+        const uint32_t cnt = listed ? rec0.w : 0u;
         uint32_t e[EV_K];
-        e[0] = ea_a.x; e[1] = ea_a.y; e[2] = ea_a.z; e[3] = ea_a.w; e[4] = eb_a.x; e[5] = eb_a.y; e[6] = eb_a.z; e[7] = eb_a.w;
-        if (cnt <= 2u) { e[0] = rec_a.y; e[1] = rec_a.z; }
-        {   // requests for the next two blocks
-            rec_a = rec_b;
-            ra = rec_a.x == NO_READ ? 0u : rec_a.x;
-            d_a = desc[ra >> 1];
-            if (rec_a.x != NO_READ && rec_a.w > 2u) {
-                ea_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[0];
-                eb_a = reinterpret_cast<const uint4 *>(A.ev_list + (size_t)ra * EV_K)[1];
-            }
-            rec_b = list_entry(blk + 2u * stride);
+        e[0] = ea0.x; e[1] = ea0.y; e[2] = ea0.z; e[3] = ea0.w; e[4] = eb0.x; e[5] = eb0.y; e[6] = eb0.z; e[7] = eb0.w;
+        if (cnt <= 2u) { e[0] = rec0.y; e[1] = rec0.z; }
+        {   // the pipeline moves on: window of the next block, coordinates / events of the one after, list entry of the third
+            rec0 = rec1; c0 = c1; ea0 = ea1; eb0 = eb1;
+            request_window(rec0, c0);
+            rec1 = rec2;
+            c1 = coords_of(rec1);
+            events_of(rec1, ea1, eb1);
+            rec2 = list_entry(blk + 3u * stride);
         }
         // (a listed read is never k_indel_fixup's already: the scan lists neither the mates of irregular pairs nor reads
         //  with more events than a list holds)
@@ -1476,7 +1535,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(
             A.ev_count[rd] = 0u;  // no script
         };
         if (ok && !(plain && !all_to_fixup && w_lo >= rec_lo && w_lo + WIN <= rec_hi)) { to_fixup(); ok = false; }
-        uint32_t *R = wave0 + lane * RW, *runs = R, *win = R + AP_RUNS;
+        uint32_t *R = wave0 + lane * RW, *runs = R, *win = R + (SINGLE ? 1 : AP_RUNS);
         uint16_t *let = reinterpret_cast<uint16_t *>(win + WW);
         const int64_t wpos = (w_lo >> 4) << 4;  // genome position of bit 0 of the window
         const int t0pos = (int)((o ? (int64_t)d.re - 1 : (int64_t)d.fs) - wpos);  // window position of token 0 (token t: t0pos +/- t)
@@ -1485,13 +1544,110 @@ __global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(
             for (int k = 0; k < WWM; ++k) if (k < WW) win[k] = wc[k];  // (requested a block ago)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        request_window();  // (the next block's: its descriptor was requested at the top of this block)
         // the walk over the steps with an event (k_indel_scan lists them in step order, one entry per step)
         auto code_at = [&](int tk) {  // 2-bit code of template token tk in read direction
             const int b = 2 * (o ? t0pos - tk : t0pos + tk);
             const uint32_t c = (win[b >> 5] >> (b & 31)) & 3u;
             return o ? c ^ 1u : c;  // complement: code ^ 1
         };
+        if (SINGLE) {
+            // ---- ONE step n with an event (mask m8), no walk: token n is the template's; the letters the step inserts wait on the
+            //      stack; a deletion lets the next token slide in (the last inserted letter, else template token n + 1); the
+            //      steps behind drain the stack; from step n + D + 1 on the read is the template again, shifted by sh1
+            const int n = (int)(e[0] >> 8);
+            const uint32_t m8 = e[0] & 0xffu;
+            uint32_t stk = 0, rem = 0, Fn = 0;
+            int D = 0, sh1 = 0;
+            if (ok) {
+                const uint32_t ch = code_at(n);
+                MutRecord row;  // --store_mutations row being built
+                row.pair = (int32_t)(A.pair_base + pair); row.mate = (int8_t)o; row.quality = -1;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if ((m8 >> x) & 1u) {
+                        const int letter = insl[((size_t)o * RL + n) * 4 + x];
+                        stk |= (uint32_t)base_index(letter) << (2u * rem);
+                        ++rem;
+                        if (STORE_MUT) {  // ref = mutable_seq[position], alt = ref + letter (__init__.py:197-207)
+                            row.type = (int8_t)(1 | (x << 2) | 32); row.position = (int16_t)n;
+                            row.ref = code_to_ascii(ch); row.alt = (uint8_t)letter;
+                            mut_emit1(A, row);
+                        }
+                    }
+                int k = n + 1;
+                Fn = ch;
+                if ((m8 >> (4 + ch)) & 1u) {  // deleted: the next token slides in
+                    if (rem > 0u) { --rem; Fn = (stk >> (2u * rem)) & 3u; }
+                    else { Fn = code_at(n + 1); k = n + 2; }
+                    if (STORE_MUT) {  // ref = mutable_seq[position] after the pop (__init__.py:211-221; it exists: n + 1 < RL)
+                        row.type = (int8_t)(2 | (4 << 2) | 32); row.position = (int16_t)n;
+                        row.ref = code_to_ascii(Fn); row.alt = '.';
+                        mut_emit1(A, row);
+                    }
+                }
+                D = min((int)rem, RL - 1 - n);  // steps n + 1 .. n + D drain the stack
+                sh1 = k - (n + D + 1);
+            }
+            // explicit letters: position n holds Fn, position n + i (1 <= i <= D) the letter (stk >> 2 (rem - i)) & 3; they lie in
+            // pieces p0 = n >> 3 and p1 = (n + D) >> 3 (the same or the next one)
+            const int p0 = n >> 3, p1 = (n + D) >> 3;
+            auto raw16 = [&](int t) {  // raw window bits of tokens t .. t + 7, the format of k_main's fb / rbr
+                const int b = 2 * (o ? t0pos - t - 7 : t0pos + t);
+                return funnel_r(win[b >> 5], win[(b >> 5) + 1], (uint32_t)b) & 0xffffu;
+            };
+            auto piece_codes = [&](int pc) {
+                const int j0 = 8 * pc;
+                const int lo_c = min(max(n - j0, 0), 8), hi_c = min(max(n + D + 1 - j0, 0), 8);  // [0, lo_c) template, [hi_c, 8) template shifted
+                const uint32_t w0 = raw16(j0), w1 = raw16(j0 + sh1);
+                const uint32_t m_lo = o ? 0xffffu & ~(0xffffu >> (2 * lo_c)) : (1u << (2 * lo_c)) - 1u;
+                const uint32_t m_hi = o ? 0xffffu >> (2 * hi_c) : 0xffffu & ~((1u << (2 * hi_c)) - 1u);
+                uint32_t nw = (w0 & m_lo) | (w1 & m_hi);
+#pragma unroll
+                for (int i = 0; i <= 4; ++i) {
+                    const int c = n + i - j0;
+                    if (i <= D && c >= 0 && c < 8) {
+                        const uint32_t code = i == 0 ? Fn : (stk >> (2u * (rem - (uint32_t)i))) & 3u;
+                        nw |= (o ? code ^ 1u : code) << (2u * (uint32_t)(o ? 7 - c : c));
+                    }
+                }
+                return nw;
+            };
+            uint32_t code0 = 0, code1 = 0;
+            if (ok) code0 = piece_codes(p0);
+            if (__ballot(ok && p1 != p0)) { if (ok && p1 != p0) code1 = piece_codes(p1); }
+            // rows: per tile and group of 8 iterations, row j4 holds the pieces s_first + 4 it + j4: those below p0 idle, p0 / p1
+            // explicit (a row holds at most one of two neighbouring pieces), those above p1 shifted by sh1
+            if (ok) {
+                uint8_t *out = A.script + (size_t)rd * (size_t)(uint32_t)M.sc_stride;
+                const int n_grp = M.n_tiles * M.sc_gpt;
+                const uint64_t fill = (uint64_t)(((uint32_t)(64 + sh1) ^ 0x40u) & 0xffu) * 0x0101010101010101ull;
+                int tile = 0, g_in_tile = 0;
+                for (int gq = 0; gq < n_grp; ++gq) {
+                    const int s_first = tile * M.TS + 32 * g_in_tile;
+                    uint4 rowv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int a = p0 - s_first - j, b = p1 - s_first - j;
+                        const int it_lo = a <= 0 ? 0 : min(8, (a + 3) >> 2), it_hi = b < 0 ? 0 : min(8, (b >> 2) + 1);
+                        uint64_t r = ((uint64_t)SC_IDLE << 32) | SC_IDLE;
+                        if (it_hi < 8) r ^= fill & (~(uint64_t)0 << (8 * it_hi));
+                        uint32_t code = 0;
+                        if (it_hi > it_lo) {
+                            r ^= (uint64_t)(0x80u ^ 0x40u) << (8 * it_lo);
+                            code = s_first + 4 * it_lo + j == p0 ? code0 : code1;
+                        }
+                        rowv[j] = make_uint4((uint32_t)r, (uint32_t)(r >> 32), code, 0u);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) reinterpret_cast<uint4 *>(out + (size_t)gq * 64)[j] = rowv[j];  // (a whole 64-byte sector)
+                    if (++g_in_tile == M.sc_gpt) { g_in_tile = 0; ++tile; }
+                }
+                ++n_scripted;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         uint64_t evmask = 0;  // pieces with an explicit letter
         uint32_t n_runs = 1, n_let = 0;
         bool bad = false;
@@ -1571,8 +1727,10 @@ __global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(
             uint8_t *out = A.script + (size_t)rd * (size_t)(uint32_t)M.sc_stride;
             const int n_grp = M.n_tiles * M.sc_gpt;
             bool over = false;
+            int tile = 0, g_in_tile = 0;
             for (int gq = 0; gq < n_grp; ++gq) {
-                const int tile = gq / M.sc_gpt, s_first = tile * M.TS + 32 * (gq - tile * M.sc_gpt), s_end = min(S, (tile + 1) * M.TS);
+                const int s_first = tile * M.TS + 32 * g_in_tile, s_end = min(S, (tile + 1) * M.TS);
+                if (++g_in_tile == M.sc_gpt) { g_in_tile = 0; ++tile; }
                 uint32_t rx[4], ry[4], ne[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { rx[j] = SC_IDLE; ry[j] = SC_IDLE; ne[j] = 0; }
@@ -1664,7 +1822,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, ISS_SCRIPT_OCC) void k_indel_script(
                         }
                     }
                     // its place: tile, group of 8 iterations, row j4, and the number of explicit pieces of the row in front of it
-                    const int tile = s / M.TS, it = (s - tile * M.TS) >> 2, grp = it >> 3, it8 = it & 7;
+                    const int tile = (int)(((uint32_t)s * inv_ts) >> 16), it = (s - tile * M.TS) >> 2, grp = it >> 3, it8 = it & 7;
                     const uint64_t row_before = (0x1111111111111111ull << (s - 4 * it8)) & (((uint64_t)1 << s) - 1u) & em;
                     uint8_t *dst = A.script + (size_t)H[0] * (size_t)(uint32_t)M.sc_stride +
                                    (size_t)((((tile * M.sc_gpt + grp) * 4 + (s & 3)) * 16) + 8 + 2 * __popcll(row_before));

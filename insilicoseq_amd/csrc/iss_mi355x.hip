@@ -46,6 +46,8 @@ struct Genome {
 
 // Records of a long work list (draft genomes: thousands of contigs) are small: their buffers are cut from slabs
 // instead of three hipMallocs each, and their letters are checked on the host instead of waiting for the pack kernel.
+constexpr size_t PK_PAD = 12;  // padding words of a packed genome: one in front (windows start a word early), the rest behind (the
+                               // 16-byte window loads of k_indel_script may reach a few words past a read's window)
 constexpr int64_t SMALL_RECORD = 1 << 20;
 constexpr size_t ARENA_SLAB = 64u << 20;
 struct GenomeArena {
@@ -166,6 +168,7 @@ struct iss_ctx {
     hipEvent_t ev_call_done[2] = {nullptr, nullptr};  // the last kernel of the last call that used the set
     bool ev_call_valid[2] = {false, false};
     hipEvent_t ev_setup_done[FIX_SLOTS_C] = {};         // k_setup of a chunk -> its k_main (ring, like the counters)
+    hipEvent_t ev_fork[FIX_SLOTS_C] = {}, ev_join[FIX_SLOTS_C] = {};  // the two k_indel_script launches of a chunk side by side
     hipEvent_t ev_slot_done[FIX_SLOTS_C] = {};          // the last kernel of the chunk that used a counter slot: the setup stream waits
     bool ev_slot_valid[FIX_SLOTS_C] = {};               //   for it before the slot's next user clears the counters
     hipEvent_t ev_inputs = nullptr;                     // tables / arena copies queued on the main stream for this call's k_setup
@@ -206,7 +209,8 @@ struct iss_ctx {
     // on the setup stream, beside the kernels of the call before (otherwise [1] aliases [0])
     uint32_t *ev_count[2] = {nullptr, nullptr}, *ev_list[2] = {nullptr, nullptr};
     uint4 *read_list[2] = {nullptr, nullptr};
-    uint32_t *read_count = nullptr;  // FIX_SLOTS counters of the read lists, like fix_count
+    uint2 *read_list1[2] = {nullptr, nullptr};  // (the reads with one event step: RunArgs::read_list1)
+    uint32_t *read_count = nullptr;  // FIX_SLOTS x 2 x SCAN_MAX_WGS segment lengths of the two read lists, like fix_count
     // models with frequent indels: the edit scripts of the reads with an event (k_indel_script -> k_main), DevModel::sc_stride
     // bytes per read, two sets like the event lists
     uint8_t *script[2] = {nullptr, nullptr};
@@ -322,13 +326,14 @@ void free_outputs(iss_ctx *ctx) {
         if (ctx->ev_count[k] && (k == 0 || ctx->ev_count[k] != ctx->ev_count[0])) (void)hipFree(ctx->ev_count[k]);
         if (ctx->ev_list[k] && (k == 0 || ctx->ev_list[k] != ctx->ev_list[0])) (void)hipFree(ctx->ev_list[k]);
         if (ctx->read_list[k] && (k == 0 || ctx->read_list[k] != ctx->read_list[0])) (void)hipFree(ctx->read_list[k]);
+        if (ctx->read_list1[k] && (k == 0 || ctx->read_list1[k] != ctx->read_list1[0])) (void)hipFree(ctx->read_list1[k]);
     }
     for (int k = 0; k < 2; ++k) {
         if (ctx->script[k]) (void)hipFree(ctx->script[k]);
         ctx->script[k] = nullptr;
     }
     for (auto &v : ctx->ev_slot_valid) v = false;  // (free_outputs follows a sync_all: nothing of the old buffers is in flight)
-    for (int k = 0; k < 2; ++k) { ctx->ev_count[k] = ctx->ev_list[k] = nullptr; ctx->read_list[k] = nullptr; }
+    for (int k = 0; k < 2; ++k) { ctx->ev_count[k] = ctx->ev_list[k] = nullptr; ctx->read_list[k] = nullptr; ctx->read_list1[k] = nullptr; }
     ctx->desc = nullptr; ctx->flags = nullptr; ctx->fix_list = nullptr;
     ctx->capacity = 0;
 }
@@ -772,8 +777,10 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_scan),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        const void *scripts[] = {reinterpret_cast<const void *>(iss::k_indel_script<false, 12>), reinterpret_cast<const void *>(iss::k_indel_script<true, 12>),
-                                 reinterpret_cast<const void *>(iss::k_indel_script<false, 26>), reinterpret_cast<const void *>(iss::k_indel_script<true, 26>)};
+        const void *scripts[] = {reinterpret_cast<const void *>(iss::k_indel_script<false, 12, false>), reinterpret_cast<const void *>(iss::k_indel_script<true, 12, false>),
+                                 reinterpret_cast<const void *>(iss::k_indel_script<false, 26, false>), reinterpret_cast<const void *>(iss::k_indel_script<true, 26, false>),
+                                 reinterpret_cast<const void *>(iss::k_indel_script<false, 12, true>), reinterpret_cast<const void *>(iss::k_indel_script<true, 12, true>),
+                                 reinterpret_cast<const void *>(iss::k_indel_script<false, 26, true>), reinterpret_cast<const void *>(iss::k_indel_script<true, 26, true>)};
         for (const void *f : scripts) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
@@ -790,6 +797,8 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     for (auto &e : ctx->ev_call_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ctx->ev_setup_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ctx->ev_slot_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : ctx->ev_join) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_inputs, hipEventDisableTiming));
     if (const char *e = getenv("ISS_SETUP_AHEAD")) ctx->setup_ahead = atoi(e) != 0;  // 0: everything in order on one stream
     read_switches(ctx);
@@ -798,9 +807,9 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
     ctx->fix_count = static_cast<uint32_t *>(p);  // FIX_SLOTS counters; +128 B stats; +192 B genome-pack status
     ctx->stats = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(p) + 128);
     HIP_TRY(ctx, hipMemset(p, 0, 256));
-    HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * FIX_SLOTS * iss::SCAN_MAX_WGS));
+    HIP_TRY(ctx, hipMalloc(&p, sizeof(uint32_t) * FIX_SLOTS * 2 * iss::SCAN_MAX_WGS));
     ctx->read_count = static_cast<uint32_t *>(p);
-    HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * FIX_SLOTS * iss::SCAN_MAX_WGS));
+    HIP_TRY(ctx, hipMemset(p, 0, sizeof(uint32_t) * FIX_SLOTS * 2 * iss::SCAN_MAX_WGS));
     ctx->max_main_grid = 2u * (unsigned)ctx->n_cu;
     *out = ctx;
     return 0;
@@ -830,6 +839,8 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     for (auto &e : ctx->ev_call_done) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_setup_done) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_slot_done) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_fork) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_join) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_inputs) (void)hipEventDestroy(ctx->ev_inputs);
     delete ctx;
 }
@@ -1209,9 +1220,9 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
             exceptions |= cls == 2;
         }
         hipError_t he = hipSuccess;
-        uint8_t *blk = ctx->arena.take((n_pk + 4) * 4 + 256 + (n_mk + 4) * 4 + 256 + (size_t)length, &he);
+        uint8_t *blk = ctx->arena.take((n_pk + PK_PAD) * 4 + 256 + (n_mk + 4) * 4 + 256 + (size_t)length, &he);
         if (!blk) return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he));
-        const size_t pk_bytes = ((n_pk + 4) * 4 + 255) & ~(size_t)255, mk_bytes = ((n_mk + 4) * 4 + 255) & ~(size_t)255;
+        const size_t pk_bytes = ((n_pk + PK_PAD) * 4 + 255) & ~(size_t)255, mk_bytes = ((n_mk + 4) * 4 + 255) & ~(size_t)255;
         G.packed_alloc = reinterpret_cast<uint32_t *>(blk);
         G.mask_alloc = reinterpret_cast<uint32_t *>(blk + pk_bytes);
         G.ascii = blk + pk_bytes + mk_bytes;
@@ -1226,7 +1237,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
         G.has_exceptions = exceptions;
     } else {
         void *p = nullptr;
-        HIP_TRY(ctx, hipMalloc(&p, (n_pk + 4) * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc(&p, (n_pk + PK_PAD) * sizeof(uint32_t)));
         G.packed_alloc = static_cast<uint32_t *>(p);
         HIP_TRY(ctx, hipMalloc(&p, (n_mk + 4) * sizeof(uint32_t)));
         G.mask_alloc = static_cast<uint32_t *>(p);
@@ -1235,7 +1246,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
         auto release = [&]() { (void)hipFree(G.packed_alloc); (void)hipFree(G.mask_alloc); (void)hipFree(G.ascii); };
         const unsigned long long init[3] = {0ull, (unsigned long long)length, 0ull};
         hipError_t he = hipMemcpyAsync(G.ascii, ascii, (size_t)length, hipMemcpyHostToDevice, ctx->stream);
-        if (he == hipSuccess) he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + 4) * sizeof(uint32_t), ctx->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + PK_PAD) * sizeof(uint32_t), ctx->stream);
         if (he == hipSuccess) he = hipMemsetAsync(G.mask_alloc, 0, (n_mk + 4) * sizeof(uint32_t), ctx->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(status, init, sizeof init, hipMemcpyHostToDevice, ctx->stream);
         if (he != hipSuccess) { release(); return fail(ctx, ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he)); }
@@ -1276,12 +1287,12 @@ int iss_genome_upload_packed(iss_ctx *ctx, const uint32_t *codes, int64_t length
         G.packed_alloc = G.mask_alloc = nullptr; G.ascii = nullptr;
     };
     void *p = nullptr;
-    hipError_t he = hipMalloc(&p, (n_pk + 4) * sizeof(uint32_t));
+    hipError_t he = hipMalloc(&p, (n_pk + PK_PAD) * sizeof(uint32_t));
     if (he == hipSuccess) { G.packed_alloc = static_cast<uint32_t *>(p); he = hipMalloc(&p, (n_mk + 4) * sizeof(uint32_t)); }
     if (he == hipSuccess) { G.mask_alloc = static_cast<uint32_t *>(p); he = hipMalloc(&p, (size_t)length); }
     if (he == hipSuccess) G.ascii = static_cast<uint8_t *>(p);
     if (he != hipSuccess) { release(); return fail(ctx, he == hipErrorOutOfMemory ? ISS_E_NOMEM : ISS_E_HIP, std::string("genome upload: ") + hipGetErrorString(he)); }
-    he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + 4) * sizeof(uint32_t), ctx->stream);
+    he = hipMemsetAsync(G.packed_alloc, 0, (n_pk + PK_PAD) * sizeof(uint32_t), ctx->stream);
     if (he == hipSuccess) he = hipMemsetAsync(G.mask_alloc, 0, (n_mk + 4) * sizeof(uint32_t), ctx->stream);
     if (he == hipSuccess)
         he = hipMemcpyAsync(G.packed_alloc + 1, codes, n_in * sizeof(uint32_t), codes_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -1352,8 +1363,10 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
         ctx->ev_list[k] = static_cast<uint32_t *>(q);
         HIP_TRY(ctx, hipMalloc(&q, sizeof(uint4) * 2 * (size_t)capacity_pairs));
         ctx->read_list[k] = static_cast<uint4 *>(q);
+        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint2) * 2 * (size_t)capacity_pairs));
+        ctx->read_list1[k] = static_cast<uint2 *>(q);
     }
-    if (!heavy) { ctx->ev_count[1] = ctx->ev_count[0]; ctx->ev_list[1] = ctx->ev_list[0]; ctx->read_list[1] = ctx->read_list[0]; }
+    if (!heavy) { ctx->ev_count[1] = ctx->ev_count[0]; ctx->ev_list[1] = ctx->ev_list[0]; ctx->read_list[1] = ctx->read_list[0]; ctx->read_list1[1] = ctx->read_list1[0]; }
     if (heavy)  // the edit scripts of the reads with an event (sparse: a read's slot is written only if it has one)
         for (int k = 0; k < 2; ++k) {
             HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.sc_stride * 2 * (size_t)capacity_pairs));
@@ -1483,7 +1496,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         // (its k_indel_fixup reads the fix-list counter on the main stream).  (The flags are cleared by k_setup itself.)
         const unsigned slot_i = (unsigned)(ctx->chunk_seq++ % FIX_SLOTS);
         uint32_t *counter = ctx->fix_count + slot_i;
-        uint32_t *read_counter = ctx->read_count + (size_t)slot_i * iss::SCAN_MAX_WGS;  // (one per workgroup of k_indel_scan, all of them written by it)
+        uint32_t *read_counter = ctx->read_count + (size_t)slot_i * 2 * iss::SCAN_MAX_WGS;  // (two per workgroup of k_indel_scan, all of them written by it)
         if (ahead && ctx->ev_slot_valid[slot_i]) HIP_TRY(ctx, hipStreamWaitEvent(s_setup, ctx->ev_slot_done[slot_i], 0));
         HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), s_setup));
         A.mut = ctx->d_pmut;
@@ -1499,6 +1512,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         A.ev_count = M.n_scan > 0 ? ctx->ev_count[par] + 2 * row0 : nullptr;
         A.ev_list = ctx->ev_list[par] + 2 * (size_t)iss::EV_K * row0;
         A.read_list = ctx->read_list[par] + 2 * row0;
+        A.read_list1 = ctx->read_list1[par] + 2 * row0;
         A.read_count = read_counter;
         A.scan_wgs = (uint32_t)std::min<uint64_t>(std::min<uint64_t>((uint64_t)ctx->n_cu * 2, iss::SCAN_MAX_WGS), (2 * (uint64_t)n + iss::SCAN_THREADS - 1) / iss::SCAN_THREADS);
         A.light = ctx->light ? (iss::setup_lds_bytes(M.n_isize, M.ev_ns, true) <= (size_t)150 * 1024 ? 1 : 2) : 0;
@@ -1561,15 +1575,32 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
             if (!ahead) HIP_TRY(ctx, mark(3, s_setup));
             hipLaunchKernelGGL(iss::k_indel_scan, dim3(A.scan_wgs), dim3(iss::SCAN_THREADS), iss::scan_lds_bytes(M.ev_ns), s_setup, M, A, desc);
             {
-                const size_t lds = iss::script_lds_bytes(M.RL, M.pitch);
-                const int64_t per_wg = (int64_t)iss::SC_WAVES * 64;  // reads per workgroup pass; at most 2 n reads (the list is usually shorter)
-                const unsigned blocks = (unsigned)std::min<int64_t>((int64_t)iss::SC_WGS_PER_CU * ctx->n_cu, (2 * n + per_wg - 1) / per_wg);
-                const dim3 grid(blocks), block(64 * iss::SC_WAVES);
+                const size_t lds = iss::script_lds_bytes(M.RL, M.pitch, false), lds1 = iss::script_lds_bytes(M.RL, M.pitch, true);
+                const int64_t per_wg = (int64_t)iss::SC_WAVES * 64, per_wg1 = (int64_t)iss::SC_WAVES1 * 64;  // reads per workgroup pass; at most 2 n reads
+                const dim3 grid((unsigned)std::min<int64_t>((int64_t)iss::SC_WGS_PER_CU * ctx->n_cu, (2 * n + per_wg - 1) / per_wg)), block(64 * iss::SC_WAVES);
+                const dim3 grid1((unsigned)std::min<int64_t>((int64_t)iss::SC_WGS_PER_CU * ctx->n_cu, (2 * n + per_wg1 - 1) / per_wg1)), block1(64 * iss::SC_WAVES1);
                 const bool narrow = iss::ap_ww(M.pitch) <= 12;  // (window words a lane prefetches in registers)
-                if (A.mut) { if (narrow) hipLaunchKernelGGL((iss::k_indel_script<true, 12>), grid, block, lds, s_setup, M, dg, A, desc, ctx->stats);
-                             else hipLaunchKernelGGL((iss::k_indel_script<true, 26>), grid, block, lds, s_setup, M, dg, A, desc, ctx->stats); }
-                else { if (narrow) hipLaunchKernelGGL((iss::k_indel_script<false, 12>), grid, block, lds, s_setup, M, dg, A, desc, ctx->stats);
-                       else hipLaunchKernelGGL((iss::k_indel_script<false, 26>), grid, block, lds, s_setup, M, dg, A, desc, ctx->stats); }
+                // (two launches: the reads with one event step -- straight-line code --, then the reads with more)
+                // On the setup stream the two run SIDE BY SIDE (the second on the auxiliary stream, forked behind the scan and joined
+                // in front of k_main): both spend half of their time waiting for loads, and one workgroup of each fits a CU.
+                hipStream_t s_multi = s_setup;
+                if (ahead) {
+                    s_multi = ctx->indel_stream;
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork[slot_i], s_setup));
+                    HIP_TRY(ctx, hipStreamWaitEvent(s_multi, ctx->ev_fork[slot_i], 0));
+                }
+#define ISS_LAUNCH_SCRIPT(MUT, WW)                                                                                                     \
+    do {                                                                                                                               \
+        hipLaunchKernelGGL((iss::k_indel_script<MUT, WW, true>), grid1, block1, lds1, s_setup, M, dg, A, desc, ctx->stats);             \
+        hipLaunchKernelGGL((iss::k_indel_script<MUT, WW, false>), grid, block, lds, s_multi, M, dg, A, desc, ctx->stats);               \
+    } while (0)
+                if (A.mut) { if (narrow) ISS_LAUNCH_SCRIPT(true, 12); else ISS_LAUNCH_SCRIPT(true, 26); }
+                else { if (narrow) ISS_LAUNCH_SCRIPT(false, 12); else ISS_LAUNCH_SCRIPT(false, 26); }
+#undef ISS_LAUNCH_SCRIPT
+                if (ahead) {
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_join[slot_i], s_multi));
+                    HIP_TRY(ctx, hipStreamWaitEvent(s_setup, ctx->ev_join[slot_i], 0));
+                }
             }
             if (!ahead) HIP_TRY(ctx, mark(4, s_setup));
         }

@@ -1,9 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "hip_matches_oracle or both_indel_paths or scripted or bam_built or tuning or back_to_back or counter_rings or store_mutations or chunked or randomized_differential" > gpurun_out/t1.log 2>&1; echo "pytest rc $?" >> gpurun_out/t1.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "hip_matches_oracle or both_indel_paths or scripted or bam_built or tuning or back_to_back or counter_rings or store_mutations or chunked or randomized_differential or more_work_items" > gpurun_out/t1.log 2>&1; echo "pytest rc $?" >> gpurun_out/t1.log
 tail -25 gpurun_out/t1.log
 timeout 300 python bench.py --steps 10 --warmup 3 --indel 0.001 0.003 --no-cpu-baseline --no-end-to-end --no-other-workloads > gpurun_out/b_indel.json 2> gpurun_out/b_indel.err; echo "bench indel rc $?"
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-other-workloads > gpurun_out/b_main.json 2> gpurun_out/b_main.err; echo "bench main rc $?"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_indel_a
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
