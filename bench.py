@@ -56,15 +56,146 @@ def algorithmic_bytes_per_pair(read_length):
     return 4 * read_length + 2 * ((read_length + 3) // 4)
 
 
+def run_leg(args, label, model, reads, n_genomes, strong, indel, steps, warmup, rank, local_rank, world, dist, force_dist):
+    """One leg of the bench on this rank: rank 0 builds model + genomes, ONE broadcast to the other ranks (only when a process
+    group exists), every rank takes chunk `rank` of the reference's divider (iss/app.py:81-83, 99-106), `warmup` untimed and
+    `steps` timed steps bracketed by barriers; the ranks' (pairs, seconds) are gathered.  Returns everything the line needs."""
+    import torch
+
+    from insilicoseq_amd.distributed import broadcast_model_and_genomes, rank_work
+    from insilicoseq_amd.engine import ReadEngine
+    from insilicoseq_amd.generator import Record, lognormal_abundance
+    from insilicoseq_amd.model import DenseModel
+
+    dense, genomes = None, None
+    if rank == 0:
+        dense = DenseModel.load(os.path.join(ROOT, "insilicoseq_amd", "profiles", model + ".dense.npz"))
+        if indel is not None:
+            dense.ins[:] = indel[0]
+            dense.dele[:] = indel[1]
+        genomes = synthetic_genomes(n_genomes, GENOME_LEN, 123)
+    t_b = time.time()
+    dense, grefs = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank), as_refs=True,
+                                               force=force_dist)
+    torch.cuda.synchronize()
+    bcast_s = time.time() - t_b if dist is not None else 0.0
+
+    eng = ReadEngine(local_rank)
+    eng.load_model(dense)
+    # records: id + length for the work divider, letters only where the CPU legs need them (rank 0)
+    records = [Record(_SeqLen(g.length), id="genome_%d" % i) for i, g in enumerate(grefs)]
+    letters = {id(r): g for r, g in zip(records, genomes)} if rank == 0 else {}
+    gid_of = {id(r): g.upload(eng) for r, g in zip(records, grefs)}  # (N > 1: straight from the broadcast buffer in HBM)
+    abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(123))
+    total_reads = reads if strong else reads * world
+
+    def work_of(n_ranks, r):  # the reference's sharding: chunk r of the divider with cpus = n_ranks
+        chunk, _, _ = rank_work(records, None, abundance, total_reads, None, None, dense, "bench", n_ranks, r)
+        return [(rec, n) for rec, n, _ in (chunk or [])]
+
+    work = work_of(world, rank)
+    total_pairs_step = sum(n for _, n in work)
+    eng.reserve(max(total_pairs_step, 1))
+    worker_seed = SEED + rank
+    ordinal = [0]
+    item_ids = [gid_of[id(rec)] for rec, _ in work]
+    item_pairs = [n for _, n in work]
+
+    def step():  # the step's whole work list in one set of launches (iss_generate_batch)
+        eng.generate_batch(item_ids, item_pairs, first_ordinal=ordinal[0], seed=worker_seed, out_first_pair=0)
+        ordinal[0] += total_pairs_step
+
+    def sync_all():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # Warm-up: HIP events around every kernel (the per-kernel split reported below).  Timed region: events around
+    # k_main only -- the roofline's kernel duration is measured live over the timed region, but every event is a
+    # bubble in the stream and the five-kernel timing costs ~6 % of a step.
+    eng.timing_read()
+    eng.timing_enable(1)
+    for _ in range(warmup):
+        step()
+    sync_all()
+    tm_warm = eng.timing_read()
+    eng.timing_enable(0 if os.environ.get("ISS_BENCH_NO_KERNEL_EVENTS") == "1" else 2)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timing_read()
+    eng.timing_enable(0)
+    stats = eng.stats_read()
+    per_rank = [(total_pairs_step, elapsed)]
+    if dist is not None:
+        mine = torch.tensor([float(total_pairs_step), elapsed], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [(int(x[0].item()), float(x[1].item())) for x in allr]
+    elapsed_max = max(e for _, e in per_rank)  # the slowest rank's time
+
+    # ---- after the timed region: windows of the LAST timed step recomputed by the CPU oracle (rank 0's rows)
+    parity = None
+    if rank == 0 and total_pairs_step:
+        parity = parity_window(eng, dense, work, letters, ordinal[0] - total_pairs_step, worker_seed)
+
+    # ---- what ONE GPU does on the whole job (N > 1, strong leg): rank 0 alone, the other ranks wait at the barrier behind it.
+    #      The weak leg needs no such run: a rank's own step IS the N = 1 shape.
+    one_gpu = None
+    if strong and world > 1:
+        if rank == 0:
+            w1 = work_of(1, 0)
+            ids1, pairs1 = [gid_of[id(rec)] for rec, _ in w1], [n for _, n in w1]
+            tot1 = sum(pairs1)
+            eng.reserve(max(tot1, 1))
+            eng.generate_batch(ids1, pairs1, first_ordinal=0, seed=SEED, out_first_pair=0)
+            eng.synchronize()
+            k = max(2, min(steps, 5))
+            t0 = time.perf_counter()
+            for i in range(k):
+                eng.generate_batch(ids1, pairs1, first_ordinal=(i + 1) * tot1, seed=SEED, out_first_pair=0)
+            eng.synchronize()
+            one_gpu = {"value": tot1 * k / (time.perf_counter() - t0), "pairs_per_step": tot1, "steps": k}
+        dist.barrier()
+    return dict(label=label, model=model, reads=reads, n_genomes=n_genomes, strong=strong, indel=indel, steps=steps, warmup=warmup,
+                dense=dense, genomes=genomes, records=records, letters=letters, abundance=abundance, work=work, eng=eng,
+                total_pairs_step=total_pairs_step, elapsed=elapsed_max, per_rank=per_rank, tm=tm, tm_warm=tm_warm, stats=stats,
+                bcast_s=bcast_s, parity=parity, one_gpu=one_gpu)
+
+
+def leg_summary(L, world):
+    """The scaling view of a leg (N > 1 lines carry one per leg): whole-job rate, every rank's share and own rate, and the
+    scaling efficiency value_N / (N x value of ONE GPU on the N = 1 shape) -- weak: a rank's own step is that shape, so the
+    denominator is the sum of the ranks' own rates; strong: rank 0 ran the whole job alone (`one_gpu`)."""
+    pairs = [n for n, _ in L["per_rank"]]
+    own = [n * L["steps"] / e if e > 0 else None for n, e in L["per_rank"]]
+    value = sum(pairs) * L["steps"] / L["elapsed"]
+    if L["strong"]:
+        base = world * L["one_gpu"]["value"] if L["one_gpu"] else None
+    else:
+        base = sum(v for v in own if v)
+    return {"workload": L["label"], "scaling": "strong" if L["strong"] else "weak", "value": value, "unit": "read-pairs/s",
+            "ms_per_step": L["elapsed"] / L["steps"] * 1e3, "steps": L["steps"], "pairs_per_step_per_gpu": pairs,
+            "per_rank_pairs_per_sec": own, "model_broadcast_s": L["bcast_s"], "n_ranks_seen": len(L["per_rank"]),
+            "one_gpu_whole_job": L["one_gpu"], "scaling_efficiency": (value / base) if base else None,
+            "parity_window": L["parity"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="configs2", choices=["configs2", "configs3"],
+    ap.add_argument("--workload", default=None, choices=["configs2", "configs3"],
                     help="configs2: BASELINE configs[2], 10 M NovaSeq reads per step PER GPU over 5 genomes (weak scaling); "
-                         "configs3: BASELINE configs[3], 100 M HiSeq reads per step IN TOTAL over 50 genomes (strong scaling)")
+                         "configs3: BASELINE configs[3], 100 M HiSeq reads per step IN TOTAL over 50 genomes (strong scaling).  "
+                         "Default: configs2 is the line's metric; with --gpus N > 1 the line ALSO carries the configs3 leg (`strong_leg`)")
     ap.add_argument("--reads", type=int, default=None, help="reads per step (configs2: per GPU; configs3: in total)")
+    ap.add_argument("--strong-reads", type=int, default=100_000_000, help="total reads per step of the strong leg of a default N > 1 run")
     ap.add_argument("--model", default=None)
     ap.add_argument("--n-genomes", type=int, default=None, help="records of the synthetic community")
     ap.add_argument("--indel", type=float, nargs=2, default=None, metavar=("P_INS", "P_DEL"),
@@ -72,13 +203,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short legs on the other shipped models and the indel-heavy model (rank 0, N = 1, default workload only)")
-    ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTQ-on-tmpfs leg (rank 0, N = 1 only)")
-    ap.add_argument("--e2e-pairs", type=int, default=20_000_000)
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the FASTQ-on-tmpfs legs (rank 0, N = 1 only)")
+    ap.add_argument("--e2e-pairs", type=int, default=200_000_000)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo: a dry run of "
                     "the multi-rank logic, e.g. with ISS_BENCH_SHARE_GPU=1 on a single-GPU box)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1_500_000)
     ap.add_argument("--cpu-threads", type=int, default=None, help="threads of the all-cores CPU leg (default: min(host cores, 64))")
     args = ap.parse_args()
+    both_legs = args.workload is None  # the default invocation
     strong = args.workload == "configs3"
     if args.reads is None:
         args.reads = 100_000_000 if strong else READS_PER_STEP
@@ -133,90 +265,26 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    from insilicoseq_amd.engine import ReadEngine
-    from insilicoseq_amd.generator import Record, generate_work_divider, lognormal_abundance
-    from insilicoseq_amd.model import DenseModel
+    from insilicoseq_amd.generator import Record, lognormal_abundance
 
-    # ---- inputs: rank 0 builds them; ONE RCCL broadcast to the other ranks (only when N > 1)
-    from insilicoseq_amd.distributed import broadcast_model_and_genomes
-
-    model_path = os.path.join(ROOT, "insilicoseq_amd", "profiles", args.model + ".dense.npz")
-    dense, genomes = None, None
-    if rank == 0:
-        dense = DenseModel.load(model_path)
-        if args.indel is not None:
-            dense.ins[:] = args.indel[0]
-            dense.dele[:] = args.indel[1]
-        genomes = synthetic_genomes(args.n_genomes, GENOME_LEN, 123)
-    t_b = time.time()
-    dense, grefs = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank), as_refs=True,
-                                               force=force_dist)
-    torch.cuda.synchronize()
-    bcast_s = time.time() - t_b if dist is not None else 0.0
-
-    eng = ReadEngine(local_rank)
-    eng.load_model(dense)
-    # records: id + length for the work divider, letters only where the CPU legs need them (rank 0)
-    records = [Record(_SeqLen(g.length), id="genome_%d" % i) for i, g in enumerate(grefs)]
-    letters = {id(r): g for r, g in zip(records, genomes)} if rank == 0 else {}
-    gid_of = {id(r): g.upload(eng) for r, g in zip(records, grefs)}  # (N > 1: straight from the broadcast buffer in HBM)
-    abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(123))
-    # the reference's sharding: chunk `rank` of the divider with cpus = world (iss/app.py:81-83, 99-106)
-    from insilicoseq_amd.distributed import rank_work
-
-    total_reads = args.reads if strong else args.reads * world
-    chunk, chunk_size, n_chunks = rank_work(records, None, abundance, total_reads, None, None, dense, "bench", world, rank)
-    work = [(r, n) for r, n, _ in (chunk or [])]
-    total_pairs_step = sum(n for _, n in work)
-    eng.reserve(max(total_pairs_step, 1))
-    worker_seed = SEED + rank
-    ordinal = [0]
-
-    item_ids = [gid_of[id(rec)] for rec, _ in work]
-    item_pairs = [n for _, n in work]
-
-    def step():  # the step's whole work list in one set of launches (iss_generate_batch)
-        eng.generate_batch(item_ids, item_pairs, first_ordinal=ordinal[0], seed=worker_seed, out_first_pair=0)
-        ordinal[0] += total_pairs_step
-
-    def sync_all():
-        eng.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    # Warm-up: HIP events around every kernel (the per-kernel split reported below).  Timed region: events around
-    # k_main only -- the roofline's kernel duration is measured live over the timed region, but every event is a
-    # bubble in the stream and the five-kernel timing costs ~6 % of a step.
-    eng.timing_read()
-    eng.timing_enable(1)
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    tm_warm = eng.timing_read()
-    eng.timing_enable(0 if os.environ.get("ISS_BENCH_NO_KERNEL_EVENTS") == "1" else 2)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    tm = eng.timing_read()
-    eng.timing_enable(0)
-    stats = eng.stats_read()
-    per_rank = [(total_pairs_step, elapsed)]
-    if dist is not None:
-        mine = torch.tensor([float(total_pairs_step), elapsed], dtype=torch.float64, device="cuda")
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [(int(x[0].item()), float(x[1].item())) for x in allr]
-        elapsed = max(e for _, e in per_rank)  # the slowest rank's time
-
-    # ---- after the timed region: windows of the LAST timed step recomputed by the CPU oracle (rank 0's rows)
-    parity = None
-    if rank == 0 and total_pairs_step:
-        parity = parity_window(eng, dense, work, letters, ordinal[0] - total_pairs_step, worker_seed)
+    label = ("BASELINE configs[3]: %d reads/step in total" % args.reads) if strong else (
+        "BASELINE configs[2]: %d reads/step/GPU" % args.reads)
+    L = run_leg(args, label, args.model, args.reads, args.n_genomes, strong, args.indel, args.steps, args.warmup, rank, local_rank,
+                world, dist, force_dist)
+    # N > 1, default invocation: the line ALSO carries BASELINE configs[3] -- 100 M HiSeq reads per step in TOTAL over 50
+    # records, chunk r of the divider per rank (strong scaling); a weak curve alone says nothing about a path without a
+    # data-path collective
+    L3 = None
+    if both_legs and dist is not None and world > 1:
+        L["eng"].close()
+        L["eng"] = None
+        L3 = run_leg(args, "BASELINE configs[3]: %d reads/step in total" % args.strong_reads, "hiseq", args.strong_reads, 50, True,
+                     None, max(3, min(args.steps, 10)), min(args.warmup, 2), rank, local_rank, world, dist, force_dist)
+        L3["eng"].close()
+        L3["eng"] = None
+    eng, dense, work, letters, records, genomes, abundance = (L[k] for k in ("eng", "dense", "work", "letters", "records", "genomes", "abundance"))
+    total_pairs_step, elapsed, per_rank, tm, tm_warm, stats = (L[k] for k in ("total_pairs_step", "elapsed", "per_rank", "tm", "tm_warm", "stats"))
+    parity, bcast_s = L["parity"], L["bcast_s"]
 
     if rank == 0:
         RL = dense.read_length
@@ -230,8 +298,6 @@ def main():
         other = {k: (tm_warm[k] / args.warmup if args.warmup else None) for k in ("setup_ms", "indel_scan_ms", "indel_fixup_ms")}
         all_kernels_s = (tm["main_ms"] + sum(v or 0.0 for v in other.values()) * args.steps) / 1e3
         traffic = committed_traffic()
-        label = ("BASELINE configs[3]: %d reads/step in total" % args.reads) if strong else (
-            "BASELINE configs[2]: %d reads/step/GPU" % args.reads)
         out = {
             "metric": "read_pairs_per_sec", "value": value, "unit": "read-pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -261,16 +327,24 @@ def main():
                              main_s / max(n_main_launches, 1)) if main_s > 0 else None},
             },
             "kernel_ms_per_step": dict(other, main_ms=tm["main_ms"] / args.steps,
-                                       note="main_ms: HIP events over the timed region; the others: over the warm-up steps"),
+                                       note="main_ms: HIP events over the timed region; the others: over the warm-up steps "
+                                            "(indel_scan_ms: k_indel_scan + the two k_indel_script launches)"),
             "all_kernels_GBps": (total_pairs_step * args.steps * b_pair) / all_kernels_s / 1e9 if all_kernels_s else 0,
-            "indel_fixup_reads_per_step": stats["fixup_reads"] / max(args.steps, 1),
+            "indel_fixup_reads_per_step": stats["fixup_reads"] / max(args.steps + args.warmup, 1),
+            "indel_scripted_reads_per_step": stats["scripted_reads"] / max(args.steps + args.warmup, 1),
             "model_broadcast_s": bcast_s,
             "parity_window": parity,
+            "library_build_id": library_build_id(),
         }
         out["n_ranks_seen"] = dist.get_world_size() if dist is not None else 1
         out["backend"] = (args.backend if dist is not None else None)
         if dist is not None:
             out["per_rank_pairs_per_sec"] = [n * args.steps / e if e > 0 else None for n, e in per_rank]
+            leg = leg_summary(L, world)
+            out["weak_leg" if not strong else "strong_leg"] = leg
+            out["scaling_efficiency"] = leg["scaling_efficiency"]
+            if L3 is not None:
+                out["strong_leg"] = leg_summary(L3, world)
         if world == 1 and not args.no_other_workloads and not strong and args.model == "novaseq" and args.indel is None:
             # the same work list on the other models of the parity suite (a few steps each; BASELINE's metric stays the line above)
             out["other_workloads"] = {}
@@ -288,10 +362,17 @@ def main():
                 del g50
             except Exception as e:
                 out["other_workloads"]["configs3_one_gpu"] = {"error": repr(e)}
+            try:  # the reference-identical mode (rng="mt"): the one whose FASTQ equals `iss generate`'s byte for byte
+                out["other_workloads"]["mt_mode"] = mt_mode_leg(local_rank, dense, genomes[0])
+            except Exception as e:
+                out["other_workloads"]["mt_mode"] = {"error": repr(e)}
         if world == 1 and not args.no_end_to_end:
+            eng.close()  # (the legs below bring their own engines: the rows of the timed region go back to the allocator first)
+            eng = None
             e2e_records = [Record(letters[id(r)], id=r.id) for r in records]
             out["end_to_end"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs)
             out["end_to_end_gzip"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs, compress=True)
+            out["end_to_end_4_workers"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs, workers=4)
         if world == 1 and not args.no_cpu_baseline:
             cpu_work = [(letters[id(r)], n) for r, n in work]
             out["cpu_baseline"] = cpu_baseline(dense, cpu_work, args.cpu_sample_pairs)
@@ -303,7 +384,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    if eng is not None:
+        eng.close()
 
 
 def parity_window(eng, dense, work, letters, step_first_ordinal, worker_seed, n=64):
@@ -400,28 +482,23 @@ def side_workload(device, model, indel, genomes, records, abundance, reads, step
         eng.close()
 
 
-def kernel_source_hash():
-    """Hash of the HIP sources (comments and white space aside): a committed PMC summary says which sources it was
-    measured on."""
-    import hashlib
-    import re
+def library_build_id():
+    """iss_build_id() of the library this process loaded: a hash of the sources it was COMPILED from (set by
+    __graft_entry__.build()); "unknown" for a library built some other way."""
+    from insilicoseq_amd import _native
 
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "insilicoseq_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        with open(os.path.join(d, f), "r", errors="replace") as fh:
-            text = fh.read()
-        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
-        text = re.sub(r"//[^\n]*", " ", text)  # (no string literal of these sources holds "//")
-        h.update(f.encode() + b"\0" + " ".join(text.split()).encode())
-    return h.hexdigest()[:16]
+    try:
+        return _native.lib().iss_build_id().decode()
+    except Exception:  # noqa: BLE001
+        return "unknown"
 
 
 def committed_traffic():
     """HBM-side bytes per k_main launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc
     runs of this same command, corrected with the calibration kernels as MI355X_MICROARCH.md prescribes).  PMC
     collection cannot run inside the timed region, so the latest committed measurement is reported, with `fresh` =
-    whether it was taken on the kernel sources this run was built from."""
+    whether it was taken on the very library build this run has loaded (`library_build_id` of the summary against
+    iss_build_id() of the loaded binary -- not a re-hash of whatever sources lie beside it)."""
     import glob
 
     import re
@@ -434,19 +511,50 @@ def committed_traffic():
         return {"note": "no PMC pass committed"}
     with open(files[-1]) as fh:
         t = json.load(fh)
-    t["fresh"] = t.get("kernel_source_hash") == kernel_source_hash()
+    bid = library_build_id()
+    t["fresh"] = bid != "unknown" and t.get("library_build_id") == bid
     t["note"] = "bytes per launch (%d pairs), from %s%s" % (
         t.get("pairs_per_launch_avg", 0), os.path.basename(files[-1]),
-        "" if t["fresh"] else " -- STALE: measured on other kernel sources than this run's")
+        "" if t["fresh"] else " -- STALE: measured on another build of the library (%s) than the one loaded (%s)" % (
+            t.get("library_build_id", "?"), bid))
     return t
 
 
-def end_to_end(dense, records, abundance, n_pairs, compress=False):
-    """SURVEY.md 8d "report both": one worker from genomes in HBM to FASTQ FILES (worker_iterator: generation, FASTQ text
-    built on the device, copy, pwrite) on tmpfs.  Informational: `value` above stays the kernel-side rate.
-    compress: `--compress`, the text is deflated on the device and only gzip members are copied and written."""
+def mt_mode_leg(device, dense, genome, n_pairs=1_500_000):
+    """Pairs per second of ONE worker in the reference-identical mode (rng="mt": the device consumes the reference's two
+    MT19937 streams in the reference's order; tests/test_gpu_mt_compat.py holds the byte-for-byte comparisons)."""
+    from insilicoseq_amd.engine import ReadEngine
+
+    eng = ReadEngine(device)
+    try:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        eng.seed_mt(SEED)
+        batch = 1 << 18
+        eng.reserve(batch)
+        assert eng.generate_mt(gid, batch) == batch  # warm-up
+        eng.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        while done < n_pairs:
+            done += eng.generate_mt(gid, batch)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": done / dt, "unit": "read-pairs/s", "workers": 1, "sample": "%d pairs in %.2f s, rows left in HBM" % (done, dt)}
+    finally:
+        eng.close()
+
+
+def end_to_end(dense, records, abundance, n_pairs, compress=False, workers=1):
+    """SURVEY.md 8d "report both": from genomes in HBM to FASTQ FILES (worker_iterator: generation, FASTQ text built on the
+    device, copy, pwrite) on tmpfs.  Informational: `value` above stays the kernel-side rate.  `value` here is the STEADY
+    STATE -- from the moment the first batch has been handed to the files to the end -- and the start-up (engine, model,
+    pinned buffers, first batch) is reported beside it.  compress: `--compress`, the text is deflated on the device and only
+    gzip members are copied and written.  workers > 1: that many reference workers (`--cpus N`: one temp file pair each,
+    iss/app.py:73, 123-127) as threads sharing the GPU -- tmpfs serialises the writes to ONE file on its inode."""
     import shutil
     import tempfile
+    import threading
 
     from insilicoseq_amd.generator import worker_iterator
 
@@ -456,21 +564,48 @@ def end_to_end(dense, records, abundance, n_pairs, compress=False):
         # keep well inside the free space of the file system (2 files x ~330 B per pair as text)
         need = 2 * 340 * n_pairs * (0.4 if compress else 1.0)
         free = shutil.disk_usage(d).free
-        if need > 0.5 * free:
-            n_pairs = max(1000, int(n_pairs * 0.5 * free / need))
+        if need > 0.4 * free:
+            n_pairs = max(1000, int(n_pairs * 0.4 * free / need))
         work = [(r, int(n_pairs * abundance[r.id]), "default") for r in records]
-        prefix = os.path.join(d, "w")
-        worker_iterator([(records[0], 1000, "default")], dense, 0, prefix, SEED, "metagenomics", False, device=0,
-                        compress=compress)  # warm-up
+        # the reference's chunks of the flattened list (iss/app.py:81-83), one per worker
+        flat = [(r, 1 << 18, m) for r, n, m in work for _ in range(n >> 18)] + [(r, n & ((1 << 18) - 1), m) for r, n, m in work if n & ((1 << 18) - 1)]
+        per = -(-len(flat) // workers)
+        chunks = [flat[k * per:(k + 1) * per] for k in range(workers)]
+        worker_iterator([(records[0], 1000, "default")], dense, 0, os.path.join(d, "warm"), SEED, "metagenomics", False, device=0,
+                        compress=compress)  # warm-up (library, kernels)
+        timings = [dict() for _ in range(workers)]
+        errors = []
+
+        def run(k):
+            try:
+                worker_iterator(chunks[k], dense, k, os.path.join(d, "w%d" % k), SEED, "metagenomics", False, device=0,
+                                compress=compress, timings=timings[k])
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
         t0 = time.perf_counter()
-        worker_iterator(work, dense, 0, prefix, SEED, "metagenomics", False, device=0, compress=compress)
+        ts = [threading.Thread(target=run, args=(k,)) for k in range(workers)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
         dt = time.perf_counter() - t0
-        size = os.path.getsize(prefix + "_R1.fastq") + os.path.getsize(prefix + "_R2.fastq")
-        n = sum(k for _, k, _ in work)
-        return {"value": n / dt, "unit": "read-pairs/s", "written_GB_per_s": size / dt / 1e9,
-                "sample": "%d pairs -> %.2f GB of %s on %s in %.2f s (incl. engine start-up), one worker" % (
-                    n, size / 1e9, "gzip members (text deflated on the device)" if compress else "FASTQ",
-                    base or "the temp dir", dt)}
+        if errors:
+            raise RuntimeError(errors[0])
+        size = sum(os.path.getsize(os.path.join(d, "w%d_R%d.fastq" % (k, m))) for k in range(workers) for m in (1, 2))
+        n = sum(k for c in chunks for _, k, _ in c)
+        # steady state: behind the moment every worker has handed its first batch to the files
+        first = max(t["batches"][0][0] for t in timings if t.get("batches"))
+        after = sum(p for t in timings for ts_, p in t.get("batches", []) if ts_ > first)
+        t_end = max(t["t_end"] for t in timings)
+        steady = after / (t_end - first) if t_end > first and after else None
+        return {"value": steady, "unit": "read-pairs/s", "workers": workers, "files": 2 * workers,
+                "written_GB_per_s": (size / n * steady / 1e9) if steady else None,
+                "incl_startup": {"value": n / dt, "seconds": dt, "engine_startup_s": max(t["t_ready"] - t["t_start"] for t in timings),
+                                 "first_batch_queued_after_s": first - t0},
+                "sample": "%d pairs -> %.2f GB of %s on %s in %.2f s; steady state = the %d pairs queued after every worker's first "
+                          "batch, %.2f s" % (n, size / 1e9, "gzip members (text deflated on the device)" if compress else "FASTQ",
+                                             base or "the temp dir", dt, after, t_end - first)}
     except Exception as e:  # a leg of extra information must not take the benchmark line down
         return {"value": None, "error": repr(e)}
     finally:

@@ -111,7 +111,7 @@ def lib():
     L.iss_ev_step.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
     L.iss_fastq_write.argtypes = [C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i32, i32, vp, vp, vp, vp, i32]
     for name in EXPORTS:
-        if name not in ("iss_ctx_destroy", "iss_last_error"):
+        if name not in ("iss_ctx_destroy", "iss_last_error", "iss_build_id"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -2119,7 +2119,10 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
                     const size_t want[2] = {0, used + 256};
                     { int rc_ = mt_ensure(ctx, want); if (rc_) return rc_; }
                     uint32_t w[256];
-                    HIP_TRY(ctx, hipMemcpy(w, m.buf[1][m.cur[1]] + m.used[1] + used, sizeof w, hipMemcpyDeviceToHost));
+                    // (on the context's stream, which mt_ensure has made wait for the refill: the streams are non-blocking, a copy
+                    //  on the null stream would not be ordered behind the fill kernel and the leftover copy)
+                    HIP_TRY(ctx, hipMemcpyAsync(w, m.buf[1][m.cur[1]] + m.used[1] + used, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                     bool done = false;
                     for (int c = 0; c < 64 && !done; ++c) {
                         auto res53 = [](uint32_t a, uint32_t b) { return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0); };
@@ -2140,7 +2143,8 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
                     if (done) { m.used[1] += used; break; }
                 }
             }
-            HIP_TRY(ctx, hipMemcpy(m.d_gauss, &gs, sizeof gs, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpyAsync(m.d_gauss, &gs, sizeof gs, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return fail(ctx, ISS_E_SHORT_RECORD, "record shorter than read length for this ErrorModel");
         }
         if (!basic) {  // (BasicErrorModel.random_insert_size is a constant: nothing is drawn)

@@ -20,6 +20,7 @@ CPU oracle in Philox mode, which in MT mode is bit-identical to the reference (D
 import logging
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -196,6 +197,7 @@ class Worker(object):
         self.has_fragment = (getattr(error_model, "fragment_length", None) is not None and
                              getattr(error_model, "fragment_sd", None) is not None)
         self.ordinal = 0
+        self.timings = None
         self._gids = {}  # id(record) -> (record, genome id on the device)
         self._resident = 0
 
@@ -348,6 +350,8 @@ def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_ha
             row += n
         eng.fastq_emit_batch(forward_handle.fileno(), reverse_handle.fileno(), emit, w.cpu_number)  # one text job
         w.ordinal += row
+        if w.timings is not None:  # (measurement: when each batch was handed to the FASTQ pipeline, and how many pairs it held)
+            w.timings.setdefault("batches", []).append((time.perf_counter(), row))
         pending, cur = [], 0
 
     for fh in (forward_handle, reverse_handle):
@@ -404,13 +408,17 @@ def simulate_reads(record, error_model, n_pairs, cpu_number, forward_handle, rev
 
 
 def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence_type, gc_bias, device=None,
-                    rng="philox", compress=False):
+                    rng="philox", compress=False, timings=None):
     """iss/generator.py:223-251 on GPU ``device`` (default: ``cpu_number``).  ``rng="mt"`` consumes the
     reference's two Mersenne-Twister streams on the device: the files then equal the reference's byte for
     byte (sequential, ~1e5 pairs/s); ``rng="philox"`` is the parallel path.  ``compress=True``: the two FASTQ files
     (same names) hold gzip members built on the device instead of text -- `--compress` without the text ever leaving
-    the GPU; gunzipped they are the files ``compress=False`` writes."""
+    the GPU; gunzipped they are the files ``compress=False`` writes.  ``timings``: a dict that receives ``t_start``, ``t_ready``
+    (engine created, model uploaded), ``batches`` [(time a batch was queued for the files, its pairs)] and ``t_end`` (files
+    complete) -- bench.py's end-to-end legs report the steady state apart from the start-up."""
     logger = logging.getLogger(__name__)
+    if timings is not None:
+        timings["t_start"] = time.perf_counter()
     store_mutations = bool(getattr(error_model, "store_mutations", False))
     if sequence_type not in _native.SEQ_TYPES:
         raise RuntimeError("sequence type '%s' is not supported" % sequence_type)  # generator.py:139
@@ -422,6 +430,9 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
         logger.error("Failed to write temporary output file(s): %s" % e)
         sys.exit(1)
     w = Worker(error_model, cpu_number, seed, device=device, rng=rng, compress=compress)
+    w.timings = timings
+    if timings is not None:
+        timings["t_ready"] = time.perf_counter()
     if store_mutations:
         w.store_mutations = True
         # row buffers of a batch, from the model's own error rates (twice the expectation + slack; the Philox kernels
@@ -440,6 +451,8 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
                     w.simulate_reads(record, n_pairs, forward_handle, reverse_handle, mutation_handle, sequence_type,
                                      gc_bias, flush=False)  # keep the text pipeline running across work items
             w.engine.fastq_flush()
+            if timings is not None:
+                timings["t_end"] = time.perf_counter()
     finally:
         w.close()
 

@@ -397,3 +397,40 @@ def test_fragment_length_host_guard_path(monkeypatch):
                 assert np.array_equal(got[k], z[k]), (case, k)
             py, npw = eng.mt_peek(8)
             assert list(_res53(py)) == list(z["tail_py"]) and list(_res53(npw)) == list(z["tail_np"])
+
+
+@pytest.mark.parametrize("n_short", [1, 3, 40])
+def test_short_record_first_after_seeding_keeps_the_streams(n_short):
+    """Regression (round-3 advice): with --fragment-length a record shorter than a read still costs the reference one
+    np.random.normal draw before its assertion fails (iss/generator.py:121-130).  The host replays that gaussian from the
+    stream words -- which must be read BEHIND the refill mt_ensure queues on the engine's (non-blocking) streams.  Short
+    records as the very first calls after seeding (nothing filled yet; n_short > 1: cached second values in between, 40: past
+    a refill), then a normal record: its reads and the positions of both streams equal the oracle's in MT mode."""
+    from helpers import random_genome
+    from insilicoseq_amd._native import EngineError
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    dense = dense_model("novaseq")
+    short, genome = random_genome(71, dense.read_length - 3), random_genome(72, 40000)
+    n = 300
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        g_short, g_long = eng.add_genome(short), eng.add_genome(genome)
+        eng.seed_mt(991)
+        eng.mt_set_fragment(400.0, 35.0)
+        for _ in range(n_short):
+            with pytest.raises(EngineError):
+                eng.generate_mt(g_short, 5)
+        assert eng.generate_mt(g_long, n) == n
+        got = eng.download(0, n)
+        py, npw = eng.mt_peek(8)
+    orc, rng = O.Oracle(dense), O.Rng().seed_mt(991)
+    for _ in range(n_short):
+        assert orc.simulate(rng, short, 5, fragment_length=400.0, fragment_sd=35.0)["status"] != 0
+    exp = orc.simulate(rng, genome, n, fragment_length=400.0, fragment_sd=35.0)
+    assert exp["status"] == 0
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert [int(x) for x in py] == [rng.py_word() for _ in range(8)]  # both streams stand where the oracle's stand
+    assert [int(x) for x in npw] == [rng.np_word() for _ in range(8)]

@@ -106,12 +106,13 @@ def test_bench_multirank_dry_run(world):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    reads = 300000
+    reads, strong_reads = 300000, 1_200_000
     env = dict(os.environ, ISS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world),
-                          "--backend", "gloo", "--reads", str(reads), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                          "--no-end-to-end", "--no-other-workloads"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                          "--backend", "gloo", "--reads", str(reads), "--strong-reads", str(strong_reads), "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-end-to-end", "--no-other-workloads"], cwd=root, env=env, capture_output=True,
+                         text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE line
@@ -123,6 +124,19 @@ def test_bench_multirank_dry_run(world):
     assert len(d["per_rank_pairs_per_sec"]) == world and all(v > 0 for v in d["per_rank_pairs_per_sec"])
     assert abs(d["value"] - sum(pairs) * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]  # whole-job pairs / the slowest rank's time
     assert str(d["parity_window"]).startswith("ok")
+    # the default N > 1 line carries BOTH legs: configs[2] per GPU (weak) and configs[3] in total (strong), each with every rank's
+    # share and own rate, the broadcast time, the ranks seen and a scaling efficiency against ONE GPU on the N = 1 shape
+    weak, strong = d["weak_leg"], d["strong_leg"]
+    assert weak["scaling"] == "weak" and weak["pairs_per_step_per_gpu"] == pairs and abs(weak["value"] - d["value"]) <= 1e-9 * d["value"]
+    assert strong["scaling"] == "strong" and "configs[3]" in strong["workload"]
+    sp = strong["pairs_per_step_per_gpu"]
+    assert len(sp) == world and min(sp) > 0 and abs(sum(sp) - strong_reads // 2) <= 64  # (50 records: rounding + the dropped surplus chunk)
+    assert abs(strong["one_gpu_whole_job"]["pairs_per_step"] - strong_reads // 2) <= 64
+    for leg in (weak, strong):
+        assert leg["n_ranks_seen"] == world and len(leg["per_rank_pairs_per_sec"]) == world and all(v > 0 for v in leg["per_rank_pairs_per_sec"])
+        assert leg["model_broadcast_s"] > 0 and 0 < leg["scaling_efficiency"] < 2.0 and str(leg["parity_window"]).startswith("ok")
+        assert abs(leg["value"] - sum(leg["pairs_per_step_per_gpu"]) * leg["steps"] / (leg["ms_per_step"] * leg["steps"] * 1e-3)) <= 1e-6 * leg["value"]
+    assert d["scaling_efficiency"] == weak["scaling_efficiency"]
 
 
 def test_bench_refuses_a_mismatched_launch():
