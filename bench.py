@@ -308,7 +308,7 @@ def main():
                             "seed %d; sharded by the reference's chunk rule (rank = cpu_number); outputs left in HBM" % (
                                 label, args.model, RL, args.n_genomes, GENOME_LEN, SEED),
                 "pairs_per_step_per_gpu": [n for n, _ in per_rank] if world > 1 else total_pairs_step, "read_length": RL,
-                "work_items": len(work), "rng": "philox4x32-10",
+                "work_items": len(work), "rng": "philox4x32 (7 rounds for the hot digit blocks K_QM, 10 for every other draw)",
                 "parallelism": "1 worker/GPU, chunk r of ceil(pairs/N) per rank (iss/app.py:81-83), no data-path collective",
                 "indel_override": args.indel,
             },

@@ -15,7 +15,8 @@
  * Arithmetic contract: every f64 comparison of the reference is carried out as an
  * exact integer comparison on 53-bit uniforms m = (w0>>5)*2^26 + (w1>>6) against
  * thresholds prepared on the host (floor/ceil of table*2^53, exact), see DESIGN.md.
- * Uniform words come from Philox4x32-10 addressed by
+ * Uniform words come from Philox4x32 (Salmon et al., SC'11; ten rounds, seven -- the fewest that pass
+ * BigCrush -- for the hot digit blocks since ABI 6) addressed by
  * (seed, pair ordinal, attempt, kind, index, sub) -- the address map is part of the
  * contract and is documented in DESIGN.md ("RNG address map").
  */

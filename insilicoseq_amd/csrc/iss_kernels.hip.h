@@ -43,10 +43,18 @@ struct u32x4 {
     uint32_t x, y, z, w;
 };
 
-__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                               uint32_t k1) {
+// Philox4x32 with ROUNDS rounds (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11).  Ten rounds
+// is the generator's default; SEVEN is the fewest the authors found to pass every test of BigCrush ("Crush-resistant",
+// their table 2; philox4x32_R(7, ...) of Random123) and what the HOT digit blocks (K_QM: three per 16 bases, all of k_main's
+// 64-bit multiplies) use since round 4 -- measured: 1.32 -> 1.11 ms per 5 M-pair launch, the multiplies being the kernel's
+// scarcest issue slots.  Every other draw keeps ten rounds.  The CPU oracle follows the same rule; both round counts are checked
+// against Random123's known-answer vectors (tests/).
+constexpr int PHILOX_HOT_ROUNDS = 7;
+template <int ROUNDS = 10>
+__device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);  // 3-input xor
@@ -69,8 +77,10 @@ __device__ __forceinline__ Addr make_addr(uint64_t seed, uint64_t ordinal, uint3
     return {(uint32_t)ordinal, (uint32_t)((ordinal >> 32) & 0xffffu) | (attempt << 16), (uint32_t)seed,
             (uint32_t)(seed >> 32)};
 }
+// (`kind` is a constant at every call site: the test folds away)
 __device__ __forceinline__ u32x4 draw_block(const Addr &a, uint32_t kind, uint32_t index, uint32_t sub) {
-    return philox4x32_10(a.c0, a.c1, (kind << 24) | (index & 0xffffffu), sub, a.k0, a.k1);
+    if (kind == K_QM) return philox4x32<PHILOX_HOT_ROUNDS>(a.c0, a.c1, (kind << 24) | (index & 0xffffffu), sub, a.k0, a.k1);
+    return philox4x32<10>(a.c0, a.c1, (kind << 24) | (index & 0xffffffu), sub, a.k0, a.k1);
 }
 __device__ __forceinline__ uint32_t word_of(const u32x4 &v, int i) {
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
@@ -837,13 +847,18 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
 // its error-test digit in byte BYTE; row_g / row_e = byte offsets of the row's guide / entries.  Returns the selected
 // entry; `flag`: lane mask of the bases that need the exact path (digit tie, > 2 thresholds of the guide bucket below the digit,
 // substitution test fires or ties).
+// (LDS is addressed by ABSOLUTE byte offsets -- row_g / row_e include the address of the kernel's dynamic LDS array -- through
+//  address-space-3 pointers made from integers: with a generic pointer the compiler adds the array's address, a link-time zero,
+//  to every row offset again: eight additions of 0 per lane-item)
+typedef const __attribute__((address_space(3))) uint8_t lds_u8_t;
+typedef const __attribute__((address_space(3))) uint32_t lds_u32_t;
 template <int HI, int BYTE>
-__device__ __forceinline__ uint32_t hot_lookup(const uint8_t *ldsb, uint32_t row_g, uint32_t row_e, uint32_t off, uint32_t wq,
+__device__ __forceinline__ uint32_t hot_lookup(uint32_t row_g, uint32_t row_e, uint32_t off, uint32_t wq,
                                                uint32_t we, uint32_t gsh, uint32_t gb, unsigned long long &flag) {
     const uint32_t h = HI ? (wq >> 16) : (wq & 0xffffu);
     const uint32_t gi = HI ? (wq >> (gsh + 16u)) : __builtin_amdgcn_ubfe(wq, gsh, gb);
-    const uint32_t j = ldsb[row_g + off + gi];
-    const uint32_t *ent = reinterpret_cast<const uint32_t *>(ldsb + row_e + off + j);  // guide bytes hold 4 * index
+    const uint32_t j = *reinterpret_cast<lds_u8_t *>(row_g + off + gi);
+    lds_u32_t *ent = reinterpret_cast<lds_u32_t *>(row_e + off + j);  // guide bytes hold 4 * index
     const uint32_t e0 = ent[0], e1 = ent[1];
     const uint32_t sel = (e0 >> 16) < h ? e1 : e0;   // first entry with t16 >= h (if among the two)
     const uint32_t e8 = (we >> (8 * BYTE)) & 0xffu;
@@ -855,12 +870,12 @@ __device__ __forceinline__ uint32_t hot_lookup(const uint8_t *ldsb, uint32_t row
 // word (byte BYTE of w) of the letter table at byte offset OFF of the LDS: the address is ONE instruction (byte select and
 // "* 4" in an SDWA multiply), the table base the load's immediate offset
 template <int BYTE, int OFF>
-__device__ __forceinline__ uint32_t lut_at(const uint32_t *lds0, uint32_t w) {
+__device__ __forceinline__ uint32_t lut_at(uint32_t lds0, uint32_t w) {
     uint32_t a;
     const uint32_t four = 4u;
     if (BYTE == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(a) : "v"(w), "v"(four));
     else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(w), "v"(four));
-    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(lds0) + OFF + a);
+    return *reinterpret_cast<lds_u32_t *>(lds0 + OFF + a);
 }
 
 // r = r << 1 | flag in one instruction: the flag's lane mask is the carry-in of v_addc
@@ -924,7 +939,8 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         }
     }
     __syncthreads();
-    const uint8_t *ldsb = reinterpret_cast<const uint8_t *>(lds_all);  // (row offsets below count from the start of LDS: ds_read2's offsets are too narrow to skip the letter tables)
+    // (row offsets below are absolute LDS addresses: ds_read2's offsets are too narrow to skip the letter tables)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_all;
     auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     const uint32_t n_iter = sgpr((T.ts + 3u) >> 2);
     const uint32_t it_max = ((uint32_t)M.TS + 3u) / 4u - 1u;  // largest iteration number of a pass
@@ -1043,12 +1059,9 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 if (valid_n) sc_rows(pair_n, ec, 0u, scn_f, scn_r);
             }
         };
-#ifdef ISS_REQUEST_AT_TOP
-        request_next();
-#endif
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
         // LDS byte offsets of the pair's rows (its bin slots) at this lane's first superitem; one iteration = 8 groups on
-        const uint32_t lane_row = j4 * 2u * gs_b + (uint32_t)MAIN_LUT_WORDS * 4u;
+        const uint32_t lane_row = j4 * 2u * gs_b + (uint32_t)MAIN_LUT_WORDS * 4u + lds0;
         uint32_t rowf = __umul24(d.meta & 3u, slot_b) + lane_row, rowf_e = rowf + gbytes;
         uint32_t rowr = __umul24((uint32_t)M.NB + ((d.meta >> 2) & 3u), slot_b) + lane_row, rowr_e = rowr + gbytes;
         const uint32_t s_lane = (uint32_t)T.s0 + j4;
@@ -1089,12 +1102,10 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                     gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pr_e >> 4) + 1) << 2));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef ISS_REQUEST_AT_TOP
                 if (it == 0u) {  // (every lane with work in this tile has an iteration 0; the others need no descriptor)
                     request_next();
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
                 // ---- hot digits: 16 quality digits (16 bits) + 16 error-test digits (8 bits)
                 const u32x4 q0 = draw_block(a, K_QM, s_abs, 0);
                 const u32x4 ee = draw_block(a, K_QM, s_abs, 1);
@@ -1103,7 +1114,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 uint32_t sel[16];
                 unsigned long long fl;
 #define ISS_LOOKUP(K, ROW, C, HI, BYTE, WQ, WE, RARE)                                                                \
-                sel[K] = hot_lookup<HI, BYTE>(ldsb, ROW, ROW##_e, off_g[C], WQ, WE, gsh, gb, fl);                      \
+                sel[K] = hot_lookup<HI, BYTE>(ROW, ROW##_e, off_g[C], WQ, WE, gsh, gb, fl);                            \
                 RARE = shift_in(RARE, fl);
                 // half 0: positions 0-3; bit 15 - (8 * half + s) of rare0 <=> base s = mate * 4 + cc of that half
                 ISS_LOOKUP(0, rowf, 0, 0, 0, q0.x, ee.x, rare0)
@@ -1145,8 +1156,8 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 }
                 // (letters from the LDS tables: forward a byte of codes as it stands; reverse mate: read position c <-> genome
                 //  position pr + 7 - c, complemented)
-                uint2 base_f = {lut_at<0, 0>(lds_all, fb), lut_at<1, 0>(lds_all, fb)};
-                uint2 base_r = {lut_at<1, 1024>(lds_all, rbr), lut_at<0, 1024>(lds_all, rbr)};
+                uint2 base_f = {lut_at<0, 0>(lds0, fb), lut_at<1, 0>(lds0, fb)};
+                uint2 base_r = {lut_at<1, 1024>(lds0, rbr), lut_at<0, 1024>(lds0, rbr)};
                 if (!PLAIN && (fm | rm)) {  // IUPAC / lower-case letters: patch from the ASCII copy
                     for (int c = 0; c < 8; ++c) {
                         if ((fm >> c) & 1u) {
@@ -1162,6 +1173,10 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                     }
                 }
                 // (the padding bytes of the last superitem hold the clamped last row's values; nothing reads them)
+                // (Whole 128-byte lines per store instruction -- lanes l / l + 32 exchanging a forward for a reverse piece with
+                //  v_permlane32_swap, so that one store writes both halves of eight pairs' lines -- measured in round 4: 1.273 /
+                //  1.248 against 1.275 / 1.235 ms, interleaved on one box: nothing.  tools/store_bench.hip: the write stream
+                //  alone takes 0.56 ms per 5 M pairs in either form.)
                 uint4 *dst = reinterpret_cast<uint4 *>(A.out[0] + (size_t)out_b);  // two 16-byte pieces of the pair's 128-byte line
                 dst[0] = make_uint4(base_f.x, base_f.y, qual_f.x, qual_f.y);
                 dst[4] = make_uint4(base_r.x, base_r.y, qual_r.x, qual_r.y);

@@ -350,7 +350,7 @@ def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_ha
             row += n
         eng.fastq_emit_batch(forward_handle.fileno(), reverse_handle.fileno(), emit, w.cpu_number)  # one text job
         w.ordinal += row
-        if w.timings is not None:  # (measurement: when each batch was handed to the FASTQ pipeline, and how many pairs it held)
+        if getattr(w, "timings", None) is not None:  # (measurement: when each batch was handed to the FASTQ pipeline, and how many pairs it held)
             w.timings.setdefault("batches", []).append((time.perf_counter(), row))
         pending, cur = [], 0
 

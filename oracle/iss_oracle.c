@@ -36,7 +36,7 @@
  *   ISS_RNG_MT      two sequential MT19937 streams (CPython `random` + numpy),
  *                   consumed in the reference's exact order -> equals the
  *                   reference for a given seed;
- *   ISS_RNG_PHILOX  Philox4x32-10, every draw addressed by
+ *   ISS_RNG_PHILOX  Philox4x32 (7 rounds for the hot digit blocks, 10 otherwise: philox_at), every draw addressed by
  *                   (pair ordinal, attempt, kind, index, sub, word) -> equals the
  *                   HIP kernels (which use the same address map).
  * They feed the same semantic function draw for draw EXCEPT in two places, where the
@@ -131,11 +131,15 @@ static double res53(uint32_t w0, uint32_t w1) {
     return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
 }
 
-/* ------------------------------------------------------------ Philox4x32-10 */
-static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+/* ------------------------------------------------------------ Philox4x32-R
+ * Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11).  R = 10 is the generator's default;
+ * R = 7 is the fewest rounds the authors found to pass all of BigCrush ("Crush-resistant") and what the Philox address map
+ * uses for the HOT digit blocks (K_QM) since round 4 -- see philox_at and iss_kernels.hip.h (draw_block). */
+#define PHILOX_HOT_ROUNDS 7
+static void philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < rounds; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -149,8 +153,8 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-void iss_oracle_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
-    philox4x32_10(ctr, key, out);
+void iss_oracle_philox4x32(const uint32_t *ctr, const uint32_t *key, int rounds, uint32_t *out) {
+    philox4x32(ctr, key, rounds, out);
 }
 
 /* Draw kinds of the Philox address map (DESIGN.md "RNG address map").
@@ -238,7 +242,7 @@ static void philox_at(const iss_rng *r, int kind, uint32_t index, uint32_t sub, 
     ctr[1] = (uint32_t)((r->ordinal >> 32) & 0xffffu) | (r->attempt << 16);
     ctr[2] = ((uint32_t)kind << 24) | (index & 0xffffffu);
     ctr[3] = sub;
-    philox4x32_10(ctr, r->key, out);
+    philox4x32(ctr, r->key, kind == K_QM ? PHILOX_HOT_ROUNDS : 10, out);
 }
 
 #define STREAM_PY 0

@@ -66,7 +66,7 @@ def lib():
         L.iss_oracle_np_normal.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.iss_oracle_py_randbelow.restype = C.c_uint64
         L.iss_oracle_py_randbelow.argtypes = [C.c_void_p, C.c_uint64]
-        L.iss_oracle_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.iss_oracle_philox4x32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.iss_oracle_simulate.restype = C.c_int
         L.iss_oracle_simulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                           C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -85,12 +85,16 @@ def lib():
     return _lib
 
 
-def philox4x32_10(ctr, key):
+def philox4x32(ctr, key, rounds=10):
     c = np.asarray(ctr, dtype=np.uint32).copy()
     k = np.asarray(key, dtype=np.uint32).copy()
     out = np.zeros(4, dtype=np.uint32)
-    lib().iss_oracle_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    lib().iss_oracle_philox4x32(c.ctypes.data, k.ctypes.data, int(rounds), out.ctypes.data)
     return out
+
+
+def philox4x32_10(ctr, key):
+    return philox4x32(ctr, key, 10)
 
 
 def _as_bytes(seq):

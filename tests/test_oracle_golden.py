@@ -27,6 +27,12 @@ def test_philox_known_answers():
     assert [hex(x) for x in O.philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344],
                                             [0xA4093822, 0x299F31D0])] == [
         "0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    # Random123 kat_vectors, philox4x32-7 (the hot digit blocks of the address map: K_QM)
+    assert [hex(x) for x in O.philox4x32([0] * 4, [0] * 2, 7)] == ["0x5f6fb709", "0xd893f64", "0x4f121f81", "0x4f730a48"]
+    assert [hex(x) for x in O.philox4x32([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, 7)] == [
+        "0x5207ddc2", "0x45165e59", "0x4d8ee751", "0x8c52f662"]
+    assert [hex(x) for x in O.philox4x32([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], 7)] == [
+        "0x4dfccaba", "0x190a87f0", "0xc47362ba", "0xb6b5242a"]
 
 
 def test_mt_streams_match_cpython_and_numpy_taps():

@@ -9,7 +9,7 @@ __global__ __launch_bounds__(256) void k_philox(uint32_t *out, int n_calls, uint
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t acc = 0;
     for (int i = 0; i < n_calls; ++i) {
-        iss::u32x4 w = iss::philox4x32_10(t, (uint32_t)i, 3u << 24, 0, k0, k1);
+        iss::u32x4 w = iss::philox4x32<ROUNDS_N>(t, (uint32_t)i, 3u << 24, 0, k0, k1);
         acc ^= w.x ^ w.y ^ w.z ^ w.w;
     }
     out[t] = acc;
