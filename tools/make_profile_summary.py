@@ -48,10 +48,15 @@ def main(src, tag):
     fetch = m["FETCH_SIZE"] / n * 1024 * cal.get("fetch_factor", 2.0)
     write = m["WRITE_SIZE"] / calls[key]["WRITE_SIZE"] * 1024 * cal.get("write_factor", 1.0)
     valu = m.get("SQ_INSTS_VALU", 0.0) / max(calls[key].get("SQ_INSTS_VALU", 1), 1)
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import kernel_source_hash
+    # the build of the library the passes ran on: iss_build_id() as the profiled bench run printed it (bench.py compares it
+    # with the id of the library IT has loaded -- "traffic_fresh")
+    build_id = "unknown"
+    for log in glob.glob(src + "/*.log"):
+        for line in open(log, errors="replace"):
+            if line.startswith("{") and "library_build_id" in line:
+                build_id = json.loads(line).get("library_build_id", build_id)
     summary = {"kernel": "iss::k_main", "launches": n, "calibration": cal, "valu_insts_per_launch": valu,
-               "kernel_source_hash": kernel_source_hash(),
+               "library_build_id": build_id,
                "fetch_bytes_per_launch": fetch,
                "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
                "command": "bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads (5,000,000 pairs per step in one k_main launch)",
