@@ -216,12 +216,25 @@ struct DevGenome {
 };
 
 struct PairDesc {
-    int32_t fs;     // forward_start
-    int32_t re;     // reverse_end (reverse_start = re - RL)
+    int32_t fs;     // forward_start, low 32 bits
+    int32_t re;     // reverse_end (reverse_start = re - RL), low 32 bits
     uint32_t meta;  // bits 0-1 bin slot fwd, 2-3 bin slot rev, 4 / 5 fwd / rev window has IUPAC or lower-case letters,
-                    // 6 irregular geometry (custom fragment lengths only), 16-31 attempt
+                    // 6 irregular geometry (custom fragment lengths only), 8-11 / 12-15 bits 32-35 of fs / re (signed: round 4,
+                    // records of 2^31 - 1 bases and more -- the reference spills them to a memmap, generator.py:313-331),
+                    // 16-31 attempt
     int32_t isz;    // insert size
 };
+// coordinates of a pair: 36-bit signed (a record holds up to MAX_RECORD bases; a custom fragment length can make re negative)
+constexpr int64_t MAX_RECORD = ((int64_t)1 << 34) - 64;  // word offsets into the packed genome (16 bases / word) stay below 2^32 bytes
+__host__ __device__ __forceinline__ int64_t desc_fs(const PairDesc &d) {
+    return ((int64_t)((int32_t)(d.meta << 20) >> 28) << 32) | (uint32_t)d.fs;
+}
+__host__ __device__ __forceinline__ int64_t desc_re(const PairDesc &d) {
+    return ((int64_t)((int32_t)(d.meta << 16) >> 28) << 32) | (uint32_t)d.re;
+}
+__host__ __device__ __forceinline__ uint32_t desc_hi_bits(int64_t fs, int64_t re) {
+    return (((uint32_t)(fs >> 32) & 15u) << 8) | (((uint32_t)(re >> 32) & 15u) << 12);
+}
 
 // one VCF row of --store_mutations (iss/error_models/__init__.py:98-108, 197-221; generator.py:598-620)
 struct MutRecord {
@@ -377,10 +390,10 @@ __device__ __forceinline__ int fetch_ascii(const DevGenome &g, int64_t pos) {
 // -- template (k < RL) and adjust_seq_length padding (k >= RL) in one rule, __init__.py:141-155
 __device__ __forceinline__ int read_dir_base(const DevGenome &g, int o, const PairDesc &d, int k) {
     if (o == 0) {
-        const int64_t pos = (int64_t)d.fs + k;
+        const int64_t pos = desc_fs(d) + k;
         return pos < g.L ? fetch_ascii(g, pos) : 'A';
     }
-    const int64_t pos = (int64_t)d.re - 1 - k;
+    const int64_t pos = desc_re(d) - 1 - k;
     return pos >= 0 ? complement_ascii(fetch_ascii(g, pos)) : 'A';
 }
 
@@ -392,15 +405,16 @@ struct MateGeom {
     int64_t fe, rs;   // un-normalised forward end / reverse start (the padding rule uses them)
     int t_len;        // template length (<= RL)
 };
-__device__ __forceinline__ MateGeom mate_geom(int o, const PairDesc &d, int RL, int64_t L) {
+__device__ __forceinline__ MateGeom mate_geom(int o, const PairDesc &d, int RL, int64_t L, int64_t coord_off = 0) {
     MateGeom m;
-    m.fe = (int64_t)d.fs + RL;
-    m.rs = (int64_t)d.re - RL;
+    const int64_t fs = desc_fs(d) - coord_off, re = desc_re(d) - coord_off;
+    m.fe = fs + RL;
+    m.rs = re - RL;
     if (o == 0) {
-        m.lo = d.fs < L ? d.fs : L;
+        m.lo = fs < L ? fs : L;
         m.hi = m.fe < L ? m.fe : L;
     } else {
-        m.lo = m.rs; m.hi = d.re;
+        m.lo = m.rs; m.hi = re;
         if (m.lo < 0) { m.lo += L; if (m.lo < 0) m.lo = 0; } else if (m.lo > L) m.lo = L;
         if (m.hi < 0) { m.hi += L; if (m.hi < 0) m.hi = 0; } else if (m.hi > L) m.hi = L;
     }
@@ -435,13 +449,24 @@ __device__ __forceinline__ int count_le(const uint64_t *thr, int n, uint64_t m) 
     return lo;
 }
 
-// CPython _randbelow_with_getrandbits(n), 1 <= n < 2^32, words from the K_FS / K_RS streams
-__device__ __forceinline__ uint32_t randbelow(const Addr &a, uint32_t kind, uint32_t n) {
-    const int k = 32 - __clz(n);
+// CPython _randbelow_with_getrandbits(n), n >= 1, words from the K_FS / K_RS streams.  getrandbits(k) (_randommodule.c): k <= 32:
+// one word >> (32 - k); else 32-bit words from the least significant on, the top one shifted (records of 2^32 bases and more)
+__device__ __forceinline__ uint64_t randbelow(const Addr &a, uint32_t kind, uint64_t n) {
+    const int k = 64 - __clzll((long long)n);
     u32x4 blk = {0, 0, 0, 0};
-    for (uint32_t t = 0;; ++t) {
+    for (uint32_t t = 0;;) {
         if ((t & 3u) == 0) blk = draw_block(a, kind, t >> 2, 0);
-        const uint32_t r = word_of(blk, (int)(t & 3u)) >> (32 - k);
+        uint64_t r;
+        if (k <= 32) {
+            r = word_of(blk, (int)(t & 3u)) >> (32 - k);
+            ++t;
+        } else {
+            r = word_of(blk, (int)(t & 3u));
+            ++t;
+            if ((t & 3u) == 0) blk = draw_block(a, kind, t >> 2, 0);
+            r |= (uint64_t)(word_of(blk, (int)(t & 3u)) >> (64 - k)) << 32;
+            ++t;
+        }
         if (r < n) return r;
     }
 }
@@ -594,8 +619,8 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
     int64_t fs, rs, re;
     if (A.sequence_type == 0) {
         const int64_t width = L - frag;                     // generator.py:135
-        if (width > 0) fs = randbelow(a, K_FS, (uint32_t)width);
-        else fs = randbelow(a, K_FS, (uint32_t)(L - RL));   // generator.py:144
+        if (width > 0) fs = (int64_t)randbelow(a, K_FS, (uint64_t)width);
+        else fs = (int64_t)randbelow(a, K_FS, (uint64_t)(L - RL));   // generator.py:144
         rs = fs + RL + isz;                                 // generator.py:165
         re = rs + RL;
     } else {
@@ -604,7 +629,7 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
         re = L;
     }
     if (re > L) {                                           // generator.py:172-176
-        re = RL + (int64_t)randbelow(a, K_RS, (uint32_t)(L - RL));
+        re = RL + (int64_t)randbelow(a, K_RS, (uint64_t)(L - RL));
         rs = re - RL;
     }
     // a template cut by the genome end / a reverse start before the genome start: only with custom fragment
@@ -642,10 +667,10 @@ __device__ __forceinline__ void setup_pair(const DevModel &M, const DevGenome &g
         if (((fl_new & ~fl) >> o) & 1u) A.fix_list[atomicAdd(A.fix_count, 1u)] = (uint32_t)i * 2u + o;
     if (fl_new != fl || !ov_frag) A.flags[i] = fl_new;
     PairDesc d;
-    d.fs = (int32_t)(fs + coord_off);  // (batch calls: arena coordinates)
-    d.re = (int32_t)(re + coord_off);
+    d.fs = (int32_t)(uint32_t)(fs + coord_off);  // (batch calls: arena coordinates)
+    d.re = (int32_t)(uint32_t)(re + coord_off);
     d.meta = (uint32_t)(M.bin_slot[bin_f] & 3) | ((uint32_t)(M.bin_slot[4 + bin_r] & 3) << 2) | exc | (irregular ? 64u : 0u) |
-             (attempt << 16);
+             desc_hi_bits(fs + coord_off, re + coord_off) | (attempt << 16);
     d.isz = (int32_t)isz;
     desc[i] = d;
 }
@@ -799,7 +824,10 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
     uint32_t q = (e >> 8) & 0xffu;
     if ((e >> 16) == h) q = (uint32_t)quality_exact(M, a, o, (int)slot, p, h);
     // (most bases come here for their substitution test, their phred stands: a byte store into a line that has left the L2
-    //  is a read-modify-write in HBM -- the byte patches were measured at 0.26 of the kernel's 1.41 ms)
+    //  is a read-modify-write in HBM -- round 4's ablations, interleaved on one box: without the two byte stores of this
+    //  function 1.19 -> 1.10 ms for NovaSeq and 1.28 -> 1.02 ms for HiSeq; with them redirected into a 2 MB window that stays
+    //  in the L2: 1.12 / 1.05 -- the patches that MISS are what costs, and rounds of 32 instead of 64 did not land them
+    //  sooner for less: 1.21 / 1.30)
     if (q != q_hot) A.out[2 * o + 1][byte_off] = (uint8_t)q;
     // substitution test (__init__.py:94)
     const uint64_t thr = reinterpret_cast<const uint64_t *>(lds + M.tile_words)[q];
@@ -813,7 +841,7 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
     if (!PLAIN && !(INDEL && scripted)) {  // the letter may be IUPAC / lower case, the pair irregular (custom fragment lengths)
         const PairDesc d = desc[pair];
         if (A.has_frag && (d.meta & 64u)) return 0;  // irregular pair: the fix-up kernel builds its bases
-        base = fetch_ascii(g, o ? (int64_t)d.re - 1 - p : (int64_t)d.fs + p);
+        base = fetch_ascii(g, o ? desc_re(d) - 1 - p : desc_fs(d) + p);
         if (o) base = complement_ascii(base);
         bi = base_index(base);
         if (bi < 0) return 0;  // nucl.upper() in "RYWSMKHBVDN": left alone
@@ -834,7 +862,7 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
     int orig = base;
     if (INDEL && STORE_MUT && scripted) {
         const PairDesc d = desc[pair];
-        orig = fetch_ascii(g, o ? (int64_t)d.re - 1 - p : (int64_t)d.fs + p);
+        orig = fetch_ascii(g, o ? desc_re(d) - 1 - p : desc_fs(d) + p);
         if (o) orig = complement_ascii(orig);
     }
     rec.pair = (int32_t)(A.pair_base + pair); rec.mate = (int8_t)o; rec.type = 0; rec.position = (int16_t)p;
@@ -1065,8 +1093,12 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         uint32_t rowf = __umul24(d.meta & 3u, slot_b) + lane_row, rowf_e = rowf + gbytes;
         uint32_t rowr = __umul24((uint32_t)M.NB + ((d.meta >> 2) & 3u), slot_b) + lane_row, rowr_e = rowr + gbytes;
         const uint32_t s_lane = (uint32_t)T.s0 + j4;
-        int32_t pf = d.fs + (int32_t)(s_lane * 8u);           // genome position of the lane's first forward base
-        int32_t pr = d.re - 8 - (int32_t)(s_lane * 8u);       // lowest genome position of its 8 reverse bases
+        // genome position of the lane's first forward base / lowest genome position of its 8 reverse bases, as (word of the packed
+        // genome incl. its leading padding word, base within the word): positions need up to 35 bits (records of 2^31 bases and
+        // more), word numbers 32 -- and the base within the word is the same for every iteration of the pass
+        const int64_t pf64 = desc_fs(d) + (int64_t)(s_lane * 8u), pr64 = desc_re(d) - 8 - (int64_t)(s_lane * 8u);
+        uint32_t pfw = (uint32_t)((pf64 >> 4) + 1), prw = (uint32_t)((pr64 >> 4) + 1);
+        const uint32_t pfs = (uint32_t)pf64 & 15u, prs = (uint32_t)pr64 & 15u;
         uint32_t out_b = pair * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u;  // (tiles start at multiples of 4 superitems: whole lines)
         const bool regular = PLAIN || !(A.has_frag && (d.meta & 64u));  // irregular pairs are built by the fix-up kernel
         const uint32_t tag0 = (pass << (19u + it_bits)) | (lane << 13) | ((d.meta & 15u) << 8) | has_ev;
@@ -1078,7 +1110,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 //      first, used last (the wait for them would otherwise also be a wait for the previous stores)
                 uint2 gf = {0u, 0u}, gr = {0u, 0u};
                 // INDEL: this piece of each mate per its script row -- shifted template (the window moves) or explicit codes
-                int32_t pf_e = pf, pr_e = pr;
+                uint32_t pfw_e = pfw, prw_e = prw, pfs_e = pfs, prs_e = prs;
                 uint32_t code_f = 0u, code_r = 0u;
                 bool ex_f = false, ex_r = false;
                 if (INDEL) {
@@ -1090,16 +1122,17 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                     const uint32_t bf = sc_f.x & 0xffu, br = sc_r.x & 0xffu;
                     ex_f = bf >= 128u;
                     ex_r = br >= 128u;
-                    pf_e = pf + (ex_f ? 0 : (int32_t)bf - 64);
-                    pr_e = pr - (ex_r ? 0 : (int32_t)br - 64);
+                    const int32_t tf = (int32_t)pfs + (ex_f ? 0 : (int32_t)bf - 64), tr = (int32_t)prs - (ex_r ? 0 : (int32_t)br - 64);
+                    pfw_e = pfw + (uint32_t)(tf >> 4); pfs_e = (uint32_t)tf & 15u;
+                    prw_e = prw + (uint32_t)(tr >> 4); prs_e = (uint32_t)tr & 15u;
                     code_f = (uint32_t)((((uint64_t)sc_f.w << 32) | sc_f.z) >> (bf & 63u));  // (128 + 16 k) & 63 = 16 k
                     code_r = (uint32_t)((((uint64_t)sc_r.w << 32) | sc_r.z) >> (br & 63u));
                     sc_f.x = __builtin_amdgcn_alignbit(sc_f.y, sc_f.x, 8u); sc_f.y >>= 8;
                     sc_r.x = __builtin_amdgcn_alignbit(sc_r.y, sc_r.x, 8u); sc_r.y >>= 8;
                 }
                 if (regular) {
-                    gf = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pf_e >> 4) + 1) << 2));
-                    gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(uint32_t)(((pr_e >> 4) + 1) << 2));
+                    gf = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(pfw_e << 2));
+                    gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(prw_e << 2));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (it == 0u) {  // (every lane with work in this tile has an iteration 0; the others need no descriptor)
@@ -1142,17 +1175,18 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 uint2 qual_f = {quals(0), quals(8)}, qual_r = {quals(4), quals(12)};
                 // ---- template bases
                 uint32_t fm = 0, rm = 0;
-                uint32_t fb = funnel_r(gf.x, gf.y, (uint32_t)(pf_e & 15) * 2);
-                uint32_t rbr = funnel_r(gr.x, gr.y, (uint32_t)(pr_e & 15) * 2);
+                uint32_t fb = funnel_r(gf.x, gf.y, pfs_e * 2u);
+                uint32_t rbr = funnel_r(gr.x, gr.y, prs_e * 2u);
                 if (INDEL) { fb = ex_f ? code_f : fb; rbr = ex_r ? code_r : rbr; }
                 windows = __builtin_amdgcn_perm(rbr ^ 0x5555u, fb, 0x05040100u);  // fb[15:0] | complemented (code ^ 1) rb[15:0] << 16
                 if (!PLAIN && regular && (d.meta & 0x30u)) {  // only pairs whose windows hold IUPAC / lower-case letters (k_setup)
                     // (a scripted mate lies in a record of plain A/C/G/T -- k_indel_script -- so pf_e / pr_e differ from pf / pr
                     //  only where the mask is clear)
-                    const uint32_t *mw = g.mask + (pf_e >> 5);
-                    fm = funnel_r(mw[0], mw[1], (uint32_t)(pf_e & 31)) & 0xffu;
-                    const uint32_t *nw = g.mask + (pr_e >> 5);
-                    rm = funnel_r(nw[0], nw[1], (uint32_t)(pr_e & 31)) & 0xffu;
+                    // (genome position = 16 * (word - 1) + base within the word; mask word = position >> 5)
+                    const uint32_t *mw = g.mask + ((int32_t)(pfw_e - 1u) >> 1);
+                    fm = funnel_r(mw[0], mw[1], ((pfw_e - 1u) & 1u) * 16u + pfs_e) & 0xffu;
+                    const uint32_t *nw = g.mask + ((int32_t)(prw_e - 1u) >> 1);
+                    rm = funnel_r(nw[0], nw[1], ((prw_e - 1u) & 1u) * 16u + prs_e) & 0xffu;
                 }
                 // (letters from the LDS tables: forward a byte of codes as it stands; reverse mate: read position c <-> genome
                 //  position pr + 7 - c, complemented)
@@ -1161,12 +1195,12 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 if (!PLAIN && (fm | rm)) {  // IUPAC / lower-case letters: patch from the ASCII copy
                     for (int c = 0; c < 8; ++c) {
                         if ((fm >> c) & 1u) {
-                            const uint32_t ch = g.ascii[(int64_t)pf_e + c];
+                            const uint32_t ch = g.ascii[(int64_t)(int32_t)(pfw_e - 1u) * 16 + pfs_e + c];
                             uint32_t &w = c < 4 ? base_f.x : base_f.y;
                             w = (w & ~(0xffu << (8 * (c & 3)))) | (ch << (8 * (c & 3)));
                         }
                         if ((rm >> (7 - c)) & 1u) {
-                            const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)pr_e + 7 - c]);
+                            const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)(int32_t)(prw_e - 1u) * 16 + prs_e + 7 - c]);
                             uint32_t &w = c < 4 ? base_r.x : base_r.y;
                             w = (w & ~(0xffu << (8 * (c & 3)))) | (ch << (8 * (c & 3)));
                         }
@@ -1185,8 +1219,8 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
             push(rare0, tag0 | (it << 19), windows);
             rowf += 8u * gs_b; rowf_e += 8u * gs_b;
             rowr += 8u * gs_b; rowr_e += 8u * gs_b;
-            pf += 32;
-            pr -= 32;
+            pfw += 2u;
+            prw -= 2u;
             out_b += 128u;
         }
     }
@@ -1467,10 +1501,10 @@ __global__ __launch_bounds__(SINGLE ? 64 * SC_WAVES1 : 64 * SC_WAVES, SINGLE ? 8
     // software pipeline of the block loop, three deep: the list entry is requested three blocks ahead, what hangs on the read
     // number (the descriptor's two coordinates, the events of a read with more than two) two blocks ahead, the window of the
     // packed genome -- it hangs on the descriptor -- one block ahead: every load of the chain has a whole block to arrive
-    struct Coords { int32_t fs, re; };
+    struct Coords { int64_t fs, re; };
     auto coords_of = [&](const uint4 &rec) {
-        const PairDesc *dp = desc + ((rec.x == NO_READ ? 0u : rec.x) >> 1);
-        return Coords{dp->fs, dp->re};
+        const PairDesc dd = desc[(rec.x == NO_READ ? 0u : rec.x) >> 1];
+        return Coords{desc_fs(dd), desc_re(dd)};
     };
     auto events_of = [&](const uint4 &rec, uint4 &ea, uint4 &eb) {
         ea = make_uint4(0u, 0u, 0u, 0u); eb = ea;
@@ -1481,7 +1515,7 @@ __global__ __launch_bounds__(SINGLE ? 64 * SC_WAVES1 : 64 * SC_WAVES, SINGLE ? 8
     };
     uint32_t wn[WWM];
     auto request_window = [&](const uint4 &rec, const Coords &c) {
-        const int64_t wl = (rec.x != NO_READ && (rec.x & 1u)) ? (int64_t)c.re - WIN : (int64_t)c.fs;
+        const int64_t wl = (rec.x != NO_READ && (rec.x & 1u)) ? c.re - WIN : c.fs;
         // (16 bytes per load instruction, 4-byte aligned: a lane's window is 1-2 cache lines and every instruction brings 64
         //  lanes' lines through the L1 -- twelve single words per lane were measured at twice the kernel's time)
         const uint4 *src = reinterpret_cast<const uint4 *>(packed_b + (size_t)(((wl >> 4) + 1) << 2));
@@ -1509,8 +1543,7 @@ __global__ __launch_bounds__(SINGLE ? 64 * SC_WAVES1 : 64 * SC_WAVES, SINGLE ? 8
         const uint32_t rd = listed ? rec0.x : 0u;
         const uint32_t pair = rd >> 1;
         const int o = (int)(rd & 1u);
-        PairDesc d;
-        d.fs = c0.fs; d.re = c0.re;
+        const int64_t d_fs = c0.fs, d_re = c0.re;
         const uint32_t cnt = listed ? rec0.w : 0u;
         uint32_t e[EV_K];
         e[0] = ea0.x; e[1] = ea0.y; e[2] = ea0.z; e[3] = ea0.w; e[4] = eb0.x; e[5] = eb0.y; e[6] = eb0.z; e[7] = eb0.w;
@@ -1544,7 +1577,7 @@ __global__ __launch_bounds__(SINGLE ? 64 * SC_WAVES1 : 64 * SC_WAVES, SINGLE ? 8
         // window: tokens 0 .. WIN - 1 = genome positions fs .. fs + WIN - 1 (forward) / re - 1 down to re - WIN (reverse).  Beyond
         // the record's ends the reference pads with 'A' (__init__.py:141-155), which k_main's windows cannot: such reads -- a few
         // in 10^5 -- are the fix-up kernel's
-        const int64_t w_lo = o ? (int64_t)d.re - WIN : (int64_t)d.fs;
+        const int64_t w_lo = o ? d_re - WIN : d_fs;
         auto to_fixup = [&]() {
             if (!(atomicOr(&A.flags[pair], 1u << o) & (1u << o))) A.fix_list[atomicAdd(A.fix_count, 1u)] = rd;
             A.ev_count[rd] = 0u;  // no script
@@ -1553,7 +1586,7 @@ __global__ __launch_bounds__(SINGLE ? 64 * SC_WAVES1 : 64 * SC_WAVES, SINGLE ? 8
         uint32_t *R = wave0 + lane * RW, *runs = R, *win = R + (SINGLE ? 1 : AP_RUNS);
         uint16_t *let = reinterpret_cast<uint16_t *>(win + WW);
         const int64_t wpos = (w_lo >> 4) << 4;  // genome position of bit 0 of the window
-        const int t0pos = (int)((o ? (int64_t)d.re - 1 : (int64_t)d.fs) - wpos);  // window position of token 0 (token t: t0pos +/- t)
+        const int t0pos = (int)((o ? d_re - 1 : d_fs) - wpos);  // window position of token 0 (token t: t0pos +/- t)
         if (ok) {
 #pragma unroll
             for (int k = 0; k < WWM; ++k) if (k < WW) win[k] = wc[k];  // (requested a block ago)
@@ -1932,14 +1965,14 @@ __global__ __launch_bounds__(64 * FIX_WAVES, 5) void k_indel_fixup(DevModel M, D
         const int o = (int)(e & 1u);
         PairDesc d = desc[pair];
         DevGenome gl = g;  // the record of the read: the launch's genome, or its slice of the arena (batch calls)
+        int64_t coord_off = 0;
         if (A.items) {
             const BatchItem it = A.items[batch_item_of(A, A.pair_base + pair)];
             gl = batch_genome(g, it);
-            d.fs -= (int32_t)it.off;
-            d.re -= (int32_t)it.off;
+            coord_off = it.off;
         }
         const Addr a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
-        const MateGeom geo = mate_geom(o, d, RL, gl.L);
+        const MateGeom geo = mate_geom(o, d, RL, gl.L, coord_off);
         uint8_t *out_base = A.out[2 * o] + (size_t)pair * M.row;
         const uint8_t *out_qual = A.out[2 * o + 1] + (size_t)pair * M.row;
         // ---- phase 0: the error-test digits, one Philox block per LANE (a K_QM block holds those of 8 positions)

@@ -1196,7 +1196,9 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
 
 int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_t *genome_id) {
     if (!ctx || !ascii || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload: NULL argument");
-    if (length < 1 || length >= (int64_t)0x7fffffff) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^31-2]");
+    // (records of 2^31 - 1 bases and more: the reference spills them to a memmap, generator.py:313-331; here coordinates are
+    //  36-bit and word offsets into the packed genome 32-bit -- iss::MAX_RECORD; MT mode keeps the 2^31 limit: iss_generate_mt)
+    if (length < 1 || length > iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^34 - 64]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // ASCII -> HBM, then packed on the device (k_pack_genome).  One readable padding word in front
     // (k_main's funnel shifts touch positions >= -3) and three behind.
@@ -1277,7 +1279,9 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
 
 int iss_genome_upload_packed(iss_ctx *ctx, const uint32_t *codes, int64_t length, int32_t codes_on_device, int32_t *genome_id) {
     if (!ctx || !codes || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload_packed: NULL argument");
-    if (length < 1 || length >= (int64_t)0x7fffffff) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^31-2]");
+    // (records of 2^31 - 1 bases and more: the reference spills them to a memmap, generator.py:313-331; here coordinates are
+    //  36-bit and word offsets into the packed genome 32-bit -- iss::MAX_RECORD; MT mode keeps the 2^31 limit: iss_generate_mt)
+    if (length < 1 || length > iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^34 - 64]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n_mk = (size_t)(length + 31) / 32, n_pk = 2 * n_mk, n_in = (size_t)(length + 15) / 16;
     Genome G;
@@ -1996,9 +2000,9 @@ int iss_output_download_coords(iss_ctx *ctx, int64_t first_pair, int64_t n_pairs
             const size_t k = (size_t)(std::upper_bound(ctx->last_first.begin(), ctx->last_first.end(), r) - ctx->last_first.begin()) - 1;
             off = ctx->last_off[k];
         }
-        coords[4 * i + 0] = tmp[i].fs - off;
-        coords[4 * i + 1] = (int64_t)tmp[i].re - off - ctx->M.RL;
-        coords[4 * i + 2] = tmp[i].re - off;
+        coords[4 * i + 0] = iss::desc_fs(tmp[i]) - off;
+        coords[4 * i + 1] = iss::desc_re(tmp[i]) - off - ctx->M.RL;
+        coords[4 * i + 2] = iss::desc_re(tmp[i]) - off;
         coords[4 * i + 3] = tmp[i].isz;
     }
     return 0;
@@ -2098,6 +2102,8 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
     const Genome &G = ctx->genomes[genome_id];
     const iss::DevModel &M = ctx->M;
+    if (G.L >= (int64_t)0x7fffffff)
+        return fail(ctx, ISS_E_INVALID, "iss_generate_mt: records of 2^31 - 1 bases and more are the Philox path's (iss_generate)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     const int64_t CH = 8192;

@@ -98,6 +98,8 @@ def philox4x32_10(ctr, key):
 
 
 def _as_bytes(seq):
+    if isinstance(seq, np.ndarray) and seq.dtype == np.uint8 and seq.flags["C_CONTIGUOUS"]:
+        return seq  # (as it is: a record of 2^31 bases is not copied twice)
     if isinstance(seq, str):
         seq = seq.encode("ascii")
     return np.frombuffer(bytes(seq), dtype=np.uint8).copy()

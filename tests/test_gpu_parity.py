@@ -798,7 +798,7 @@ def test_engine_limits_match_oracle(RL, n_q, n_isize, n):
 
 
 def test_genome_positions_beyond_2_30():
-    """A 1.2 Gbp record (the engine takes genomes below 2^31 bp): 32-bit position arithmetic near its limit, on both RNG
+    """A 1.2 Gbp record (MT mode takes genomes below 2^31 bp): position arithmetic near that limit, on both RNG
     paths, against the oracle at the pairs with the largest / smallest coordinates and a random sample."""
     from insilicoseq_amd.engine import ReadEngine
     from oracle import oracle as O
@@ -831,6 +831,54 @@ def test_genome_positions_beyond_2_30():
         exp = orc.simulate(O.Rng().seed_mt(9), gs, 1500)
         for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
             assert np.array_equal(got[k], exp[k]), ("mt", k)
+
+
+@pytest.mark.parametrize("model,indel,mixed,L", [("novaseq", (0.001, 0.003), False, 2**31 + 3_000_001), ("hiseq", None, True, 2**32 + 70_000_003)])
+def test_records_of_2_31_bases_and_more(model, indel, mixed, L):
+    """Round 4: records of 2^31 - 1 bases and more (the reference spills them to a memmap and carries on:
+    iss/generator.py:313-331, util.py:271-304).  Coordinates are 36-bit in the pair descriptors, `random.randrange` draws a
+    second word once the record passes 2^32 (CPython's getrandbits), k_main addresses the packed genome by 32-bit WORD numbers.
+    A 2.15 Gbp record on the indel-heavy path (scripts at coordinates beyond 2^31) and a 4.36 Gbp record with IUPAC / lower-case
+    stretches (mask and ASCII indexing up there; two-word randrange): the pairs with the largest and smallest coordinates and a
+    random sample against the oracle, coordinates included.  The content has a prime period, so a coordinate off by a power of
+    two reads other letters.  MT mode keeps the 2^31 limit and says so."""
+    from insilicoseq_amd._native import EngineError
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    period = 67_108_859  # prime
+    if mixed:
+        block = np.frombuffer(mixed_genome(5, period).encode(), dtype=np.uint8)
+    else:
+        block = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.RandomState(5).randint(0, 4, size=period)]
+    g = np.ascontiguousarray(np.tile(block, L // period + 1)[:L])
+    dense = dense_model(model, indel)
+    orc = O.Oracle(dense)
+    n = 150_000
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(g)
+        eng.generate(gid, n, first_ordinal=7, seed=13)
+        eng.synchronize()
+        coords = eng.coords(0, n)
+        assert int(coords[:, 0].max()) >= 2**31 and int(coords[:, 2].max()) <= L and int(coords[:, 0].min()) >= 0
+        if L > 2**32:
+            assert int((coords[:, 0] >= 2**32).sum()) > n // 100
+        order = np.argsort(coords[:, 2])
+        picks = list(order[-24:]) + list(order[:8]) + list(np.random.RandomState(2).randint(0, n, 32))
+        picks += [int(i) for i in np.flatnonzero((coords[:, 0] < 2**31) & (coords[:, 2] > 2**31))[:8]]  # pairs across 2^31
+        for i in picks:
+            got = eng.download(int(i), 1)
+            exp = orc.simulate(O.Rng().seed_philox(13), g, 1, first_ordinal=7 + int(i), want_coords=True)
+            assert exp["status"] == 0
+            assert np.array_equal(coords[i], exp["coords"][0]), int(i)
+            for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                assert np.array_equal(got[k], exp[k]), (int(i), k)
+        if indel is not None:
+            assert eng.stats_read()["scripted_reads"] > n // 2
+        eng.seed_mt(9)
+        with pytest.raises(EngineError):
+            eng.generate_mt(gid, 10)
 
 
 def _fuzz_config(k):

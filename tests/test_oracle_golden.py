@@ -422,3 +422,16 @@ def test_event_process_exact_synthetic_models(case):
     for o in (0, 1):
         n, worst = _event_process_exact(d, o, all_pairs=True)
         assert worst <= bound, (case, o, worst)
+
+
+def test_randbelow_beyond_2_32_equals_cpython():
+    """Records of 2^32 bases and more (the reference takes them: generator.py:313-331): `random.randrange(n)` is
+    `_randbelow_with_getrandbits(n)` with getrandbits(k > 32) built from 32-bit words, least significant first, the top one
+    shifted (_randommodule.c).  The oracle's restatement against CPython itself, in stream order."""
+    import random
+
+    for seed, n in ((1, 2**32), (2, 2**32 + 1), (3, 2**33 - 7), (4, 3 * 2**31 + 12345), (5, 2**34 - 65), (6, 2**31 - 2), (7, 2**31 + 5)):
+        random.seed(seed)
+        want = [random.randrange(n) for _ in range(200)]
+        r = O.Rng().seed_py(seed)
+        assert [r.py_randbelow(n) for _ in range(200)] == want, (seed, n)
