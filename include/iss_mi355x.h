@@ -210,7 +210,7 @@ typedef struct {
  * counts 256-row reservation chunks per wavefront, so reserve generously: ~2 rows per expected mutation + 64 k);
  * iss_mutations_download waits for the call, drops the rows of reads the indel fix-up rebuilt, sorts into the
  * reference's order (pair, mate, indel rows in loop order, substitution rows by position) and returns them.
- * ISS_E_NOMEM when the buffer was too small for the call. */
+ * ISS_E_NOMEM when the buffer was too small for the call; *n_rows is then the number of row slots the call asked for. */
 int iss_mutations_reserve(iss_ctx *ctx, int64_t capacity);
 int iss_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, int64_t *n_rows);
 

@@ -2412,8 +2412,10 @@ int iss_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity, in
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     uint32_t reserved = 0;
     HIP_TRY(ctx, hipMemcpy(&reserved, ctx->d_pmut_count, sizeof reserved, hipMemcpyDeviceToHost));
-    if ((int64_t)reserved > ctx->pmut_cap)
+    if ((int64_t)reserved > ctx->pmut_cap) {
+        if (n_rows) *n_rows = (int64_t)reserved;  // (the slots the call asked for: what a retry has to reserve)
         return fail(ctx, ISS_E_NOMEM, "mutation buffer too small for this call (reserve more with iss_mutations_reserve)");
+    }
     std::vector<iss::MutRecord> rows(reserved);
     std::vector<uint32_t> flags((size_t)ctx->last_n);
     if (reserved) HIP_TRY(ctx, hipMemcpy(rows.data(), ctx->d_pmut, (size_t)reserved * sizeof(iss::MutRecord), hipMemcpyDeviceToHost));

@@ -221,8 +221,15 @@ class ReadEngine(object):
         if buf is None or buf.size < cap:  # (one landing buffer per engine: tens of MB, not per call)
             buf = self._pmut_buf = np.empty(cap, dtype=MUT_DTYPE)
         n = C.c_int64(0)
-        self._check(self._lib.iss_mutations_download(self._ctx, buf.ctypes.data, cap, C.byref(n)))
+        rc = self._lib.iss_mutations_download(self._ctx, buf.ctypes.data, cap, C.byref(n))
+        self.mutation_slots_needed = n.value if rc == _native.E_NOMEM else 0  # (what a retry has to reserve)
+        self._check(rc)
         return buf[: n.value].copy()
+
+    @property
+    def mutations_capacity(self):
+        """Row slots reserved by mutations_reserve()."""
+        return int(getattr(self, "_pmut_cap", 0))
 
     # ------------------------------------------------------------------ reference-compatible MT mode
     def seed_mt(self, seed):

@@ -291,10 +291,16 @@ def mutation_rows(eng, regenerate):
         except _native.EngineError as e:
             if e.code != _native.E_NOMEM:
                 raise
-            cap = int(getattr(eng, "_pmut_cap", 0))
+            cap = eng.mutations_capacity
             if cap >= 0x7fffffff:
                 raise
-            eng.mutations_reserve(min(2 * max(cap, 1 << 16), 0x7fffffff))
+            # the call says how many slots it asked for: reserve them (+ 1/8, the kernels hand slots out in 256-row chunks
+            # per wavefront) in ONE step and repeat the call once
+            need = int(getattr(eng, "mutation_slots_needed", 0)) or 2 * max(cap, 1 << 16)
+            new_cap = min(need + need // 8 + (1 << 16), 0x7fffffff)
+            logging.getLogger(__name__).info("mutation rows: %d slots reserved, the call needs %d: reserving %d and repeating it" % (
+                cap, need, new_cap))
+            eng.mutations_reserve(new_cap)
             regenerate()
 
 

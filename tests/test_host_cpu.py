@@ -598,27 +598,32 @@ def test_batched_worker_loop_falls_back_to_single_calls():
 
 
 def test_mutation_rows_retry_on_overflow():
-    """A --store_mutations batch that overflows its row buffer (ISS_E_NOMEM) is repeated with twice the reservation
-    instead of aborting the worker (generation is a pure function of seed and ordinal); other errors propagate."""
+    """A --store_mutations batch that overflows its row buffer (ISS_E_NOMEM) is repeated ONCE with the reservation the call
+    itself asked for (iss_mutations_download reports the slots needed) instead of aborting the worker (generation is a pure
+    function of seed and ordinal); an engine that does not say how many doubles; other errors propagate."""
     import insilicoseq_amd.generator as G
     from insilicoseq_amd import _native
 
     class FakeEngine:
-        def __init__(self, need):
-            self._pmut_cap, self.need, self.calls = 1 << 17, need, []
+        def __init__(self, need, tells=True):
+            self.mutations_capacity, self.need, self.calls, self.tells = 1 << 17, need, [], tells
 
         def mutations(self):
-            if self._pmut_cap < self.need:
+            if self.mutations_capacity < self.need:
+                self.mutation_slots_needed = self.need if self.tells else 0
                 raise _native.EngineError(_native.E_NOMEM, "mutation rows overflow")
             return "rows"
 
         def mutations_reserve(self, cap):
             self.calls.append(("reserve", cap))
-            self._pmut_cap = cap
+            self.mutations_capacity = cap
 
     eng, regen = FakeEngine(1 << 19), []
     assert G.mutation_rows(eng, lambda: regen.append(1)) == "rows"
-    assert eng.calls == [("reserve", 1 << 18), ("reserve", 1 << 19)] and len(regen) == 2
+    assert len(eng.calls) == 1 and (1 << 19) <= eng.calls[0][1] <= (1 << 20) and len(regen) == 1
+    eng, regen = FakeEngine(1 << 19, tells=False), []
+    assert G.mutation_rows(eng, lambda: regen.append(1)) == "rows"
+    assert len(regen) == len(eng.calls) >= 1 and eng.mutations_capacity >= 1 << 19
 
     class Broken(FakeEngine):
         def mutations(self):
