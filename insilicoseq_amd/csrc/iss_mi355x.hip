@@ -969,7 +969,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     // Guide bits and position tiles, chosen together by a small cost model fitted to measurements (DESIGN.md section 7:
     // NovaSeq / HiSeq / NextSeq / MiSeq sweeps): a workgroup keeps ONE tile of tables in LDS (<= 158 KB: one workgroup per
     // CU is as fast as two, bigger tiles are what pays), the work of a pass has a fixed part next to its ceil(TS / 4)
-    // iterations, and every base the two-probe lookup cannot decide costs about eight hot bases.
+    // iterations, and every base the two-probe lookup cannot decide costs about twelve hot bases.
     auto tiles_needed = [&](int gb, int *ts_out) {  // fewest tiles whose tables fit one workgroup per CU
         const size_t gs = 4 * ((size_t)(1 << gb) / 4 + s_max) + 1;
         for (int nt = 1; nt <= M.S; ++nt) {
@@ -989,7 +989,10 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         for (int gb = 6; gb <= 8; ++gb) {
             int ts = 0;
             if (!tiles_needed(gb, &ts)) continue;
-            const double cost = (1.0 + 8.0 * more_rate(gb)) * (1.0 + 0.3 / (double)((ts + 3) / 4));
+            // (round 4 refit -- tools/gpu_round4_i.sh, guide bits 6 / 7 / 8 for four model families: a base the two-probe lookup
+            //  cannot decide costs about TWELVE hot bases since its late phred patch is a read-modify-write in HBM (round 2's
+            //  fit said eight): HiSeq now takes 8 guide bits and two tiles, 1.37 -> 1.24 ms per 5 M pairs)
+            const double cost = (1.0 + 12.0 * more_rate(gb)) * (1.0 + 0.3 / (double)((ts + 3) / 4));
             if (cost < best - 1e-9) { best = cost; M.GB = gb; }
         }
     }
