@@ -32,7 +32,7 @@ def main(src, tag):
              "kernel,counter,total,per_dispatch,dispatches"]
     for k in sorted(acc):
         for c in sorted(acc[k]):
-            lines.append("%s,%s,%.6g,%.6g,%d" % (k, c, acc[k][c], acc[k][c] / calls[k][c], calls[k][c]))
+            lines.append('"%s",%s,%.6g,%.6g,%d' % (k, c, acc[k][c], acc[k][c] / calls[k][c], calls[k][c]))  # (template names hold commas)
     open(os.path.join(out_dir, tag + "_pmc.csv"), "w").write("\n".join(lines) + "\n")
     if not any("FETCH_SIZE" in acc[k] for k in acc):  # tools/prof_indel.sh: SQ counters only, no traffic pass
         return
