@@ -989,7 +989,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
         for (int gb = 6; gb <= 8; ++gb) {
             int ts = 0;
             if (!tiles_needed(gb, &ts)) continue;
-            // (round 4 refit -- tools/gpu_round4_i.sh, guide bits 6 / 7 / 8 for four model families: a base the two-probe lookup
+            // (round 4 refit -- tools/guide_bits_sweep.sh, guide bits 6 / 7 / 8 for four model families: a base the two-probe lookup
             //  cannot decide costs about TWELVE hot bases since its late phred patch is a read-modify-write in HBM (round 2's
             //  fit said eight): HiSeq now takes 8 guide bits and two tiles, 1.37 -> 1.24 ms per 5 M pairs)
             const double cost = (1.0 + 12.0 * more_rate(gb)) * (1.0 + 0.3 / (double)((ts + 3) / 4));
