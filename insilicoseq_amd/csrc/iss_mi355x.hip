@@ -217,6 +217,7 @@ struct iss_ctx {
     double light_below = 2e-3;  // ISS_LIGHT_INDELS (read once, at iss_ctx_create): models whose reads have an event less often are "light"
     int env_tiles = 0, env_guide_bits = 0;  // ISS_TILES / ISS_GUIDE_BITS: tuning aids of the tile sweeps (0: the cost model decides)
     bool debug_model = false;               // ISS_DEBUG_MODEL
+    int64_t env_chunk_pairs = 0;            // ISS_CHUNK_PAIRS: pairs per launch chunk at most (tests: a call of many chunks)
     double mt_guard = 1e-6;                 // ISS_MT_GUARD: how close to a rounding boundary the device still decides (tests widen it)
     bool light = false;  // reads with an indel are rare (< ISS_LIGHT_INDELS of the reads, default 2e-3): all of them take k_indel_fixup
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
@@ -301,6 +302,7 @@ void read_switches(iss_ctx *ctx) {
     ctx->env_guide_bits = (e = getenv("ISS_GUIDE_BITS")) ? std::min(8, std::max(6, atoi(e))) : 0;
     ctx->mt_guard = (e = getenv("ISS_MT_GUARD")) ? atof(e) : 1e-6;
     ctx->debug_model = getenv("ISS_DEBUG_MODEL") != nullptr;
+    ctx->env_chunk_pairs = (e = getenv("ISS_CHUNK_PAIRS")) ? std::max<int64_t>(1, atoll(e)) : 0;
 }
 
 void free_model(iss_ctx *ctx) {
@@ -1452,6 +1454,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
     const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)1 << 31) / std::max(M.n_scan, 1),
                                                                                       (((int64_t)1 << 32) - 1) / M.row),
                                                                     max_passes * iss::MAIN_PAIRS * min_tile_wg));
+    const int64_t chunk_pairs = ctx->env_chunk_pairs ? std::min(max_chunk, ctx->env_chunk_pairs) : max_chunk;
     if (ctx->d_pmut) {  // rows of THIS call only
         ctx->d_pmut_count = reinterpret_cast<uint32_t *>(ctx->fix_count) + 60;  // +240 B of the scratch block
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_pmut, 0xff, (size_t)ctx->pmut_cap * sizeof(iss::MutRecord), ctx->stream));
@@ -1475,7 +1478,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
     }
     ctx->inputs_pending = false;
     for (int64_t done = 0; done < n_pairs;) {
-        const int64_t n = std::min(max_chunk, n_pairs - done);
+        const int64_t n = std::min(chunk_pairs, n_pairs - done);
         const int64_t row0 = out_first_pair + done;
         iss::RunArgs A{};
         A.n_pairs = n;

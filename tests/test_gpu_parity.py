@@ -1374,3 +1374,36 @@ def test_exact_path_store_order_stress():
             exp = orc.simulate(O.Rng().seed_philox(77), genome, 64, first_ordinal=5 + int(start))
             for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
                 assert np.array_equal(got[key], exp[key]), (int(start), key)
+
+
+@pytest.mark.parametrize("ahead", ["1", "0"])
+@pytest.mark.parametrize("model,indel", [("novaseq", (0.001, 0.003)), ("novaseq", None), ("miseq-legacy", None)])
+def test_calls_of_many_chunks_reuse_the_counter_rings(model, indel, ahead, monkeypatch):
+    """Regression (round-3 advice): the fix-up / read-list counters live in rings of 16 slots indexed by the chunk number, and
+    the kernels in front of k_main run on the setup stream, ahead of the main stream.  A call of more than 16 chunks (here 40
+    and 25: ISS_CHUNK_PAIRS) comes back to a slot while the chunk that used it last may still be waiting on the main stream:
+    the setup stream now waits for that chunk's last kernel before it clears the slot.  Two calls back to back into the same
+    rows, then the oracle: every byte, and the coordinates."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    monkeypatch.setenv("ISS_SETUP_AHEAD", ahead)
+    monkeypatch.setenv("ISS_CHUNK_PAIRS", "1500")
+    dense = dense_model(model, indel)
+    genome = random_genome(88, 90000)
+    orc = O.Oracle(dense)
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gid = eng.add_genome(genome)
+        eng.generate(gid, 60000, first_ordinal=0, seed=21)
+        eng.generate(gid, 37000, first_ordinal=1000, seed=22)  # (no synchronisation in between)
+        eng.synchronize()
+        got, cg = eng.download(0, 37000), eng.coords(0, 37000)
+        exp = orc.simulate(O.Rng().seed_philox(22), genome, 37000, first_ordinal=1000, want_coords=True)
+        for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(got[key], exp[key]), key
+        assert np.array_equal(np.asarray(cg), exp["coords"])
+        tail = eng.download(37000, 23000)  # rows 37000.. still hold the FIRST call's pairs
+        exp1 = orc.simulate(O.Rng().seed_philox(21), genome, 23000, first_ordinal=37000)
+        for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(tail[key], exp1[key]), ("first call", key)
