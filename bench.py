@@ -75,8 +75,9 @@ def run_leg(args, label, model, reads, n_genomes, strong, indel, steps, warmup, 
             dense.dele[:] = indel[1]
         genomes = synthetic_genomes(n_genomes, GENOME_LEN, 123)
     t_b = time.time()
+    binfo = {}
     dense, grefs = broadcast_model_and_genomes(dense, genomes, dist, device=torch.device("cuda", local_rank), as_refs=True,
-                                               force=force_dist)
+                                               force=force_dist, info=binfo)
     torch.cuda.synchronize()
     bcast_s = time.time() - t_b if dist is not None else 0.0
 
@@ -85,7 +86,7 @@ def run_leg(args, label, model, reads, n_genomes, strong, indel, steps, warmup, 
     # records: id + length for the work divider, letters only where the CPU legs need them (rank 0)
     records = [Record(_SeqLen(g.length), id="genome_%d" % i) for i, g in enumerate(grefs)]
     letters = {id(r): g for r, g in zip(records, genomes)} if rank == 0 else {}
-    gid_of = {id(r): g.upload(eng) for r, g in zip(records, grefs)}  # (N > 1: straight from the broadcast buffer in HBM)
+    gref_of = {id(r): g for r, g in zip(records, grefs)}
     abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(123))
     total_reads = reads if strong else reads * world
 
@@ -98,8 +99,19 @@ def run_leg(args, label, model, reads, n_genomes, strong, indel, steps, warmup, 
     eng.reserve(max(total_pairs_step, 1))
     worker_seed = SEED + rank
     ordinal = [0]
-    item_ids = [gid_of[id(rec)] for rec, _ in work]
+    # A rank uploads the records its chunk names and no others (the reference's workers receive only their own
+    # chunk's records too: iss/app.py:99-106) -- N > 1: straight from the broadcast buffer in HBM (2-bit codes; the ASCII copy
+    # is expanded on the device).  configs[3] on 8 ranks: ~7 of 50 records, 35 MB instead of 250 MB of ASCII per rank.
+    gid_of = {}
+
+    def gid(rec):
+        if id(rec) not in gid_of:
+            gid_of[id(rec)] = gref_of[id(rec)].upload(eng)
+        return gid_of[id(rec)]
+
+    item_ids = [gid(rec) for rec, _ in work]
     item_pairs = [n for _, n in work]
+    genomes_uploaded = len(gid_of)
 
     def step():  # the step's whole work list in one set of launches (iss_generate_batch)
         eng.generate_batch(item_ids, item_pairs, first_ordinal=ordinal[0], seed=worker_seed, out_first_pair=0)
@@ -137,6 +149,13 @@ def run_leg(args, label, model, reads, n_genomes, strong, indel, steps, warmup, 
         dist.all_gather(allr, mine)
         per_rank = [(int(x[0].item()), float(x[1].item())) for x in allr]
     elapsed_max = max(e for _, e in per_rank)  # the slowest rank's time
+    uploaded = [genomes_uploaded]
+    if dist is not None:
+        mine = torch.tensor([float(genomes_uploaded), bcast_s], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        uploaded = [int(x[0].item()) for x in allr]
+        bcast_s = max(float(x[1].item()) for x in allr)  # the broadcast is over when the slowest rank holds the payload
 
     # ---- after the timed region: windows of the LAST timed step recomputed by the CPU oracle (rank 0's rows)
     parity = None
@@ -149,7 +168,7 @@ def run_leg(args, label, model, reads, n_genomes, strong, indel, steps, warmup, 
     if strong and world > 1:
         if rank == 0:
             w1 = work_of(1, 0)
-            ids1, pairs1 = [gid_of[id(rec)] for rec, _ in w1], [n for _, n in w1]
+            ids1, pairs1 = [gid(rec) for rec, _ in w1], [n for _, n in w1]  # (rank 0 now holds every record of the job)
             tot1 = sum(pairs1)
             eng.reserve(max(tot1, 1))
             eng.generate_batch(ids1, pairs1, first_ordinal=0, seed=SEED, out_first_pair=0)
@@ -164,7 +183,7 @@ def run_leg(args, label, model, reads, n_genomes, strong, indel, steps, warmup, 
     return dict(label=label, model=model, reads=reads, n_genomes=n_genomes, strong=strong, indel=indel, steps=steps, warmup=warmup,
                 dense=dense, genomes=genomes, records=records, letters=letters, abundance=abundance, work=work, eng=eng,
                 total_pairs_step=total_pairs_step, elapsed=elapsed_max, per_rank=per_rank, tm=tm, tm_warm=tm_warm, stats=stats,
-                bcast_s=bcast_s, parity=parity, one_gpu=one_gpu)
+                bcast_s=bcast_s, parity=parity, one_gpu=one_gpu, bcast_info=binfo, genomes_uploaded=uploaded)
 
 
 def leg_summary(L, world):
@@ -180,7 +199,9 @@ def leg_summary(L, world):
         base = sum(v for v in own if v)
     return {"workload": L["label"], "scaling": "strong" if L["strong"] else "weak", "value": value, "unit": "read-pairs/s",
             "ms_per_step": L["elapsed"] / L["steps"] * 1e3, "steps": L["steps"], "pairs_per_step_per_gpu": pairs,
-            "per_rank_pairs_per_sec": own, "model_broadcast_s": L["bcast_s"], "n_ranks_seen": len(L["per_rank"]),
+            "per_rank_pairs_per_sec": own, "model_broadcast_s": L["bcast_s"], "model_broadcast_bytes": L["bcast_info"].get("payload_bytes"),
+            "model_broadcast": L["bcast_info"], "genomes_uploaded_per_rank": L["genomes_uploaded"], "n_genomes": L["n_genomes"],
+            "n_ranks_seen": len(L["per_rank"]),
             "one_gpu_whole_job": L["one_gpu"], "scaling_efficiency": (value / base) if base else None,
             "parity_window": L["parity"]}
 
@@ -332,7 +353,8 @@ def main():
             "all_kernels_GBps": (total_pairs_step * args.steps * b_pair) / all_kernels_s / 1e9 if all_kernels_s else 0,
             "indel_fixup_reads_per_step": stats["fixup_reads"] / max(args.steps + args.warmup, 1),
             "indel_scripted_reads_per_step": stats["scripted_reads"] / max(args.steps + args.warmup, 1),
-            "model_broadcast_s": bcast_s,
+            "model_broadcast_s": bcast_s, "model_broadcast_bytes": L["bcast_info"].get("payload_bytes"),
+            "genomes_uploaded_per_rank": L["genomes_uploaded"],
             "parity_window": parity,
             "library_build_id": library_build_id(),
         }

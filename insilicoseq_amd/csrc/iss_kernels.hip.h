@@ -810,7 +810,7 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
     const Addr a = make_addr(A.seed, A.first_ordinal + pair, attempt);
     const uint32_t h = hot_h16(draw_block(a, K_QM, s_abs, half ? 2u : 0u), o, cc);
     const uint32_t e8 = hot_e8(draw_block(a, K_QM, s_abs, 1u), half, o, cc);
-    const uint32_t byte_off = pair * (uint32_t)M.row + (uint32_t)xp(p);  // (a launch's rows span < 2^32 bytes)
+    const size_t byte_off = (size_t)pair * (size_t)(uint32_t)M.row + (size_t)xp(p);  // (a launch's rows may span more than 2^32 bytes: MiSeq, 5 M pairs)
     const uint32_t slot = (slots >> (2 * o)) & 3u;
     // quality: full search of the LDS row, exact thresholds on a tie
     const uint32_t gwords = (1u << M.GB) / 4;
@@ -1099,7 +1099,10 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         const int64_t pf64 = desc_fs(d) + (int64_t)(s_lane * 8u), pr64 = desc_re(d) - 8 - (int64_t)(s_lane * 8u);
         uint32_t pfw = (uint32_t)((pf64 >> 4) + 1), prw = (uint32_t)((pr64 >> 4) + 1);
         const uint32_t pfs = (uint32_t)pf64 & 15u, prs = (uint32_t)pr64 & 15u;
-        uint32_t out_b = pair * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u;  // (tiles start at multiples of 4 superitems: whole lines)
+        // rows: a 64-bit scalar base per pass (the row of the block's first pair) + a 32-bit lane offset below 256 rows -- a launch's
+        // rows may span more than 2^32 bytes (round 5: 5 M MiSeq pairs are ONE launch), and the stores keep their scalar-base form
+        uint8_t *const out_pass = A.out[0] + (size_t)blk * (size_t)MAIN_PAIRS * (size_t)(uint32_t)M.row;
+        uint32_t out_b = (wave_pair0 + (lane >> 2)) * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u;  // (tiles start at multiples of 4 superitems: whole lines)
         const bool regular = PLAIN || !(A.has_frag && (d.meta & 64u));  // irregular pairs are built by the fix-up kernel
         const uint32_t tag0 = (pass << (19u + it_bits)) | (lane << 13) | ((d.meta & 15u) << 8) | has_ev;
         for (uint32_t it = 0; it < n_iter; ++it) {
@@ -1211,7 +1214,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
                 //  v_permlane32_swap, so that one store writes both halves of eight pairs' lines -- measured in round 4: 1.273 /
                 //  1.248 against 1.275 / 1.235 ms, interleaved on one box: nothing.  tools/store_bench.hip: the write stream
                 //  alone takes 0.56 ms per 5 M pairs in either form.)
-                uint4 *dst = reinterpret_cast<uint4 *>(A.out[0] + (size_t)out_b);  // two 16-byte pieces of the pair's 128-byte line
+                uint4 *dst = reinterpret_cast<uint4 *>(out_pass + (size_t)out_b);  // two 16-byte pieces of the pair's 128-byte line
                 dst[0] = make_uint4(base_f.x, base_f.y, qual_f.x, qual_f.y);
                 dst[4] = make_uint4(base_r.x, base_r.y, qual_r.x, qual_r.y);
             }
@@ -1763,7 +1766,22 @@ __global__ __launch_bounds__(SINGLE ? 64 * SC_WAVES1 : 64 * SC_WAVES, SINGLE ? 8
                 if (last + 1 < pitch) { runs[n_runs] = (uint32_t)(last + 1) | ((uint32_t)(k - (last + 1)) << 16); ++n_runs; }
             }
         };
-        if (STORE_MUT) { walk(false); if (ok && bad) { to_fixup(); ok = false; } }
+        // more than SC_ROW_CODES explicit pieces in one 16-byte row of a group (the rows loop below finds the same overflow, but
+        // only after walk(true) has emitted the read's rows: k_indel_fixup would then write them a second time)
+        auto rows_over = [&]() {
+            bool ov = false;
+            int tile = 0, g_in_tile = 0;
+            for (int gq = 0; gq < M.n_tiles * M.sc_gpt; ++gq) {
+                const int s_first = tile * M.TS + 32 * g_in_tile, s_end = min(S, (tile + 1) * M.TS);
+                if (++g_in_tile == M.sc_gpt) { g_in_tile = 0; ++tile; }
+                if (s_first >= s_end) continue;
+                const uint64_t below_end = ((uint64_t)1 << s_end) - 1u;  // (S <= AP_MAX_PITCH / 8 = 48 pieces)
+                for (int j = 0; j < 4; ++j)
+                    if (__popcll(evmask & below_end & ((uint64_t)0x11111111u << (s_first + j))) > SC_ROW_CODES) ov = true;
+            }
+            return ov;
+        };
+        if (STORE_MUT) { walk(false); if (ok && (bad || rows_over())) { to_fixup(); ok = false; } }
         walk(true);
         if (ok && bad) { to_fixup(); ok = false; }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

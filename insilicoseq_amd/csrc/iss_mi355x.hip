@@ -1449,10 +1449,9 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
     for (int t = 0; t < M.n_tiles; ++t) weight_all += 1u + (unsigned)(std::min(M.TS, M.S - t * M.TS) + 3) / 4u;
     const unsigned last_weight = 1u + (unsigned)(M.S - (M.n_tiles - 1) * M.TS + 3) / 4u;
     const unsigned min_tile_wg = std::max(1u, (unsigned)((uint64_t)budget_all * last_weight / weight_all));
-    // the pass number of a workgroup (>= 1 workgroup per tile, 256 pairs per pass); 32 bits for a row's byte offset and for the
-    // read numbers of k_indel_scan
-    const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)1 << 31) / std::max(M.n_scan, 1),
-                                                                                      (((int64_t)1 << 32) - 1) / M.row),
+    // the pass number of a workgroup (>= 1 workgroup per tile, 256 pairs per pass); 32 bits for the read numbers of k_indel_scan
+    // and for k_main's pair numbers (row offsets are 64-bit since round 5: 5 M MiSeq pairs of 1 280-byte rows are one launch)
+    const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(((int64_t)1 << 31) / std::max(M.n_scan, 1) - iss::MAIN_PAIRS,
                                                                     max_passes * iss::MAIN_PAIRS * min_tile_wg));
     const int64_t chunk_pairs = ctx->env_chunk_pairs ? std::min(max_chunk, ctx->env_chunk_pairs) : max_chunk;
     if (ctx->d_pmut) {  // rows of THIS call only

@@ -86,7 +86,7 @@ def _align16(n):
     return (n + 15) & ~15
 
 
-def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, as_refs=False, force=False):
+def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, as_refs=False, force=False, info=None):
     """Rank ``src`` passes (DenseModel, list of uint8 arrays / bytes); other ranks pass (None, None).
     Returns (DenseModel, genomes) on every rank; no-op when ``dist`` is None / world == 1 (``force``: go through the
     collectives even then -- a one-rank RCCL group on a single-GPU box runs the very calls of an 8-GPU run).
@@ -95,11 +95,14 @@ def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, 
     letters -- 62.5 MB for BASELINE configs[3]'s 250 Mbp) or ASCII (records with IUPAC / lower-case letters), sent by one
     broadcast (RCCL over xGMI with backend "nccl") after an 8-byte size announcement.  ``as_refs``: return
     BroadcastGenome objects -- on a GPU they point INTO the received device buffer, which ``upload`` hands to
-    iss_genome_upload_packed without a detour through the host; otherwise uint8 ASCII arrays (host consumers)."""
+    iss_genome_upload_packed without a detour through the host; otherwise uint8 ASCII arrays (host consumers).
+    ``info``: an optional dict that receives what went over the wire (payload_bytes, model_bytes, genome_bytes, collective)."""
     def as_u8(g):
         return np.frombuffer(g, dtype=np.uint8) if isinstance(g, (bytes, bytearray)) else np.ascontiguousarray(g, dtype=np.uint8)
 
     if dist is None or (dist.get_world_size() == 1 and not force):
+        if info is not None:
+            info.update(payload_bytes=0, model_bytes=0, genome_bytes=0, collective=None)
         glist = [as_u8(g) for g in genomes]
         return dense, ([BroadcastGenome(g.size, False, g) for g in glist] if as_refs else glist)
     import json
@@ -163,6 +166,11 @@ def broadcast_model_and_genomes(dense, genomes, dist=None, device="cpu", src=0, 
         off += _align16(nbytes)
     if rank != src:
         dense = DenseModel(meta["read_length"], *out_fields)
+    if info is not None:
+        gbytes = sum(_align16(nb) for _, _, nb in meta["genomes"])
+        info.update(payload_bytes=total, genome_bytes=gbytes, model_bytes=total - gbytes, n_genomes=len(meta["genomes"]),
+                    packed_genomes=sum(1 for _, pk, _ in meta["genomes"] if pk),
+                    collective="one broadcast (%s), %d ranks" % (backend, dist.get_world_size()))
     if as_refs:
         for r in refs:
             r._keep = t  # the device buffer must outlive the uploads

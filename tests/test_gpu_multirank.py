@@ -95,12 +95,13 @@ def test_two_ranks_through_the_device(tmp_path):
     mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_multirank_dry_run(world):
     """bench.py's own N > 1 code -- torch.distributed.run rendezvous on 127.0.0.1, the process group, the one broadcast of
     tables + packed genomes, chunk r of the reference's divider per rank (iss/app.py:81-83), the barrier-bracketed timed
     region, the all_gather of every rank's (pairs, seconds), elapsed = max over ranks -- as a dry run on ONE GPU (gloo;
-    ISS_BENCH_SHARE_GPU=1).  The driver's 8-GPU run differs in the backend name ("nccl" = RCCL) and the device per rank."""
+    ISS_BENCH_SHARE_GPU=1).  The driver's 8-GPU run differs in the backend name ("nccl" = RCCL) and the device per rank; world 8
+    is that run's shape: eight chunks of both legs, a rank uploading only the records its chunk names."""
     import json
     import subprocess
     import sys
@@ -135,6 +136,13 @@ def test_bench_multirank_dry_run(world):
     for leg in (weak, strong):
         assert leg["n_ranks_seen"] == world and len(leg["per_rank_pairs_per_sec"]) == world and all(v > 0 for v in leg["per_rank_pairs_per_sec"])
         assert leg["model_broadcast_s"] > 0 and 0 < leg["scaling_efficiency"] < 2.0 and str(leg["parity_window"]).startswith("ok")
+        # ONE payload: the tables (< 2 MB) + the records as 2-bit codes (a quarter of a byte per base, 16-byte aligned)
+        n_g = leg["n_genomes"]
+        assert leg["model_broadcast"]["packed_genomes"] == n_g and leg["model_broadcast_bytes"] == leg["model_broadcast"]["payload_bytes"]
+        assert n_g * 1_250_000 <= leg["model_broadcast"]["genome_bytes"] <= n_g * 1_250_016 and 0 < leg["model_broadcast"]["model_bytes"] < 4 << 20
+        # a rank uploads the records of ITS chunk only (contiguous in record order: neighbours share at most one record)
+        up = leg["genomes_uploaded_per_rank"]
+        assert len(up) == world and min(up) >= 1 and n_g - 3 <= sum(up) <= n_g + world - 1  # (a record whose share rounds to 0 pairs is nobody's)
         assert abs(leg["value"] - sum(leg["pairs_per_step_per_gpu"]) * leg["steps"] / (leg["ms_per_step"] * leg["steps"] * 1e-3)) <= 1e-6 * leg["value"]
     assert d["scaling_efficiency"] == weak["scaling_efficiency"]
 

@@ -604,6 +604,48 @@ def test_store_mutations_rows_match_oracle(engine, case):
         assert bad.size == 0, (f, bad[:5], got_rows[bad[:3]], rows[bad[:3]])
 
 
+@pytest.mark.parametrize("kind", ["del", "ins"])
+def test_store_mutations_script_row_overflow(engine, kind, monkeypatch):
+    """A read whose edit script needs more than four explicit pieces in ONE 16-byte row (pieces 0, 4, 8, 12, 16 of a
+    one-tile model: an event every 32 positions) leaves k_indel_script for k_indel_fixup.  With --store_mutations the
+    script kernel must notice that BEFORE it emits the read's indel rows (round-4 advice: it noticed afterwards, and the
+    fix-up kernel wrote the rows a second time).  Every read of this model takes that exit."""
+    from oracle import oracle as O
+
+    monkeypatch.setenv("ISS_LIGHT_INDELS", "0")
+    dense = dense_model("novaseq", (0.0, 0.0))
+    for pos in (4, 36, 68, 100, 132):  # five steps with an event, 32 positions apart: one residue class of pieces
+        if kind == "del":
+            dense.dele[:, pos, :] = 1.0
+        else:
+            dense.ins[:, pos, 2] = 1.0
+    genome = random_genome(57, 60000)
+    n, seed = 1500, 9
+    engine.load_model(dense)
+    engine.clear_genomes()
+    gid = engine.add_genome(genome)
+    engine.mutations_reserve(1_000_000)
+    engine.stats_read()
+    try:
+        engine.generate(gid, n, first_ordinal=5, seed=seed)
+        engine.synchronize()
+        got_rows = engine.mutations()
+        got = engine.download(0, n)
+        stats = engine.stats_read()
+    finally:
+        engine.mutations_reserve(0)
+    exp = O.Oracle(dense).simulate(O.Rng().seed_philox(seed), genome, n, first_ordinal=5, store_mutations=True)
+    assert exp["status"] == 0
+    for k in ("r1_qual", "r2_qual", "r1_base", "r2_base"):
+        assert np.array_equal(got[k], exp[k]), k
+    rows = exp["mutations"]
+    assert len(rows) >= 10 * n  # five indel rows per read at least
+    assert len(got_rows) == len(rows), "duplicate or missing --store_mutations rows: %d against %d" % (len(got_rows), len(rows))
+    for f in ("pair", "mate", "type", "position", "ref", "alt", "quality"):
+        assert np.array_equal(got_rows[f], rows[f]), f
+    assert stats["fixup_reads"] >= 2 * n and stats["scripted_reads"] == 0  # the overflow exit, for every read
+
+
 def test_worker_vcf_philox(tmp_path):
     """worker_iterator with store_mutations on the Philox path writes the rows in VCF form."""
     from insilicoseq_amd.generator import Record, worker_iterator
@@ -717,7 +759,9 @@ def test_fastq_pipeline_many_tiny_jobs(compress, tmp_path):
 
 @pytest.mark.parametrize("model,indel,n_genomes,pairs_total,batch", [("novaseq", None, 5, 5_000_000, True), ("hiseq", None, 50, 6_250_000, True),
                                                                      ("novaseq", None, 5, 5_000_000, False),
-                                                                     ("novaseq", (0.001, 0.003), 1, 5_000_000, True)])
+                                                                     ("novaseq", (0.001, 0.003), 1, 5_000_000, True),
+                                                                     # 5 M MiSeq pairs: 6.4 GB of rows in ONE k_main launch (64-bit row offsets, round 5)
+                                                                     ("miseq", None, 5, 5_000_000, True)])
 def test_baseline_sizes_sampled_against_oracle(model, indel, n_genomes, pairs_total, batch):
     """BASELINE.json's full sizes (configs[2]: 10 M NovaSeq reads over 5 x 5 Mbp; one rank's 6.25 M-pair share of
     configs[3]: HiSeq, 50 x 5 Mbp genomes; configs[4]: 10 M reads of an indel-heavy NovaSeq-shaped model over ONE 5 Mbp
