@@ -542,9 +542,11 @@ def committed_traffic():
     return t
 
 
-def mt_mode_leg(device, dense, genome, n_pairs=1_500_000):
-    """Pairs per second of ONE worker in the reference-identical mode (rng="mt": the device consumes the reference's two
-    MT19937 streams in the reference's order; tests/test_gpu_mt_compat.py holds the byte-for-byte comparisons)."""
+def mt_mode_leg(device, dense, genome, n_pairs=1_000_000, worker_sets=(1, 8, 64, 256), budget_s=2.5):
+    """Pairs per second in the reference-identical mode (rng="mt": the device consumes the reference's MT19937 streams in the
+    reference's order; tests/test_gpu_mt_compat.py holds the byte-for-byte comparisons).  ONE worker through iss_generate_mt
+    (the figure of the rounds before), then W workers side by side in one context (iss_generate_mt_workers: the reference's own
+    `--cpus W` parallelism -- seeds seed + cpu_number, iss/generator.py:234-236 -- one workgroup per worker and kernel)."""
     from insilicoseq_amd.engine import ReadEngine
 
     eng = ReadEngine(device)
@@ -562,7 +564,33 @@ def mt_mode_leg(device, dense, genome, n_pairs=1_500_000):
             done += eng.generate_mt(gid, batch)
         eng.synchronize()
         dt = time.perf_counter() - t0
-        return {"value": done / dt, "unit": "read-pairs/s", "workers": 1, "sample": "%d pairs in %.2f s, rows left in HBM" % (done, dt)}
+        out = {"value": done / dt, "unit": "read-pairs/s", "workers": 1,
+               "sample": "%d pairs in %.2f s, rows left in HBM" % (done, dt), "worker_sets": {}}
+        for W in worker_sets:
+            try:
+                per = max(2048, (1 << 21) // W)  # pairs per worker and call: every call is several turns of every worker
+                eng.seed_mt_workers([SEED + w for w in range(W)])
+                gids, ns, rows = [gid] * W, [per] * W, [w * per for w in range(W)]
+                d, st = eng.generate_mt_workers(gids, ns, rows)  # warm-up (stream buffers, tables)
+                assert int(d.sum()) == per * W and not st.any()
+                eng.synchronize()
+                t0 = time.perf_counter()
+                total, calls = 0, 0
+                while time.perf_counter() - t0 < budget_s or calls < 2:
+                    d, st = eng.generate_mt_workers(gids, ns, rows)
+                    total += int(d.sum())
+                    calls += 1
+                eng.synchronize()
+                dt = time.perf_counter() - t0
+                out["worker_sets"][str(W)] = {"workers": W, "value": total / dt, "per_worker": total / dt / W, "pairs": total,
+                                              "seconds": dt, "calls": calls, "pairs_per_worker_and_call": per}
+            except Exception as e:  # noqa: BLE001
+                out["worker_sets"][str(W)] = {"workers": W, "error": repr(e)}
+        best = max((v for v in out["worker_sets"].values() if v.get("value")), key=lambda v: v["value"], default=None)
+        if best:
+            out["best"] = {"workers": best["workers"], "value": best["value"]}
+        out["path_counts"] = dict(zip(("resolved", "walked"), eng.mt_path_counts()))
+        return out
     finally:
         eng.close()
 

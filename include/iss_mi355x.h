@@ -35,7 +35,7 @@ extern "C" {
  *    Philox address map of the hot draws: three blocks per 16 bases.
  * 3: iss_fastq_compress / iss_deflate_code_build (gzip members built on the device), iss_generate_batch,
  *    iss_fastq_emit_batch (a whole work list per call).  2: iss_fastq_emit / iss_fastq_flush, MT-mode path counters. */
-#define ISS_ABI_VERSION 6
+#define ISS_ABI_VERSION 7
 
 #define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
 #define ISS_E_HIP (-2)         /* HIP runtime failure (message has the hip error)  */
@@ -251,6 +251,22 @@ int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n)
  * (plain pairs) and the sequential walker (pairs with an indel candidate, letters outside ACGT or a template cut by
  * a genome end; indel-heavy models, the BasicErrorModel; everything when ISS_MT_PATH=walk is set in the environment). */
 int iss_mt_path_counts(iss_ctx *ctx, int64_t *n_resolved, int64_t *n_walked);
+/*
+ * W reference workers side by side in ONE context (ABI 7).  The reference's own parallelism is N workers, each a sequential
+ * chain over its two MT19937 streams seeded `seed + cpu_number` (pool.starmap over worker_iterator: iss/app.py:99-106,
+ * iss/generator.py:234-236).  iss_mt_workers_seed(ctx, W, seeds) == W times iss_mt_seed(seeds[w]);
+ * iss_generate_mt_workers == for every worker w: iss_generate_mt(genome_ids[w], n_pairs[w], ..., out_first_pair[w]) on ITS streams
+ * -- same rows, same stream positions afterwards -- but every kernel of the path is launched once for all workers, one workgroup
+ * per worker (n_pairs[w] == 0: the worker sits this call out).  status[w] (may be NULL): 0, or ISS_E_SHORT_RECORD for a worker whose
+ * record is not longer than a read (its draw is consumed like iss_generate_mt does); any other failure fails the call.  The
+ * workers' row ranges must not overlap.  Custom fragment lengths and the BasicErrorModel run the workers one after the other
+ * through iss_generate_mt (draws the host's libm settles); --store_mutations rows are per context (ISS_E_INVALID here).
+ * iss_mt_workers_peek: iss_mt_peek for worker w.  iss_mt_path_counts counts the set's pairs too.
+ */
+int iss_mt_workers_seed(iss_ctx *ctx, int32_t n_workers, const uint64_t *seeds);
+int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *genome_ids, const int64_t *n_pairs,
+                            const int64_t *out_first_pair, int32_t sequence_type, int32_t gc_bias, int64_t *n_done, int32_t *status);
+int iss_mt_workers_peek(iss_ctx *ctx, int32_t worker, uint32_t *py_words, uint32_t *np_words, int32_t n);
 /* Custom fragment length in MT mode (--fragment-length / --fragment-length-sd, iss/generator.py:121-123):
  * fragment = int(np.random.normal(mu, sd)) with numpy's legacy polar Box-Muller incl. its cached second value
  * (reset by iss_mt_seed like np.random.seed does).  The device evaluates it; draws that land within 1e-6 of an

@@ -22,7 +22,7 @@ EXPORTS = (
     "iss_mt_set_fragment", "iss_set_fragment", "iss_mutations_reserve", "iss_mutations_download",
     "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush", "iss_fastq_compress", "iss_deflate_code_build",
     "iss_generate_batch", "iss_fastq_emit_batch", "iss_gen_phred_scores", "iss_mut_sequence", "iss_random_insert_size",
-    "iss_introduce_indels", "iss_ev_step",
+    "iss_introduce_indels", "iss_ev_step", "iss_mt_workers_seed", "iss_generate_mt_workers", "iss_mt_workers_peek",
 )
 
 
@@ -92,6 +92,9 @@ def lib():
     L.iss_generate_mt.argtypes = [vp, i32, i64, i32, i32, i64, C.POINTER(i64)]
     L.iss_mt_peek.argtypes = [vp, vp, vp, i32]
     L.iss_mt_path_counts.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.iss_mt_workers_seed.argtypes = [vp, i32, vp]
+    L.iss_generate_mt_workers.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp, vp]
+    L.iss_mt_workers_peek.argtypes = [vp, i32, vp, vp, i32]
     L.iss_mt_mutations_reserve.argtypes = [vp, i64]
     L.iss_mt_set_fragment.argtypes = [vp, i32, C.c_double, C.c_double]
     L.iss_set_fragment.argtypes = [vp, i32, C.c_double, C.c_double]

@@ -22,7 +22,7 @@ import sys
 import numpy as np
 
 from .distributed import VCF_HEADER, concatenate_rank_files, temp_prefix
-from .generator import generate_work_divider, parse_fasta, worker_iterator
+from .generator import generate_work_divider, parse_fasta, worker_iterator, worker_set_iterator
 from .model import BasicErrorModel, KDErrorModel
 
 PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
@@ -255,6 +255,12 @@ def generate_reads(args):
     if workers == 1:
         for j in jobs:
             _worker(*j, records=records)
+    elif args.rng == "mt" and args.devices == 1 and not args.store_mutations and args.seed is not None:
+        # the reference's N workers as N chains side by side on ONE GPU: one workgroup per worker and kernel
+        # (worker_set_iterator; the files are those of N worker processes)
+        works = [[(records[idx], n, "default") for idx, n in j[3]] for j in jobs]
+        worker_set_iterator(works, error_model, [j[0] for j in jobs], [j[6] for j in jobs], args.seed, args.sequence_type,
+                            args.gc_bias, device=0, compress=device_gzip)
     else:
         with mp.get_context("spawn").Pool(workers) as pool:
             pool.starmap(_worker, jobs)

@@ -6,25 +6,28 @@
 //   gen_phred_scores/random_insert_size iss/error_models/kde.py:52-98
 //   mut_sequence                       iss/error_models/__init__.py:69-112
 //
-// Kernel plan (one iss_generate / iss_generate_batch call = up to four launches on one stream; in a batch call the
-// records stand side by side in one arena and the pair descriptors carry arena coordinates):
-//   k_setup  : 1 lane / pair   -> PairDesc {forward_start, reverse_end, bin slots, attempt, insert}
-//   k_main   : persistent workgroups (1024 lanes, one per CU); the compressed per-position quality
-//              CDF rows of a position tile are staged ONCE per workgroup in LDS; 4 lanes / pair, a lane
-//              takes 8 consecutive positions of both mates at a time: three Philox calls give its
-//              quality digits (16 bits) and error-test digits (8 bits); CDF inversion = LDS guide byte +
-//              packed (threshold, phred, error threshold) entries; bases come from the 2-bit genome with
-//              funnel shifts and one v_perm; two 16-byte stores per lane, 64 contiguous bytes per pair.
-//              Digits that tie with a table entry, and positions whose error test fires, are queued in a
-//              per-wave LDS ring and settled exactly (no global loads) every few iterations.
-//              Assumes "no indel in this read".
-//   k_indel_scan : 1 lane / read: the read's indel events (step, event mask), sampled by skipping from one firing
-//              test to the next; lists every read with an event.
-//   k_indel_apply: 8 lanes (16 / 32 for long reads) / listed read: replays the read's event list through the token
-//              transducer, re-derives the read (template, substitutions) and rewrites its base row.
-//   k_indel_fixup: 1 wavefront / flagged read (irregular pairs, reads with more events than a list
-//              holds): exact sequential indel semantics (lane 0 walks the token transducer over the
-//              read's event masks) + re-mutation by all lanes, rewrites that read's base row.
+// Kernel plan (one iss_generate / iss_generate_batch call; in a batch call the records stand side by side in one arena and the
+// pair descriptors carry arena coordinates).  Launch order per chunk of a call:
+//   k_setup        : 1 lane / pair -> PairDesc {forward_start, reverse_end, bin slots, attempt, insert}; models whose reads
+//                    rarely have an indel ("light", DevModel::p_read_event): + the pair's two indel event processes, a read
+//                    with an event goes straight to k_indel_fixup's list.  On the setup stream, beside the call before.
+//   k_indel_scan   : heavy models only.  1 lane / read: the read's indel events (step, event mask), sampled by skipping from
+//                    one firing test to the next; two segmented lists of the reads with an event (one event step / more).
+//   k_indel_script : heavy models only, two launches side by side (reads with ONE event step: closed form; the others: the
+//                    walk of the token transducer).  1 lane / listed read: introduce_indels + adjust_seq_length as an EDIT
+//                    SCRIPT -- per 8-position piece a shift of the template or 8 explicit letters (SC_* below).
+//   k_main         : persistent workgroups (1024 lanes, one per CU); the compressed per-position quality CDF rows of a
+//                    position tile are staged ONCE per workgroup in LDS; 4 lanes / pair, a lane takes 8 consecutive
+//                    positions of both mates per iteration: three Philox blocks give its 16 quality digits (16 bits) and
+//                    16 error-test digits (8 bits); CDF inversion = LDS guide byte + two packed (threshold, phred, error
+//                    threshold) entries; letters from the 2-bit genome through LDS letter tables; two 16-byte stores per
+//                    lane, 64 contiguous bytes per pair and mate.  Digits that tie with a table entry, and positions whose
+//                    error test fires, are queued in a per-wavefront LDS ring and settled exactly (no global loads) every
+//                    few iterations.  <.., INDEL>: a scripted read's pieces come from the shifted genome window or the
+//                    script's explicit letters -- the read is built once, mut_sequence sees the final letters.
+//   k_indel_fixup  : 1 wavefront / listed read (irregular pairs, reads with more events than a script holds, IUPAC records,
+//                    windows that leave the record; every read with an event of a light model): exact sequential indel
+//                    semantics (lane 0 walks the token transducer) + re-mutation by all lanes, rewrites that read's letters.
 // No MFMA anywhere: this is sampling/indexing.  All f64 comparisons of the reference are exact
 // integer comparisons here (thresholds prepared on the host, see iss_mi355x.h / DESIGN.md); the indel tests are
 // sampled as an event process with the same joint distribution (indel_events below).
@@ -279,7 +282,7 @@ struct RunArgs {
     const int64_t *ov_frags;      // ... with these host-evaluated fragment lengths
     uint32_t n_ov;
     uint32_t *flags, *fix_list, *fix_count;  // irregular pairs (template shorter than the read, ...) go straight to the fix-up
-    // indel events (k_indel_scan -> k_indel_apply): reads (2 * pair + mate) with an event are listed once in read_list as
+    // indel events (k_indel_scan -> k_indel_script): reads (2 * pair + mate) with an event are listed once in read_list as
     // {read, first event, second event, number of steps with an event}, an event = step << 8 | event mask; a read with
     // more than two such steps keeps all of them in its EV_K words of ev_list.  ev_count[read] = min(steps with an
     // event, 15) | first such step << 4 (0: none) for every read of the launch.
@@ -294,7 +297,7 @@ struct RunArgs {
     PairDesc *desc_out;  // k_main copies the descriptors it works from here (the call's own set is double-buffered: k_setup of the
                          // next call may be rewriting it while the host asks for this call's coordinates)
     int32_t light;  // 1: reads with an indel are rare (DevModel::p_read_event): k_indel_scan hands every one of them to k_indel_fixup
-                    // (no substitution list, no k_indel_apply / k_indel_resub launches)
+                    // (no k_indel_scan / k_indel_script launches, k_main's plain variant)
     uint16_t tile_wg0[MAX_TILES + 2];  // k_main: workgroups [tile_wg0[t], tile_wg0[t + 1]) work on position tile t
     MutRecord *mut;               // --store_mutations rows (NULL: off)
     uint32_t *mut_count;          // slots reserved so far
@@ -1233,21 +1236,21 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
 // ================================================================== k_indel_scan
 // One lane per READ: the read's indel events (indel_events above: a draw per firing test + one per segment of the
 // survival table, i.e. one for a read without events) in step order into its event list (EV_K words, step << 8 | event
-// mask); no event => provably no indel, k_main's output stands.  k_indel_apply replays the lists.  A read with more than
+// mask); no event => provably no indel, the read is its template.  k_indel_script turns the lists into edit scripts.  A read with more than
 // EV_K events goes to the wavefront-per-read kernel instead (k_indel_fixup: extreme models only).  The reads with events
 // are collected per wavefront in LDS and reach the read list >= 64 at a time.  The list is SEGMENTED: a workgroup's
 // reads go to read_list[first read of its range ...], the place reserved by an LDS atomic of the workgroup -- a global
 // counter everybody adds to takes ~10 ns per add, 0.2-0.5 ms per 5 M pairs of configs[4] -- and the segments' lengths
-// to read_count[workgroup]; k_indel_apply walks the segments through a prefix sum of their 64-read blocks.  Consecutive
-// lanes take consecutive reads, so the list is in pair order, more or less, and k_indel_apply's wavefronts share cache
+// to read_count[workgroup]; k_indel_script walks the segments through a prefix sum of their 64-read blocks.  Consecutive
+// lanes take consecutive reads, so the list is in pair order, more or less, and k_indel_script's wavefronts share cache
 // lines, DRAM pages and TLB entries.
 constexpr int SCAN_THREADS = 1024;  // two workgroups per CU: 8 wavefronts / SIMD (the kernel is bound by the latency of its dependent LDS reads)
 constexpr int SCAN_LISTN = 96;    // listed reads (two or more event steps) a wavefront collects before they go to the global list
 constexpr int SCAN_LIST1 = 128;   // ... reads with one event step
 constexpr int EV_K = 8;           // events kept per read
-constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 mate rebuilt by k_indel_apply,
+constexpr uint32_t FLAG_LISTED = 16u;  // RunArgs::flags: bits 0-1 mate goes to k_indel_fixup, bits 2-3 unused since round 4,
                                        // bits 4-5 mate is in read_list
-constexpr int SCAN_MAX_WGS = 512; // (k_indel_apply keeps the segment table in LDS)
+constexpr int SCAN_MAX_WGS = 512; // (k_indel_script keeps the segment table in LDS)
 __host__ __device__ inline uint32_t scan_per_wg(uint32_t n_reads, uint32_t wgs) {  // reads of a workgroup's contiguous range
     return ((n_reads + wgs - 1) / wgs + SCAN_THREADS - 1) / SCAN_THREADS * SCAN_THREADS;
 }
@@ -1389,7 +1392,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_indel_scan(DevModel M, RunA
 // transducer of k_indel_fixup (below) -- the list prefix [0, n) is final when step n starts; the not-yet-visited suffix is
 // (stack of freshly inserted letters, LIFO) ++ E(k), E(k+1), ... -- but instead of rebuilding the read it leaves the EDIT
 // SCRIPT k_main<.., INDEL> builds the read from (SC_* above).  Round 4: round 3 rewrote the letters behind k_main
-// (k_indel_apply: every rewritten piece crossed HBM twice more, 3.1 GB per 5 M pairs of BASELINE configs[4], and the
+// (a pass behind k_main: every rewritten piece crossed HBM twice more, 3.1 GB per 5 M pairs of BASELINE configs[4], and the
 // substitutions k_main had applied were listed and re-applied to the letters standing there afterwards); now the walk runs in
 // FRONT of k_main, which takes a piece's window from the shifted genome position, and nothing is written twice.
 //   * descriptor, events (registers), the read's window of the 2-bit genome (LDS), the walk over the steps with an event:

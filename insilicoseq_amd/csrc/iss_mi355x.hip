@@ -257,7 +257,32 @@ struct iss_ctx {
         int32_t *d_mut_cnt = nullptr;     // k_mt_emit, --store_mutations: rows per (pair, mate), then their offsets
         int64_t *d_mut_off = nullptr;
         int64_t n_resolved = 0, n_walked = 0;  // pairs by path (statistics, iss_mt_path_counts)
+        int64_t pool_ch = 0;  // != 0: the chain (streams, buffers, records) is a worker's of the set below, lent for one call:
+                              // iss_generate_mt takes turns of this many pairs and leaves the buffers as they are
     } mt;
+    // MT mode, W workers per launch (iss_mt_workers_seed / iss_generate_mt_workers): the reference's N workers (seed + cpu_number,
+    // iss/generator.py:234-236) as N chains side by side -- one workgroup per worker and kernel, job tables in HBM
+    struct MtSet {
+        int W = 0;
+        int64_t ch = 0;                      // pairs per worker and turn
+        size_t cap[2] = {0, 0};              // words per (worker, stream, ping-pong buffer)
+        iss::MtState *d_state = nullptr;     // [W][2]: CPython random, numpy
+        uint32_t *buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [stream][ping-pong]: W x cap[stream] words
+        iss::MtWalkResult *d_res = nullptr;  // [W]
+        iss::MtGauss *d_gauss = nullptr;     // [W]
+        iss::MtPairRec *d_rec = nullptr;     // [2][W][ch]: the resolver of turn t + 1 runs beside the emitter of turn t
+        hipEvent_t ev_emit[2] = {nullptr, nullptr};  // the emitter of the last turn of either parity
+        hipEvent_t ev_side = nullptr, ev_turn = nullptr;  // side stream (walker, emitter) <-> main stream
+        std::vector<int> cur;                // [W * 2]
+        std::vector<size_t> fill, used;      // [W * 2]
+        // job tables: pinned host staging + device copies, two sets (turn parity) of
+        // [fill: ensure 2W | fill: ahead 2W | move: ensure 2W | move: commit 2W] and [resolve W | walk W | emit W]
+        uint8_t *h_jobs = nullptr, *d_jobs = nullptr;
+        size_t jobs_bytes = 0;               // of ONE set
+        iss::MtWalkResult *h_res = nullptr;  // pinned [W]
+        int64_t turns = 0;
+        int64_t n_resolved = 0, n_walked = 0;
+    } mts;
     FastqPipe fq;
     // timing
     bool timing = false, timing_main_only = false;
@@ -340,7 +365,27 @@ void free_outputs(iss_ctx *ctx) {
     ctx->capacity = 0;
 }
 
+void free_mt_set(iss_ctx *ctx) {
+    auto &t = ctx->mts;
+    if (t.d_state) (void)hipFree(t.d_state);
+    if (t.d_res) (void)hipFree(t.d_res);
+    if (t.d_gauss) (void)hipFree(t.d_gauss);
+    if (t.d_rec) (void)hipFree(t.d_rec);
+    for (auto &st : t.buf) for (auto &b : st) { if (b) (void)hipFree(b); b = nullptr; }
+    if (t.h_jobs) (void)hipHostFree(t.h_jobs);
+    if (t.d_jobs) (void)hipFree(t.d_jobs);
+    if (t.h_res) (void)hipHostFree(t.h_res);
+    for (auto &e : t.ev_emit) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (t.ev_side) (void)hipEventDestroy(t.ev_side);
+    if (t.ev_turn) (void)hipEventDestroy(t.ev_turn);
+    t.ev_side = t.ev_turn = nullptr;
+    t.d_state = nullptr; t.d_res = nullptr; t.d_gauss = nullptr; t.d_rec = nullptr; t.h_jobs = nullptr; t.d_jobs = nullptr; t.h_res = nullptr;
+    t.W = 0; t.ch = 0; t.cap[0] = t.cap[1] = 0; t.jobs_bytes = 0;
+    t.cur.clear(); t.fill.clear(); t.used.clear();
+}
+
 void free_mt(iss_ctx *ctx) {
+    free_mt_set(ctx);
     if (ctx->mt.d_state) (void)hipFree(ctx->mt.d_state);
     if (ctx->mt.d_res) (void)hipFree(ctx->mt.d_res);
     if (ctx->mt.d_mut) (void)hipFree(ctx->mt.d_mut);
@@ -1141,7 +1186,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
     M.ev_ns = ev_ns;
     M.n_scan = any_indel ? 1 : 0;
     {   // how often a read has an event at all: models where that is rare (the shipped NovaSeq / HiSeq profiles: a few reads in
-        // 10^5) keep k_main free of the substitution list and hand those reads to the one-wavefront-per-read kernel
+        // 10^5) keep k_main's plain variant and hand those reads to the one-wavefront-per-read kernel
         double p_any = 0;
         for (int o = 0; o < 2; ++o) {
             double none = 1.0;
@@ -2111,11 +2156,11 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         return fail(ctx, ISS_E_INVALID, "iss_generate_mt: records of 2^31 - 1 bases and more are the Philox path's (iss_generate)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
-    const int64_t CH = 8192;
+    auto &m = ctx->mt;
+    const int64_t CH = m.pool_ch ? m.pool_ch : 8192;  // (a worker of a set, lent for this call: its own turn length and buffers)
     const bool basic = M.quality_mode == 1;
     const size_t py_need = iss::mt_py_need(M.RL), np_need = iss::mt_np_need(M.RL, basic);
-    { int rc_ = mt_reserve(ctx, 3 * ((size_t)(CH + 1) * py_need + 1248), 3 * ((size_t)(CH + 1) * np_need + 1248)); if (rc_) return rc_; }
-    auto &m = ctx->mt;
+    if (!m.pool_ch) { int rc_ = mt_reserve(ctx, 3 * ((size_t)(CH + 1) * py_need + 1248), 3 * ((size_t)(CH + 1) * np_need + 1248)); if (rc_) return rc_; }
     if (!(M.RL < G.L)) {
         // the reference draws the insert size BEFORE its assertion fails (generator.py:121-126, 130)
         if (m.has_frag) {
@@ -2203,9 +2248,12 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
                 void *p = nullptr;
                 HIP_TRY(ctx, hipMalloc(&p, (size_t)CH * sizeof(iss::MtPairRec)));
                 m.d_rec = static_cast<iss::MtPairRec *>(p);
-                HIP_TRY(ctx, hipMalloc(&p, (size_t)2 * CH * sizeof(int32_t)));
+            }
+            if (!m.d_mut_cnt) {  // (sized for the longest turn: a lent chain brings its own, shorter, d_rec)
+                void *p = nullptr;
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)2 * 8192 * sizeof(int32_t)));
                 m.d_mut_cnt = static_cast<int32_t *>(p);
-                HIP_TRY(ctx, hipMalloc(&p, (size_t)2 * CH * sizeof(int64_t)));
+                HIP_TRY(ctx, hipMalloc(&p, (size_t)2 * 8192 * sizeof(int64_t)));
                 m.d_mut_off = static_cast<int64_t *>(p);
             }
         }
@@ -2385,6 +2433,487 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
     return 0;
 }
 
+// ------------------------------------------------------------------ MT mode: W workers per launch (round 5)
+// The reference's own parallelism is N workers, each a sequential chain over ITS two MT19937 streams seeded seed + cpu_number
+// (iss/generator.py:234-236, iss/app.py:81-106).  One chain keeps one workgroup busy (k_mt_resolve: 2.3 us per NovaSeq pair);
+// a set of W workers is W chains side by side: per turn ONE launch of each kernel of the path with one workgroup (k_mt_fill_w,
+// k_mt_resolve_w, k_mt_walk_w) or one grid row (k_mt_emit_w) per worker, the jobs in tables in HBM.  Every worker's rows and
+// stream positions are exactly those of iss_mt_seed(seed_w) + iss_generate_mt(...) in a context of its own.
+int iss_mt_workers_seed(iss_ctx *ctx, int32_t n_workers, const uint64_t *seeds) {
+    if (!ctx || n_workers < 1 || n_workers > 1024 || !seeds) return fail(ctx, ISS_E_INVALID, "iss_mt_workers_seed: 1 .. 1024 workers");
+    for (int32_t w = 0; w < n_workers; ++w)
+        if (seeds[w] > 0xffffffffull) return fail(ctx, ISS_E_INVALID, "seed must be < 2^32 (numpy's legacy seeding raises)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    free_mt_set(ctx);
+    auto &t = ctx->mts;
+    const size_t W = (size_t)n_workers;
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, 2 * W * sizeof(iss::MtState)));
+    t.d_state = static_cast<iss::MtState *>(p);
+    HIP_TRY(ctx, hipMalloc(&p, W * sizeof(iss::MtWalkResult)));
+    t.d_res = static_cast<iss::MtWalkResult *>(p);
+    HIP_TRY(ctx, hipMalloc(&p, W * sizeof(iss::MtGauss)));
+    t.d_gauss = static_cast<iss::MtGauss *>(p);
+    HIP_TRY(ctx, hipMemset(t.d_gauss, 0, W * sizeof(iss::MtGauss)));  // np.random.seed() drops the cached gaussian
+    HIP_TRY(ctx, hipHostMalloc(&p, W * sizeof(iss::MtWalkResult), hipHostMallocDefault));
+    t.h_res = static_cast<iss::MtWalkResult *>(p);
+    std::vector<iss::MtState> st(2 * W);
+    for (size_t w = 0; w < W; ++w) {
+        const uint32_t key[1] = {(uint32_t)seeds[w]};
+        mt_init_by_array(st[2 * w].mt, key, 1);               // random.seed(seed)
+        mt_init_genrand(st[2 * w + 1].mt, (uint32_t)seeds[w]);  // np.random.seed(seed)
+    }
+    HIP_TRY(ctx, hipMemcpy(t.d_state, st.data(), st.size() * sizeof(iss::MtState), hipMemcpyHostToDevice));
+    t.W = n_workers;
+    t.cur.assign(2 * W, 0);
+    t.fill.assign(2 * W, 0);
+    t.used.assign(2 * W, 0);
+    t.n_resolved = t.n_walked = 0;
+    return 0;
+}
+
+namespace {
+
+// stream buffers, pair records and job tables of the set, sized for the model (called by every generate call; a model with longer
+// reads than the buffers were cut for is refused: seed the set again)
+int mt_set_reserve(iss_ctx *ctx) {
+    auto &t = ctx->mts;
+    const iss::DevModel &M = ctx->M;
+    const size_t W = (size_t)t.W;
+    const bool basic = M.quality_mode == 1;
+    const size_t need[2] = {iss::mt_py_need(M.RL), iss::mt_np_need(M.RL, basic)};
+    if (!t.ch) {
+        const char *e = getenv("ISS_MT_SET_TURN");  // pairs per worker and turn (tests: many turns)
+        t.ch = e ? std::max<int64_t>(1, std::min<int64_t>(8192, atoll(e))) : std::max<int64_t>(512, std::min<int64_t>(8192, 131072 / (int64_t)W));
+    }
+    const size_t want[2] = {3 * ((size_t)(t.ch + 1) * need[0] + 1248), 3 * ((size_t)(t.ch + 1) * need[1] + 1248)};
+    if (t.cap[0] && (t.cap[0] < want[0] || t.cap[1] < want[1]))
+        return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: the set's stream buffers were sized for a model with shorter reads (seed the set again)");
+    if (!t.cap[0]) {
+        for (int s = 0; s < 2; ++s)
+            for (int b = 0; b < 2; ++b) {
+                void *p = nullptr;
+                if (hipMalloc(&p, W * want[s] * sizeof(uint32_t)) != hipSuccess)
+                    return fail(ctx, ISS_E_NOMEM, "iss_generate_mt_workers: no memory for the workers' stream buffers");
+                t.buf[s][b] = static_cast<uint32_t *>(p);
+            }
+        t.cap[0] = want[0];
+        t.cap[1] = want[1];
+        void *p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, 2 * W * (size_t)t.ch * sizeof(iss::MtPairRec)));
+        t.d_rec = static_cast<iss::MtPairRec *>(p);
+        for (auto &e : t.ev_emit) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&t.ev_side, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&t.ev_turn, hipEventDisableTiming));
+        t.jobs_bytes = (((4 * 2 * W) * std::max(sizeof(iss::MtFillJob), sizeof(iss::MtMoveJob)) +
+                         W * (sizeof(iss::MtResolveJob) + sizeof(iss::MtWalkJob) + sizeof(iss::MtEmitJob))) + 255) & ~(size_t)255;
+        HIP_TRY(ctx, hipHostMalloc(&p, 2 * t.jobs_bytes, hipHostMallocDefault));
+        t.h_jobs = static_cast<uint8_t *>(p);
+        HIP_TRY(ctx, hipMalloc(&p, 2 * t.jobs_bytes));
+        t.d_jobs = static_cast<uint8_t *>(p);
+    }
+    return 0;
+}
+
+// One worker of the set through the single-worker path (iss_generate_mt): its chain is lent to ctx->mt for the call.  For what
+// the side-by-side loop below does not do itself: records shorter than a read (the reference draws before its assertion
+// fails), custom fragment lengths and the BasicErrorModel (draws the host's libm has to settle).
+struct MtChainLoan {
+    struct Chain {
+        bool seeded; iss::MtState *d_state; uint32_t *buf[2][2]; int cur[2]; size_t cap[2], fill[2], used[2];
+        iss::MtWalkResult *d_res; iss::MtGauss *d_gauss; iss::MtPairRec *d_rec; int64_t pool_ch;
+    };
+    iss_ctx *ctx;
+    int w;
+    Chain own;
+    int64_t r0, w0;
+    typedef decltype(iss_ctx::mt) MtLegacy;
+    static Chain save(const MtLegacy &m) {
+        Chain c;
+        c.seeded = m.seeded; c.d_state = m.d_state; c.d_res = m.d_res; c.d_gauss = m.d_gauss; c.d_rec = m.d_rec; c.pool_ch = m.pool_ch;
+        for (int s = 0; s < 2; ++s) {
+            c.cur[s] = m.cur[s]; c.cap[s] = m.cap[s]; c.fill[s] = m.fill[s]; c.used[s] = m.used[s];
+            for (int b = 0; b < 2; ++b) c.buf[s][b] = m.buf[s][b];
+        }
+        return c;
+    }
+    static void load(MtLegacy &m, const Chain &c) {
+        m.seeded = c.seeded; m.d_state = c.d_state; m.d_res = c.d_res; m.d_gauss = c.d_gauss; m.d_rec = c.d_rec; m.pool_ch = c.pool_ch;
+        for (int s = 0; s < 2; ++s) {
+            m.cur[s] = c.cur[s]; m.cap[s] = c.cap[s]; m.fill[s] = c.fill[s]; m.used[s] = c.used[s];
+            for (int b = 0; b < 2; ++b) m.buf[s][b] = c.buf[s][b];
+        }
+    }
+    MtChainLoan(iss_ctx *ctx_, int w_) : ctx(ctx_), w(w_) {
+        auto &t = ctx->mts;
+        auto &m = ctx->mt;
+        own = save(m);
+        r0 = m.n_resolved; w0 = m.n_walked;
+        Chain c;
+        c.seeded = true; c.d_state = t.d_state + 2 * (size_t)w; c.d_res = t.d_res + w; c.d_gauss = t.d_gauss + w;
+        c.d_rec = t.d_rec + (size_t)w * (size_t)t.ch; c.pool_ch = t.ch;  // (the first of its two sets of pair records)
+        for (int s = 0; s < 2; ++s) {
+            c.cur[s] = t.cur[2 * w + s]; c.cap[s] = t.cap[s]; c.fill[s] = t.fill[2 * w + s]; c.used[s] = t.used[2 * w + s];
+            for (int b = 0; b < 2; ++b) c.buf[s][b] = t.buf[s][b] + (size_t)w * t.cap[s];
+        }
+        load(m, c);
+    }
+    ~MtChainLoan() {
+        auto &t = ctx->mts;
+        auto &m = ctx->mt;
+        for (int s = 0; s < 2; ++s) { t.cur[2 * w + s] = m.cur[s]; t.fill[2 * w + s] = m.fill[s]; t.used[2 * w + s] = m.used[s]; }
+        t.n_resolved += m.n_resolved - r0;
+        t.n_walked += m.n_walked - w0;
+        m.n_resolved = r0;
+        m.n_walked = w0;
+        load(m, own);
+    }
+};
+int mt_set_single(iss_ctx *ctx, int w, int32_t genome_id, int64_t n_pairs, int32_t sequence_type, int32_t gc_bias, int64_t out_first_pair,
+                  int64_t *n_done) {
+    MtChainLoan loan(ctx, w);
+    return iss_generate_mt(ctx, genome_id, n_pairs, sequence_type, gc_bias, out_first_pair, n_done);
+}
+
+}  // namespace
+
+int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *genome_ids, const int64_t *n_pairs, const int64_t *out_first_pair,
+                            int32_t sequence_type, int32_t gc_bias, int64_t *n_done, int32_t *status) {
+    if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: upload a model first");
+    auto &t = ctx->mts;
+    if (n_workers < 1 || n_workers != t.W || !genome_ids || !n_pairs || !out_first_pair)
+        return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: call iss_mt_workers_seed for this many workers first");
+    if (sequence_type != ISS_SEQ_METAGENOMICS && sequence_type != ISS_SEQ_AMPLICON)
+        return fail(ctx, ISS_E_INVALID, "sequence type is not supported");
+    if (ctx->mt.d_mut) return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: --store_mutations rows are per context (one context per worker)");
+    const int W = n_workers;
+    const iss::DevModel &M = ctx->M;
+    for (int w = 0; w < W; ++w) {
+        if (n_done) n_done[w] = 0;
+        if (status) status[w] = 0;
+        if (n_pairs[w] == 0) continue;
+        if (genome_ids[w] < 0 || genome_ids[w] >= (int32_t)ctx->genomes.size()) return fail(ctx, ISS_E_INVALID, "unknown genome id");
+        if (n_pairs[w] < 0 || out_first_pair[w] < 0 || out_first_pair[w] + n_pairs[w] > ctx->capacity)
+            return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
+        if (ctx->genomes[genome_ids[w]].L >= (int64_t)0x7fffffff)
+            return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: records of 2^31 - 1 bases and more are the Philox path's (iss_generate)");
+        for (int v = 0; v < w; ++v)  // (the workers' rows must not overlap)
+            if (n_pairs[v] > 0 && out_first_pair[w] < out_first_pair[v] + n_pairs[v] && out_first_pair[v] < out_first_pair[w] + n_pairs[w])
+                return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: two workers' output rows overlap");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    { int rc_ = mt_set_reserve(ctx); if (rc_) return rc_; }
+    auto &m = ctx->mt;
+    const bool basic = M.quality_mode == 1;
+    // the resolver (k_mt_resolve_w + k_mt_emit_w) for plain runs, the walker for indel-heavy models and for the single pairs the
+    // resolver hands back -- the choice of iss_generate_mt
+    typedef void (*resolve_fn)(iss::DevModel, const iss::MtResolveJob *);
+    resolve_fn resolve = nullptr;
+    size_t resolve_lds = 0;
+    {
+        const char *force = getenv("ISS_MT_PATH");  // "walk": sequential walker only (testing aid)
+        const bool allowed = !(force && !strcmp(force, "walk")) && ctx->mt_bounce_rate < 0.05 && M.n_isize <= 4096 && !basic;
+        const size_t budget = 160 * 1024 - 256;
+        const uint32_t need_py = iss::mt_res_need_py(M.RL), need_np = iss::mt_res_need_np(M.RL);
+        struct Cand { int pyv, npv; bool rows; resolve_fn fn; };
+        const Cand cands[8] = {
+            {8, 2, true, iss::k_mt_resolve_w<8, 2, true>},   {4, 2, true, iss::k_mt_resolve_w<4, 2, true>},
+            {8, 4, true, iss::k_mt_resolve_w<8, 4, true>},   {4, 4, true, iss::k_mt_resolve_w<4, 4, true>},
+            {8, 2, false, iss::k_mt_resolve_w<8, 2, false>}, {4, 2, false, iss::k_mt_resolve_w<4, 2, false>},
+            {8, 4, false, iss::k_mt_resolve_w<8, 4, false>}, {4, 4, false, iss::k_mt_resolve_w<4, 4, false>}};
+        for (const Cand &c : cands) {
+            if (!allowed || resolve) break;
+            if (need_py > (uint32_t)c.pyv * 1024u || need_np > (uint32_t)c.npv * 1024u) continue;
+            const size_t b = iss::mt_res_lds_bytes(M, c.pyv, c.npv, c.rows);
+            if (b > budget) continue;
+            resolve = c.fn;
+            resolve_lds = b;
+        }
+        if (resolve) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(resolve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_mt_walk_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));
+    }
+    // ---- what the side-by-side loop does not do itself goes through the single-worker path, one worker after the other
+    struct WS { int64_t n = 0, done = 0, row0 = 0; int32_t gid = 0; bool walk_one = false; int64_t boost = 0; };
+    std::vector<WS> ws((size_t)W);
+    const bool one_by_one = m.has_frag || basic;
+    for (int w = 0; w < W; ++w) {
+        if (n_pairs[w] == 0) continue;
+        const Genome &G = ctx->genomes[genome_ids[w]];
+        if (one_by_one || !(M.RL < G.L)) {
+            int64_t dn = 0;
+            const int rc = mt_set_single(ctx, w, genome_ids[w], n_pairs[w], sequence_type, gc_bias, out_first_pair[w], &dn);
+            if (n_done) n_done[w] = dn;
+            if (rc == ISS_E_SHORT_RECORD) { if (status) status[w] = rc; continue; }
+            if (rc) return rc;
+            continue;
+        }
+        ws[w].n = n_pairs[w];
+        ws[w].row0 = out_first_pair[w];
+        ws[w].gid = genome_ids[w];
+        ws[w].boost = gc_bias ? 4 : 0;
+    }
+    const size_t need[2] = {iss::mt_py_need(M.RL), iss::mt_np_need(M.RL, basic)};
+    // Words a turn is given: `need` is the most ONE attempt at a pair can consume (the kernels stop in front of a pair they
+    // might not finish: "starved"), but a turn of n pairs consumes n times the USUAL amount -- a plain pair takes 2 x (10 (RL - 1)
+    // + 2 RL) + ~2 words of `random` and 2 + 2 x (2 + 2 RL + 2 per substitution) (+ 2) of numpy, a gc_bias rejection a whole
+    // pair's more (10 %) -- and what is left over is moved in front of the next turn's words: sized for the usual amount (+ 3 %,
+    // + a few whole attempts), a turn leaves a few per cent of its words instead of half of numpy's.  A turn that runs out early
+    // ends early, with its pairs done; the next one carries on.
+    const double gcf = gc_bias ? 1.15 : 1.0;
+    const double est[2] = {gcf * 1.03 * (2.0 * (10.0 * (M.RL - 1) + 2.0 * M.RL) + 4.0),
+                           gcf * 1.03 * (2.0 + 2.0 * (2.0 + 2.0 * M.RL) + 8.0 * (0.02 * 2.0 * M.RL) + 4.0)};  // (2 words per substitution pick and mate... 2 % of the bases substituted: generous for every shipped model)
+    auto words_for = [&](int s, int64_t n, int64_t boost) {
+        return std::min((size_t)(n + 1 + boost) * need[s], (size_t)((double)n * est[s]) + (size_t)(4 + boost) * need[s]);
+    };
+    const size_t fixed_lds = iss::mt_walk_fixed_lds_bytes(M.RL);
+    const size_t rows_bytes = (((size_t)2 * M.NB * M.RL * M.mt_row_w + 1) & ~(size_t)1) * 4;
+    const bool use_rows = !basic && rows_bytes + fixed_lds <= 150 * 1024;
+    const double guard = getenv("ISS_MT_GUARD") ? atof(getenv("ISS_MT_GUARD")) : 1e-6;
+    if (!m.ev_main) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&m.ev_main, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&m.ev_fill, hipEventDisableTiming));
+    }
+    auto bufp = [&](int w, int s, int b) { return t.buf[s][b] + (size_t)w * t.cap[s]; };
+    const size_t fm_sz = std::max(sizeof(iss::MtFillJob), sizeof(iss::MtMoveJob));
+    std::vector<int64_t> n_w((size_t)W);
+    std::vector<size_t> want(2 * (size_t)W);
+    struct PF { bool on = false; size_t at = 0; uint32_t blocks = 0; };
+    std::vector<PF> pf(2 * (size_t)W);
+    for (;;) {
+        bool any = false;
+        for (int w = 0; w < W; ++w) {
+            n_w[w] = ws[w].done < ws[w].n ? (ws[w].walk_one ? 1 : std::min(t.ch, ws[w].n - ws[w].done)) : 0;
+            any |= n_w[w] > 0;
+        }
+        if (!any) break;
+        const int par = (int)(t.turns++ & 1);
+        uint8_t *hj = t.h_jobs + (size_t)par * t.jobs_bytes, *dj = t.d_jobs + (size_t)par * t.jobs_bytes;
+        auto tab = [&](size_t k, uint8_t *base) { return base + k * 2 * (size_t)W * fm_sz; };  // tables 0..3 (fill / move), then the rest
+        iss::MtFillJob *h_fill_e = reinterpret_cast<iss::MtFillJob *>(tab(0, hj)), *h_fill_a = reinterpret_cast<iss::MtFillJob *>(tab(1, hj));
+        iss::MtMoveJob *h_move_e = reinterpret_cast<iss::MtMoveJob *>(tab(2, hj)), *h_move_c = reinterpret_cast<iss::MtMoveJob *>(tab(3, hj));
+        uint8_t *h_rest = tab(4, hj), *d_rest = tab(4, dj);
+        iss::MtResolveJob *h_rj = reinterpret_cast<iss::MtResolveJob *>(h_rest);
+        iss::MtWalkJob *h_wj = reinterpret_cast<iss::MtWalkJob *>(h_rest + (size_t)W * sizeof(iss::MtResolveJob));
+        iss::MtEmitJob *h_ej = reinterpret_cast<iss::MtEmitJob *>(h_rest + (size_t)W * (sizeof(iss::MtResolveJob) + sizeof(iss::MtWalkJob)));
+        auto dev_of = [&](const void *h) { return dj + (reinterpret_cast<const uint8_t *>(h) - hj); };
+        hipStream_t s_side = ctx->setup_stream;  // the walker beside the resolver, the emitter beside the NEXT turn's resolver
+        // ---- (a) every worker of the turn has the words of n + 1 pairs (+ boost) in front of it: mt_ensure, for all at once
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));  // (words produced ahead during the turn before)
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par], 0));  // (this parity's pair records: their last reader, two turns ago)
+        bool fill_e = false;
+        for (int w = 0; w < W; ++w)
+            for (int s = 0; s < 2; ++s) {
+                const int k = 2 * w + s;
+                h_fill_e[k] = iss::MtFillJob{nullptr, nullptr, 0u, 0u};
+                h_move_e[k] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u};
+                want[k] = n_w[w] ? std::min(t.cap[s] / 624 * 624 - 624, words_for(s, n_w[w], ws[w].boost)) : 0;
+                const size_t left = t.fill[k] - t.used[k];
+                if (left >= want[k]) continue;
+                const int nxt = t.cur[k] ^ 1;
+                h_move_e[k] = iss::MtMoveJob{bufp(w, s, t.cur[k]) + t.used[k], bufp(w, s, nxt), (uint32_t)left, 0u};
+                const size_t room = (t.cap[s] - left) / 624;
+                const uint32_t blocks = (uint32_t)std::min(room, (want[k] - left + 623) / 624);
+                h_fill_e[k] = iss::MtFillJob{t.d_state + k, bufp(w, s, nxt) + left, blocks, 0u};
+                t.cur[k] = nxt;
+                t.used[k] = 0;
+                t.fill[k] = left + (size_t)blocks * 624;
+                fill_e = true;
+            }
+        if (fill_e) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par ^ 1], 0));  // (the emitter of the turn before reads the buffers written now)
+            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_move_e), h_move_e, 2 * (size_t)W * sizeof(iss::MtMoveJob), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(iss::k_mt_move_w, dim3(2 * W, iss::MOVE_BLOCKS), dim3(256), 0, ctx->stream, reinterpret_cast<const iss::MtMoveJob *>(dev_of(h_move_e)));
+            HIP_TRY(ctx, hipEventRecord(m.ev_main, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, m.ev_main, 0));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, t.ev_emit[par ^ 1], 0));  // (the emitter of the turn before reads the target)
+            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_fill_e), h_fill_e, 2 * (size_t)W * sizeof(iss::MtFillJob), hipMemcpyHostToDevice, ctx->indel_stream));
+            hipLaunchKernelGGL(iss::k_mt_fill_w, dim3(2 * W), dim3(iss::FILL_THREADS), 0, ctx->indel_stream, reinterpret_cast<const iss::MtFillJob *>(dev_of(h_fill_e)));
+            HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->indel_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));
+        }
+        // ---- (b) the words of the turn AFTER this one are produced beside it (mt_prefetch_begin)
+        bool fill_a = false;
+        for (int w = 0; w < W; ++w)
+            for (int s = 0; s < 2; ++s) {
+                const int k = 2 * w + s;
+                pf[k] = PF{};
+                h_fill_a[k] = iss::MtFillJob{nullptr, nullptr, 0u, 0u};
+                if (!n_w[w] || ws[w].walk_one || ws[w].done + n_w[w] >= ws[w].n) continue;
+                const int64_t n_next = std::min(t.ch, ws[w].n - ws[w].done - n_w[w]);
+                const size_t want_next = words_for(s, n_next, 0);
+                const size_t avail = t.fill[k] - t.used[k];
+                if (avail >= want[k] + want_next) continue;
+                // (only what is missing: everything in front of the turn is moved behind it -- a backlog would be copied every turn)
+                const size_t blocks = (want[k] + want_next - avail + 623) / 624;
+                if (avail + blocks * 624 > t.cap[s]) continue;
+                pf[k].on = true; pf[k].at = avail; pf[k].blocks = (uint32_t)blocks;
+                h_fill_a[k] = iss::MtFillJob{t.d_state + k, bufp(w, s, t.cur[k] ^ 1) + avail, (uint32_t)blocks, 0u};
+                fill_a = true;
+            }
+        if (fill_a) {  // (behind everything queued on the main stream so far, and behind the emitter of the turn before: it reads the target)
+            HIP_TRY(ctx, hipEventRecord(m.ev_main, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, m.ev_main, 0));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, t.ev_emit[par ^ 1], 0));
+            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_fill_a), h_fill_a, 2 * (size_t)W * sizeof(iss::MtFillJob), hipMemcpyHostToDevice, ctx->indel_stream));
+            hipLaunchKernelGGL(iss::k_mt_fill_w, dim3(2 * W), dim3(iss::FILL_THREADS), 0, ctx->indel_stream, reinterpret_cast<const iss::MtFillJob *>(dev_of(h_fill_a)));
+            HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->indel_stream));
+        }
+        // ---- (c) the turn: the resolver for the workers on the fast path, the walker for the others
+        bool any_res = false, any_walk = false, walk_rows = false;
+        for (int w = 0; w < W; ++w) {
+            const Genome &G = ctx->genomes[ws[w].gid];
+            const iss::DevGenome dg{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
+            const int64_t row0 = ws[w].row0 + ws[w].done;
+            const bool walker = n_w[w] > 0 && (!resolve || ws[w].walk_one);
+            iss::MtResolveJob &rj = h_rj[w];
+            rj = iss::MtResolveJob{};
+            iss::MtWalkJob &wj = h_wj[w];
+            wj = iss::MtWalkJob{};
+            if (n_w[w] > 0 && !walker) {
+                iss::MtResolveArgs &R = rj.A;
+                R.py_base = bufp(w, 0, t.cur[2 * w]);
+                R.np_base = bufp(w, 1, t.cur[2 * w + 1]);
+                R.py_off = (uint32_t)t.used[2 * w];
+                R.np_off = (uint32_t)t.used[2 * w + 1];
+                R.py_fill = (uint32_t)t.fill[2 * w];
+                R.np_fill = (uint32_t)t.fill[2 * w + 1];
+                R.py_cap = (uint32_t)t.cap[0];
+                R.np_cap = (uint32_t)t.cap[1];
+                R.n_pairs = n_w[w];
+                R.sequence_type = sequence_type;
+                R.gc_bias = gc_bias ? 1 : 0;
+                R.gc_thr = 8106479329266893ull;
+                R.res = t.d_res + w;
+                R.rec = t.d_rec + ((size_t)par * (size_t)W + (size_t)w) * (size_t)t.ch;
+                R.has_frag = 0;
+                R.guard = guard;
+                R.gauss = t.d_gauss + w;
+                rj.g = dg;
+                rj.desc = ctx->desc + row0;
+                any_res = true;
+            } else if (walker) {
+                iss::MtWalkArgs &A = wj.A;
+                A.py = bufp(w, 0, t.cur[2 * w]) + t.used[2 * w];
+                A.np = bufp(w, 1, t.cur[2 * w + 1]) + t.used[2 * w + 1];
+                A.py_avail = (uint32_t)(t.fill[2 * w] - t.used[2 * w]);
+                A.np_avail = (uint32_t)(t.fill[2 * w + 1] - t.used[2 * w + 1]);
+                A.n_pairs = n_w[w];
+                A.sequence_type = sequence_type;
+                A.gc_bias = gc_bias ? 1 : 0;
+                A.gc_thr = 8106479329266893ull;
+                for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.row;
+                A.res = t.d_res + w;
+                A.use_rows = use_rows && n_w[w] > 64 ? 1 : 0;
+                A.pair_base = ws[w].done;
+                A.guard = guard;
+                A.gauss = t.d_gauss + w;
+                wj.g = dg;
+                wj.desc = ctx->desc + row0;
+                any_walk = true;
+                walk_rows |= A.use_rows != 0;
+            }
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(d_rest, h_rest, (size_t)W * (sizeof(iss::MtResolveJob) + sizeof(iss::MtWalkJob)), hipMemcpyHostToDevice, ctx->stream));
+        if (any_walk) {  // (beside the resolver: other workers; behind the words and tables the main stream has waited for / copied)
+            HIP_TRY(ctx, hipEventRecord(t.ev_turn, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(s_side, t.ev_turn, 0));
+            hipLaunchKernelGGL(iss::k_mt_walk_w, dim3(W), dim3(64), walk_rows ? fixed_lds + rows_bytes : fixed_lds, s_side, M, reinterpret_cast<const iss::MtWalkJob *>(dev_of(h_wj)));
+            HIP_TRY(ctx, hipEventRecord(t.ev_side, s_side));
+        }
+        if (any_res) hipLaunchKernelGGL(resolve, dim3(W), dim3(iss::RES_THREADS), resolve_lds, ctx->stream, M, reinterpret_cast<const iss::MtResolveJob *>(dev_of(h_rj)));
+        if (any_walk) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_side, 0));
+        HIP_TRY(ctx, hipMemcpyAsync(t.h_res, t.d_res, (size_t)W * sizeof(iss::MtWalkResult), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipGetLastError());
+        // ---- (d) the reads of the resolved pairs, all workers in one launch
+        int64_t emit_max = 0;
+        for (int w = 0; w < W; ++w) {
+            iss::MtEmitJob &ej = h_ej[w];
+            ej = iss::MtEmitJob{};
+            if (!(n_w[w] > 0 && h_rj[w].A.n_pairs > 0) || t.h_res[w].n_done <= 0) continue;
+            const int64_t row0 = ws[w].row0 + ws[w].done;
+            ej.py = h_rj[w].A.py_base;
+            ej.np = h_rj[w].A.np_base;
+            ej.n_pairs = t.h_res[w].n_done;
+            ej.desc = ctx->desc + row0;
+            ej.rec = h_rj[w].A.rec;
+            for (int k = 0; k < 4; ++k) ej.out[k] = ctx->out[k] + (size_t)row0 * M.row;
+            ej.g = h_rj[w].g;
+            emit_max = std::max(emit_max, ej.n_pairs);
+        }
+        if (emit_max > 0) {  // (on the side stream: the next turn's resolver does not wait for it -- the main stream is idle here: synchronized above)
+            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_ej), h_ej, (size_t)W * sizeof(iss::MtEmitJob), hipMemcpyHostToDevice, s_side));
+            hipLaunchKernelGGL(iss::k_mt_emit_w, dim3((unsigned)((2 * emit_max + 3) / 4), (unsigned)W), dim3(256), 0, s_side, M,
+                               reinterpret_cast<const iss::MtEmitJob *>(dev_of(h_ej)));
+        }
+        HIP_TRY(ctx, hipEventRecord(t.ev_emit[par], s_side));
+        // ---- (e) the streams move on (mt_prefetch_commit: the unconsumed words in front of those produced ahead)
+        bool move_c = false;
+        for (int w = 0; w < W; ++w) {
+            if (!n_w[w]) { for (int s = 0; s < 2; ++s) h_move_c[2 * w + s] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u}; continue; }
+            const iss::MtWalkResult &res = t.h_res[w];
+            const bool walker = h_wj[w].A.n_pairs > 0;
+            if (res.need_host) return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: a draw for the host's libm on the side-by-side path");
+            t.used[2 * w] += res.py_used;
+            t.used[2 * w + 1] += res.np_used;
+            for (int s = 0; s < 2; ++s) {
+                const int k = 2 * w + s;
+                h_move_c[k] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u};
+                if (!pf[k].on) continue;
+                const size_t left = t.fill[k] - t.used[k];  // <= pf.at
+                const int nxt = t.cur[k] ^ 1;
+                h_move_c[k] = iss::MtMoveJob{bufp(w, s, t.cur[k]) + t.used[k], bufp(w, s, nxt) + (pf[k].at - left), (uint32_t)left, 0u};
+                t.cur[k] = nxt;
+                t.used[k] = pf[k].at - left;
+                t.fill[k] = pf[k].at + (size_t)pf[k].blocks * 624;
+                move_c = true;
+            }
+            ws[w].done += res.n_done;
+            if (walker) {
+                t.n_walked += res.n_done;
+                if (res.n_done == 0 && res.starved && h_wj[w].A.py_avail >= want[2 * w] && h_wj[w].A.np_avail >= want[2 * w + 1]) {
+                    if (ws[w].boost >= 256) return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+                    ws[w].boost = 2 * ws[w].boost + 4;
+                }
+                if (res.n_done > 0) ws[w].walk_one = false;
+            } else {
+                t.n_resolved += res.n_done;
+                if (res.pad) {
+                    ws[w].walk_one = true;  // the next pair is not plain: one turn of the walker
+                } else if (res.n_done == 0 && res.starved && (size_t)(h_rj[w].A.py_fill - h_rj[w].A.py_off) >= want[2 * w] &&
+                           (size_t)(h_rj[w].A.np_fill - h_rj[w].A.np_off) >= want[2 * w + 1]) {
+                    if (ws[w].boost >= 256) return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
+                    ws[w].boost = 2 * ws[w].boost + 4;
+                }
+            }
+        }
+        if (move_c) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par ^ 1], 0));  // (the target: what the emitter of the turn before reads)
+            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_move_c), h_move_c, 2 * (size_t)W * sizeof(iss::MtMoveJob), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(iss::k_mt_move_w, dim3(2 * W, iss::MOVE_BLOCKS), dim3(256), 0, ctx->stream, reinterpret_cast<const iss::MtMoveJob *>(dev_of(h_move_c)));
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));
+    for (auto &e : t.ev_emit) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e, 0));  // (the rows are complete once the main stream is)
+    for (int w = 0; w < W; ++w)
+        if (n_done && ws[w].n) n_done[w] = ws[w].done;
+    return 0;
+}
+
+/* iss_mt_peek for worker w of the set (tests: the stream positions after a run) */
+int iss_mt_workers_peek(iss_ctx *ctx, int32_t worker, uint32_t *py_words, uint32_t *np_words, int32_t n) {
+    if (!ctx || worker < 0 || worker >= ctx->mts.W || n < 0 || n > 624) return fail(ctx, ISS_E_INVALID, "iss_mt_workers_peek: bad argument");
+    if (!ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_mt_workers_peek: upload a model first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc_ = sync_all(ctx); if (rc_) return rc_; }
+    { int rc_ = mt_set_reserve(ctx); if (rc_) return rc_; }
+    MtChainLoan loan(ctx, worker);
+    return iss_mt_peek(ctx, py_words, np_words, n);
+}
+
 int iss_set_fragment(iss_ctx *ctx, int32_t enabled, double fragment_length, double fragment_sd) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
     ctx->has_frag = enabled != 0;
@@ -2490,8 +3019,8 @@ int iss_mt_mutations_download(iss_ctx *ctx, iss_mutation *out, int64_t capacity,
 
 int iss_mt_path_counts(iss_ctx *ctx, int64_t *n_resolved, int64_t *n_walked) {
     if (!ctx) return fail(nullptr, ISS_E_INVALID, "ctx is NULL");
-    if (n_resolved) *n_resolved = ctx->mt.n_resolved;
-    if (n_walked) *n_walked = ctx->mt.n_walked;
+    if (n_resolved) *n_resolved = ctx->mt.n_resolved + ctx->mts.n_resolved;  // (single-worker calls + the worker set)
+    if (n_walked) *n_walked = ctx->mt.n_walked + ctx->mts.n_walked;
     return 0;
 }
 

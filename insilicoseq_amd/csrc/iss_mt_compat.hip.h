@@ -53,14 +53,11 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 //   n[454 + j] = n[227 + j] ^ F(454 + j)                                  j < 169
 //   n[623]     = n[396] ^ twist(o[623], n[0])
 constexpr int FILL_THREADS = 320;
-__global__ __launch_bounds__(FILL_THREADS) void k_mt_fill(MtState *states, uint32_t *out0, uint32_t *out1, uint32_t blocks0,
-                                                          uint32_t blocks1) {
+// (one stream: its state, where its next n_blocks blocks of 624 tempered words go)
+__device__ __forceinline__ void mt_fill_body(MtState *state, uint32_t *out, uint32_t n_blocks) {
     __shared__ uint32_t buf[2][624];
-    const int s = blockIdx.x;
-    uint32_t *out = s ? out1 : out0;
-    const uint32_t n_blocks = s ? blocks1 : blocks0;
     const int tid = threadIdx.x;
-    for (int k = tid; k < 624; k += FILL_THREADS) buf[0][k] = states[s].mt[k];
+    for (int k = tid; k < 624; k += FILL_THREADS) buf[0][k] = state->mt[k];
     __syncthreads();
     int cur = 0;
     for (uint32_t b = 0; b < n_blocks; ++b) {
@@ -90,7 +87,39 @@ __global__ __launch_bounds__(FILL_THREADS) void k_mt_fill(MtState *states, uint3
         cur ^= 1;
         lds_barrier();
     }
-    for (int k = tid; k < 624; k += FILL_THREADS) states[s].mt[k] = buf[cur][k];
+    for (int k = tid; k < 624; k += FILL_THREADS) state->mt[k] = buf[cur][k];
+}
+__global__ __launch_bounds__(FILL_THREADS) void k_mt_fill(MtState *states, uint32_t *out0, uint32_t *out1, uint32_t blocks0,
+                                                          uint32_t blocks1) {
+    const int s = blockIdx.x;
+    mt_fill_body(states + s, s ? out1 : out0, s ? blocks1 : blocks0);
+}
+
+// ---- W workers per launch (round 5).  The reference's own parallelism is N independent workers, each with its two streams
+// seeded seed + cpu_number (iss/generator.py:234-236, iss/app.py:99-106): a worker is one chain, W workers are W chains --
+// one workgroup each per kernel of the path, a job table in global memory instead of kernel arguments.  Every *_w kernel
+// runs exactly the single-worker kernel's code on its worker's job; a job with nothing to do leaves at once.
+struct MtFillJob {
+    MtState *state;
+    uint32_t *out;
+    uint32_t n_blocks, pad;
+};
+__global__ __launch_bounds__(FILL_THREADS) void k_mt_fill_w(const MtFillJob *jobs) {
+    const MtFillJob j = jobs[blockIdx.x];
+    if (!j.n_blocks) return;  // (uniform)
+    mt_fill_body(j.state, j.out, j.n_blocks);
+}
+// the unconsumed words of a stream move in front of the words produced ahead (the single-worker path: a device-to-device copy
+// per stream and turn; 2 W of them would be 2 W launches)
+struct MtMoveJob {
+    const uint32_t *src;
+    uint32_t *dst;
+    uint32_t n, pad;
+};
+constexpr int MOVE_BLOCKS = 16;  // workgroups per job (grid.y)
+__global__ __launch_bounds__(256) void k_mt_move_w(const MtMoveJob *jobs) {
+    const MtMoveJob j = jobs[blockIdx.x];
+    for (uint32_t k = blockIdx.y * 256u + threadIdx.x; k < j.n; k += 256u * (uint32_t)MOVE_BLOCKS) j.dst[k] = j.src[k];
 }
 
 struct MtWalkResult {
@@ -177,7 +206,7 @@ __device__ __forceinline__ uint32_t mt_randbelow(const uint32_t *py, uint32_t &o
     }
 }
 
-__global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkArgs A, PairDesc *desc) {
+__device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome &g, const MtWalkArgs &A, PairDesc *desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const int RL = M.RL;
@@ -557,6 +586,17 @@ __global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkA
         *A.gauss = gs;
     }
 }
+__global__ __launch_bounds__(64) void k_mt_walk(DevModel M, DevGenome g, MtWalkArgs A, PairDesc *desc) { mt_walk_body(M, g, A, desc); }
+struct MtWalkJob {
+    MtWalkArgs A;
+    DevGenome g;
+    PairDesc *desc;
+};
+__global__ __launch_bounds__(64) void k_mt_walk_w(DevModel M, const MtWalkJob *jobs) {
+    const MtWalkJob j = jobs[blockIdx.x];
+    if (j.A.n_pairs <= 0) return;  // (uniform: this worker has no turn of the walker)
+    mt_walk_body(M, j.g, j.A, j.desc);
+}
 
 // ====================================================================== resolver + emitter
 // The stream offsets are the only thing that chains the pairs of a worker: once a pair's offsets are known
@@ -601,7 +641,7 @@ __host__ __device__ inline size_t mt_res_lds_bytes(const DevModel &M, int pyv, i
 }
 
 template <int PYV, int NPV, bool ROWS_LDS>
-__global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenome g, MtResolveArgs A, PairDesc *desc) {
+__device__ __forceinline__ void mt_resolve_body(const DevModel &M, const DevGenome &g, const MtResolveArgs &A, PairDesc *desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t HPY = PYV * 1024u, WPY = 2u * HPY, HNP = NPV * 1024u, WNP = 2u * HNP;
     constexpr uint32_t CHUNK = RES_THREADS * 4u;  // words one load / store instruction of the workgroup moves
@@ -908,6 +948,21 @@ __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenom
         *A.gauss = gs;
     }
 }
+template <int PYV, int NPV, bool ROWS_LDS>
+__global__ __launch_bounds__(RES_THREADS) void k_mt_resolve(DevModel M, DevGenome g, MtResolveArgs A, PairDesc *desc) {
+    mt_resolve_body<PYV, NPV, ROWS_LDS>(M, g, A, desc);
+}
+struct MtResolveJob {
+    MtResolveArgs A;
+    DevGenome g;
+    PairDesc *desc;
+};
+template <int PYV, int NPV, bool ROWS_LDS>
+__global__ __launch_bounds__(RES_THREADS) void k_mt_resolve_w(DevModel M, const MtResolveJob *jobs) {
+    const MtResolveJob j = jobs[blockIdx.x];
+    if (j.A.n_pairs <= 0) return;  // (uniform: the worker is done, or this turn is its walker's)
+    mt_resolve_body<PYV, NPV, ROWS_LDS>(M, j.g, j.A, j.desc);
+}
 
 // reads of the pairs k_mt_resolve resolved: one wavefront per (pair, mate); the read is the template
 // (no indel, only ACGT), phred scores and substitutions come from the recorded stream offsets
@@ -922,9 +977,9 @@ struct MtEmitMut {
     int64_t pair_base;        // pair index (within the call) of this launch's first pair
 };
 
-__global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const uint32_t *py, const uint32_t *np,
-                                                 int64_t n_pairs, const PairDesc *desc, const MtPairRec *rec, uint8_t *out0,
-                                                 uint8_t *out1, uint8_t *out2, uint8_t *out3, MtEmitMut E) {
+__device__ __forceinline__ void mt_emit_body(const DevModel &M, const DevGenome &g, const uint32_t *py, const uint32_t *np,
+                                             int64_t n_pairs, const PairDesc *desc, const MtPairRec *rec, uint8_t *out0,
+                                             uint8_t *out1, uint8_t *out2, uint8_t *out3, const MtEmitMut &E) {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= 2 * n_pairs) return;
@@ -979,6 +1034,25 @@ __global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const 
     }
     if (E.mut_cnt && lane == 0) E.mut_cnt[item] = (int32_t)n_rows;
     for (int p = RL + lane; p < M.pitch; p += 64) { ob[xp(p)] = 0; oq[xp(p)] = 0; }
+}
+__global__ __launch_bounds__(256) void k_mt_emit(DevModel M, DevGenome g, const uint32_t *py, const uint32_t *np,
+                                                 int64_t n_pairs, const PairDesc *desc, const MtPairRec *rec, uint8_t *out0,
+                                                 uint8_t *out1, uint8_t *out2, uint8_t *out3, MtEmitMut E) {
+    mt_emit_body(M, g, py, np, n_pairs, desc, rec, out0, out1, out2, out3, E);
+}
+struct MtEmitJob {  // (grid.y = worker; no --store_mutations rows on this path)
+    const uint32_t *py, *np;
+    int64_t n_pairs;
+    const PairDesc *desc;
+    const MtPairRec *rec;
+    uint8_t *out[4];
+    DevGenome g;
+};
+__global__ __launch_bounds__(256) void k_mt_emit_w(DevModel M, const MtEmitJob *jobs) {
+    const MtEmitJob j = jobs[blockIdx.y];
+    if ((int64_t)blockIdx.x * 4 >= 2 * j.n_pairs) return;
+    const MtEmitMut none{};
+    mt_emit_body(M, j.g, j.py, j.np, j.n_pairs, j.desc, j.rec, j.out[0], j.out[1], j.out[2], j.out[3], none);
 }
 
 }  // namespace iss

@@ -246,6 +246,40 @@ class ReadEngine(object):
                                               int(bool(gc_bias)), int(out_first_pair), C.byref(done)))
         return done.value
 
+    def seed_mt_workers(self, seeds):
+        """W reference workers side by side in this context: worker w == seed_mt(seeds[w]) in a context of its own
+        (its two MT19937 streams; iss/generator.py:234-236 with seed + cpu_number)."""
+        a = np.ascontiguousarray(seeds, dtype=np.uint64)
+        self._check(self._lib.iss_mt_workers_seed(self._ctx, int(a.size), a.ctypes.data))
+        self._mt_workers = int(a.size)
+
+    def generate_mt_workers(self, genome_ids, n_pairs, out_first_pair, sequence_type="metagenomics", gc_bias=False):
+        """One work item (or piece of one) per worker, every kernel of the path launched once for all workers: worker w
+        generates n_pairs[w] pairs of genome genome_ids[w] into rows [out_first_pair[w], +n_pairs[w]) from ITS streams --
+        the rows and stream positions of generate_mt per worker.  Returns (pairs emitted per worker, status per worker:
+        0 or E_SHORT_RECORD)."""
+        if sequence_type not in SEQ_TYPES:
+            raise ValueError("Sequence type %s not known" % sequence_type)
+        g = np.ascontiguousarray(genome_ids, dtype=np.int32)
+        n = np.ascontiguousarray(n_pairs, dtype=np.int64)
+        r = np.ascontiguousarray(out_first_pair, dtype=np.int64)
+        if not (g.size == n.size == r.size == getattr(self, "_mt_workers", -1)):
+            raise ValueError("generate_mt_workers: one genome id, pair count and first row per seeded worker")
+        self.reserve(int((r + n).max()) if n.size else 0)
+        done = np.zeros(n.size, dtype=np.int64)
+        status = np.zeros(n.size, dtype=np.int32)
+        self._check(self._lib.iss_generate_mt_workers(self._ctx, int(n.size), g.ctypes.data, n.ctypes.data, r.ctypes.data,
+                                                      SEQ_TYPES[sequence_type], int(bool(gc_bias)), done.ctypes.data,
+                                                      status.ctypes.data))
+        return done, status
+
+    def mt_workers_peek(self, worker, n=8):
+        """mt_peek for worker ``worker`` of the set."""
+        a = np.zeros(n, dtype=np.uint32)
+        b = np.zeros(n, dtype=np.uint32)
+        self._check(self._lib.iss_mt_workers_peek(self._ctx, int(worker), a.ctypes.data, b.ctypes.data, int(n)))
+        return a, b
+
     def mt_set_fragment(self, fragment_length=None, fragment_sd=None):
         """Custom fragment length for generate_mt (None, None switches back to the model's insert sizes)."""
         on = fragment_length is not None and fragment_sd is not None

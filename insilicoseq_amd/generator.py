@@ -463,6 +463,98 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
         w.close()
 
 
+def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, sequence_type, gc_bias, device=None,
+                        compress=False, batch_pairs=None):
+    """W reference workers (``rng="mt"``) on ONE GPU, side by side: the files of ``worker_iterator(works[k], error_model,
+    cpu_numbers[k], worker_prefixes[k], seed, ..., rng="mt")`` for every k -- byte for byte the reference's
+    ``iss generate --cpus W`` temp files (iss/app.py:99-106, iss/generator.py:223-251) -- but the workers' chains run in the
+    same kernel launches, one workgroup per worker (ReadEngine.generate_mt_workers).  A worker is a sequential chain over its
+    two MT19937 streams (seed + cpu_number, generator.py:234-236); W of them are what the reference itself runs in parallel.
+    ``--store_mutations`` rows are per engine: such a run takes one worker after the other through worker_iterator."""
+    logger = logging.getLogger(__name__)
+    W = len(works)
+    if not (W == len(cpu_numbers) == len(worker_prefixes)) or W < 1:
+        raise ValueError("worker_set_iterator: one work list, cpu number and file prefix per worker")
+    if sequence_type not in _native.SEQ_TYPES:
+        raise RuntimeError("sequence type '%s' is not supported" % sequence_type)  # generator.py:139
+    if bool(getattr(error_model, "store_mutations", False)) or seed is None:
+        # (unseeded workers draw their seeds from the OS one by one, like the reference's processes)
+        for work, cpu, prefix in zip(works, cpu_numbers, worker_prefixes):
+            worker_iterator(work, error_model, cpu, prefix, seed, sequence_type, gc_bias, device=device, rng="mt", compress=compress)
+        return
+    handles = []
+    try:
+        for prefix in worker_prefixes:
+            handles.append((open("%s_R1.fastq" % prefix, "w"), open("%s_R2.fastq" % prefix, "w"), open("%s.vcf" % prefix, "w")))
+    except PermissionError as e:
+        logger.error("Failed to write temporary output file(s): %s" % e)
+        sys.exit(1)
+    eng = ReadEngine(0 if device is None else device)
+    try:
+        dense = _dense_of(error_model)
+        eng.load_model(dense)
+        if compress:
+            eng.fastq_compress(True)
+        eng.seed_mt_workers([worker_seed(seed, c) for c in cpu_numbers])
+        eng.mt_set_fragment(getattr(error_model, "fragment_length", None), getattr(error_model, "fragment_sd", None))
+        per = int(batch_pairs or max(1024, min(Worker.BATCH_PAIRS, (1 << 20) // W)))  # rows per worker and round
+        gids = {}
+
+        def gid_of(record):
+            hit = gids.get(id(record))
+            if hit is None or hit[0] is not record:
+                seq = record.seq
+                if not isinstance(seq, (str, bytes, bytearray, np.ndarray)):
+                    seq = str(seq)
+                hit = gids[id(record)] = (record, eng.add_genome(seq))
+            return hit[1]
+
+        def pieces(work, cpu):  # (record, genome id, pairs, id of the piece's first pair, short record?)
+            for record, n_pairs, _mode in work:
+                logger.debug("Cpu #%s: Generating %s read pairs" % (cpu, n_pairs))
+                if not (eng.read_length < len(record.seq)):
+                    # AssertionError in simulate_read -> warning + record skipped (generator.py:77-80); the reference has
+                    # drawn the insert size (or its gaussian) by then (generator.py:121-130): the engine consumes that draw
+                    logger.warning("%s shorter than read length for this ErrorModel" % record.id)
+                    logger.warning("Skipping %s. You will have less reads than specified" % record.id)
+                    if n_pairs > 0:
+                        yield record, gid_of(record), 1, 0, True
+                    continue
+                done = 0
+                while done < n_pairs:
+                    n = min(per, n_pairs - done)
+                    yield record, gid_of(record), n, done, False
+                    done += n
+
+        its = [pieces(work, cpu) for work, cpu in zip(works, cpu_numbers)]
+        for fh3 in handles:
+            for fh in fh3[:2]:
+                fh.flush()
+        while True:
+            cur = [next(it, None) for it in its]
+            if all(c is None for c in cur):
+                break
+            g = [c[1] if c else 0 for c in cur]
+            n = [c[2] if c else 0 for c in cur]
+            row = np.concatenate(([0], np.cumsum(n)[:-1])).astype(np.int64)
+            done, status = eng.generate_mt_workers(g, n, row, sequence_type=sequence_type, gc_bias=gc_bias)
+            for k, c in enumerate(cur):
+                if c is None:
+                    continue
+                if c[4]:
+                    assert status[k] == _native.E_SHORT_RECORD and done[k] == 0, (k, int(status[k]), int(done[k]))
+                    continue
+                assert status[k] == 0 and done[k] == c[2], (k, int(status[k]), int(done[k]), c[2])
+                eng.fastq_emit(handles[k][0].fileno(), handles[k][1].fileno(), c[0].id, c[3], cpu_numbers[k], int(row[k]), c[2],
+                               n_threads=1)
+        eng.fastq_flush()
+    finally:
+        eng.close()
+        for fh3 in handles:
+            for fh in fh3:
+                fh.close()
+
+
 def lognormal_abundance(record_ids, rng):
     """iss/abundance.py:137-154 with an explicit RandomState."""
     dist = rng.lognormal(size=len(record_ids))

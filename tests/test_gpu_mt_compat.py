@@ -113,6 +113,74 @@ def test_generate_cli_equals_reference(cpus, tmp_path):
     assert open(out + "_R2.fastq", "rb").read() == z["r2"].tobytes()
 
 
+@pytest.mark.parametrize("case", ["genomes_hiseq_n1600_seed42", "syn3_novaseq_n3000_seed7"])
+def test_generate_cli_cpus8_equals_reference(case, tmp_path):
+    """`iss generate --cpus 8` -- the reference's own parallelism, eight workers seeded seed + cpu_number (iss/app.py:81-106,
+    iss/generator.py:234-236) -- as eight chains side by side on ONE GPU (iss_generate_mt_workers: every kernel of the MT
+    path launched once for all workers, one workgroup each): the assembled files equal the reference's byte for byte.
+    genomes_hiseq: data/genomes.fasta (short low-complexity records: genome-end fallbacks, a skipped record);
+    syn3_novaseq: three random 20 kbp records carried in the fixture (the resolver's fast path)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(GOLDEN, "generate", case + "_cpus8.npz"))
+    fasta = os.path.join(GOLDEN, "genomes.fasta")
+    if "fasta" in z.files:
+        fasta = str(tmp_path / "in.fasta")
+        with open(fasta, "wb") as fh:
+            fh.write(z["fasta"].tobytes())
+    model, n, seed = case.split("_")[1], case.split("_")[2][1:], case.split("_")[3][4:]
+    out = str(tmp_path / "run")
+    subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes", fasta, "--model", model, "-n", n,
+                           "--seed", seed, "--cpus", "8", "--devices", "1", "--rng", "mt", "-o", out, "--quiet"], cwd=root)
+    assert open(out + "_abundance.txt", "rb").read() == z["abundance"].tobytes()
+    assert open(out + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(out + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+
+
+@pytest.mark.parametrize("turn", [None, "37"])
+@pytest.mark.parametrize("case", ["novaseq", "hiseq_gc", "miseq", "indel_heavy", "basic", "novaseq_frag", "novaseq_gzip"])
+def test_worker_set_equals_separate_workers(case, turn, tmp_path, monkeypatch):
+    """W workers side by side in one context (worker_set_iterator -> iss_generate_mt_workers) write the files of W
+    separate worker_iterator(rng="mt") runs -- which are the reference's (tests above) -- for work lists of different
+    lengths over a plain record, a record with IUPAC / lower-case letters (the resolver hands such pairs to the walker) and
+    a record shorter than a read (skipped after its draw).  turn = 37: many short turns per call (stream words produced
+    ahead, moved, consumed across turn boundaries); indel_heavy: the walker only; basic / novaseq_frag: the workers take
+    the single-worker path one after the other (draws the host's libm settles)."""
+    import gzip
+
+    from helpers import mixed_genome, random_genome
+    from insilicoseq_amd.generator import Record, worker_iterator, worker_set_iterator
+
+    if turn:
+        monkeypatch.setenv("ISS_MT_SET_TURN", turn)
+    model = {"hiseq_gc": "hiseq", "indel_heavy": "novaseq", "novaseq_frag": "novaseq", "novaseq_gzip": "novaseq"}.get(case, case)
+    em = dense_model(model, (0.01, 0.03) if case == "indel_heavy" else None)
+    if case == "novaseq_frag":
+        em.fragment_length, em.fragment_sd = 420.0, 35.0
+    gc = case == "hiseq_gc"
+    compress = case == "novaseq_gzip"
+    recs = [Record(random_genome(201, 30000), id="plain"), Record(mixed_genome(202, 9000), id="mixed"),
+            Record(random_genome(203, 120), id="short"), Record(random_genome(204, 2500), id="small")]
+    r = np.random.RandomState(5)
+    scale = 1 if case in ("indel_heavy", "basic", "miseq") else 4
+    works = []
+    for w in range(5):
+        items = [(recs[int(k)], int(r.randint(1, 260 * scale)), "default") for k in r.randint(0, 4, size=int(r.randint(1, 5)))]
+        works.append(items)
+    works[3] = [(recs[0], 700 * scale, "default")]  # one long item: its worker is still busy when the others are done
+    cpus = [0, 1, 2, 5, 9]
+    seed = 77
+    set_prefix = [str(tmp_path / ("set%d" % c)) for c in cpus]
+    worker_set_iterator(works, em, cpus, set_prefix, seed, "metagenomics", gc, device=0, compress=compress, batch_pairs=300)
+    rd = (lambda p: gzip.open(p, "rb").read()) if compress else (lambda p: open(p, "rb").read())
+    for work, c, sp in zip(works, cpus, set_prefix):
+        one = str(tmp_path / ("one%d" % c))
+        worker_iterator(work, em, c, one, seed, "metagenomics", gc, device=0, rng="mt", compress=compress)
+        for suffix in ("_R1.fastq", "_R2.fastq"):
+            a, b = rd(sp + suffix), rd(one + suffix)
+            assert a == b, (case, c, suffix, len(a), len(b))
+    assert sum(len(rd(sp + "_R1.fastq")) for sp in set_prefix) > 100_000  # (a worker whose items are all short records writes nothing)
+
+
 @pytest.mark.parametrize("cpus", [1, 2])
 def test_generate_cli_compress_equals_reference(cpus, tmp_path):
     """`--compress` (gzip members built on the device, one per worker batch, concatenated in worker order; the .vcf

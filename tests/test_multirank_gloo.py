@@ -87,6 +87,50 @@ def test_ranks_reproduce_reference_generate(world, tmp_path):
     mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path), GOLDEN), nprocs=world, join=True)
 
 
+@pytest.mark.parametrize("case,model,n_reads,seed", [("genomes_hiseq_n1600_seed42", "hiseq", 1600, 42),
+                                                     ("syn3_novaseq_n3000_seed7", "novaseq", 3000, 7)])
+def test_eight_workers_reproduce_reference_generate(case, model, n_reads, seed, tmp_path):
+    """`iss generate --cpus 8` (goldens of tests/golden/tooling/make_golden_cpus8.py): chunk r of the reference's divider with
+    cpus = 8, worker seed = seed + r, temp files concatenated in worker order -- the CPU oracle (MT streams) standing in for
+    the device.  The same fixtures pin the device's W-workers-per-launch mode (tests/test_gpu_mt_compat.py)."""
+    from insilicoseq_amd import distributed as D
+    from insilicoseq_amd.engine import fastq_write
+    from insilicoseq_amd.generator import lognormal_abundance, parse_fasta
+    from insilicoseq_amd.model import DenseModel
+    from oracle import oracle as O
+
+    z = np.load(os.path.join(GOLDEN, "generate", case + "_cpus8.npz"))
+    fasta = os.path.join(GOLDEN, "genomes.fasta")
+    if "fasta" in z.files:
+        fasta = str(tmp_path / "in.fasta")
+        with open(fasta, "wb") as fh:
+            fh.write(z["fasta"].tobytes())
+    dense = DenseModel.load(os.path.join(GOLDEN, "..", "..", "insilicoseq_amd", "profiles", model + ".dense.npz"))
+    records = list(parse_fasta(fasta))
+    abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(seed))
+    output = str(tmp_path / "out")
+    world, n_files = 8, 0
+    for rank in range(world):
+        work, _, n_chunks = D.rank_work(records, None, abundance, n_reads, None, None, dense, output, world, rank)
+        if work is None:
+            continue
+        orc, rng = O.Oracle(dense), O.Rng().seed_mt(seed + rank)
+        prefix = D.temp_prefix(output, rank)
+        with open(prefix + "_R1.fastq", "wb") as f1, open(prefix + "_R2.fastq", "wb") as f2:
+            for rec, n, _ in work:
+                res = orc.simulate(rng, rec.seq, n)
+                if res["status"] == O.SKIP_RECORD:
+                    continue
+                assert res["status"] == 0
+                fastq_write(f1.fileno(), f2.fileno(), rec.id, 0, rank, res["n_done"], dense.read_length, dense.read_length,
+                            res["r1_base"], res["r1_qual"], res["r2_base"], res["r2_qual"], 2)
+        n_files += 1
+    assert n_files == world
+    D.concatenate_rank_files(output, world)
+    assert open(output + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(output + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+
+
 def test_single_rank_is_a_noop_broadcast():
     from insilicoseq_amd import distributed as D
     from insilicoseq_amd.model import DenseModel

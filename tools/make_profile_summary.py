@@ -19,6 +19,68 @@ def counters(root):
     return acc, calls
 
 
+N_SE, N_SIMD, N_CU = 32, 1024, 256  # MI355X: 8 XCDs x 4 shader engines (the SQ counters' instances), 256 CUs x 4 SIMDs
+
+
+def derived_summary(src, tag, out_dir, acc, calls, stats_csv, cmd):
+    """<tag>_summary.json: per k_main variant of the run, what the counters say about WHY the launch takes what it takes --
+    the figures bench.py's other_workloads legs carry (`pmc`).  Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* /
+    SQ_ACTIVE_INST_* count quad-cycles; SQ_BUSY_CYCLES counts cycles per shader engine (32 of them): cycles per launch and
+    engine / launch duration = the clock the chip actually ran the kernel at (it clocks to its power budget)."""
+    dur = {}
+    for r in csv.DictReader(open(stats_csv)):
+        if "k_main" in r["Name"]:
+            dur[r["Name"].split("(")[0]] = (float(r["AverageNs"]) * 1e-9, int(r["Calls"]))
+    build_id, line = "unknown", None
+    for log in glob.glob(src + "/*.log"):
+        for ln in open(log, errors="replace"):
+            if ln.startswith("{") and "library_build_id" in ln:
+                line = json.loads(ln)
+                build_id = line.get("library_build_id", build_id)
+    out = {"command": cmd, "library_build_id": build_id, "kernels": {}}
+    if line:
+        out["pairs_per_step"] = line["config"].get("pairs_per_step_per_gpu")
+        out["algorithmic_bytes_per_pair"] = line["roofline"].get("algorithmic_bytes_per_pair")
+    for k in sorted(acc):
+        if "k_main" not in k:
+            continue
+        per = {c: acc[k][c] / calls[k][c] for c in acc[k]}
+        d = {"launches_per_pass": max(calls[k].values()), "counters_per_launch": {c: per[c] for c in sorted(per)}}
+        t = dur.get(k)
+        if t:
+            d["avg_launch_ms"] = t[0] * 1e3
+            d["launches_in_stats_pass"] = t[1]
+        g = per.get
+        if g("SQ_BUSY_CYCLES") and t:
+            d["effective_clock_ghz"] = g("SQ_BUSY_CYCLES") / N_SE / t[0] / 1e9
+        if g("SQ_BUSY_CYCLES") and g("SQ_ACTIVE_INST_VALU"):
+            d["valu_issue_busy_frac"] = g("SQ_ACTIVE_INST_VALU") * 4.0 / (g("SQ_BUSY_CYCLES") / N_SE * N_SIMD)
+        if g("SQ_INSTS_VALU") and t:
+            d["valu_issue_busy_frac_est_1p8ns"] = g("SQ_INSTS_VALU") * 1.8e-9 / N_SIMD / t[0]
+        if g("SQ_WAVE_CYCLES"):
+            for c, name in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_any_frac"), ("SQ_WAIT_INST_LDS", "wait_inst_lds_frac")):
+                if g(c) is not None:
+                    d[name] = g(c) / g("SQ_WAVE_CYCLES") if c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") or True else None
+        if g("SQ_LDS_IDX_ACTIVE"):
+            if g("SQ_LDS_BANK_CONFLICT") is not None:
+                d["lds_bank_conflict_ratio"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+            if g("SQ_BUSY_CYCLES"):
+                d["lds_active_frac"] = g("SQ_LDS_IDX_ACTIVE") / (g("SQ_BUSY_CYCLES") / N_SE * N_CU)
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            d["fetch_bytes_per_launch"] = g("FETCH_SIZE") * 1024 * 2.0  # (x 2: the guide's gfx950 correction, calibrated in the default set)
+            d["write_bytes_per_launch"] = g("WRITE_SIZE") * 1024
+            if out.get("pairs_per_step") and out.get("algorithmic_bytes_per_pair") and isinstance(out["pairs_per_step"], int):
+                launches_per_step = max(1, round(d["launches_per_pass"] / max(1, (line or {}).get("steps", 1) + (line or {}).get("warmup", 0))))
+                alg = out["pairs_per_step"] * out["algorithmic_bytes_per_pair"] / launches_per_step
+                d["k_main_launches_per_step"] = launches_per_step
+                d["traffic_over_algorithmic"] = (d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"]) / alg
+                if t:
+                    d["frac_of_hbm_peak"] = alg / t[0] / 1e9 / 8000.0
+        out["kernels"][k] = d
+    json.dump(out, open(os.path.join(out_dir, tag + "_summary.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1)[:3000])
+
+
 def main(src, tag):
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     stats = glob.glob(src + "/stats/*kernel_stats.csv")[0]
@@ -34,8 +96,11 @@ def main(src, tag):
         for c in sorted(acc[k]):
             lines.append('"%s",%s,%.6g,%.6g,%d' % (k, c, acc[k][c], acc[k][c] / calls[k][c], calls[k][c]))  # (template names hold commas)
     open(os.path.join(out_dir, tag + "_pmc.csv"), "w").write("\n".join(lines) + "\n")
+    derived_summary(src, tag, out_dir, acc, calls, stats, cmd)
     if not any("FETCH_SIZE" in acc[k] for k in acc):  # tools/prof_indel.sh: SQ counters only, no traffic pass
         return
+    if "--model" in cmd or "--indel" in cmd or "--workload" in cmd:  # a side leg: its traffic is in <tag>_summary.json (bench.py takes the
+        return                                                          # roofline's traffic from the newest *_traffic.json: the default leg's)
     # HBM-side traffic of k_main per launch, corrected per MI355X_MICROARCH.md (FETCH_SIZE x2 for coalesced
     # reads, calibrated here on k_read_dwordx2; WRITE_SIZE x1, calibrated on k_fill_dword); unit KiB
     cal = {}
