@@ -343,6 +343,7 @@ def main():
                 # what actually bounds k_main: integer VALU issue.  Wavefront-level VALU instructions per launch from the
                 # committed PMC pass; measured issue cost 1.8 ns per wavefront instruction and SIMD (tools/instr_rate.hip:
                 # 4 cycles), 1024 SIMDs
+                "pmc": committed_pmc("a"),
                 "valu": {"insts_per_launch": traffic.get("valu_insts_per_launch"),
                          "issue_busy_frac_est": (traffic.get("valu_insts_per_launch") or 0) * 1.8e-9 / 1024 / (
                              main_s / max(n_main_launches, 1)) if main_s > 0 else None},
@@ -374,6 +375,7 @@ def main():
                                        ("nextseq", "nextseq", None), ("miseq", "miseq", None)):
                 try:
                     out["other_workloads"][name] = side_workload(local_rank, model, indel, genomes, records, abundance, args.reads)
+                    out["other_workloads"][name]["pmc"] = committed_pmc("indel" if indel else model)
                 except Exception as e:  # (never let a side leg take the line down)
                     out["other_workloads"][name] = {"error": repr(e)}
             try:  # BASELINE configs[3] at its real shape on ONE GPU: 100 M HiSeq reads per step over 50 records of 5 Mbp
@@ -540,6 +542,28 @@ def committed_traffic():
         "" if t["fresh"] else " -- STALE: measured on another build of the library (%s) than the one loaded (%s)" % (
             t.get("library_build_id", "?"), bid))
     return t
+
+
+def committed_pmc(leg):
+    """What the counters say about a side leg's k_main (tools/prof_model.sh -> tools/make_profile_summary.py ->
+    profiles/<round>_<leg>_summary.json): the clock the chip ran the kernel at, VALU issue / wait / LDS-conflict fractions, HBM-side
+    traffic against the algorithmic bytes.  PMC passes cannot run inside a timed region: the newest committed summary is reported,
+    with `fresh` = taken on the very library build this run has loaded."""
+    import glob
+    import re
+
+    def natural(path):
+        return [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", os.path.basename(path))]
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_summary.json" % leg)), key=natural)
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        t = json.load(fh)
+    keep = ("avg_launch_ms", "effective_clock_ghz", "valu_issue_busy_frac", "wait_any_frac", "wait_inst_any_frac", "lds_bank_conflict_ratio",
+            "lds_active_frac", "traffic_over_algorithmic", "frac_of_hbm_peak", "k_main_launches_per_step")
+    kern = {k.replace("void iss::", ""): {f: v.get(f) for f in keep if v.get(f) is not None} for k, v in t.get("kernels", {}).items()}
+    return {"from": os.path.basename(files[-1]), "fresh": t.get("library_build_id") == library_build_id(), "k_main": kern}
 
 
 def mt_mode_leg(device, dense, genome, n_pairs=1_000_000, worker_sets=(1, 8, 64, 256), budget_s=2.5):

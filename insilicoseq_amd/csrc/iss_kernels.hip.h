@@ -203,7 +203,7 @@ struct DevModel {
     // reference-compatible MT mode, k_mt_resolve (iss_mt_compat.hip.h)
     int32_t mt_row_w;             // 32-bit words per row of mt_rows (odd)
     const uint16_t *mt_rows;      // [2][NB][RL] rows of n_q leading digits min(q_thr >> 37, 0xffff) (no merging: index == phred)
-    const uint32_t *mt_lim;       // [2][RL][5] thr >> 26 of the 4 insertion thresholds and the largest deletion threshold    // BasicErrorModel (iss/error_models/basic.py)
+    const uint32_t *mt_lim;       // [2][RL][5] ceil(thr / 2^26) of the 4 insertion thresholds and the largest deletion threshold    // BasicErrorModel (iss/error_models/basic.py)
     int32_t quality_mode;         // 0 KDE tables; 1 basic: phred = round(-10 log10(1 - min(N(basic_mean, basic_sd), basic_cap)))
     int32_t basic_insert_size;    // basic.py:21, :56-63 (no draw)
     double basic_mean, basic_sd, basic_cap;
@@ -228,7 +228,10 @@ struct PairDesc {
     int32_t isz;    // insert size
 };
 // coordinates of a pair: 36-bit signed (a record holds up to MAX_RECORD bases; a custom fragment length can make re negative)
-constexpr int64_t MAX_RECORD = ((int64_t)1 << 34) - 64;  // word offsets into the packed genome (16 bases / word) stay below 2^32 bytes
+constexpr int64_t MAX_RECORD = ((int64_t)1 << 34) - 4096;  // word offsets into the packed genome (16 bases / word) stay below 2^32 bytes
+// (k_main addresses a window word as a 32-bit BYTE offset, `word << 2`: the last word a lane can ask for lies behind the record's
+//  last base by at most a read's padded length (8 bases x 128 superitems) + the windows' overhang -- with room to spare)
+static_assert((((MAX_RECORD + 8 * 128 + 64) / 16 + 2) * 4) < ((int64_t)1 << 32) - 512, "k_main: 32-bit byte offsets into the packed genome");
 __host__ __device__ __forceinline__ int64_t desc_fs(const PairDesc &d) {
     return ((int64_t)((int32_t)(d.meta << 20) >> 28) << 32) | (uint32_t)d.fs;
 }

@@ -157,7 +157,14 @@ struct iss_ctx {
     int n_cu = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // setup + main kernels
-    hipStream_t indel_stream = nullptr;  // MT mode: the stream words are produced here, one chunk ahead of their consumption
+    hipStream_t indel_stream = nullptr;  // the second k_indel_script launch of a heavy model's step, beside the first
+    // MT mode: the stream words are produced here, one turn ahead of their consumption.  LOWEST priority: its hardware queue then
+    // comes from another pool than the main stream's (as the setup stream's does, at the highest).  Streams of one priority share
+    // four hardware queues, handed out as the streams are first used: with another engine and torch's streams alive in the process
+    // (bench.py) the fill stream and the main stream of an MT-mode engine sat on ONE queue, fill and resolver ran one after the
+    // other and a worker made 2.3e5 pairs/s instead of 3.8e5 (round 4's "2.2e5 in the bench line, 3.7e5 by itself";
+    // tools/mt_context_probe2.py: 2.31e5 -> 3.84e5 with GPU_MAX_HW_QUEUES=8, and with this priority without the variable).
+    hipStream_t fill_stream = nullptr;
     // k_setup of a call runs on its own stream, beside the kernels of the call (or chunk) before: it reads nothing they
     // write, and what it writes -- descriptors, flags, the fix-up list -- is double-buffered by call parity (`desc`, `flags`,
     // `fix_list` below point at the current call's set).  ISS_SETUP_AHEAD=0: everything in order on one stream.
@@ -267,7 +274,12 @@ struct iss_ctx {
         int64_t ch = 0;                      // pairs per worker and turn
         size_t cap[2] = {0, 0};              // words per (worker, stream, ping-pong buffer)
         iss::MtState *d_state = nullptr;     // [W][2]: CPython random, numpy
-        uint32_t *buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [stream][ping-pong]: W x cap[stream] words
+        // [stream][buffer]: W x cap[stream] words, MT_SET_BUFS buffers in rotation.  Two: the words of turn t + 1 are produced into
+        // the buffer the emitter of turn t - 1 read, so that fill starts behind the emitter of the turn before.  (Three -- the
+        // fill never waits for an emitter -- were built and measured in round 5: 3.1e7 against 4.2e7 pairs/s at W = 256: fill,
+        // emitter and resolver then all start together and the resolver, the chain everything waits for, is the one that loses.)
+        uint32_t *buf[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+        std::vector<int64_t> last_read;      // [W * 2][3]: the turn whose emitter reads that buffer (-1: none in flight)
         iss::MtWalkResult *d_res = nullptr;  // [W]
         iss::MtGauss *d_gauss = nullptr;     // [W]
         iss::MtPairRec *d_rec = nullptr;     // [2][W][ch]: the resolver of turn t + 1 runs beside the emitter of turn t
@@ -381,7 +393,7 @@ void free_mt_set(iss_ctx *ctx) {
     t.ev_side = t.ev_turn = nullptr;
     t.d_state = nullptr; t.d_res = nullptr; t.d_gauss = nullptr; t.d_rec = nullptr; t.h_jobs = nullptr; t.d_jobs = nullptr; t.h_res = nullptr;
     t.W = 0; t.ch = 0; t.cap[0] = t.cap[1] = 0; t.jobs_bytes = 0;
-    t.cur.clear(); t.fill.clear(); t.used.clear();
+    t.cur.clear(); t.fill.clear(); t.used.clear(); t.last_read.clear();
 }
 
 void free_mt(iss_ctx *ctx) {
@@ -443,7 +455,7 @@ int64_t host_int_normal(double x1v, double x2v, bool cached, double loc, double 
     return (int64_t)x;
 }
 
-// MT19937 blocks are generated on the auxiliary stream (ctx->indel_stream) so that the NEXT chunk's words can be
+// MT19937 blocks are generated on the auxiliary stream (ctx->fill_stream) so that the NEXT chunk's words can be
 // produced while the current chunk is consumed on ctx->stream.  The fill first waits for everything queued on
 // ctx->stream so far (an earlier k_mt_emit may still read the target buffer); ctx->stream waits for ev_fill
 // before it touches the new words (mt_fill_join).
@@ -455,10 +467,10 @@ int mt_fill_async(iss_ctx *ctx, uint32_t *const dst[2], const uint32_t blocks[2]
         HIP_TRY(ctx, hipEventCreateWithFlags(&m.ev_fill, hipEventDisableTiming));
     }
     HIP_TRY(ctx, hipEventRecord(m.ev_main, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, m.ev_main, 0));
-    hipLaunchKernelGGL(iss::k_mt_fill, dim3(2), dim3(iss::FILL_THREADS), 0, ctx->indel_stream, m.d_state, dst[0], dst[1], blocks[0],
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill_stream, m.ev_main, 0));
+    hipLaunchKernelGGL(iss::k_mt_fill, dim3(2), dim3(iss::FILL_THREADS), 0, ctx->fill_stream, m.d_state, dst[0], dst[1], blocks[0],
                        blocks[1]);
-    HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->indel_stream));
+    HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->fill_stream));
     return 0;
 }
 int mt_fill_join(iss_ctx *ctx) {
@@ -580,6 +592,7 @@ int sync_all(iss_ctx *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->setup_stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->indel_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->fill_stream));
     return 0;
 }
 
@@ -840,6 +853,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         int prio_least = 0, prio_greatest = 0;
         HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->setup_stream, hipStreamNonBlocking, prio_greatest));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->fill_stream, hipStreamNonBlocking, prio_least));  // (MT mode: see iss_ctx::fill_stream)
     }
     for (auto &e : ctx->ev_call_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ctx->ev_setup_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -868,6 +882,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     fastq_shutdown(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->indel_stream) (void)hipStreamSynchronize(ctx->indel_stream);
+    if (ctx->fill_stream) (void)hipStreamSynchronize(ctx->fill_stream);
     if (ctx->setup_stream) (void)hipStreamSynchronize(ctx->setup_stream);
     for (auto &t : ctx->timed) for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
     free_model(ctx);
@@ -882,6 +897,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     free_mt(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->indel_stream) (void)hipStreamDestroy(ctx->indel_stream);
+    if (ctx->fill_stream) (void)hipStreamDestroy(ctx->fill_stream);
     if (ctx->setup_stream) (void)hipStreamDestroy(ctx->setup_stream);
     for (auto &e : ctx->ev_call_done) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_setup_done) if (e) (void)hipEventDestroy(e);
@@ -1208,15 +1224,20 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                 uint16_t *dst = mt_rows.data() + ((size_t)(o * M.NB + sl) * RL + p) * M.mt_row_w * 2;
                 for (int i = 0; i < nq; ++i) dst[i] = (uint16_t)std::min<uint64_t>(row[i] >> 37, 0xffffu);
             }
+    // mt_lim = ceil(thr / 2^26): the test `m < thr` (m a 53-bit numerator, thr the integer threshold of DESIGN.md section 3) can
+    // only fire if the 27 leading bits of m are BELOW it -- 0 for a probability of zero: such a test is never a candidate (round 5:
+    // `leading bits <= thr >> 26` made every one of the 1 500 zero-probability tests of a NovaSeq pair a candidate with
+    // probability 2^-27 -- 1.1e-5 per pair, most of the pairs the resolver handed to the walker)
+    auto lim_of = [](uint64_t thr) { return (uint32_t)((thr + (((uint64_t)1 << 26) - 1)) >> 26); };
     std::vector<uint32_t> mt_lim((size_t)2 * RL * 5);
     for (size_t e = 0; e < (size_t)2 * RL; ++e) {
-        for (int x = 0; x < 4; ++x) mt_lim[e * 5 + x] = (uint32_t)(t->ins_thr[e * 4 + x] >> 26);
-        mt_lim[e * 5 + 4] = (uint32_t)(del_max[e] >> 26);
+        for (int x = 0; x < 4; ++x) mt_lim[e * 5 + x] = lim_of(t->ins_thr[e * 4 + x]);
+        mt_lim[e * 5 + 4] = lim_of(del_max[e]);
     }
     {   // expected share of pairs the resolver hands to the sequential walker (an indel candidate in either mate)
         double rate = 0;
         for (size_t e = 0; e < (size_t)2 * RL; ++e)
-            for (int x = 0; x < 5; ++x) rate += ((double)mt_lim[e * 5 + x] + 1.0) / 134217728.0;
+            for (int x = 0; x < 5; ++x) rate += (double)mt_lim[e * 5 + x] / 134217728.0;
         ctx->mt_bounce_rate = rate;
     }
     int rc = 0;
@@ -1248,7 +1269,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
     if (!ctx || !ascii || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload: NULL argument");
     // (records of 2^31 - 1 bases and more: the reference spills them to a memmap, generator.py:313-331; here coordinates are
     //  36-bit and word offsets into the packed genome 32-bit -- iss::MAX_RECORD; MT mode keeps the 2^31 limit: iss_generate_mt)
-    if (length < 1 || length > iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^34 - 64]");
+    if (length < 1 || length > iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^34 - 4096]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // ASCII -> HBM, then packed on the device (k_pack_genome).  One readable padding word in front
     // (k_main's funnel shifts touch positions >= -3) and three behind.
@@ -1331,7 +1352,7 @@ int iss_genome_upload_packed(iss_ctx *ctx, const uint32_t *codes, int64_t length
     if (!ctx || !codes || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload_packed: NULL argument");
     // (records of 2^31 - 1 bases and more: the reference spills them to a memmap, generator.py:313-331; here coordinates are
     //  36-bit and word offsets into the packed genome 32-bit -- iss::MAX_RECORD; MT mode keeps the 2^31 limit: iss_generate_mt)
-    if (length < 1 || length > iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^34 - 64]");
+    if (length < 1 || length > iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^34 - 4096]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n_mk = (size_t)(length + 31) / 32, n_pk = 2 * n_mk, n_in = (size_t)(length + 15) / 16;
     Genome G;
@@ -1392,40 +1413,59 @@ int iss_output_reserve(iss_ctx *ctx, int64_t capacity_pairs) {
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     free_outputs(ctx);
     void *q = nullptr;
+    // (every buffer of the reservation through one checked allocation: out of memory frees what the call has allocated so far and
+    //  is reported as ISS_E_NOMEM with the reservation's footprint -- the edit scripts of a five-tile heavy model are 1.3 KB per
+    //  pair, more than its rows)
+    const bool heavy_ = ctx->M.n_scan > 0 && !ctx->light;
+    const double per_pair = (double)ctx->M.row + 3.0 * sizeof(iss::PairDesc) + 2.0 * 12.0 +
+                            (heavy_ ? 2.0 : 1.0) * (8.0 + 8.0 * iss::EV_K + 32.0 + 16.0) + (heavy_ ? 4.0 * ctx->M.sc_stride : 0.0);
+#define ISS_RES_ALLOC(bytes)                                                                                                        \
+    do {                                                                                                                            \
+        const hipError_t e_ = hipMalloc(&q, (bytes));                                                                               \
+        if (e_ != hipSuccess) {                                                                                                     \
+            (void)hipGetLastError();                                                                                                \
+            free_outputs(ctx);                                                                                                      \
+            char msg_[256];                                                                                                         \
+            snprintf(msg_, sizeof msg_, "iss_output_reserve: %lld pairs need %.1f GB of HBM (%.0f B per pair%s): %s", (long long)capacity_pairs, \
+                     per_pair * (double)capacity_pairs / 1e9, per_pair, heavy_ ? ", edit scripts included" : "", hipGetErrorString(e_));  \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? ISS_E_NOMEM : ISS_E_HIP, msg_);                                           \
+        }                                                                                                                           \
+    } while (0)
     // (plain hipMalloc: physically contiguous rows -- hipExtMallocWithFlags(hipDeviceMallocContiguous) -- were measured at 1.82-1.88
     //  instead of 1.25-1.34 ms per step of the default bench, whatever the grid)
     //  instead of 1.25-1.34 ms per step of the default bench, whatever the grid; rows mapped from separately created physical
     //  chunks -- hipMemCreate / hipMemMap, 64 KB to 16 MB, in order or shuffled -- at 1.23-1.9: no layout helped on every box)
-    HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.row * (size_t)capacity_pairs));
+    ISS_RES_ALLOC((size_t)ctx->M.row * (size_t)capacity_pairs);
     for (int k = 0; k < 4; ++k) ctx->out[k] = static_cast<uint8_t *>(q) + iss::row_array_off(k);
     for (int k = 0; k < 2; ++k) {  // (two sets: k_setup of a call runs beside the kernels of the call before)
-        HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));
+        ISS_RES_ALLOC(sizeof(iss::PairDesc) * (size_t)capacity_pairs);
         ctx->desc_buf[k] = static_cast<iss::PairDesc *>(q);
-        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * (size_t)capacity_pairs));
+        ISS_RES_ALLOC(sizeof(uint32_t) * (size_t)capacity_pairs);
         ctx->flags_buf[k] = static_cast<uint32_t *>(q);
-        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
+        ISS_RES_ALLOC(sizeof(uint32_t) * 2 * (size_t)capacity_pairs);
         ctx->fixl_buf[k] = static_cast<uint32_t *>(q);
     }
-    HIP_TRY(ctx, hipMalloc(&q, sizeof(iss::PairDesc) * (size_t)capacity_pairs));
+    ISS_RES_ALLOC(sizeof(iss::PairDesc) * (size_t)capacity_pairs);
     ctx->desc = static_cast<iss::PairDesc *>(q);  // what the host reads (iss_output_download_coords) and the MT kernels write
     ctx->flags = ctx->flags_buf[0]; ctx->fix_list = ctx->fixl_buf[0];
     const bool heavy = ctx->M.n_scan > 0 && !ctx->light;
     for (int k = 0; k < (heavy ? 2 : 1); ++k) {
-        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * (size_t)capacity_pairs));
+        ISS_RES_ALLOC(sizeof(uint32_t) * 2 * (size_t)capacity_pairs);
         ctx->ev_count[k] = static_cast<uint32_t *>(q);
-        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint32_t) * 2 * iss::EV_K * (size_t)capacity_pairs));
+        ISS_RES_ALLOC(sizeof(uint32_t) * 2 * iss::EV_K * (size_t)capacity_pairs);
         ctx->ev_list[k] = static_cast<uint32_t *>(q);
-        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint4) * 2 * (size_t)capacity_pairs));
+        ISS_RES_ALLOC(sizeof(uint4) * 2 * (size_t)capacity_pairs);
         ctx->read_list[k] = static_cast<uint4 *>(q);
-        HIP_TRY(ctx, hipMalloc(&q, sizeof(uint2) * 2 * (size_t)capacity_pairs));
+        ISS_RES_ALLOC(sizeof(uint2) * 2 * (size_t)capacity_pairs);
         ctx->read_list1[k] = static_cast<uint2 *>(q);
     }
     if (!heavy) { ctx->ev_count[1] = ctx->ev_count[0]; ctx->ev_list[1] = ctx->ev_list[0]; ctx->read_list[1] = ctx->read_list[0]; ctx->read_list1[1] = ctx->read_list1[0]; }
     if (heavy)  // the edit scripts of the reads with an event (sparse: a read's slot is written only if it has one)
         for (int k = 0; k < 2; ++k) {
-            HIP_TRY(ctx, hipMalloc(&q, (size_t)ctx->M.sc_stride * 2 * (size_t)capacity_pairs));
+            ISS_RES_ALLOC((size_t)ctx->M.sc_stride * 2 * (size_t)capacity_pairs);
             ctx->script[k] = static_cast<uint8_t *>(q);
         }
+#undef ISS_RES_ALLOC
     ctx->capacity = capacity_pairs;
     return 0;
 }
@@ -2063,7 +2103,7 @@ int iss_timing_enable(iss_ctx *ctx, int enable) {
     int rc = settle_timing(ctx);
     ctx->timing = enable != 0;
     ctx->timing_main_only = enable == 2;
-    ctx->timing_all = enable == 1;  // (a split by kernel needs the kernels one after the other)
+    ctx->timing_all = enable != 0 && enable != 2;  // (a split by kernel needs the kernels one after the other: every value but 2)
     return rc;
 }
 
@@ -2469,11 +2509,14 @@ int iss_mt_workers_seed(iss_ctx *ctx, int32_t n_workers, const uint64_t *seeds) 
     t.cur.assign(2 * W, 0);
     t.fill.assign(2 * W, 0);
     t.used.assign(2 * W, 0);
+    t.last_read.assign(6 * W, -1);
     t.n_resolved = t.n_walked = 0;
     return 0;
 }
 
 namespace {
+
+constexpr int MT_SET_BUFS = 2;  // stream buffers per (worker, stream) in rotation (see iss_ctx::MtSet::buf)
 
 // stream buffers, pair records and job tables of the set, sized for the model (called by every generate call; a model with longer
 // reads than the buffers were cut for is refused: seed the set again)
@@ -2492,7 +2535,7 @@ int mt_set_reserve(iss_ctx *ctx) {
         return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: the set's stream buffers were sized for a model with shorter reads (seed the set again)");
     if (!t.cap[0]) {
         for (int s = 0; s < 2; ++s)
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < MT_SET_BUFS; ++b) {
                 void *p = nullptr;
                 if (hipMalloc(&p, W * want[s] * sizeof(uint32_t)) != hipSuccess)
                     return fail(ctx, ISS_E_NOMEM, "iss_generate_mt_workers: no memory for the workers' stream buffers");
@@ -2528,6 +2571,7 @@ struct MtChainLoan {
     int w;
     Chain own;
     int64_t r0, w0;
+    int base[2];
     typedef decltype(iss_ctx::mt) MtLegacy;
     static Chain save(const MtLegacy &m) {
         Chain c;
@@ -2553,16 +2597,17 @@ struct MtChainLoan {
         Chain c;
         c.seeded = true; c.d_state = t.d_state + 2 * (size_t)w; c.d_res = t.d_res + w; c.d_gauss = t.d_gauss + w;
         c.d_rec = t.d_rec + (size_t)w * (size_t)t.ch; c.pool_ch = t.ch;  // (the first of its two sets of pair records)
-        for (int s = 0; s < 2; ++s) {
-            c.cur[s] = t.cur[2 * w + s]; c.cap[s] = t.cap[s]; c.fill[s] = t.fill[2 * w + s]; c.used[s] = t.used[2 * w + s];
-            for (int b = 0; b < 2; ++b) c.buf[s][b] = t.buf[s][b] + (size_t)w * t.cap[s];
+        for (int s = 0; s < 2; ++s) {  // (the single-worker path ping-pongs between the current buffer and the next of the rotation)
+            base[s] = t.cur[2 * w + s];
+            c.cur[s] = 0; c.cap[s] = t.cap[s]; c.fill[s] = t.fill[2 * w + s]; c.used[s] = t.used[2 * w + s];
+            for (int b = 0; b < 2; ++b) c.buf[s][b] = t.buf[s][(base[s] + b) % MT_SET_BUFS] + (size_t)w * t.cap[s];
         }
         load(m, c);
     }
     ~MtChainLoan() {
         auto &t = ctx->mts;
         auto &m = ctx->mt;
-        for (int s = 0; s < 2; ++s) { t.cur[2 * w + s] = m.cur[s]; t.fill[2 * w + s] = m.fill[s]; t.used[2 * w + s] = m.used[s]; }
+        for (int s = 0; s < 2; ++s) { t.cur[2 * w + s] = (base[s] + m.cur[s]) % MT_SET_BUFS; t.fill[2 * w + s] = m.fill[s]; t.used[2 * w + s] = m.used[s]; }
         t.n_resolved += m.n_resolved - r0;
         t.n_walked += m.n_walked - w0;
         m.n_resolved = r0;
@@ -2681,6 +2726,10 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
     std::vector<size_t> want(2 * (size_t)W);
     struct PF { bool on = false; size_t at = 0; uint32_t blocks = 0; };
     std::vector<PF> pf(2 * (size_t)W);
+    std::vector<int> res_buf(2 * (size_t)W);
+    const bool dbg = getenv("ISS_MT_SET_DEBUG") != nullptr;  // per call: turns, words produced / moved, pairs handed to the walker
+    uint64_t dbg_turns = 0, dbg_moved[2] = {0, 0}, dbg_filled[2] = {0, 0}, dbg_bounce = 0, dbg_moves = 0, dbg_big = 0, dbg_pairs = 0;
+    std::fill(t.last_read.begin(), t.last_read.end(), (int64_t)-1);  // (everything before this call has been waited for: sync_all above)
     for (;;) {
         bool any = false;
         for (int w = 0; w < W; ++w) {
@@ -2688,7 +2737,11 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             any |= n_w[w] > 0;
         }
         if (!any) break;
-        const int par = (int)(t.turns++ & 1);
+        const int64_t turn = ++t.turns;  // (>= 1)
+        const int par = (int)(turn & 1);
+        // a buffer about to be WRITTEN (produced into, moved into) may still be read by an emitter: the one of two turns ago has
+        // been waited for at the top of the turn, the one of the turn before only if a target says so
+        auto read_by_last_turn = [&](int k, int b) { return t.last_read[(size_t)k * 3 + b] == turn - 1; };
         uint8_t *hj = t.h_jobs + (size_t)par * t.jobs_bytes, *dj = t.d_jobs + (size_t)par * t.jobs_bytes;
         auto tab = [&](size_t k, uint8_t *base) { return base + k * 2 * (size_t)W * fm_sz; };  // tables 0..3 (fill / move), then the rest
         iss::MtFillJob *h_fill_e = reinterpret_cast<iss::MtFillJob *>(tab(0, hj)), *h_fill_a = reinterpret_cast<iss::MtFillJob *>(tab(1, hj));
@@ -2702,7 +2755,7 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
         // ---- (a) every worker of the turn has the words of n + 1 pairs (+ boost) in front of it: mt_ensure, for all at once
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));  // (words produced ahead during the turn before)
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par], 0));  // (this parity's pair records: their last reader, two turns ago)
-        bool fill_e = false;
+        bool fill_e = false, wait_prev_e = false;
         for (int w = 0; w < W; ++w)
             for (int s = 0; s < 2; ++s) {
                 const int k = 2 * w + s;
@@ -2711,30 +2764,30 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 want[k] = n_w[w] ? std::min(t.cap[s] / 624 * 624 - 624, words_for(s, n_w[w], ws[w].boost)) : 0;
                 const size_t left = t.fill[k] - t.used[k];
                 if (left >= want[k]) continue;
-                const int nxt = t.cur[k] ^ 1;
+                const int nxt = (t.cur[k] + 1) % MT_SET_BUFS;
                 h_move_e[k] = iss::MtMoveJob{bufp(w, s, t.cur[k]) + t.used[k], bufp(w, s, nxt), (uint32_t)left, 0u};
                 const size_t room = (t.cap[s] - left) / 624;
                 const uint32_t blocks = (uint32_t)std::min(room, (want[k] - left + 623) / 624);
                 h_fill_e[k] = iss::MtFillJob{t.d_state + k, bufp(w, s, nxt) + left, blocks, 0u};
+                wait_prev_e |= read_by_last_turn(k, nxt);
                 t.cur[k] = nxt;
                 t.used[k] = 0;
                 t.fill[k] = left + (size_t)blocks * 624;
                 fill_e = true;
             }
         if (fill_e) {
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par ^ 1], 0));  // (the emitter of the turn before reads the buffers written now)
+            if (wait_prev_e) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par ^ 1], 0));  // (the emitter of the turn before reads a buffer written now)
             HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_move_e), h_move_e, 2 * (size_t)W * sizeof(iss::MtMoveJob), hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(iss::k_mt_move_w, dim3(2 * W, iss::MOVE_BLOCKS), dim3(256), 0, ctx->stream, reinterpret_cast<const iss::MtMoveJob *>(dev_of(h_move_e)));
             HIP_TRY(ctx, hipEventRecord(m.ev_main, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, m.ev_main, 0));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, t.ev_emit[par ^ 1], 0));  // (the emitter of the turn before reads the target)
-            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_fill_e), h_fill_e, 2 * (size_t)W * sizeof(iss::MtFillJob), hipMemcpyHostToDevice, ctx->indel_stream));
-            hipLaunchKernelGGL(iss::k_mt_fill_w, dim3(2 * W), dim3(iss::FILL_THREADS), 0, ctx->indel_stream, reinterpret_cast<const iss::MtFillJob *>(dev_of(h_fill_e)));
-            HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->indel_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill_stream, m.ev_main, 0));  // (incl. the main stream's wait for that emitter)
+            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_fill_e), h_fill_e, 2 * (size_t)W * sizeof(iss::MtFillJob), hipMemcpyHostToDevice, ctx->fill_stream));
+            hipLaunchKernelGGL(iss::k_mt_fill_w, dim3(2 * W), dim3(iss::FILL_THREADS), 0, ctx->fill_stream, reinterpret_cast<const iss::MtFillJob *>(dev_of(h_fill_e)));
+            HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->fill_stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));
         }
         // ---- (b) the words of the turn AFTER this one are produced beside it (mt_prefetch_begin)
-        bool fill_a = false;
+        bool fill_a = false, wait_prev_a = false;
         for (int w = 0; w < W; ++w)
             for (int s = 0; s < 2; ++s) {
                 const int k = 2 * w + s;
@@ -2749,16 +2802,18 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 const size_t blocks = (want[k] + want_next - avail + 623) / 624;
                 if (avail + blocks * 624 > t.cap[s]) continue;
                 pf[k].on = true; pf[k].at = avail; pf[k].blocks = (uint32_t)blocks;
-                h_fill_a[k] = iss::MtFillJob{t.d_state + k, bufp(w, s, t.cur[k] ^ 1) + avail, (uint32_t)blocks, 0u};
+                h_fill_a[k] = iss::MtFillJob{t.d_state + k, bufp(w, s, (t.cur[k] + 1) % MT_SET_BUFS) + avail, (uint32_t)blocks, 0u};
+                wait_prev_a |= read_by_last_turn(k, (t.cur[k] + 1) % MT_SET_BUFS);
                 fill_a = true;
             }
-        if (fill_a) {  // (behind everything queued on the main stream so far, and behind the emitter of the turn before: it reads the target)
+        if (fill_a) {  // (behind everything queued on the main stream so far -- incl. its wait for the emitter of two turns ago -- and
+                       //  behind the emitter of the turn before where that one reads a target: the rule with two buffers)
             HIP_TRY(ctx, hipEventRecord(m.ev_main, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, m.ev_main, 0));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->indel_stream, t.ev_emit[par ^ 1], 0));
-            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_fill_a), h_fill_a, 2 * (size_t)W * sizeof(iss::MtFillJob), hipMemcpyHostToDevice, ctx->indel_stream));
-            hipLaunchKernelGGL(iss::k_mt_fill_w, dim3(2 * W), dim3(iss::FILL_THREADS), 0, ctx->indel_stream, reinterpret_cast<const iss::MtFillJob *>(dev_of(h_fill_a)));
-            HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->indel_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill_stream, m.ev_main, 0));
+            if (wait_prev_a) HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill_stream, t.ev_emit[par ^ 1], 0));
+            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_fill_a), h_fill_a, 2 * (size_t)W * sizeof(iss::MtFillJob), hipMemcpyHostToDevice, ctx->fill_stream));
+            hipLaunchKernelGGL(iss::k_mt_fill_w, dim3(2 * W), dim3(iss::FILL_THREADS), 0, ctx->fill_stream, reinterpret_cast<const iss::MtFillJob *>(dev_of(h_fill_a)));
+            HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->fill_stream));
         }
         // ---- (c) the turn: the resolver for the workers on the fast path, the walker for the others
         bool any_res = false, any_walk = false, walk_rows = false;
@@ -2775,6 +2830,8 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 iss::MtResolveArgs &R = rj.A;
                 R.py_base = bufp(w, 0, t.cur[2 * w]);
                 R.np_base = bufp(w, 1, t.cur[2 * w + 1]);
+                res_buf[2 * w] = t.cur[2 * w];
+                res_buf[2 * w + 1] = t.cur[2 * w + 1];
                 R.py_off = (uint32_t)t.used[2 * w];
                 R.np_off = (uint32_t)t.used[2 * w + 1];
                 R.py_fill = (uint32_t)t.fill[2 * w];
@@ -2842,6 +2899,7 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             for (int k = 0; k < 4; ++k) ej.out[k] = ctx->out[k] + (size_t)row0 * M.row;
             ej.g = h_rj[w].g;
             emit_max = std::max(emit_max, ej.n_pairs);
+            for (int s = 0; s < 2; ++s) t.last_read[(size_t)(2 * w + s) * 3 + res_buf[2 * w + s]] = turn;
         }
         if (emit_max > 0) {  // (on the side stream: the next turn's resolver does not wait for it -- the main stream is idle here: synchronized above)
             HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_ej), h_ej, (size_t)W * sizeof(iss::MtEmitJob), hipMemcpyHostToDevice, s_side));
@@ -2850,7 +2908,7 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
         }
         HIP_TRY(ctx, hipEventRecord(t.ev_emit[par], s_side));
         // ---- (e) the streams move on (mt_prefetch_commit: the unconsumed words in front of those produced ahead)
-        bool move_c = false;
+        bool move_c = false, wait_prev_c = false;
         for (int w = 0; w < W; ++w) {
             if (!n_w[w]) { for (int s = 0; s < 2; ++s) h_move_c[2 * w + s] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u}; continue; }
             const iss::MtWalkResult &res = t.h_res[w];
@@ -2863,8 +2921,10 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 h_move_c[k] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u};
                 if (!pf[k].on) continue;
                 const size_t left = t.fill[k] - t.used[k];  // <= pf.at
-                const int nxt = t.cur[k] ^ 1;
+                const int nxt = (t.cur[k] + 1) % MT_SET_BUFS;
                 h_move_c[k] = iss::MtMoveJob{bufp(w, s, t.cur[k]) + t.used[k], bufp(w, s, nxt) + (pf[k].at - left), (uint32_t)left, 0u};
+                wait_prev_c |= read_by_last_turn(k, nxt);
+                if (dbg) { dbg_moved[s] += left; dbg_filled[s] += (uint64_t)pf[k].blocks * 624; ++dbg_moves; dbg_big += left > want[k] / 4; }
                 t.cur[k] = nxt;
                 t.used[k] = pf[k].at - left;
                 t.fill[k] = pf[k].at + (size_t)pf[k].blocks * 624;
@@ -2881,6 +2941,7 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             } else {
                 t.n_resolved += res.n_done;
                 if (res.pad) {
+                    ++dbg_bounce;
                     ws[w].walk_one = true;  // the next pair is not plain: one turn of the walker
                 } else if (res.n_done == 0 && res.starved && (size_t)(h_rj[w].A.py_fill - h_rj[w].A.py_off) >= want[2 * w] &&
                            (size_t)(h_rj[w].A.np_fill - h_rj[w].A.np_off) >= want[2 * w + 1]) {
@@ -2890,11 +2951,19 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             }
         }
         if (move_c) {
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par ^ 1], 0));  // (the target: what the emitter of the turn before reads)
+            if (wait_prev_c) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par ^ 1], 0));  // (a target the emitter of the turn before reads)
             HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_move_c), h_move_c, 2 * (size_t)W * sizeof(iss::MtMoveJob), hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(iss::k_mt_move_w, dim3(2 * W, iss::MOVE_BLOCKS), dim3(256), 0, ctx->stream, reinterpret_cast<const iss::MtMoveJob *>(dev_of(h_move_c)));
         }
         HIP_TRY(ctx, hipGetLastError());
+        ++dbg_turns;
+    }
+    if (dbg) {
+        for (int w = 0; w < W; ++w) dbg_pairs += (uint64_t)ws[w].done;
+        fprintf(stderr, "[mt set] W %d turn %lld: %llu turns, %llu pairs, %llu to the walker; commits %llu (%llu moved > want / 4); words moved py %llu np %llu, "
+                        "produced ahead py %llu np %llu\n", W, (long long)t.ch, (unsigned long long)dbg_turns, (unsigned long long)dbg_pairs,
+                (unsigned long long)dbg_bounce, (unsigned long long)dbg_moves, (unsigned long long)dbg_big, (unsigned long long)dbg_moved[0],
+                (unsigned long long)dbg_moved[1], (unsigned long long)dbg_filled[0], (unsigned long long)dbg_filled[1]);
     }
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));
     for (auto &e : t.ev_emit) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e, 0));  // (the rows are complete once the main stream is)
