@@ -2907,29 +2907,18 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                                reinterpret_cast<const iss::MtEmitJob *>(dev_of(h_ej)));
         }
         HIP_TRY(ctx, hipEventRecord(t.ev_emit[par], s_side));
-        // ---- (e) the streams move on (mt_prefetch_commit: the unconsumed words in front of those produced ahead)
-        bool move_c = false, wait_prev_c = false;
+        // ---- (e) what the turn consumed and produced; a resolver that stopped in front of a pair for the walker (an indel candidate,
+        //      a letter outside ACGT, a genome end in a template) gets that ONE pair walked right here, behind the turn, so that
+        //      its worker is back on the fast path with the next turn (a turn of its own for one pair cost a worker 1.5 turns
+        //      per such pair: 21 turns instead of 16 for a call of 16 full ones at W = 64)
+        bool any_odd = false;
         for (int w = 0; w < W; ++w) {
-            if (!n_w[w]) { for (int s = 0; s < 2; ++s) h_move_c[2 * w + s] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u}; continue; }
+            if (!n_w[w]) continue;
             const iss::MtWalkResult &res = t.h_res[w];
             const bool walker = h_wj[w].A.n_pairs > 0;
             if (res.need_host) return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: a draw for the host's libm on the side-by-side path");
             t.used[2 * w] += res.py_used;
             t.used[2 * w + 1] += res.np_used;
-            for (int s = 0; s < 2; ++s) {
-                const int k = 2 * w + s;
-                h_move_c[k] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u};
-                if (!pf[k].on) continue;
-                const size_t left = t.fill[k] - t.used[k];  // <= pf.at
-                const int nxt = (t.cur[k] + 1) % MT_SET_BUFS;
-                h_move_c[k] = iss::MtMoveJob{bufp(w, s, t.cur[k]) + t.used[k], bufp(w, s, nxt) + (pf[k].at - left), (uint32_t)left, 0u};
-                wait_prev_c |= read_by_last_turn(k, nxt);
-                if (dbg) { dbg_moved[s] += left; dbg_filled[s] += (uint64_t)pf[k].blocks * 624; ++dbg_moves; dbg_big += left > want[k] / 4; }
-                t.cur[k] = nxt;
-                t.used[k] = pf[k].at - left;
-                t.fill[k] = pf[k].at + (size_t)pf[k].blocks * 624;
-                move_c = true;
-            }
             ws[w].done += res.n_done;
             if (walker) {
                 t.n_walked += res.n_done;
@@ -2942,7 +2931,8 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 t.n_resolved += res.n_done;
                 if (res.pad) {
                     ++dbg_bounce;
-                    ws[w].walk_one = true;  // the next pair is not plain: one turn of the walker
+                    ws[w].walk_one = true;  // (unless the walk behind this turn takes it)
+                    any_odd = true;
                 } else if (res.n_done == 0 && res.starved && (size_t)(h_rj[w].A.py_fill - h_rj[w].A.py_off) >= want[2 * w] &&
                            (size_t)(h_rj[w].A.np_fill - h_rj[w].A.np_off) >= want[2 * w + 1]) {
                     if (ws[w].boost >= 256) return fail(ctx, ISS_E_INVALID, "MT stream buffers too small for one read pair");
@@ -2950,6 +2940,69 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 }
             }
         }
+        if (any_odd) {
+            int n_odd = 0;
+            for (int w = 0; w < W; ++w) {
+                const bool odd = n_w[w] > 0 && h_rj[w].A.n_pairs > 0 && t.h_res[w].pad && ws[w].done < ws[w].n;
+                iss::MtWalkJob &wj = h_wj[w];
+                wj = iss::MtWalkJob{};
+                // (the words of one attempt at a pair must stand in front of the walker: else the pair waits for its own turn)
+                if (!odd || t.fill[2 * w] - t.used[2 * w] < 2 * need[0] || t.fill[2 * w + 1] - t.used[2 * w + 1] < 2 * need[1]) continue;
+                const Genome &G = ctx->genomes[ws[w].gid];
+                const int64_t row0 = ws[w].row0 + ws[w].done;
+                iss::MtWalkArgs &A = wj.A;
+                A.py = bufp(w, 0, t.cur[2 * w]) + t.used[2 * w];
+                A.np = bufp(w, 1, t.cur[2 * w + 1]) + t.used[2 * w + 1];
+                A.py_avail = (uint32_t)(t.fill[2 * w] - t.used[2 * w]);
+                A.np_avail = (uint32_t)(t.fill[2 * w + 1] - t.used[2 * w + 1]);
+                A.n_pairs = 1;
+                A.sequence_type = sequence_type;
+                A.gc_bias = gc_bias ? 1 : 0;
+                A.gc_thr = 8106479329266893ull;
+                for (int k = 0; k < 4; ++k) A.out[k] = ctx->out[k] + (size_t)row0 * M.row;
+                A.res = t.d_res + w;
+                A.pair_base = ws[w].done;
+                A.guard = guard;
+                A.gauss = t.d_gauss + w;
+                wj.g = iss::DevGenome{G.packed, G.mask, G.ascii, G.L, G.has_exceptions ? 1 : 0};
+                wj.desc = ctx->desc + row0;
+                ++n_odd;
+            }
+            if (n_odd) {
+                HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_wj), h_wj, (size_t)W * sizeof(iss::MtWalkJob), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(iss::k_mt_walk_w, dim3(W), dim3(64), fixed_lds, ctx->stream, M, reinterpret_cast<const iss::MtWalkJob *>(dev_of(h_wj)));
+                HIP_TRY(ctx, hipMemcpyAsync(t.h_res, t.d_res, (size_t)W * sizeof(iss::MtWalkResult), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipGetLastError());
+                for (int w = 0; w < W; ++w) {
+                    if (h_wj[w].A.n_pairs <= 0) continue;
+                    const iss::MtWalkResult &res = t.h_res[w];
+                    if (res.need_host) return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: a draw for the host's libm on the side-by-side path");
+                    t.used[2 * w] += res.py_used;
+                    t.used[2 * w + 1] += res.np_used;
+                    ws[w].done += res.n_done;
+                    t.n_walked += res.n_done;
+                    if (res.n_done > 0) ws[w].walk_one = false;  // (a gc_bias rejection, or starved: the pair takes a turn of its own)
+                }
+            }
+        }
+        // ---- (f) the streams move on (mt_prefetch_commit: the unconsumed words in front of those produced ahead)
+        bool move_c = false, wait_prev_c = false;
+        for (int w = 0; w < W; ++w)
+            for (int s = 0; s < 2; ++s) {
+                const int k = 2 * w + s;
+                h_move_c[k] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u};
+                if (!n_w[w] || !pf[k].on) continue;
+                const size_t left = t.fill[k] - t.used[k];  // <= pf.at
+                const int nxt = (t.cur[k] + 1) % MT_SET_BUFS;
+                h_move_c[k] = iss::MtMoveJob{bufp(w, s, t.cur[k]) + t.used[k], bufp(w, s, nxt) + (pf[k].at - left), (uint32_t)left, 0u};
+                wait_prev_c |= read_by_last_turn(k, nxt);
+                if (dbg) { dbg_moved[s] += left; dbg_filled[s] += (uint64_t)pf[k].blocks * 624; ++dbg_moves; dbg_big += left > want[k] / 4; }
+                t.cur[k] = nxt;
+                t.used[k] = pf[k].at - left;
+                t.fill[k] = pf[k].at + (size_t)pf[k].blocks * 624;
+                move_c = true;
+            }
         if (move_c) {
             if (wait_prev_c) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par ^ 1], 0));  // (a target the emitter of the turn before reads)
             HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_move_c), h_move_c, 2 * (size_t)W * sizeof(iss::MtMoveJob), hipMemcpyHostToDevice, ctx->stream));
