@@ -131,6 +131,90 @@ def test_eight_workers_reproduce_reference_generate(case, model, n_reads, seed, 
     assert open(output + "_R2.fastq", "rb").read() == z["r2"].tobytes()
 
 
+@pytest.mark.parametrize("case,model,n_reads,seed", [("genomes_hiseq_n1600_seed42", "hiseq", 1600, 42),
+                                                     ("syn3_novaseq_n3000_seed7", "novaseq", 3000, 7)])
+def test_worker_set_iterator_host_logic_reproduces_cpus8(case, model, n_reads, seed, tmp_path, monkeypatch):
+    """worker_set_iterator -- W reference workers in ONE engine: rounds of one piece per worker, short records (a draw, no
+    rows), per-worker files -- with the device replaced by an engine whose generate_mt_workers runs the CPU oracle on every
+    worker's own MT streams: the assembled files are `iss generate --cpus 8`'s (goldens of make_golden_cpus8.py).  The
+    device's side of the same call is tests/test_gpu_mt_compat.py."""
+    import insilicoseq_amd.generator as G
+    from insilicoseq_amd import _native
+    from insilicoseq_amd import distributed as D
+    from insilicoseq_amd.engine import fastq_write
+    from insilicoseq_amd.model import DenseModel
+    from oracle import oracle as O
+
+    dense = DenseModel.load(os.path.join(GOLDEN, "..", "..", "insilicoseq_amd", "profiles", model + ".dense.npz"))
+
+    class OracleEngine(object):
+        def __init__(self, device):
+            self.genomes, self.rows, self.calls = [], {}, 0
+
+        read_length = dense.read_length
+
+        def load_model(self, d):
+            self.orc = O.Oracle(d)
+
+        def seed_mt_workers(self, seeds):
+            self.rngs = [O.Rng().seed_mt(int(sd)) for sd in seeds]
+
+        def mt_set_fragment(self, a, b):
+            assert a is None and b is None
+
+        def add_genome(self, seq):
+            self.genomes.append(seq)
+            return len(self.genomes) - 1
+
+        def generate_mt_workers(self, g, n, row, sequence_type="metagenomics", gc_bias=False):
+            self.calls += 1
+            done, status = np.zeros(len(n), dtype=np.int64), np.zeros(len(n), dtype=np.int32)
+            for w in range(len(n)):
+                if n[w] == 0:
+                    continue
+                res = self.orc.simulate(self.rngs[w], self.genomes[g[w]], int(n[w]), gc_bias=gc_bias)
+                if res["status"] == O.SKIP_RECORD:
+                    status[w] = _native.E_SHORT_RECORD
+                    continue
+                assert res["status"] == 0
+                done[w] = res["n_done"]
+                self.rows[int(row[w])] = res
+            return done, status
+
+        def fastq_emit(self, fd1, fd2, rid, first_i, cpu, first_pair, n_pairs, n_threads=1):
+            res = self.rows.pop(int(first_pair))
+            assert res["n_done"] == n_pairs
+            fastq_write(fd1, fd2, rid, first_i, cpu, n_pairs, dense.read_length, dense.read_length, res["r1_base"], res["r1_qual"],
+                        res["r2_base"], res["r2_qual"], 1)
+
+        def fastq_flush(self):
+            pass
+
+        def close(self):
+            pass
+
+    made = []
+    monkeypatch.setattr(G, "ReadEngine", lambda device: made.append(OracleEngine(device)) or made[-1])
+    z = np.load(os.path.join(GOLDEN, "generate", case + "_cpus8.npz"))
+    fasta = os.path.join(GOLDEN, "genomes.fasta")
+    if "fasta" in z.files:
+        fasta = str(tmp_path / "in.fasta")
+        with open(fasta, "wb") as fh:
+            fh.write(z["fasta"].tobytes())
+    records = list(G.parse_fasta(fasta))
+    abundance = G.lognormal_abundance([r.id for r in records], np.random.RandomState(seed))
+    output = str(tmp_path / "out")
+    world = 8
+    works = [D.rank_work(records, None, abundance, n_reads, None, None, dense, output, world, r)[0] for r in range(world)]
+    assert all(w is not None for w in works)
+    G.worker_set_iterator(works, dense, list(range(world)), [D.temp_prefix(output, r) for r in range(world)], seed, "metagenomics",
+                          False, device=0, batch_pairs=64)
+    assert len(made) == 1 and made[0].calls > 2  # ONE engine for the eight workers, several rounds
+    D.concatenate_rank_files(output, world)
+    assert open(output + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(output + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+
+
 def test_single_rank_is_a_noop_broadcast():
     from insilicoseq_amd import distributed as D
     from insilicoseq_amd.model import DenseModel
