@@ -278,7 +278,7 @@ struct iss_ctx {
         // the buffer the emitter of turn t - 1 read, so that fill starts behind the emitter of the turn before.  (Three -- the
         // fill never waits for an emitter -- were built and measured in round 5: 3.1e7 against 4.2e7 pairs/s at W = 256: fill,
         // emitter and resolver then all start together and the resolver, the chain everything waits for, is the one that loses.)
-        uint32_t *buf[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+        uint32_t *buf[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // (the first MT_SET_BUFS of each are allocated)
         std::vector<int64_t> last_read;      // [W * 2][3]: the turn whose emitter reads that buffer (-1: none in flight)
         iss::MtWalkResult *d_res = nullptr;  // [W]
         iss::MtGauss *d_gauss = nullptr;     // [W]

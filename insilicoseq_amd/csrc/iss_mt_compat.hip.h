@@ -16,8 +16,12 @@
 //   k_mt_resolve / k_mt_emit : the fast path for plain pairs (see below): only the stream offsets are
 //               chained, by one workgroup working from LDS; the reads are then built in parallel.
 //
-// This mode is chained by construction (~3e5 pairs/s per worker): it exists for bit-identity with the
-// reference; the Philox path (iss_kernels.hip.h) is the performance path.
+//   k_mt_fill_w / k_mt_resolve_w / k_mt_walk_w / k_mt_emit_w / k_mt_move_w (round 5): the same bodies for W workers per
+//               launch -- the reference's own parallelism is N workers with seeds seed + cpu_number (iss/app.py:99-106,
+//               iss/generator.py:234-236): one workgroup (wavefront, grid row) per worker, the jobs in a table in HBM.
+//
+// This mode is chained by construction (~3.8e5 pairs/s per worker, 4.6e7 with 256 workers side by side): it exists for
+// bit-identity with the reference; the Philox path (iss_kernels.hip.h) is the performance path.
 #pragma once
 #include "iss_kernels.hip.h"
 

@@ -498,7 +498,7 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
         eng.seed_mt_workers([worker_seed(seed, c) for c in cpu_numbers])
         eng.mt_set_fragment(getattr(error_model, "fragment_length", None), getattr(error_model, "fragment_sd", None))
         per = int(batch_pairs or max(1024, min(Worker.BATCH_PAIRS, (1 << 20) // W)))  # rows per worker and round
-        gids = {}
+        gids, resident = {}, [0]
 
         def gid_of(record):
             hit = gids.get(id(record))
@@ -507,6 +507,7 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
                 if not isinstance(seq, (str, bytes, bytearray, np.ndarray)):
                     seq = str(seq)
                 hit = gids[id(record)] = (record, eng.add_genome(seq))
+                resident[0] += len(seq)
             return hit[1]
 
         def pieces(work, cpu):  # (record, genome id, pairs, id of the piece's first pair, short record?)
@@ -531,6 +532,11 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
             for fh in fh3[:2]:
                 fh.flush()
         while True:
+            if resident[0] > Worker.GENOME_BUDGET:
+                # between rounds nothing names an uploaded record: drop them all (a round uploads what its pieces need again)
+                eng.clear_genomes()  # (waits for the device and the FASTQ pipeline first)
+                gids.clear()
+                resident[0] = 0
             cur = [next(it, None) for it in its]
             if all(c is None for c in cur):
                 break
