@@ -70,6 +70,10 @@ CASES = [
     ("basic", None, lambda: mixed_genome(33, 20000), 3000, 26, 2**35 + 3, "metagenomics", True),
     ("basic", None, lambda: random_genome(34, 460), 1500, 27, 0, "amplicon", False),
     ("basic", None, lambda: random_genome(35, 300), 1000, 28, 0, "metagenomics", False),  # record < fragment: generator.py:144
+    # BASELINE configs[4] as written: the model the reference's own `iss model` builds from its data/ecoli.bam (minted on a pysam
+    # stand-in by tests/golden/tooling/make_golden_bam_model.py; read_length 20, a 2 000-point insert-size CDF, no indel detected)
+    ("ecoli-bam", None, lambda: random_genome(36, 3000), 4000, 29, 0, "metagenomics", False),
+    ("ecoli-bam", None, lambda: mixed_genome(37, 2500), 3000, 30, 5, "metagenomics", True),
 ]
 
 

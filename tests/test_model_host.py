@@ -155,3 +155,32 @@ def test_basic_dense_model_carries_the_rows_and_round_trips(tmp_path):
     assert e.quality_mode == 1 and (e.qcdf == d.qcdf).all()
     t = d.device_tables()
     assert (t["q_thr"][0, 0, 0] == np.floor(row * 2.0**53).astype(np.uint64)).all()
+
+
+def test_bam_built_model_is_the_shipped_ecoli_profile():
+    """BASELINE configs[4] names "a custom .npz from data/ecoli.bam via iss model".  tests/golden/models/ecoli-bam.dense.npz is that
+    model: the reference's own `iss model` run on the reference's own BAM file in the build container (on a stand-in for pysam,
+    after the reference's bam / modeller tests passed on it: tests/golden/tooling/make_golden_bam_model.py).  It equals the
+    reference's shipped data/ecoli.npz -- our `ecoli` profile, which every parity suite runs -- in every table but two: the
+    insert-size CDF (today's modeller uses a 2 000-point grid, the shipped file has 1 000 points) and KDE round-off in the
+    quality CDFs (<= 1e-20).  All of its indel rates are zero: the twenty reads of data/ecoli.bam hold one insertion, which the
+    reference's dispatch never counts (iss/modeller.py:182-190 flags a read for indel treatment only when it meets a letter
+    outside ACGT) -- the insertion / deletion path of configs[4] is exercised by the synthetic rates of `--indel`, not by
+    this file."""
+    import os
+
+    from helpers import GOLDEN, dense_model
+    from insilicoseq_amd.model import DenseModel
+
+    a = DenseModel.load(os.path.join(GOLDEN, "models", "ecoli-bam.dense.npz"))
+    b = dense_model("ecoli")
+    assert a.read_length == b.read_length == 20
+    for k in DenseModel.FIELDS:
+        x, y = getattr(a, k), getattr(b, k)
+        if k == "isize_cdf":
+            assert x.shape == (2000,) and y.shape == (1000,) and x[-1] == y[-1] == 1.0
+        elif k == "qcdf":
+            assert x.shape == y.shape and np.nanmax(np.abs(x - y)) < 1e-20
+        else:
+            assert x.shape == y.shape and np.array_equal(x, y), k
+    assert not a.ins.any() and not a.dele.any()
