@@ -148,7 +148,8 @@ int iss_generate(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, uint64_t firs
  * the ordinals and output rows that n_items consecutive iss_generate calls would give them (first_ordinal /
  * out_first_pair onwards), so the rows are identical to those calls' -- without a kernel launch sequence per record.
  * The records are laid side by side in one device arena (kept until a call names another list of records) and pair
- * descriptors carry arena coordinates; iss_output_download_coords returns record coordinates as before.  Custom
+ * descriptors carry arena coordinates (36-bit like a single record's: the records of one call may hold 2^34 - 4096 bases
+ * together, ISS_E_INVALID beyond -- ABI 7; 2^31 until then); iss_output_download_coords returns record coordinates as before.  Custom
  * fragment lengths (iss_set_fragment) apply as in iss_generate.  A record not longer than the read
  * length: ISS_E_SHORT_RECORD, nothing generated (leave such records out, as reads_generator skips them).
  */

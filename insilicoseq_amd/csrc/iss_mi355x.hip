@@ -1864,7 +1864,9 @@ int iss_generate_batch(iss_ctx *ctx, int32_t n_items, const int32_t *genome_ids,
                 items[(size_t)k] = iss::BatchItem{place[ids[k]], G.L, G.has_exceptions ? 1 : 0, 0};
                 exceptions |= G.has_exceptions;
             }
-            if (coord >= ((int64_t)1 << 31) - 4096) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: the records of one call must stay below 2^31 bases");
+            // (arena coordinates are the pair descriptors' 36-bit coordinates and k_main's 32-bit word numbers, like a single
+            //  record's: round 5 -- until then the records of a call had to stay below 2^31 bases)
+            if (coord >= iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "iss_generate_batch: the records of one call must stay below 2^34 - 4096 bases");
             if (coord > ctx->comm_cap) {
                 { int rc_ = sync_all(ctx); if (rc_) return rc_; }
                 free_community(ctx);

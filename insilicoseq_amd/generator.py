@@ -326,7 +326,7 @@ def _simulate_work_batched(w, work, forward_handle, reverse_handle, mutations_ha
             if w.store_mutations:
                 rows = mutation_rows(eng, gen)
         except _native.EngineError as e:
-            if e.code != _native.E_INVALID or "2^31" not in str(e):
+            if e.code != _native.E_INVALID or "records of one call must stay below" not in str(e):
                 raise
             # records too long to stand side by side in one arena: the same rows from one call per item
             eng.reserve(sum(p[2] for p in pending))

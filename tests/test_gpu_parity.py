@@ -929,6 +929,45 @@ def test_records_of_2_31_bases_and_more(model, indel, mixed, L):
             eng.generate_mt(gid, 10)
 
 
+def test_batch_arena_beyond_2_31_bases():
+    """Round 5: the records of ONE iss_generate_batch call stand side by side in an arena of up to 2^34 - 4096 bases (until then:
+    below 2^31, the worker fell back to one call per record).  Three records of 0.9 / 0.9 / 0.6 Gbp -- the third one's arena
+    coordinates lie beyond 2^31 -- of an indel-heavy model (edit scripts, fix-up, scan at those coordinates): the pairs of every
+    item with the largest and smallest coordinates and a random sample against the oracle, record coordinates included.  The
+    content has a prime period: an arena coordinate off by a power of two reads other letters."""
+    from insilicoseq_amd.engine import ReadEngine
+    from oracle import oracle as O
+
+    period = 33_554_393  # prime
+    block = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.RandomState(8).randint(0, 4, size=period)]
+    lengths = [900_000_011, 900_000_017, 600_000_007]
+    genomes = [np.ascontiguousarray(np.tile(np.roll(block, 1000 * k), L // period + 1)[:L]) for k, L in enumerate(lengths)]
+    dense = dense_model("novaseq", (0.001, 0.003))
+    orc = O.Oracle(dense)
+    counts = [60_000, 50_000, 70_000]
+    with ReadEngine(0) as eng:
+        eng.load_model(dense)
+        gids = [eng.add_genome(g) for g in genomes]
+        eng.generate_batch(gids, counts, first_ordinal=11, seed=17, out_first_pair=0)
+        eng.synchronize()
+        row0, ord0 = 0, 11
+        for k, n in enumerate(counts):
+            coords = eng.coords(row0, n)
+            assert int(coords[:, 0].min()) >= 0 and int(coords[:, 2].max()) <= lengths[k]
+            order = np.argsort(coords[:, 2])
+            picks = list(order[-12:]) + list(order[:6]) + list(np.random.RandomState(k).randint(0, n, 24))
+            for i in picks:
+                got = eng.download(row0 + int(i), 1)
+                exp = orc.simulate(O.Rng().seed_philox(17), genomes[k], 1, first_ordinal=ord0 + int(i), want_coords=True)
+                assert exp["status"] == 0
+                assert np.array_equal(coords[i], exp["coords"][0]), (k, int(i))
+                for key in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+                    assert np.array_equal(got[key], exp[key]), (k, int(i), key)
+            row0 += n
+            ord0 += n
+        assert eng.stats_read()["scripted_reads"] > sum(counts) // 2
+
+
 def _fuzz_config(k):
     """Random but reproducible (model shape, tables, genome, options) for the differential test below."""
     from helpers import synthetic_model

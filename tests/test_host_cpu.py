@@ -541,7 +541,7 @@ def test_parse_fasta_fast_path_equals_line_parser(tmp_path):
 
 
 def test_batched_worker_loop_falls_back_to_single_calls():
-    """Records too long for one arena (iss_generate_batch: ISS_E_INVALID, "... 2^31 bases"): the batch is generated item
+    """Records too long for one arena (iss_generate_batch: ISS_E_INVALID, "... must stay below 2^34 - 4096 bases"): the batch is generated item
     by item into the same rows (running ordinals), mutation rows renumbered to the batch, one emit job as before."""
     import io
 
@@ -556,7 +556,7 @@ def test_batched_worker_loop_falls_back_to_single_calls():
             self.calls, self.last = [], None
 
         def generate_batch(self, *a, **k):
-            raise _native.EngineError(_native.E_INVALID, "iss_generate_batch: the records of one call must stay below 2^31 bases")
+            raise _native.EngineError(_native.E_INVALID, "iss_generate_batch: the records of one call must stay below 2^34 - 4096 bases")
 
         def reserve(self, n):
             self.calls.append(("reserve", n))
