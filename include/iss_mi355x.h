@@ -105,7 +105,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *tables);
  * rejected here with ISS_E_INVALID); stored in HBM as 2-bit codes (A,T,C,G = 0..3) + a
  * 1-bit "exception" mask (IUPAC / lower case) + the ASCII copy the exceptions are read from.
  * 1 <= length <= 2^34 - 4096 (ABI 6: the reference takes records of 2^31 - 1 bases and more through its memmap
- * spill, iss/generator.py:313-331; iss_generate_mt keeps the limit 2^31 - 2).
+ * spill, iss/generator.py:313-331; ABI 7: iss_generate_mt takes them too -- 36-bit coordinates, two stream words per
+ * `randrange` candidate once the bound passes 2^32, as CPython's getrandbits).
  */
 int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_t *genome_id);
 /* The same for a record of plain A/C/G/T handed over as 2-bit codes (16 bases per little-endian 32-bit word, base i in

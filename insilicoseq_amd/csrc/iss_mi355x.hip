@@ -1268,7 +1268,7 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
 int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_t *genome_id) {
     if (!ctx || !ascii || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload: NULL argument");
     // (records of 2^31 - 1 bases and more: the reference spills them to a memmap, generator.py:313-331; here coordinates are
-    //  36-bit and word offsets into the packed genome 32-bit -- iss::MAX_RECORD; MT mode keeps the 2^31 limit: iss_generate_mt)
+    //  36-bit and word offsets into the packed genome 32-bit -- iss::MAX_RECORD, on both RNG paths since round 5)
     if (length < 1 || length > iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^34 - 4096]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // ASCII -> HBM, then packed on the device (k_pack_genome).  One readable padding word in front
@@ -1351,7 +1351,7 @@ int iss_genome_upload(iss_ctx *ctx, const uint8_t *ascii, int64_t length, int32_
 int iss_genome_upload_packed(iss_ctx *ctx, const uint32_t *codes, int64_t length, int32_t codes_on_device, int32_t *genome_id) {
     if (!ctx || !codes || !genome_id) return fail(ctx, ISS_E_INVALID, "iss_genome_upload_packed: NULL argument");
     // (records of 2^31 - 1 bases and more: the reference spills them to a memmap, generator.py:313-331; here coordinates are
-    //  36-bit and word offsets into the packed genome 32-bit -- iss::MAX_RECORD; MT mode keeps the 2^31 limit: iss_generate_mt)
+    //  36-bit and word offsets into the packed genome 32-bit -- iss::MAX_RECORD, on both RNG paths since round 5)
     if (length < 1 || length > iss::MAX_RECORD) return fail(ctx, ISS_E_INVALID, "genome length must be in [1, 2^34 - 4096]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n_mk = (size_t)(length + 31) / 32, n_pk = 2 * n_mk, n_in = (size_t)(length + 15) / 16;
@@ -2194,8 +2194,6 @@ int iss_generate_mt(iss_ctx *ctx, int32_t genome_id, int64_t n_pairs, int32_t se
         return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
     const Genome &G = ctx->genomes[genome_id];
     const iss::DevModel &M = ctx->M;
-    if (G.L >= (int64_t)0x7fffffff)
-        return fail(ctx, ISS_E_INVALID, "iss_generate_mt: records of 2^31 - 1 bases and more are the Philox path's (iss_generate)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     auto &m = ctx->mt;
@@ -2643,8 +2641,6 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
         if (genome_ids[w] < 0 || genome_ids[w] >= (int32_t)ctx->genomes.size()) return fail(ctx, ISS_E_INVALID, "unknown genome id");
         if (n_pairs[w] < 0 || out_first_pair[w] < 0 || out_first_pair[w] + n_pairs[w] > ctx->capacity)
             return fail(ctx, ISS_E_INVALID, "output rows out of the reserved range");
-        if (ctx->genomes[genome_ids[w]].L >= (int64_t)0x7fffffff)
-            return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: records of 2^31 - 1 bases and more are the Philox path's (iss_generate)");
         for (int v = 0; v < w; ++v)  // (the workers' rows must not overlap)
             if (n_pairs[v] > 0 && out_first_pair[w] < out_first_pair[v] + n_pairs[v] && out_first_pair[v] < out_first_pair[w] + n_pairs[w])
                 return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: two workers' output rows overlap");

@@ -202,7 +202,8 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 // worst-case stream words one attempt at a pair can consume (randrange bounded at 64 words each)
-__host__ __device__ inline uint32_t mt_py_need(int RL) { return 128u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
+// (a randrange round: 64 candidates of one word, of two words once the bound passes 2^32 -- records of 2^32 bases and more)
+__host__ __device__ inline uint32_t mt_py_need(int RL) { return 256u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
 __host__ __device__ inline uint32_t mt_np_need(int RL, bool basic = false) {
     // basic: the phreds of a mate are RL gaussians = RL/2 accepted polar candidates of 4 words (acceptance pi/4, expected
     // 2.55 * RL words); 8 * RL + 1024 is tens of standard deviations above that (k_mt_walk also checks every round)
@@ -214,17 +215,23 @@ __host__ __device__ inline size_t mt_walk_fixed_lds_bytes(int RL) {
 }
 
 // CPython _randbelow_with_getrandbits on the stream: 64 candidate words per round, first one < n wins
-__device__ __forceinline__ uint32_t mt_randbelow(const uint32_t *py, uint32_t &opy, uint32_t n, int lane) {
-    const int k = 32 - __clz(n);
+// getrandbits(k) for k > 32 (_randommodule.c): 32-bit words from the least significant on, the top one shifted -- records of 2^32
+// bases and more (round 5: MT mode takes records up to MAX_RECORD like the Philox path; the reference spills them to a memmap and
+// carries on, iss/generator.py:313-331); a candidate is then two words
+__device__ __forceinline__ uint64_t mt_randbelow(const uint32_t *py, uint32_t &opy, uint64_t n, int lane) {
+    const int k = 64 - __clzll((long long)n);
     for (;;) {
-        const uint32_t r = py[opy + lane] >> (32 - k);
+        uint64_t r;
+        if (k <= 32) r = py[opy + lane] >> (32 - k);
+        else r = (uint64_t)py[opy + 2 * lane] | ((uint64_t)(py[opy + 2 * lane + 1] >> (64 - k)) << 32);
         const unsigned long long ok = __ballot(r < n);
+        const uint32_t per = k <= 32 ? 1u : 2u;
         if (ok) {
             const int t = __ffsll(ok) - 1;
-            opy += (uint32_t)t + 1u;
-            return (uint32_t)__shfl((int)r, t);
+            opy += per * ((uint32_t)t + 1u);
+            return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(r >> 32), t) << 32) | (uint32_t)__shfl((int)(uint32_t)r, t);
         }
-        opy += 64u;
+        opy += per * 64u;
     }
 }
 
@@ -404,12 +411,12 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
         int64_t fs, rs = 0, re = 0;
         if (A.sequence_type == 0) {  // generator.py:134-135, 142-144
             const int64_t width = L - frag;
-            fs = mt_randbelow(py, opy, (uint32_t)(width > 0 ? width : L - RL), lane);
+            fs = (int64_t)mt_randbelow(py, opy, (uint64_t)(width > 0 ? width : L - RL), lane);
         } else {
             fs = 0;
         }
         const int64_t fe = fs + RL;
-        d.fs = (int32_t)fs;
+        d.fs = (int32_t)(uint32_t)fs;  // (low 32 bits; bits 32-35 of both coordinates go into meta with the reverse end below)
         for (int o = 0; o < 2; ++o) {
             // ---- template = Python slice of the genome (may be shorter than RL with odd fragment lengths),
             //      then the adjust_seq_length padding rule (__init__.py:141-155)
@@ -420,7 +427,7 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
             } else {  // generator.py:164-177
                 if (A.sequence_type == 0) { rs = fe + isz; re = rs + RL; }
                 else { rs = L - RL; re = L; }
-                if (re > L) { re = RL + (int64_t)mt_randbelow(py, opy, (uint32_t)(L - RL), lane); rs = re - RL; }
+                if (re > L) { re = RL + (int64_t)mt_randbelow(py, opy, (uint64_t)(L - RL), lane); rs = re - RL; }
                 lo = rs; hi = re;
                 if (lo < 0) { lo += L; if (lo < 0) lo = 0; } else if (lo > L) lo = L;
                 if (hi < 0) { hi += L; if (hi < 0) hi = 0; } else if (hi > L) hi = L;
@@ -581,7 +588,8 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
             opy = opy0; onp = onp0; gs = gs0; n_mut = mut_mark;
             break;
         }
-        d.re = (int32_t)re;
+        d.re = (int32_t)(uint32_t)re;
+        d.meta |= desc_hi_bits(fs, re);
         bool keep = true;
         if (A.gc_bias) {  // generator.py:82-92
             keep = mk53(np[onp], np[onp + 1]) < A.gc_thr;
@@ -652,7 +660,7 @@ struct MtResolveArgs {
 
 constexpr int RES_THREADS = 512;  // two groups of four wavefronts: the mates of a pair are worked on side by side
 // the rings must show a whole pair at once (both mates are read concurrently)
-__host__ __device__ inline uint32_t mt_res_need_py(int RL) { return 128u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
+__host__ __device__ inline uint32_t mt_res_need_py(int RL) { return 256u + 2u * (10u * (uint32_t)(RL - 1) + 2u * (uint32_t)RL); }
 __host__ __device__ inline uint32_t mt_res_need_np(int RL) { return 16u + 64u /* polar loop */ + 8u * (uint32_t)RL; }
 __host__ __device__ inline size_t mt_res_lds_bytes(const DevModel &M, int pyv, int npv, bool rows_lds) {
     size_t b = (size_t)(2 * pyv + 2 * npv) * 1024 * 4 + 2 * 16 * 4;  // rings + their 16-word mirrors
@@ -879,18 +887,20 @@ __device__ __forceinline__ void mt_resolve_body(const DevModel &M, const DevGeno
         }
         const int64_t frag = isz + 2 * (int64_t)RL;
         int64_t fs = 0;
-        auto randbelow_at = [&](uint32_t &off, uint32_t n) -> uint32_t {  // one round of 64 candidate words from py[off ..]
-            const int k = 32 - __clz(n);
-            const uint32_t r = pyr(off + (uint32_t)lane) >> (32 - k);
+        auto randbelow_at = [&](uint32_t &off, uint64_t n) -> uint64_t {  // one round of 64 candidates (one word each; two beyond 2^32) from py[off ..]
+            const int k = 64 - __clzll((long long)n);
+            uint64_t r;
+            if (k <= 32) r = pyr(off + (uint32_t)lane) >> (32 - k);
+            else r = (uint64_t)pyr(off + 2u * (uint32_t)lane) | ((uint64_t)(pyr(off + 2u * (uint32_t)lane + 1u) >> (64 - k)) << 32);
             const unsigned long long ok = __ballot(r < n);
             if (!ok) { odd = true; return 0u; }
             const int t = __ffsll(ok) - 1;
-            off += (uint32_t)t + 1u;
-            return (uint32_t)__shfl((int)r, t);
+            off += (k <= 32 ? 1u : 2u) * ((uint32_t)t + 1u);
+            return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(r >> 32), t) << 32) | (uint32_t)__shfl((int)(uint32_t)r, t);
         };
         if (A.sequence_type == 0 && !odd) {  // generator.py:134-135, 142-144
             const int64_t width = L - frag;
-            fs = randbelow_at(opy, (uint32_t)(width > 0 ? width : L - RL));
+            fs = (int64_t)randbelow_at(opy, (uint64_t)(width > 0 ? width : L - RL));
         }
         const int64_t fe = fs + RL;
         auto exceptions_in = [&](int64_t lo, int64_t hi) -> bool {  // any letter outside ACGT in [lo, hi)
@@ -911,14 +921,15 @@ __device__ __forceinline__ void mt_resolve_body(const DevModel &M, const DevGeno
         int64_t rs, re;
         if (A.sequence_type == 0) { rs = fe + isz; re = rs + RL; }  // generator.py:164-177
         else { rs = L - RL; re = L; }
-        if (!odd && re > L) { re = RL + (int64_t)randbelow_at(opy1, (uint32_t)(L - RL)); rs = re - RL; }
+        if (!odd && re > L) { re = RL + (int64_t)randbelow_at(opy1, (uint64_t)(L - RL)); rs = re - RL; }
         if (fe > L || rs < 0) odd = true;  // templates cut by the genome ends (short / negative fragments): Python slice rules
         if (!odd) odd = exceptions_in(fs, fe) || exceptions_in(rs, re);
         PairDesc d;
-        d.fs = (int32_t)fs;
-        d.re = (int32_t)re;
+        d.fs = (int32_t)(uint32_t)fs;
+        d.re = (int32_t)(uint32_t)re;
         d.isz = (int32_t)isz;
         d.meta = 0;
+        const uint32_t hi_bits = desc_hi_bits(fs, re);  // (bits 32-35 of the coordinates: records of 2^31 bases and more)
         MtPairRec rc;
         if (!odd) {
             // both mates at once: group 0 the first, group 1 the second ASSUMING the first has no substitution event
@@ -939,7 +950,7 @@ __device__ __forceinline__ void mt_resolve_body(const DevModel &M, const DevGeno
                 sl ^= 1u;
             }
             odd = hit0 || hit1;
-            d.meta = slot0 | (slot1 << 2);
+            d.meta = slot0 | (slot1 << 2) | hi_bits;
             rc.opy_err[0] = opy + 10u * (uint32_t)(RL - 1);
             rc.onp_bin[0] = onp;
             rc.opy_err[1] = opy1 + 10u * (uint32_t)(RL - 1);
@@ -1022,7 +1033,7 @@ __device__ __forceinline__ void mt_emit_body(const DevModel &M, const DevGenome 
         bool err = false;
         int ch = 0, q = 0, bi = -1, before = 0;
         if (p < RL) {
-            ch = o == 0 ? fetch_ascii(g, (int64_t)d.fs + p) : complement_ascii(fetch_ascii(g, (int64_t)d.re - 1 - p));
+            ch = o == 0 ? fetch_ascii(g, desc_fs(d) + p) : complement_ascii(fetch_ascii(g, desc_re(d) - 1 - p));
             before = ch;
             const uint64_t mq = mk53(np[onp_q + 2u * (uint32_t)p], np[onp_q + 2u * (uint32_t)p + 1u]);
             q = count_lt(M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * M.n_q, M.n_q, mq);

@@ -881,7 +881,8 @@ def test_genome_positions_beyond_2_30():
             assert np.array_equal(got[k], exp[k]), ("mt", k)
 
 
-@pytest.mark.parametrize("model,indel,mixed,L", [("novaseq", (0.001, 0.003), False, 2**31 + 3_000_001), ("hiseq", None, True, 2**32 + 70_000_003)])
+@pytest.mark.parametrize("model,indel,mixed,L", [("novaseq", (0.001, 0.003), False, 2**31 + 3_000_001), ("hiseq", None, True, 2**32 + 70_000_003),
+                                                 ("novaseq", None, False, 2**32 + 90_000_001)])  # (plain: MT mode's resolver + emitter up there)
 def test_records_of_2_31_bases_and_more(model, indel, mixed, L):
     """Round 4: records of 2^31 - 1 bases and more (the reference spills them to a memmap and carries on:
     iss/generator.py:313-331, util.py:271-304).  Coordinates are 36-bit in the pair descriptors, `random.randrange` draws a
@@ -889,8 +890,7 @@ def test_records_of_2_31_bases_and_more(model, indel, mixed, L):
     A 2.15 Gbp record on the indel-heavy path (scripts at coordinates beyond 2^31) and a 4.36 Gbp record with IUPAC / lower-case
     stretches (mask and ASCII indexing up there; two-word randrange): the pairs with the largest and smallest coordinates and a
     random sample against the oracle, coordinates included.  The content has a prime period, so a coordinate off by a power of
-    two reads other letters.  MT mode keeps the 2^31 limit and says so."""
-    from insilicoseq_amd._native import EngineError
+    two reads other letters.  Round 5: the same records in MT mode (the reference's streams) against the oracle's MT mode."""
     from insilicoseq_amd.engine import ReadEngine
     from oracle import oracle as O
 
@@ -924,9 +924,24 @@ def test_records_of_2_31_bases_and_more(model, indel, mixed, L):
                 assert np.array_equal(got[k], exp[k]), (int(i), k)
         if indel is not None:
             assert eng.stats_read()["scripted_reads"] > n // 2
+        # round 5: MT mode takes such records too (36-bit coordinates in its kernels, two stream words per `randrange` candidate
+        # once the bound passes 2^32 -- CPython's getrandbits, pinned on CPython itself in tests/test_oracle_golden.py): the
+        # resolver + emitter for the plain record, the walker for the one with IUPAC stretches and for the indel-heavy model
+        n_mt = 1200
         eng.seed_mt(9)
-        with pytest.raises(EngineError):
-            eng.generate_mt(gid, 10)
+        assert eng.generate_mt(gid, n_mt) == n_mt
+        got = eng.download(0, n_mt)
+        cg = eng.coords(0, n_mt)
+        rng = O.Rng().seed_mt(9)
+        exp = orc.simulate(rng, g, n_mt, want_coords=True)
+        assert exp["status"] == 0 and exp["n_done"] == n_mt
+        assert np.array_equal(np.asarray(cg), exp["coords"]) and int(cg[:, 2].max()) >= 2**31
+        for k in ("r1_base", "r1_qual", "r2_base", "r2_qual"):
+            assert np.array_equal(got[k], exp[k]), ("mt", k)
+        py, npw = eng.mt_peek(8)  # both streams stand where the oracle's stand
+        assert [int(x) for x in py] == [rng.py_word() for _ in range(8)] and [int(x) for x in npw] == [rng.np_word() for _ in range(8)]
+        if indel is None and not mixed:
+            assert eng.mt_path_counts()[0] >= n_mt - 8  # the offset resolver + parallel emitter did it (two-word randrange candidates)
 
 
 def test_batch_arena_beyond_2_31_bases():
