@@ -169,6 +169,11 @@ struct iss_ctx {
     // write, and what it writes -- descriptors, flags, the fix-up list -- is double-buffered by call parity (`desc`, `flags`,
     // `fix_list` below point at the current call's set).  ISS_SETUP_AHEAD=0: everything in order on one stream.
     hipStream_t setup_stream = nullptr;
+    // The worker set's emitter (k_mt_emit_w: 0.5 TB/s of reads over the whole chip, beside the NEXT turn's resolver): a stream of
+    // its own at the lowest priority.  On the setup stream (highest priority) it took the resolvers' issue slots -- the chain the
+    // turn waits for: 1.79 -> 1.90e7 pairs/s at W = 64, 4.70 -> 5.04e7 at W = 256.  A stream bound to a subset of the CUs
+    // (hipExtStreamCreateWithCUMask, 32 .. 128 CUs) was worse than either: the emitter needs the chip (1.2 -> 2.1e7 at W = 64).
+    hipStream_t emit_stream = nullptr;
     bool setup_ahead = true;
     iss::PairDesc *desc_buf[2] = {nullptr, nullptr};
     uint32_t *flags_buf[2] = {nullptr, nullptr}, *fixl_buf[2] = {nullptr, nullptr};
@@ -273,9 +278,11 @@ struct iss_ctx {
         int W = 0;
         int64_t ch = 0;                      // pairs per worker and turn
         size_t cap[2] = {0, 0};              // words per (worker, stream, ping-pong buffer)
+        int buf_turns = 0;                   // ... = this many turns' words (worst case)
         iss::MtState *d_state = nullptr;     // [W][2]: CPython random, numpy
-        // [stream][buffer]: W x cap[stream] words, MT_SET_BUFS buffers in rotation.  Two: the words of turn t + 1 are produced into
-        // the buffer the emitter of turn t - 1 read, so that fill starts behind the emitter of the turn before.  (Three -- the
+        // [stream][buffer]: W x cap[stream] words, MT_SET_BUFS buffers in rotation.  A stream's words are appended to its current
+        // buffer turn after turn; at the buffer's end the stream moves to the next one of the rotation (mt_set_reserve).  Two: the
+        // words of turn t + 1 then go into the buffer the emitter of turn t - 1 may still read, so that fill starts behind it.  (Three -- the
         // fill never waits for an emitter -- were built and measured in round 5: 3.1e7 against 4.2e7 pairs/s at W = 256: fill,
         // emitter and resolver then all start together and the resolver, the chain everything waits for, is the one that loses.)
         uint32_t *buf[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // (the first MT_SET_BUFS of each are allocated)
@@ -392,7 +399,7 @@ void free_mt_set(iss_ctx *ctx) {
     if (t.ev_turn) (void)hipEventDestroy(t.ev_turn);
     t.ev_side = t.ev_turn = nullptr;
     t.d_state = nullptr; t.d_res = nullptr; t.d_gauss = nullptr; t.d_rec = nullptr; t.h_jobs = nullptr; t.d_jobs = nullptr; t.h_res = nullptr;
-    t.W = 0; t.ch = 0; t.cap[0] = t.cap[1] = 0; t.jobs_bytes = 0;
+    t.W = 0; t.ch = 0; t.buf_turns = 0; t.cap[0] = t.cap[1] = 0; t.jobs_bytes = 0;
     t.cur.clear(); t.fill.clear(); t.used.clear(); t.last_read.clear();
 }
 
@@ -593,6 +600,7 @@ int sync_all(iss_ctx *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->indel_stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->fill_stream));
+    if (ctx->emit_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->emit_stream));
     return 0;
 }
 
@@ -854,6 +862,7 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
         HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->setup_stream, hipStreamNonBlocking, prio_greatest));
         HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->fill_stream, hipStreamNonBlocking, prio_least));  // (MT mode: see iss_ctx::fill_stream)
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->emit_stream, hipStreamNonBlocking, prio_least));  // (MT mode's worker set: see iss_ctx::emit_stream)
     }
     for (auto &e : ctx->ev_call_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : ctx->ev_setup_done) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -884,6 +893,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     if (ctx->indel_stream) (void)hipStreamSynchronize(ctx->indel_stream);
     if (ctx->fill_stream) (void)hipStreamSynchronize(ctx->fill_stream);
     if (ctx->setup_stream) (void)hipStreamSynchronize(ctx->setup_stream);
+    if (ctx->emit_stream) (void)hipStreamSynchronize(ctx->emit_stream);
     for (auto &t : ctx->timed) for (auto &e : t.ev) if (e) (void)hipEventDestroy(e);
     free_model(ctx);
     free_outputs(ctx);
@@ -899,6 +909,7 @@ void iss_ctx_destroy(iss_ctx *ctx) {
     if (ctx->indel_stream) (void)hipStreamDestroy(ctx->indel_stream);
     if (ctx->fill_stream) (void)hipStreamDestroy(ctx->fill_stream);
     if (ctx->setup_stream) (void)hipStreamDestroy(ctx->setup_stream);
+    if (ctx->emit_stream) (void)hipStreamDestroy(ctx->emit_stream);
     for (auto &e : ctx->ev_call_done) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_setup_done) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_slot_done) if (e) (void)hipEventDestroy(e);
@@ -2530,31 +2541,58 @@ int mt_set_reserve(iss_ctx *ctx) {
         const char *e = getenv("ISS_MT_SET_TURN");  // pairs per worker and turn (tests: many turns)
         t.ch = e ? std::max<int64_t>(1, std::min<int64_t>(8192, atoll(e))) : std::max<int64_t>(512, std::min<int64_t>(8192, 131072 / (int64_t)W));
     }
-    const size_t want[2] = {3 * ((size_t)(t.ch + 1) * need[0] + 1248), 3 * ((size_t)(t.ch + 1) * need[1] + 1248)};
+    // A buffer holds K turns' words (worst case): the words produced ahead are APPENDED behind a stream's valid words while there
+    // is room, and only at a buffer's end the stream moves to the other buffer, its unconsumed words copied in front (round 5: with
+    // K = 3 and a move every turn, the moves of the workers whose turn had ended early -- nearly a whole turn's words each, ~ 400 MB
+    // per turn at W = 64 -- were 1 ms of a 6.5 ms turn, on the critical path).  K = 8 where 32 GB hold it, 3 at least.
+    const size_t turn_words[2] = {(size_t)(t.ch + 1) * need[0] + 1248, (size_t)(t.ch + 1) * need[1] + 1248};
+    if (!t.buf_turns) {
+        const char *e = getenv("ISS_MT_SET_BUF_TURNS");  // (tests: 3 = a move every second turn)
+        const size_t per_k = W * MT_SET_BUFS * (turn_words[0] + turn_words[1]) * sizeof(uint32_t);
+        t.buf_turns = e ? std::max(3, std::min(8, atoi(e))) : (int)std::max<size_t>(3, std::min<size_t>(8, ((size_t)32 << 30) / per_k));
+    }
+    const size_t want[2] = {(size_t)t.buf_turns * turn_words[0], (size_t)t.buf_turns * turn_words[1]};
     if (t.cap[0] && (t.cap[0] < want[0] || t.cap[1] < want[1]))
         return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: the set's stream buffers were sized for a model with shorter reads (seed the set again)");
     if (!t.cap[0]) {
-        for (int s = 0; s < 2; ++s)
-            for (int b = 0; b < MT_SET_BUFS; ++b) {
+        // (all or nothing: a reservation that failed half way leaves nothing behind and can be repeated -- cap[] marks it as made)
+        auto undo = [&]() {
+            for (auto &st : t.buf) for (auto &b : st) { if (b) (void)hipFree(b); b = nullptr; }
+            if (t.d_rec) (void)hipFree(t.d_rec);
+            if (t.h_jobs) (void)hipHostFree(t.h_jobs);
+            if (t.d_jobs) (void)hipFree(t.d_jobs);
+            t.d_rec = nullptr; t.h_jobs = nullptr; t.d_jobs = nullptr;
+            for (auto &e : t.ev_emit) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+            if (t.ev_side) (void)hipEventDestroy(t.ev_side);
+            if (t.ev_turn) (void)hipEventDestroy(t.ev_turn);
+            t.ev_side = t.ev_turn = nullptr;
+            (void)hipGetLastError();
+        };
+        const size_t jobs_bytes = (((4 * 2 * W) * std::max(sizeof(iss::MtFillJob), sizeof(iss::MtMoveJob)) +
+                                    W * (sizeof(iss::MtResolveJob) + sizeof(iss::MtWalkJob) + sizeof(iss::MtEmitJob))) + 255) & ~(size_t)255;
+        bool ok = true;
+        for (int s = 0; s < 2 && ok; ++s)
+            for (int b = 0; b < MT_SET_BUFS && ok; ++b) {
                 void *p = nullptr;
-                if (hipMalloc(&p, W * want[s] * sizeof(uint32_t)) != hipSuccess)
-                    return fail(ctx, ISS_E_NOMEM, "iss_generate_mt_workers: no memory for the workers' stream buffers");
-                t.buf[s][b] = static_cast<uint32_t *>(p);
+                ok = hipMalloc(&p, W * want[s] * sizeof(uint32_t)) == hipSuccess;
+                t.buf[s][b] = ok ? static_cast<uint32_t *>(p) : nullptr;
             }
+        void *p = nullptr;
+        if (ok && (ok = hipMalloc(&p, 2 * W * (size_t)t.ch * sizeof(iss::MtPairRec)) == hipSuccess)) t.d_rec = static_cast<iss::MtPairRec *>(p);
+        if (ok && (ok = hipHostMalloc(&p, 2 * jobs_bytes, hipHostMallocDefault) == hipSuccess)) t.h_jobs = static_cast<uint8_t *>(p);
+        if (ok && (ok = hipMalloc(&p, 2 * jobs_bytes) == hipSuccess)) t.d_jobs = static_cast<uint8_t *>(p);
+        if (!ok) {
+            undo();
+            return fail(ctx, ISS_E_NOMEM, "iss_generate_mt_workers: no memory for the workers' stream buffers (W x " + std::to_string((want[0] + want[1]) * MT_SET_BUFS * 4) + " bytes)");
+        }
+        hipError_t e = hipSuccess;
+        for (auto &ev : t.ev_emit) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&t.ev_side, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&t.ev_turn, hipEventDisableTiming);
+        if (e != hipSuccess) { undo(); HIP_TRY(ctx, e); }
+        t.jobs_bytes = jobs_bytes;
         t.cap[0] = want[0];
         t.cap[1] = want[1];
-        void *p = nullptr;
-        HIP_TRY(ctx, hipMalloc(&p, 2 * W * (size_t)t.ch * sizeof(iss::MtPairRec)));
-        t.d_rec = static_cast<iss::MtPairRec *>(p);
-        for (auto &e : t.ev_emit) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&t.ev_side, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&t.ev_turn, hipEventDisableTiming));
-        t.jobs_bytes = (((4 * 2 * W) * std::max(sizeof(iss::MtFillJob), sizeof(iss::MtMoveJob)) +
-                         W * (sizeof(iss::MtResolveJob) + sizeof(iss::MtWalkJob) + sizeof(iss::MtEmitJob))) + 255) & ~(size_t)255;
-        HIP_TRY(ctx, hipHostMalloc(&p, 2 * t.jobs_bytes, hipHostMallocDefault));
-        t.h_jobs = static_cast<uint8_t *>(p);
-        HIP_TRY(ctx, hipMalloc(&p, 2 * t.jobs_bytes));
-        t.d_jobs = static_cast<uint8_t *>(p);
     }
     return 0;
 }
@@ -2722,11 +2760,11 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
     const size_t fm_sz = std::max(sizeof(iss::MtFillJob), sizeof(iss::MtMoveJob));
     std::vector<int64_t> n_w((size_t)W);
     std::vector<size_t> want(2 * (size_t)W);
-    struct PF { bool on = false; size_t at = 0; uint32_t blocks = 0; };
+    struct PF { bool on = false, append = false; size_t at = 0; uint32_t blocks = 0; };
     std::vector<PF> pf(2 * (size_t)W);
     std::vector<int> res_buf(2 * (size_t)W);
     const bool dbg = getenv("ISS_MT_SET_DEBUG") != nullptr;  // per call: turns, words produced / moved, pairs handed to the walker
-    uint64_t dbg_turns = 0, dbg_moved[2] = {0, 0}, dbg_filled[2] = {0, 0}, dbg_bounce = 0, dbg_moves = 0, dbg_big = 0, dbg_pairs = 0;
+    uint64_t dbg_turns = 0, dbg_moved[2] = {0, 0}, dbg_filled[2] = {0, 0}, dbg_bounce = 0, dbg_moves = 0, dbg_big = 0, dbg_pairs = 0, dbg_appends = 0, dbg_starved = 0, dbg_own = 0, dbg_skip = 0, dbg_ensure = 0;
     std::fill(t.last_read.begin(), t.last_read.end(), (int64_t)-1);  // (everything before this call has been waited for: sync_all above)
     for (;;) {
         bool any = false;
@@ -2750,10 +2788,11 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
         iss::MtEmitJob *h_ej = reinterpret_cast<iss::MtEmitJob *>(h_rest + (size_t)W * (sizeof(iss::MtResolveJob) + sizeof(iss::MtWalkJob)));
         auto dev_of = [&](const void *h) { return dj + (reinterpret_cast<const uint8_t *>(h) - hj); };
         hipStream_t s_side = ctx->setup_stream;  // the walker beside the resolver, the emitter beside the NEXT turn's resolver
+        hipStream_t s_emit = ctx->emit_stream;
         // ---- (a) every worker of the turn has the words of n + 1 pairs (+ boost) in front of it: mt_ensure, for all at once
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));  // (words produced ahead during the turn before)
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par], 0));  // (this parity's pair records: their last reader, two turns ago)
-        bool fill_e = false, wait_prev_e = false;
+        bool fill_e = false, move_e = false, wait_prev_e = false;
         for (int w = 0; w < W; ++w)
             for (int s = 0; s < 2; ++s) {
                 const int k = 2 * w + s;
@@ -2762,6 +2801,15 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 want[k] = n_w[w] ? std::min(t.cap[s] / 624 * 624 - 624, words_for(s, n_w[w], ws[w].boost)) : 0;
                 const size_t left = t.fill[k] - t.used[k];
                 if (left >= want[k]) continue;
+                const size_t missing = (want[k] - left + 623) / 624;
+                ++dbg_ensure;
+                if (t.fill[k] + missing * 624 <= t.cap[s]) {  // appended in place: nothing moves, nobody reads behind `fill`
+                    h_fill_e[k] = iss::MtFillJob{t.d_state + k, bufp(w, s, t.cur[k]) + t.fill[k], (uint32_t)missing, 0u};
+                    t.fill[k] += missing * 624;
+                    fill_e = true;
+                    continue;
+                }
+                move_e = true;
                 const int nxt = (t.cur[k] + 1) % MT_SET_BUFS;
                 h_move_e[k] = iss::MtMoveJob{bufp(w, s, t.cur[k]) + t.used[k], bufp(w, s, nxt), (uint32_t)left, 0u};
                 const size_t room = (t.cap[s] - left) / 624;
@@ -2775,8 +2823,10 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             }
         if (fill_e) {
             if (wait_prev_e) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, t.ev_emit[par ^ 1], 0));  // (the emitter of the turn before reads a buffer written now)
-            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_move_e), h_move_e, 2 * (size_t)W * sizeof(iss::MtMoveJob), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(iss::k_mt_move_w, dim3(2 * W, iss::MOVE_BLOCKS), dim3(256), 0, ctx->stream, reinterpret_cast<const iss::MtMoveJob *>(dev_of(h_move_e)));
+            if (move_e) {
+                HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_move_e), h_move_e, 2 * (size_t)W * sizeof(iss::MtMoveJob), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(iss::k_mt_move_w, dim3(2 * W, iss::MOVE_BLOCKS), dim3(256), 0, ctx->stream, reinterpret_cast<const iss::MtMoveJob *>(dev_of(h_move_e)));
+            }
             HIP_TRY(ctx, hipEventRecord(m.ev_main, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill_stream, m.ev_main, 0));  // (incl. the main stream's wait for that emitter)
             HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_fill_e), h_fill_e, 2 * (size_t)W * sizeof(iss::MtFillJob), hipMemcpyHostToDevice, ctx->fill_stream));
@@ -2785,7 +2835,7 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));
         }
         // ---- (b) the words of the turn AFTER this one are produced beside it (mt_prefetch_begin)
-        bool fill_a = false, wait_prev_a = false;
+        bool fill_a = false;
         for (int w = 0; w < W; ++w)
             for (int s = 0; s < 2; ++s) {
                 const int k = 2 * w + s;
@@ -2798,17 +2848,25 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 if (avail >= want[k] + want_next) continue;
                 // (only what is missing: everything in front of the turn is moved behind it -- a backlog would be copied every turn)
                 const size_t blocks = (want[k] + want_next - avail + 623) / 624;
+                if (t.fill[k] + blocks * 624 <= t.cap[s]) {  // appended in place (committed in (f) by moving `fill` on: no copy)
+                    pf[k].on = true; pf[k].append = true; pf[k].blocks = (uint32_t)blocks;
+                    h_fill_a[k] = iss::MtFillJob{t.d_state + k, bufp(w, s, t.cur[k]) + t.fill[k], (uint32_t)blocks, 0u};
+                    fill_a = true;
+                    continue;
+                }
                 if (avail + blocks * 624 > t.cap[s]) continue;
                 pf[k].on = true; pf[k].at = avail; pf[k].blocks = (uint32_t)blocks;
                 h_fill_a[k] = iss::MtFillJob{t.d_state + k, bufp(w, s, (t.cur[k] + 1) % MT_SET_BUFS) + avail, (uint32_t)blocks, 0u};
-                wait_prev_a |= read_by_last_turn(k, (t.cur[k] + 1) % MT_SET_BUFS);
                 fill_a = true;
             }
         if (fill_a) {  // (behind everything queued on the main stream so far -- incl. its wait for the emitter of two turns ago -- and
-                       //  behind the emitter of the turn before where that one reads a target: the rule with two buffers)
+                       //  ALWAYS behind the emitter of the turn before, whether that one still reads a target (the other buffer of a
+                       //  stream at its buffer's end) or not (words appended): fill, emitter and resolver all three together is what
+                       //  the resolver -- the chain the turn waits for -- loses by: 1.53 against 1.79e7 pairs/s at W = 64, 3.3
+                       //  against 4.7e7 at W = 256 with the wait left out for appended words)
             HIP_TRY(ctx, hipEventRecord(m.ev_main, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill_stream, m.ev_main, 0));
-            if (wait_prev_a) HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill_stream, t.ev_emit[par ^ 1], 0));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->fill_stream, t.ev_emit[par ^ 1], 0));
             HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_fill_a), h_fill_a, 2 * (size_t)W * sizeof(iss::MtFillJob), hipMemcpyHostToDevice, ctx->fill_stream));
             hipLaunchKernelGGL(iss::k_mt_fill_w, dim3(2 * W), dim3(iss::FILL_THREADS), 0, ctx->fill_stream, reinterpret_cast<const iss::MtFillJob *>(dev_of(h_fill_a)));
             HIP_TRY(ctx, hipEventRecord(m.ev_fill, ctx->fill_stream));
@@ -2900,11 +2958,11 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             for (int s = 0; s < 2; ++s) t.last_read[(size_t)(2 * w + s) * 3 + res_buf[2 * w + s]] = turn;
         }
         if (emit_max > 0) {  // (on the side stream: the next turn's resolver does not wait for it -- the main stream is idle here: synchronized above)
-            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_ej), h_ej, (size_t)W * sizeof(iss::MtEmitJob), hipMemcpyHostToDevice, s_side));
-            hipLaunchKernelGGL(iss::k_mt_emit_w, dim3((unsigned)((2 * emit_max + 3) / 4), (unsigned)W), dim3(256), 0, s_side, M,
+            HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_ej), h_ej, (size_t)W * sizeof(iss::MtEmitJob), hipMemcpyHostToDevice, s_emit));
+            hipLaunchKernelGGL(iss::k_mt_emit_w, dim3((unsigned)((2 * emit_max + 3) / 4), (unsigned)W), dim3(256), 0, s_emit, M,
                                reinterpret_cast<const iss::MtEmitJob *>(dev_of(h_ej)));
         }
-        HIP_TRY(ctx, hipEventRecord(t.ev_emit[par], s_side));
+        HIP_TRY(ctx, hipEventRecord(t.ev_emit[par], s_emit));
         // ---- (e) what the turn consumed and produced; a resolver that stopped in front of a pair for the walker (an indel candidate,
         //      a letter outside ACGT, a genome end in a template) gets that ONE pair walked right here, behind the turn, so that
         //      its worker is back on the fast path with the next turn (a turn of its own for one pair cost a worker 1.5 turns
@@ -2918,6 +2976,7 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             t.used[2 * w] += res.py_used;
             t.used[2 * w + 1] += res.np_used;
             ws[w].done += res.n_done;
+            if (dbg) { dbg_starved += res.starved != 0; dbg_own += ws[w].walk_one; }
             if (walker) {
                 t.n_walked += res.n_done;
                 if (res.n_done == 0 && res.starved && h_wj[w].A.py_avail >= want[2 * w] && h_wj[w].A.np_avail >= want[2 * w + 1]) {
@@ -2945,6 +3004,7 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 iss::MtWalkJob &wj = h_wj[w];
                 wj = iss::MtWalkJob{};
                 // (the words of one attempt at a pair must stand in front of the walker: else the pair waits for its own turn)
+                if (dbg && odd && (t.fill[2 * w] - t.used[2 * w] < 2 * need[0] || t.fill[2 * w + 1] - t.used[2 * w + 1] < 2 * need[1])) ++dbg_skip;
                 if (!odd || t.fill[2 * w] - t.used[2 * w] < 2 * need[0] || t.fill[2 * w + 1] - t.used[2 * w + 1] < 2 * need[1]) continue;
                 const Genome &G = ctx->genomes[ws[w].gid];
                 const int64_t row0 = ws[w].row0 + ws[w].done;
@@ -2991,6 +3051,11 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
                 const int k = 2 * w + s;
                 h_move_c[k] = iss::MtMoveJob{nullptr, nullptr, 0u, 0u};
                 if (!n_w[w] || !pf[k].on) continue;
+                if (pf[k].append) {
+                    t.fill[k] += (size_t)pf[k].blocks * 624;
+                    if (dbg) { dbg_filled[s] += (uint64_t)pf[k].blocks * 624; ++dbg_appends; }
+                    continue;
+                }
                 const size_t left = t.fill[k] - t.used[k];  // <= pf.at
                 const int nxt = (t.cur[k] + 1) % MT_SET_BUFS;
                 h_move_c[k] = iss::MtMoveJob{bufp(w, s, t.cur[k]) + t.used[k], bufp(w, s, nxt) + (pf[k].at - left), (uint32_t)left, 0u};
@@ -3011,9 +3076,11 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
     }
     if (dbg) {
         for (int w = 0; w < W; ++w) dbg_pairs += (uint64_t)ws[w].done;
-        fprintf(stderr, "[mt set] W %d turn %lld: %llu turns, %llu pairs, %llu to the walker; commits %llu (%llu moved > want / 4); words moved py %llu np %llu, "
+        fprintf(stderr, "[mt set] turns ended starved %llu, one-pair walker turns %llu, walks behind a turn skipped for words %llu, fills in front of a turn %llu\n",
+                (unsigned long long)dbg_starved, (unsigned long long)dbg_own, (unsigned long long)dbg_skip, (unsigned long long)dbg_ensure);
+        fprintf(stderr, "[mt set] W %d turn %lld: %llu turns, %llu pairs, %llu to the walker; %llu appended, commits with a move %llu (%llu moved > want / 4); words moved py %llu np %llu, "
                         "produced ahead py %llu np %llu\n", W, (long long)t.ch, (unsigned long long)dbg_turns, (unsigned long long)dbg_pairs,
-                (unsigned long long)dbg_bounce, (unsigned long long)dbg_moves, (unsigned long long)dbg_big, (unsigned long long)dbg_moved[0],
+                (unsigned long long)dbg_bounce, (unsigned long long)dbg_appends, (unsigned long long)dbg_moves, (unsigned long long)dbg_big, (unsigned long long)dbg_moved[0],
                 (unsigned long long)dbg_moved[1], (unsigned long long)dbg_filled[0], (unsigned long long)dbg_filled[1]);
     }
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, m.ev_fill, 0));

@@ -211,7 +211,8 @@ __host__ __device__ inline uint32_t mt_np_need(int RL, bool basic = false) {
 }
 __host__ __device__ inline size_t mt_walk_fixed_lds_bytes(int RL) {
     const size_t rlp = (size_t)((RL + 63) & ~63);
-    return 64 * 8 /* mut_thr */ + (rlp + 64) /* tmpl */ + 3 * rlp /* read, qual, stack */ + (size_t)10 * RL * 4 /* window */;
+    return 64 * 8 /* mut_thr */ + (rlp + 64) /* tmpl */ + 3 * rlp /* read, qual, stack */ + (size_t)10 * RL * 4 /* window */ +
+           (size_t)8 * RL * 8 /* the slow indel path's thresholds of one mate */;
 }
 
 // CPython _randbelow_with_getrandbits on the stream: 64 candidate words per round, first one < n wins
@@ -240,7 +241,7 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
     const int lane = threadIdx.x;
     const int RL = M.RL;
     const int rlp = (RL + 63) & ~63;
-    // LDS carve: [rows (optional)] [mut_thr u64 x 64] [tmpl rlp+64] [read rlp] [qual rlp] [stk rlp] [win]
+    // LDS carve: [rows (optional)] [mut_thr u64 x 64] [tmpl rlp+64] [read rlp] [qual rlp] [stk rlp] [win 10 RL] [thr u64 x 8 RL]
     uint32_t *rows = lds;
     const uint32_t rows_words = (uint32_t)(2 * M.NB * RL * M.mt_row_w);
     uint64_t *mut_thr = reinterpret_cast<uint64_t *>(lds + (A.use_rows ? ((rows_words + 1u) & ~1u) : 0u));
@@ -249,6 +250,7 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
     uint8_t *ql = rd + rlp;
     uint8_t *stk = ql + rlp;
     uint32_t *win = reinterpret_cast<uint32_t *>(stk + rlp);
+    uint64_t *thr_l = reinterpret_cast<uint64_t *>(win + 10 * RL);  // per loop step: ins_thr x 4, del_thr x 4 (8-byte aligned: all of the above are)
     if (A.use_rows) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(M.mt_rows);
         for (uint32_t i = lane; i < rows_words; i += 64) rows[i] = src[i];
@@ -461,6 +463,14 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
             } else {
                 // exact sequential list semantics (all lanes run the same walk on wave-uniform values)
                 for (int k = lane; k < 10 * (RL - 1); k += 64) win[k] = py[opy + k];
+                // the thresholds of this mate's loop steps too: the walk below is ONE chain of RL - 1 dependent steps, and a step
+                // that waits for two loads from HBM / the L2 (an insertion row, then the deletion entry of the token it found)
+                // took 0.3 us by itself and 2 us beside a set's fill kernels -- 0.56 ms per walked pair (round 5, profiles/
+                // r05_mtset_kernel_stats.csv); from LDS a step is two LDS round trips
+                for (int k = lane; k < 4 * (RL - 1); k += 64) {
+                    thr_l[(k >> 2) * 8 + (k & 3)] = M.ins_thr[(size_t)o * RL * 4 + k];
+                    thr_l[(k >> 2) * 8 + 4 + (k & 3)] = M.del_thr[(size_t)o * RL * 4 + k];
+                }
                 __syncthreads();
                 int sp = 0, k = 0, j = 0;
                 uint32_t pos = 0;
@@ -473,10 +483,11 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
                     const int bi = base_index(tok);
                     if (bi < 0) { if (lane == 0) rd[j] = (uint8_t)tok; ++j; continue; }  // ambiguous: no draws
                     const size_t en = ((size_t)o * RL + n) * 4;
+                    const uint64_t *tl = thr_l + n * 8;
                     for (int x = 0; x < 4; ++x) {
                         const uint64_t m = mk53(win[pos], win[pos + 1]);
                         pos += 2;
-                        if (m < M.ins_thr[en + x]) {
+                        if (m < tl[x]) {
                             if (sp == rlp) { if (lane == 0) for (int z = 1; z < sp; ++z) stk[z - 1] = stk[z]; --sp; }
                             if (lane == 0) stk[sp] = M.ins_letter[en + x];
                             ++sp;
@@ -487,7 +498,7 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
                     }
                     const uint64_t m = mk53(win[pos], win[pos + 1]);
                     pos += 2;
-                    if (m < M.del_thr[en + bi]) {  // next token slides in
+                    if (m < tl[4 + bi]) {  // next token slides in
                         const bool exists = sp > 0 || k < t_len;  // else mutable_seq[position] raises IndexError: no row
                         tok = sp > 0 ? (int)stk[--sp] : src(k++);
                         if (exists) { if (lane == 0) put_mut(o, 2, n, tok, '.', -1, n_mut); ++n_mut; }

@@ -136,14 +136,15 @@ def test_generate_cli_cpus8_equals_reference(case, tmp_path):
     assert open(out + "_R2.fastq", "rb").read() == z["r2"].tobytes()
 
 
-@pytest.mark.parametrize("turn", [None, "37"])
+@pytest.mark.parametrize("turn", [None, "37", "37/3"])
 @pytest.mark.parametrize("case", ["novaseq", "hiseq_gc", "miseq", "indel_heavy", "basic", "novaseq_frag", "novaseq_gzip"])
 def test_worker_set_equals_separate_workers(case, turn, tmp_path, monkeypatch):
     """W workers side by side in one context (worker_set_iterator -> iss_generate_mt_workers) write the files of W
     separate worker_iterator(rng="mt") runs -- which are the reference's (tests above) -- for work lists of different
     lengths over a plain record, a record with IUPAC / lower-case letters (the resolver hands such pairs to the walker) and
     a record shorter than a read (skipped after its draw).  turn = 37: many short turns per call (stream words produced
-    ahead, moved, consumed across turn boundaries); indel_heavy: the walker only; basic / novaseq_frag: the workers take
+    ahead -- appended to a stream's buffer, or, at the buffer's end, into the other one with the unconsumed words moved in
+    front: "/3" = buffers of three turns, a move every second turn -- and consumed across turn boundaries); indel_heavy: the walker only; basic / novaseq_frag: the workers take
     the single-worker path one after the other (draws the host's libm settles)."""
     import gzip
 
@@ -151,7 +152,9 @@ def test_worker_set_equals_separate_workers(case, turn, tmp_path, monkeypatch):
     from insilicoseq_amd.generator import Record, worker_iterator, worker_set_iterator
 
     if turn:
-        monkeypatch.setenv("ISS_MT_SET_TURN", turn)
+        monkeypatch.setenv("ISS_MT_SET_TURN", turn.split("/")[0])
+        if "/" in turn:
+            monkeypatch.setenv("ISS_MT_SET_BUF_TURNS", turn.split("/")[1])
     model = {"hiseq_gc": "hiseq", "indel_heavy": "novaseq", "novaseq_frag": "novaseq", "novaseq_gzip": "novaseq"}.get(case, case)
     em = dense_model(model, (0.01, 0.03) if case == "indel_heavy" else None)
     if case == "novaseq_frag":
