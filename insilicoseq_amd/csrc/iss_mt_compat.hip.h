@@ -35,6 +35,27 @@ struct MtState {
 // would wait for the global stores / prefetch loads these kernels deliberately leave in flight.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// A pointer read from a job table in HBM is a GENERIC pointer to the compiler: its loads and stores become flat_* instructions,
+// which count on the LDS counter as well -- lds_barrier() above then waits for the stream words the resolver deliberately leaves
+// in flight, and every access pays the flat path (found in round 5 in the ISA: 37 flat operations in k_mt_resolve_w, 148 in
+// k_mt_walk_w, none in the single-worker kernels, whose pointers are kernel arguments).  What does turn them into global_*
+// accesses with this compiler: the pointer rebuilt as (a kernel argument -- the job table itself, known to be global) + a byte
+// distance, the distance hidden from the optimiser (which folds X + (Y - X) back into Y) behind an empty asm; a cast through
+// address_space(1) and back, and an assumption "neither shared nor private", were both folded away (tools/: none needed --
+// `grep -c flat_` on the kernel's ISA).  Costs four scalar instructions per pointer, once per workgroup.  Job pointers are
+// uniform (indexed by blockIdx): the distance lives in scalar registers.
+template <class T, class A> __device__ __forceinline__ T *as_global(T *p, const A *anchor) {
+    const long d0 = (long)p - (long)anchor;
+    int lo = __builtin_amdgcn_readfirstlane((int)d0), hi = __builtin_amdgcn_readfirstlane((int)(d0 >> 32));  // (a large job is copied through VGPRs)
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    const long d = (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+    return (T *)((const char *)anchor + d);
+}
+template <class A> __device__ __forceinline__ DevGenome genome_as_global(DevGenome g, const A *anchor) {
+    g.packed = as_global(g.packed, anchor); g.mask = as_global(g.mask, anchor); g.ascii = as_global(g.ascii, anchor);
+    return g;
+}
+
 __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b) {
     const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
     return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
@@ -111,7 +132,7 @@ struct MtFillJob {
 __global__ __launch_bounds__(FILL_THREADS) void k_mt_fill_w(const MtFillJob *jobs) {
     const MtFillJob j = jobs[blockIdx.x];
     if (!j.n_blocks) return;  // (uniform)
-    mt_fill_body(j.state, j.out, j.n_blocks);
+    mt_fill_body(as_global(j.state, jobs), as_global(j.out, jobs), j.n_blocks);
 }
 // the unconsumed words of a stream move in front of the words produced ahead (the single-worker path: a device-to-device copy
 // per stream and turn; 2 W of them would be 2 W launches)
@@ -126,8 +147,8 @@ constexpr int MOVE_BLOCKS = 64;  // workgroups per job (grid.y)
 constexpr int MOVE_UNROLL = 8;
 __global__ __launch_bounds__(256) void k_mt_move_w(const MtMoveJob *jobs) {
     const MtMoveJob j = jobs[blockIdx.x];
-    const uint32_t *__restrict__ src = j.src;
-    uint32_t *__restrict__ dst = j.dst;
+    const uint32_t *__restrict__ src = as_global(j.src, jobs);
+    uint32_t *__restrict__ dst = as_global(j.dst, jobs);
     const uint32_t span = 256u * (uint32_t)MOVE_UNROLL;
     for (uint32_t base = blockIdx.y * span; base < j.n; base += span * (uint32_t)MOVE_BLOCKS) {  // (uniform per workgroup)
         uint32_t v[MOVE_UNROLL];
@@ -634,9 +655,13 @@ struct MtWalkJob {
     PairDesc *desc;
 };
 __global__ __launch_bounds__(64) void k_mt_walk_w(DevModel M, const MtWalkJob *jobs) {
-    const MtWalkJob j = jobs[blockIdx.x];
+    MtWalkJob j = jobs[blockIdx.x];
     if (j.A.n_pairs <= 0) return;  // (uniform: this worker has no turn of the walker)
-    mt_walk_body(M, j.g, j.A, j.desc);
+    j.A.py = as_global(j.A.py, jobs); j.A.np = as_global(j.A.np, jobs); j.A.res = as_global(j.A.res, jobs); j.A.gauss = as_global(j.A.gauss, jobs);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) j.A.out[k] = as_global(j.A.out[k], jobs);
+    j.A.mut = as_global(j.A.mut, jobs); j.A.amb = as_global(j.A.amb, jobs); j.A.ovq = as_global(j.A.ovq, jobs);
+    mt_walk_body(M, genome_as_global(j.g, jobs), j.A, as_global(j.desc, jobs));
 }
 
 // ====================================================================== resolver + emitter
@@ -1003,9 +1028,11 @@ struct MtResolveJob {
 };
 template <int PYV, int NPV, bool ROWS_LDS>
 __global__ __launch_bounds__(RES_THREADS) void k_mt_resolve_w(DevModel M, const MtResolveJob *jobs) {
-    const MtResolveJob j = jobs[blockIdx.x];
+    MtResolveJob j = jobs[blockIdx.x];
     if (j.A.n_pairs <= 0) return;  // (uniform: the worker is done, or this turn is its walker's)
-    mt_resolve_body<PYV, NPV, ROWS_LDS>(M, j.g, j.A, j.desc);
+    j.A.py_base = as_global(j.A.py_base, jobs); j.A.np_base = as_global(j.A.np_base, jobs); j.A.res = as_global(j.A.res, jobs);
+    j.A.rec = as_global(j.A.rec, jobs); j.A.gauss = as_global(j.A.gauss, jobs);
+    mt_resolve_body<PYV, NPV, ROWS_LDS>(M, genome_as_global(j.g, jobs), j.A, as_global(j.desc, jobs));
 }
 
 // reads of the pairs k_mt_resolve resolved: one wavefront per (pair, mate); the read is the template
@@ -1096,7 +1123,8 @@ __global__ __launch_bounds__(256) void k_mt_emit_w(DevModel M, const MtEmitJob *
     const MtEmitJob j = jobs[blockIdx.y];
     if ((int64_t)blockIdx.x * 4 >= 2 * j.n_pairs) return;
     const MtEmitMut none{};
-    mt_emit_body(M, j.g, j.py, j.np, j.n_pairs, j.desc, j.rec, j.out[0], j.out[1], j.out[2], j.out[3], none);
+    mt_emit_body(M, genome_as_global(j.g, jobs), as_global(j.py, jobs), as_global(j.np, jobs), j.n_pairs, as_global(j.desc, jobs), as_global(j.rec, jobs),
+                 as_global(j.out[0], jobs), as_global(j.out[1], jobs), as_global(j.out[2], jobs), as_global(j.out[3], jobs), none);
 }
 
 }  // namespace iss

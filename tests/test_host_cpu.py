@@ -651,3 +651,16 @@ def test_worker_resolves_records_by_ordinal_not_by_id(tmp_path, monkeypatch):
                 (None, None))
     assert [n for _, n in seen] == [5, 7, 9]
     assert seen[0][0].startswith("ACGTACGT") and seen[1][0].startswith("TTGGCCAA") and seen[2][0].startswith("GATTACA")
+
+
+def test_two_block_fill_index_arithmetic():
+    """mt_fill_two (two MT19937 blocks per barrier, both in terms of the old block -- tools/patches/mt_fill_two_blocks.patch:
+    built, correct, slower, not merged): its index arithmetic, lane by lane in Python (tools/mt_two_block_model.py), yields
+    numpy's own words."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("mt_two_block_model", os.path.join(root, "tools", "mt_two_block_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
