@@ -2539,17 +2539,23 @@ int mt_set_reserve(iss_ctx *ctx) {
     const size_t need[2] = {iss::mt_py_need(M.RL), iss::mt_np_need(M.RL, basic)};
     if (!t.ch) {
         const char *e = getenv("ISS_MT_SET_TURN");  // pairs per worker and turn (tests: many turns)
-        t.ch = e ? std::max<int64_t>(1, std::min<int64_t>(8192, atoll(e))) : std::max<int64_t>(512, std::min<int64_t>(8192, 131072 / (int64_t)W));
+        // (98 304 / W within 512 .. 4096: a worker whose resolver meets a pair for the walker loses the rest of its turn, a turn costs
+        //  ~0.4 ms beside its resolver -- measured flat between 1024 and 1536 at W = 64, 512 and 768 at W = 256; 4096 against 8192
+        //  at W = 8: + 7 %)
+        t.ch = e ? std::max<int64_t>(1, std::min<int64_t>(8192, atoll(e))) : std::max<int64_t>(512, std::min<int64_t>(4096, 98304 / (int64_t)W));
     }
     // A buffer holds K turns' words (worst case): the words produced ahead are APPENDED behind a stream's valid words while there
     // is room, and only at a buffer's end the stream moves to the other buffer, its unconsumed words copied in front (round 5: with
     // K = 3 and a move every turn, the moves of the workers whose turn had ended early -- nearly a whole turn's words each, ~ 400 MB
-    // per turn at W = 64 -- were 1 ms of a 6.5 ms turn, on the critical path).  K = 8 where 32 GB hold it, 3 at least.
+    // per turn at W = 64 -- were 1 ms of a 6.5 ms turn, on the critical path).  K = 8 where 32 GB (and half of the free memory) hold it, 3 at least.
     const size_t turn_words[2] = {(size_t)(t.ch + 1) * need[0] + 1248, (size_t)(t.ch + 1) * need[1] + 1248};
     if (!t.buf_turns) {
         const char *e = getenv("ISS_MT_SET_BUF_TURNS");  // (tests: 3 = a move every second turn)
         const size_t per_k = W * MT_SET_BUFS * (turn_words[0] + turn_words[1]) * sizeof(uint32_t);
-        t.buf_turns = e ? std::max(3, std::min(8, atoi(e))) : (int)std::max<size_t>(3, std::min<size_t>(8, ((size_t)32 << 30) / per_k));
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)64 << 30; }
+        const size_t budget = std::min((size_t)32 << 30, free_b / 2);  // (half of what is free at most: other engines share the device)
+        t.buf_turns = e ? std::max(3, std::min(8, atoi(e))) : (int)std::max<size_t>(3, std::min<size_t>(8, budget / per_k));
     }
     const size_t want[2] = {(size_t)t.buf_turns * turn_words[0], (size_t)t.buf_turns * turn_words[1]};
     if (t.cap[0] && (t.cap[0] < want[0] || t.cap[1] < want[1]))
@@ -2957,7 +2963,10 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
             emit_max = std::max(emit_max, ej.n_pairs);
             for (int s = 0; s < 2; ++s) t.last_read[(size_t)(2 * w + s) * 3 + res_buf[2 * w + s]] = turn;
         }
-        if (emit_max > 0) {  // (on the side stream: the next turn's resolver does not wait for it -- the main stream is idle here: synchronized above)
+        if (emit_max > 0) {  // (on its own stream: the next turn's resolver does not wait for it.  Launched here, in front of the walk
+                             //  behind the turn, not after it: the walk would run on a quiet chip -- 0.19 ms beside the emitter --
+                             //  but the emitter would reach 0.1 ms further into the next resolver: 1.89 against 1.92e7 pairs/s at
+                             //  W = 64, 4.96 against 5.12e7 at W = 256)
             HIP_TRY(ctx, hipMemcpyAsync(dev_of(h_ej), h_ej, (size_t)W * sizeof(iss::MtEmitJob), hipMemcpyHostToDevice, s_emit));
             hipLaunchKernelGGL(iss::k_mt_emit_w, dim3((unsigned)((2 * emit_max + 3) / 4), (unsigned)W), dim3(256), 0, s_emit, M,
                                reinterpret_cast<const iss::MtEmitJob *>(dev_of(h_ej)));

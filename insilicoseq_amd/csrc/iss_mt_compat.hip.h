@@ -257,6 +257,35 @@ __device__ __forceinline__ uint64_t mt_randbelow(const uint32_t *py, uint32_t &o
     }
 }
 
+// One phred: #(cdf < u) of position p's quality CDF (kde.py:72-85) through the 16-bit digit rows (DevModel::mt_rows; `drows`
+// may be a copy in LDS): the leading digits first -- every 7th key, then the segment: two rounds of independent reads --, the full
+// 53-bit thresholds only among those that share the draw's digit.
+__device__ __forceinline__ int mt_phred_of(const DevModel &M, const uint16_t *drows, uint32_t row_h, int o, int slot, int bin, int p, uint64_t m) {
+    const uint32_t h = (uint32_t)(m >> 37);
+    const uint16_t *row = drows + ((size_t)(o * M.NB + slot) * M.RL + p) * row_h;
+    const int nq = M.n_q;
+    int c1 = 0;
+    bool tie = false;
+#pragma unroll
+    for (int jk = 0; jk < 9; ++jk) {  // keys 6, 13, ... (n_q <= 60); indices past n_q read the 0xffff padding
+        const uint32_t dgt = row[min(6 + 7 * jk, nq)];
+        c1 += dgt < h ? 1 : 0;
+        tie |= dgt == h;
+    }
+    int q = 7 * c1;
+#pragma unroll
+    for (int jk = 0; jk < 6; ++jk) {
+        const uint32_t dgt = row[min(7 * c1 + jk, nq)];
+        q += dgt < h ? 1 : 0;
+        tie |= dgt == h;
+    }
+    if (tie) {
+        const uint64_t *full = M.q_thr + ((size_t)(o * 4 + bin) * M.RL + p) * nq;
+        while (q < nq && full[q] < m) ++q;
+    }
+    return q;
+}
+
 __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome &g, const MtWalkArgs &A, PairDesc *desc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
@@ -549,30 +578,7 @@ __device__ __forceinline__ void mt_walk_body(const DevModel &M, const DevGenome 
             d.meta |= (uint32_t)slot << (2 * o);
             for (int p = lane; p < RL; p += 64) {
                 const uint64_t m = mk53(np[onp + 2u * (uint32_t)p], np[onp + 2u * (uint32_t)p + 1]);
-                // leading digits first (two rounds of independent reads: every 7th digit, then the segment), the full
-                // thresholds only among those that share the draw's digit
-                const uint32_t h = (uint32_t)(m >> 37);
-                const uint16_t *row = drows + ((size_t)(o * M.NB + slot) * RL + p) * row_h;
-                const int nq = M.n_q;
-                int c1 = 0;
-                bool tie = false;
-#pragma unroll
-                for (int jk = 0; jk < 9; ++jk) {  // keys 6, 13, ... (n_q <= 60); indices past n_q read the 0xffff padding
-                    const uint32_t dgt = row[min(6 + 7 * jk, nq)];
-                    c1 += dgt < h ? 1 : 0;
-                    tie |= dgt == h;
-                }
-                int q = 7 * c1;
-#pragma unroll
-                for (int jk = 0; jk < 6; ++jk) {
-                    const uint32_t dgt = row[min(7 * c1 + jk, nq)];
-                    q += dgt < h ? 1 : 0;
-                    tie |= dgt == h;
-                }
-                if (tie) {
-                    const uint64_t *full = M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * nq;
-                    while (q < nq && full[q] < m) ++q;
-                }
+                const int q = mt_phred_of(M, drows, row_h, o, slot, bin, p, m);
                 ql[p] = (uint8_t)q;
             }
             onp += 2u * (uint32_t)RL;
@@ -1062,6 +1068,10 @@ __device__ __forceinline__ void mt_emit_body(const DevModel &M, const DevGenome 
     const uint32_t onp_q = r.onp_bin[o] + 2u, onp_s = onp_q + 2u * (uint32_t)RL, opy_e = r.opy_err[o];
     int bin = count_le(M.bin_thr + 4 * o, 4, mk53(np[r.onp_bin[o]], np[r.onp_bin[o] + 1]));
     bin = bin > 3 ? 3 : bin;
+    // (the phreds through the 16-bit digit rows, as the walker and the resolver find them: a bisection of the 53-bit thresholds --
+    //  six dependent 8-byte reads per base, every lane in a row of its own -- was 27 GB of L2 -> L1 lines per 117 k pairs and
+    //  most of the emitter's 1.2 ms; a row of digits is one or two lines)
+    const int slot = M.bin_slot[o * 4 + bin] & 3;
     uint8_t *ob = (o ? out2 : out0) + (size_t)i * M.row;
     uint8_t *oq = (o ? out3 : out1) + (size_t)i * M.row;
     uint32_t nev = 0, n_rows = 0;
@@ -1074,7 +1084,7 @@ __device__ __forceinline__ void mt_emit_body(const DevModel &M, const DevGenome 
             ch = o == 0 ? fetch_ascii(g, desc_fs(d) + p) : complement_ascii(fetch_ascii(g, desc_re(d) - 1 - p));
             before = ch;
             const uint64_t mq = mk53(np[onp_q + 2u * (uint32_t)p], np[onp_q + 2u * (uint32_t)p + 1u]);
-            q = count_lt(M.q_thr + ((size_t)(o * 4 + bin) * RL + p) * M.n_q, M.n_q, mq);
+            q = mt_phred_of(M, M.mt_rows, (uint32_t)M.mt_row_w * 2u, o, slot, bin, p, mq);
             bi = base_index(ch);
             const uint64_t m = mk53(py[opy_e + 2u * (uint32_t)p], py[opy_e + 2u * (uint32_t)p + 1u]);
             err = m > M.mut_thr[q] && bi >= 0;
