@@ -291,7 +291,7 @@ struct iss_ctx {
         iss::MtGauss *d_gauss = nullptr;     // [W]
         iss::MtPairRec *d_rec = nullptr;     // [2][W][ch]: the resolver of turn t + 1 runs beside the emitter of turn t
         hipEvent_t ev_emit[2] = {nullptr, nullptr};  // the emitter of the last turn of either parity
-        hipEvent_t ev_side = nullptr, ev_turn = nullptr;  // side stream (walker, emitter) <-> main stream
+        hipEvent_t ev_side = nullptr, ev_turn = nullptr;  // side stream (the walker beside the resolver) <-> main stream
         std::vector<int> cur;                // [W * 2]
         std::vector<size_t> fill, used;      // [W * 2]
         // job tables: pinned host staging + device copies, two sets (turn parity) of

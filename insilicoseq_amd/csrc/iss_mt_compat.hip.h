@@ -20,7 +20,7 @@
 //               launch -- the reference's own parallelism is N workers with seeds seed + cpu_number (iss/app.py:99-106,
 //               iss/generator.py:234-236): one workgroup (wavefront, grid row) per worker, the jobs in a table in HBM.
 //
-// This mode is chained by construction (~3.8e5 pairs/s per worker, 4.6e7 with 256 workers side by side): it exists for
+// This mode is chained by construction (~3.8e5 pairs/s per worker, 5.1e7 with 256 workers side by side): it exists for
 // bit-identity with the reference; the Philox path (iss_kernels.hip.h) is the performance path.
 #pragma once
 #include "iss_kernels.hip.h"
