@@ -18,6 +18,7 @@ import multiprocessing as mp
 import os
 import shutil
 import sys
+import time
 
 import numpy as np
 
@@ -252,6 +253,7 @@ def generate_reads(args):
         jobs.append((rank, rank % max(args.devices, 1), genome_file, spec, error_model.npz_path, args.seed,
                      temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng, args.store_mutations,
                      (args.fragment_length, args.fragment_length_sd), device_gzip))
+    t_gen = time.perf_counter()
     if workers == 1:
         for j in jobs:
             _worker(*j, records=records)
@@ -264,11 +266,13 @@ def generate_reads(args):
     else:
         with mp.get_context("spawn").Pool(workers) as pool:
             pool.starmap(_worker, jobs)
+    t_cat = time.perf_counter()
     if args.store_mutations:  # app.py:128-133
         concatenate_rank_files(args.output, workers, suffixes=("_R1.fastq", "_R2.fastq", ".vcf"),
                                headers={".vcf": VCF_HEADER}, out_suffixes=gz)
     else:
         concatenate_rank_files(args.output, workers, out_suffixes=gz)  # raises if a worker had no chunk (util.py:233)
+    logger.info("Workers %.2f s, concatenation of their files %.2f s" % (t_cat - t_gen, time.perf_counter() - t_cat))
     os.remove(genome_file)
     if args.compress:  # util.compress (iss/util.py:255-268): <file>.gz next to the file, original removed
         for suffix in (() if device_gzip else ("_R1.fastq", "_R2.fastq")) + ((".vcf",) if args.store_mutations else ()):
