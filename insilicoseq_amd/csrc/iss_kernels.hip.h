@@ -34,6 +34,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace iss {
 
@@ -187,6 +188,7 @@ struct DevModel {
     int32_t sc_stride;          // bytes per read: n_tiles * sc_gpt * 64
     int32_t ins_plain;          // every insertion letter of the model is one of A/C/G/T (else reads with events take k_indel_fixup)
     float p_read_event;         // probability that a read has an indel event (the larger of the two mates')
+    float p_defer;              // expected share of bases that leave k_main's hot loop for the exact path (the host's choice of k_main_g)
     const uint64_t *subst_thr;  // [2][RL][4][3]
     const uint8_t *subst_alt;   // [2][RL][4][3]
     const uint64_t *ins_thr;    // [2][RL][4]
@@ -789,6 +791,26 @@ struct MainTile {  // per-workgroup constants of k_main
     uint32_t ts;   // superitems in the tile
 };
 
+// k_main's tables of position tile `tile` into LDS (the layout above), by the whole workgroup; the caller synchronises
+__device__ __forceinline__ void main_stage_tables(const DevModel &M, int tile, uint32_t *lds_all) {
+    uint32_t *const lds = lds_all + MAIN_LUT_WORDS;
+    const uint4 *src = reinterpret_cast<const uint4 *>(M.qrows + (size_t)tile * M.tile_words);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (int i = threadIdx.x; i < M.tile_words / 4; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) reinterpret_cast<uint64_t *>(lds + M.tile_words)[i] = M.mut_thr[i];
+    const uint32_t *ssrc = M.subst13 + (size_t)tile * 2 * M.TP * 4;
+    for (int i = threadIdx.x; i < 2 * M.TP * 4; i += blockDim.x) lds[M.tile_words + MAIN_MUT_WORDS + i] = ssrc[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {  // the letter tables: byte k of entry i = the letter of code k of byte i
+        uint32_t f = 0, r = 0;
+        for (int k = 0; k < 4; ++k) {
+            f |= (uint32_t)code_to_ascii(((uint32_t)i >> (2 * k)) & 3u) << (8 * k);
+            r |= (uint32_t)code_to_ascii((((uint32_t)i >> (2 * (3 - k))) & 3u) ^ 1u) << (8 * k);  // complement: code ^ 1
+        }
+        lds_all[i] = f;
+        lds_all[256 + i] = r;
+    }
+}
+
 // The rare work of ONE base, done exactly (one lane per flagged base, so the pass is dense): base s = mate*4 + cc of
 // half `half` of superitem `sl` of the tile hit a rare condition in the hot loop (leading-digit tie, more than two
 // thresholds in its guide bucket, or the substitution test fired / tied).  Everything about the base is recomputed
@@ -802,11 +824,17 @@ struct MainTile {  // per-workgroup constants of k_main
 // INDEL: `scripted` != 0 <=> the mate was built from an edit script (k_indel_script): its windows hold the FINAL letters
 // (shifted template / inserted letters, all of them plain A/C/G/T), which is what mut_sequence sees (generator.py:152-154:
 // indels first, then the phreds, then the substitutions).
-template <bool PLAIN, bool INDEL, bool STORE_MUT>
+// HOLD (k_main_g): the byte patches are not stored but handed back in `held` -- the base's row still waits in its owner's
+// registers, the patches follow it out (HeldPatch).
+struct HeldPatch {
+    uint64_t byte_off;  // of the base inside the launch's rows (both arrays of a mate: RunArgs::out[2 o] / out[2 o + 1])
+    uint32_t w;         // bits 0-7 phred, 8-15 letter, 16 the phred is to be stored, 17 the letter is, 18 mate
+};
+template <bool PLAIN, bool INDEL, bool STORE_MUT, bool HOLD = false>
 __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome &g, const RunArgs &A,
                                                const PairDesc *__restrict__ desc, const uint32_t *lds, const MainTile &T,
                                                uint32_t pair, uint32_t sl, int half, int s, uint32_t slots, uint32_t windows,
-                                               uint32_t scripted, MutRecord &rec) {
+                                               uint32_t scripted, MutRecord &rec, HeldPatch *held = nullptr) {
     const int o = s >> 2, cc = s & 3, c = half * 4 + cc;
     const uint32_t s_abs = (uint32_t)T.s0 + sl;
     const int p = (int)s_abs * 8 + c;
@@ -834,7 +862,11 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
     //  function 1.19 -> 1.10 ms for NovaSeq and 1.28 -> 1.02 ms for HiSeq; with them redirected into a 2 MB window that stays
     //  in the L2: 1.12 / 1.05 -- the patches that MISS are what costs, and rounds of 32 instead of 64 did not land them
     //  sooner for less: 1.21 / 1.30)
-    if (q != q_hot) A.out[2 * o + 1][byte_off] = (uint8_t)q;
+    if (HOLD) {
+        held->byte_off = (uint64_t)byte_off;
+        held->w = (uint32_t)o << 18;
+        if (q != q_hot) held->w |= q | (1u << 16);
+    } else if (q != q_hot) A.out[2 * o + 1][byte_off] = (uint8_t)q;
     // substitution test (__init__.py:94)
     const uint64_t thr = reinterpret_cast<const uint64_t *>(lds + M.tile_words)[q];
     const uint32_t t8 = (uint32_t)(thr >> 45);
@@ -862,7 +894,8 @@ __device__ __forceinline__ int main_slow_base(const DevModel &M, const DevGenome
         k = (m >= M.subst_thr[srow]) + (m >= M.subst_thr[srow + 1]);
     }
     const uint32_t nb = (M.alt_letters >> (8 * ((sd >> (26 + 2 * k)) & 3u))) & 0xffu;
-    A.out[2 * o][byte_off] = (uint8_t)nb;
+    if (HOLD) held->w |= (nb << 8) | (1u << 17);
+    else A.out[2 * o][byte_off] = (uint8_t)nb;
     // without indels the original read equals the template, i.e. the base just replaced (__init__.py:98); a scripted
     // mate's original letter at this index is the UN-shifted template's
     int orig = base;
@@ -955,23 +988,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     uint32_t *ring = lds + M.tile_words + MAIN_MUT_WORDS + 2 * M.TP * 4 + (threadIdx.x >> 6) * (SLOW_RING * 3);
     uint32_t q_head = 0, q_tail = 0;
     const uint32_t lane = threadIdx.x & 63u;
-    {   // stage this tile's tables in LDS (once per workgroup)
-        const uint4 *src = reinterpret_cast<const uint4 *>(M.qrows + (size_t)tile * M.tile_words);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds);
-        for (int i = threadIdx.x; i < M.tile_words / 4; i += blockDim.x) dst[i] = src[i];
-        for (int i = threadIdx.x; i <= M.n_q; i += blockDim.x) reinterpret_cast<uint64_t *>(lds + M.tile_words)[i] = M.mut_thr[i];
-        const uint32_t *ssrc = M.subst13 + (size_t)tile * 2 * M.TP * 4;
-        for (int i = threadIdx.x; i < 2 * M.TP * 4; i += blockDim.x) lds[M.tile_words + MAIN_MUT_WORDS + i] = ssrc[i];
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) {  // the letter tables: byte k of entry i = the letter of code k of byte i
-            uint32_t f = 0, r = 0;
-            for (int k = 0; k < 4; ++k) {
-                f |= (uint32_t)code_to_ascii(((uint32_t)i >> (2 * k)) & 3u) << (8 * k);
-                r |= (uint32_t)code_to_ascii((((uint32_t)i >> (2 * (3 - k))) & 3u) ^ 1u) << (8 * k);  // complement: code ^ 1
-            }
-            lds_all[i] = f;
-            lds_all[256 + i] = r;
-        }
-    }
+    main_stage_tables(M, tile, lds_all);  // this tile's tables into LDS (once per workgroup)
     __syncthreads();
     // (row offsets below are absolute LDS addresses: ds_read2's offsets are too narrow to skip the letter tables)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_all;
@@ -1234,6 +1251,274 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
         }
     }
     while (q_tail != q_head) drain_round(min(64u, q_tail - q_head));
+}
+
+// ================================================================== k_main_g
+// k_main with the exact path's byte patches IN TIME (round 6; plain launches: no --store_mutations, no edit scripts).
+//
+// What a late patch costs (rounds 3-5): a full line leaves the L2 within microseconds of being written; a
+// byte stored into it later is a masked write of a line the L2 no longer holds -- a read-modify-write behind the L2, ~200 bytes
+// of HBM time each: 10 % of a NovaSeq launch, 17-20 % of a HiSeq launch, 1.76 x the algorithmic bytes for MiSeq.  A byte stored
+// RIGHT BEHIND its row is free (tools/store_bench.hip: "delay 0").  So the rows wait: a workgroup's iterations are taken in
+// GROUPS of G = NP passes x NI iterations (the loops unrolled, the rows of a group -- 8 registers per iteration -- held in
+// registers), the wavefront's pending lane-items are settled at the END of the group in one round of the exact path whose
+// patches are handed back (main_slow_base<.., HOLD>), then the group's rows are stored and the patches follow them out, from
+// whichever lane computed them: a wavefront's vector memory operations reach an address in issue order.  Entries beyond the 64
+// of that round, and the second base of a lane-item with two, are settled behind the rows as before (their patches are late or
+// nearly in time, never early).  The ring holds 128 entries and a slot pushes up to 64: when the next slot might not fit, the
+// rows computed so far are stored and rounds run at once (models that defer most of their bases; every test configuration).
+// min_round: a group's closing round runs only with at least that many entries pending (fewer: they wait for the next group,
+// their patches will be late -- 64 gives full rounds only).
+// Everything else -- work layout, Philox addresses, lookups, ring entries -- is k_main's.
+template <bool PLAIN, int NI, int NP>
+__global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel M, DevGenome g, RunArgs A,
+                                                                       const PairDesc *__restrict__ desc, uint32_t min_round) {
+    constexpr int G = NI * NP;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    uint32_t *const lds = lds_all + MAIN_LUT_WORDS;
+    int tile = 0;
+    while (tile + 1 < M.n_tiles && blockIdx.x >= A.tile_wg0[tile + 1]) ++tile;
+    const uint32_t wg = blockIdx.x - A.tile_wg0[tile], n_wg = (uint32_t)A.tile_wg0[tile + 1] - A.tile_wg0[tile];
+    MainTile T;
+    T.s0 = tile * M.TS;
+    T.ts = (uint32_t)min(M.TS, M.S - T.s0);
+    uint32_t *ring = lds + M.tile_words + MAIN_MUT_WORDS + 2 * M.TP * 4 + (threadIdx.x >> 6) * (SLOW_RING * 3);
+    uint32_t q_head = 0, q_tail = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    main_stage_tables(M, tile, lds_all);
+    __syncthreads();
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_all;
+    auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    const uint32_t it_max = ((uint32_t)M.TS + 3u) / 4u - 1u;  // (== NI - 1: the host picks the instantiation)
+    const uint32_t it_bits = sgpr(it_max ? 32u - (uint32_t)__clz(it_max) : 0u);
+    const uint32_t n_pass = sgpr(((uint32_t)A.n_pairs + MAIN_PAIRS - 1) / MAIN_PAIRS);
+    const uint32_t blk_first = sgpr(wg), blk_step = sgpr(n_wg), blk_end = n_pass;
+    const uint32_t gsh = 16u - (uint32_t)M.GB, gb = (uint32_t)M.GB;
+    const uint32_t stride_b = (uint32_t)M.stride_w * 4u, gbytes = 1u << M.GB;
+    const uint32_t gs_b = (uint32_t)M.GS * 4u;
+    const uint32_t slot_b = (uint32_t)M.TG * gs_b;
+    uint32_t off_g[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) off_g[c] = sgpr((uint32_t)(c >> 2) * gs_b + (uint32_t)(c & 3) * stride_b);
+    const char *const packed_b = reinterpret_cast<const char *>(g.packed - 1);
+    const uint32_t wave_pair0 = (threadIdx.x >> 6) * 16u;
+    const uint32_t j4 = lane & 3u;
+    const uint32_t s_lane = (uint32_t)T.s0 + j4;
+    const uint32_t pass_bytes = sgpr(blk_step * (uint32_t)MAIN_PAIRS * (uint32_t)M.row);  // rows of one pass of the grid (the host keeps NP of them below 2^31)
+    // one round of the exact path (k_main's); HOLD: the patch of this lane's base comes back in `held` instead of being stored
+    auto drain_round = [&](uint32_t n, auto hold, HeldPatch &held) __attribute__((always_inline)) {
+        constexpr bool HOLD = decltype(hold)::value;
+        uint32_t rest_m = 0u, ent_x = 0u, ent_y = 0u;
+        MutRecord rec;
+        rec.position = 0; rec.mate = 0; rec.ref = 0;
+        if (lane < n) {
+            const uint32_t *ep = ring + ((q_head + lane) & (SLOW_RING - 1)) * 3;
+            ent_x = ep[0]; ent_y = ep[1];
+            const uint32_t e_pass = ent_x >> (19u + it_bits), e_it = (ent_x >> 19) & ((1u << it_bits) - 1u), e_lane = (ent_x >> 13) & 63u;
+            const uint32_t e_pair = __umul24(blk_first + __umul24(e_pass, blk_step), (uint32_t)MAIN_PAIRS) + wave_pair0 + (e_lane >> 2);
+            const uint32_t mask = ep[2];  // never empty
+            const int bit = 31 - __clz(mask);
+            rest_m = mask & ~(1u << bit);
+            (void)main_slow_base<PLAIN, false, false, HOLD>(M, g, A, desc, lds, T, e_pair, 4u * e_it + (e_lane & 3u), (15 - bit) >> 3,
+                                                            (15 - bit) & 7, (ent_x >> 8) & 15u, ent_y, 0u, rec, &held);
+        }
+        q_head += n;
+        const unsigned long long again = __ballot(rest_m != 0u);
+        if (again) {
+            if (rest_m) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
+                uint32_t *ep = ring + ((q_tail + rank) & (SLOW_RING - 1)) * 3;
+                ep[0] = ent_x; ep[1] = ent_y; ep[2] = rest_m;
+            }
+            q_tail += (uint32_t)__popcll(again);
+        }
+    };
+    auto push = [&](uint32_t rare, uint32_t tag, uint32_t windows) __attribute__((always_inline)) {  // (no round in here: the rows of the group wait)
+        const unsigned long long rm = __ballot(rare != 0u);
+        if (rm) {
+            if (rare) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
+                uint32_t *ep = ring + ((q_tail + rank) & (SLOW_RING - 1)) * 3;
+                ep[0] = tag; ep[1] = windows; ep[2] = rare;
+            }
+            q_tail += (uint32_t)__popcll(rm);
+        }
+    };
+    PairDesc d_next[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        d_next[pp] = PairDesc{0, 0, 0u, 0};
+        const uint32_t blk_p = blk_first + (uint32_t)pp * blk_step;
+        const uint32_t pair0 = blk_p * MAIN_PAIRS + wave_pair0 + (lane >> 2);
+        if (blk_p < blk_end && pair0 < (uint32_t)A.n_pairs) d_next[pp] = desc[pair0];
+    }
+    struct Sub {  // a pass of the group, per lane
+        PairDesc d;
+        Addr a;
+        uint32_t rowf, rowr, pfw, prw, pfs, prs, out_b, tag0;
+        bool valid, regular;
+    };
+    for (uint32_t pass = 0, blk = blk_first; blk < blk_end; pass += NP, blk += (uint32_t)NP * blk_step) {
+        Sub sub[NP];
+        uint32_t rows[G][8];  // per slot: forward letters (2), forward phreds (2), reverse letters (2), reverse phreds (2)
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            Sub &S = sub[pp];
+            const uint32_t blk_p = blk + (uint32_t)pp * blk_step;
+            const uint32_t pair = blk_p * MAIN_PAIRS + wave_pair0 + (lane >> 2);
+            S.valid = blk_p < blk_end && pair < (uint32_t)A.n_pairs;
+            S.d = d_next[pp];
+            if (tile == 0 && j4 == 0u && S.valid) A.desc_out[pair] = S.d;
+            S.a = make_addr(A.seed, A.first_ordinal + pair, S.d.meta >> 16);
+            const uint32_t lane_row = j4 * 2u * gs_b + (uint32_t)MAIN_LUT_WORDS * 4u + lds0;
+            S.rowf = __umul24(S.d.meta & 3u, slot_b) + lane_row;
+            S.rowr = __umul24((uint32_t)M.NB + ((S.d.meta >> 2) & 3u), slot_b) + lane_row;
+            const int64_t pf64 = desc_fs(S.d) + (int64_t)(s_lane * 8u), pr64 = desc_re(S.d) - 8 - (int64_t)(s_lane * 8u);
+            S.pfw = (uint32_t)((pf64 >> 4) + 1); S.prw = (uint32_t)((pr64 >> 4) + 1);
+            S.pfs = (uint32_t)pf64 & 15u; S.prs = (uint32_t)pr64 & 15u;
+            S.out_b = (wave_pair0 + (lane >> 2)) * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u + (uint32_t)pp * pass_bytes;
+            S.regular = PLAIN || !(A.has_frag && (S.d.meta & 64u));
+            S.tag0 = ((pass + (uint32_t)pp) << (19u + it_bits)) | (lane << 13) | ((S.d.meta & 15u) << 8);
+        }
+        uint8_t *const out_pass = A.out[0] + (size_t)blk * (size_t)MAIN_PAIRS * (size_t)(uint32_t)M.row;
+        auto request_next = [&]() __attribute__((always_inline)) {  // the descriptors of the next group: behind the first slot's genome windows (k_main)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                const uint32_t blk_n = blk + (uint32_t)(NP + pp) * blk_step;
+                const uint32_t pair_n = blk_n * MAIN_PAIRS + wave_pair0 + (lane >> 2);
+                if (blk_n < blk_end && pair_n < (uint32_t)A.n_pairs) d_next[pp] = desc[pair_n];
+            }
+        };
+        auto slot = [&](const int j) __attribute__((always_inline)) {  // iteration it of pass pp of the group: k_main's hot block, the row kept
+            const int pp = j / NI;
+            const uint32_t it = (uint32_t)(j % NI);
+            const Sub &S = sub[pp];
+            uint32_t rare0 = 0, windows = 0;
+            if (S.valid && 4u * it + j4 < T.ts) {
+                // (opaque copies: what a slot derives from the pass's values and its own number is invariant in the group's loop
+                //  below, and hoisted out of it -- the first Philox round, row offsets, window words, addresses -- it costs five
+                //  to eight registers per slot for the whole group)
+                uint32_t s_abs = s_lane + 4u * it, rowf = S.rowf, rowr = S.rowr, pfw_e = S.pfw, prw_e = S.prw;
+                asm volatile("" : "+v"(s_abs), "+v"(rowf), "+v"(rowr), "+v"(pfw_e), "+v"(prw_e));
+                pfw_e += 2u * it;
+                prw_e -= 2u * it;
+                uint2 gf = {0u, 0u}, gr = {0u, 0u};
+                if (S.regular) {
+                    gf = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(pfw_e << 2));
+                    gr = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(prw_e << 2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) {
+                    request_next();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const u32x4 q0 = draw_block(S.a, K_QM, s_abs, 0);
+                const u32x4 ee = draw_block(S.a, K_QM, s_abs, 1);
+                const u32x4 q1 = draw_block(S.a, K_QM, s_abs, 2);
+                rowf += it * 8u * gs_b;
+                rowr += it * 8u * gs_b;
+                const uint32_t rowf_e = rowf + gbytes, rowr_e = rowr + gbytes;
+                uint32_t sel[16];
+                unsigned long long fl;
+#define ISS_LOOKUP(K, ROW, C, HI, BYTE, WQ, WE, RARE)                                                                \
+                sel[K] = hot_lookup<HI, BYTE>(ROW, ROW##_e, off_g[C], WQ, WE, gsh, gb, fl);                            \
+                RARE = shift_in(RARE, fl);
+                ISS_LOOKUP(0, rowf, 0, 0, 0, q0.x, ee.x, rare0)
+                ISS_LOOKUP(1, rowf, 1, 1, 1, q0.x, ee.x, rare0)
+                ISS_LOOKUP(2, rowf, 2, 0, 2, q0.y, ee.x, rare0)
+                ISS_LOOKUP(3, rowf, 3, 1, 3, q0.y, ee.x, rare0)
+                ISS_LOOKUP(4, rowr, 0, 0, 0, q0.z, ee.y, rare0)
+                ISS_LOOKUP(5, rowr, 1, 1, 1, q0.z, ee.y, rare0)
+                ISS_LOOKUP(6, rowr, 2, 0, 2, q0.w, ee.y, rare0)
+                ISS_LOOKUP(7, rowr, 3, 1, 3, q0.w, ee.y, rare0)
+                ISS_LOOKUP(8, rowf, 4, 0, 0, q1.x, ee.z, rare0)
+                ISS_LOOKUP(9, rowf, 5, 1, 1, q1.x, ee.z, rare0)
+                ISS_LOOKUP(10, rowf, 6, 0, 2, q1.y, ee.z, rare0)
+                ISS_LOOKUP(11, rowf, 7, 1, 3, q1.y, ee.z, rare0)
+                ISS_LOOKUP(12, rowr, 4, 0, 0, q1.z, ee.w, rare0)
+                ISS_LOOKUP(13, rowr, 5, 1, 1, q1.z, ee.w, rare0)
+                ISS_LOOKUP(14, rowr, 6, 0, 2, q1.w, ee.w, rare0)
+                ISS_LOOKUP(15, rowr, 7, 1, 3, q1.w, ee.w, rare0)
+#undef ISS_LOOKUP
+                auto quals = [&](int k) {
+                    return __builtin_amdgcn_perm(sel[k + 1], sel[k], 0x0c0c0501u) | __builtin_amdgcn_perm(sel[k + 3], sel[k + 2], 0x05010c0cu);
+                };
+                uint32_t fm = 0, rm = 0;
+                const uint32_t fb = funnel_r(gf.x, gf.y, S.pfs * 2u);
+                const uint32_t rbr = funnel_r(gr.x, gr.y, S.prs * 2u);
+                windows = __builtin_amdgcn_perm(rbr ^ 0x5555u, fb, 0x05040100u);
+                if (!PLAIN && S.regular && (S.d.meta & 0x30u)) {
+                    const uint32_t *mw = g.mask + ((int32_t)(pfw_e - 1u) >> 1);
+                    fm = funnel_r(mw[0], mw[1], ((pfw_e - 1u) & 1u) * 16u + S.pfs) & 0xffu;
+                    const uint32_t *nw = g.mask + ((int32_t)(prw_e - 1u) >> 1);
+                    rm = funnel_r(nw[0], nw[1], ((prw_e - 1u) & 1u) * 16u + S.prs) & 0xffu;
+                }
+                uint2 base_f = {lut_at<0, 0>(lds0, fb), lut_at<1, 0>(lds0, fb)};
+                uint2 base_r = {lut_at<1, 1024>(lds0, rbr), lut_at<0, 1024>(lds0, rbr)};
+                if (!PLAIN && (fm | rm)) {
+                    for (int c = 0; c < 8; ++c) {
+                        if ((fm >> c) & 1u) {
+                            const uint32_t ch = g.ascii[(int64_t)(int32_t)(pfw_e - 1u) * 16 + S.pfs + c];
+                            uint32_t &w = c < 4 ? base_f.x : base_f.y;
+                            w = (w & ~(0xffu << (8 * (c & 3)))) | (ch << (8 * (c & 3)));
+                        }
+                        if ((rm >> (7 - c)) & 1u) {
+                            const uint32_t ch = (uint32_t)complement_ascii(g.ascii[(int64_t)(int32_t)(prw_e - 1u) * 16 + S.prs + 7 - c]);
+                            uint32_t &w = c < 4 ? base_r.x : base_r.y;
+                            w = (w & ~(0xffu << (8 * (c & 3)))) | (ch << (8 * (c & 3)));
+                        }
+                    }
+                }
+                rows[j][0] = base_f.x; rows[j][1] = base_f.y; rows[j][2] = quals(0); rows[j][3] = quals(8);
+                rows[j][4] = base_r.x; rows[j][5] = base_r.y; rows[j][6] = quals(4); rows[j][7] = quals(12);
+            }
+            push(rare0, S.tag0 | (it << 19), windows);
+        };
+        auto store_slot = [&](const int j) __attribute__((always_inline)) {
+            const int pp = j / NI;
+            const uint32_t it = (uint32_t)(j % NI);
+            const Sub &S = sub[pp];
+            if (S.valid && 4u * it + j4 < T.ts) {
+                uint32_t ob = S.out_b;
+                asm volatile("" : "+v"(ob));  // (as in slot())
+                uint4 *dst = reinterpret_cast<uint4 *>(out_pass + (size_t)(ob + it * 128u));
+                dst[0] = make_uint4(rows[j][0], rows[j][1], rows[j][2], rows[j][3]);
+                dst[4] = make_uint4(rows[j][4], rows[j][5], rows[j][6], rows[j][7]);
+            }
+        };
+        uint32_t k = 0, first = 0;
+        for (;;) {
+            bool stop = false;
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (k == (uint32_t)j && !stop) {
+                    slot(j);
+                    k = (uint32_t)j + 1u;
+                    stop = j + 1 < G && q_tail - q_head > (uint32_t)SLOW_RING - 64u;  // the next slot's pushes might not fit
+                }
+            }
+            const bool end = k == (uint32_t)G;
+            HeldPatch held = {0ull, 0u};
+            if (end) {  // the group's closing round: its patches wait for the rows
+                const uint32_t pending = q_tail - q_head;
+                if (pending && pending >= min_round) drain_round(min(64u, pending), std::true_type{}, held);
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                if ((uint32_t)j >= first && (uint32_t)j < k) store_slot(j);
+            first = k;
+            if (held.w & (3u << 16)) {
+                uint8_t *const at = A.out[0] + held.byte_off + ((held.w >> 18) & 1u) * 64u;  // (row_array_off: mate 64 bytes on, phreds 8)
+                if (held.w & (1u << 16)) at[8] = (uint8_t)held.w;
+                if (held.w & (1u << 17)) at[0] = (uint8_t)(held.w >> 8);
+            }
+            HeldPatch none;
+            while (q_tail - q_head >= 64u) drain_round(64u, std::false_type{}, none);
+            if (end) break;
+        }
+    }
+    HeldPatch none;
+    while (q_tail != q_head) drain_round(min(64u, q_tail - q_head), std::false_type{}, none);
 }
 
 // ================================================================== k_indel_scan

@@ -230,6 +230,7 @@ struct iss_ctx {
     int env_tiles = 0, env_guide_bits = 0;  // ISS_TILES / ISS_GUIDE_BITS: tuning aids of the tile sweeps (0: the cost model decides)
     bool debug_model = false;               // ISS_DEBUG_MODEL
     int64_t env_chunk_pairs = 0;            // ISS_CHUNK_PAIRS: pairs per launch chunk at most (tests: a call of many chunks)
+    int env_group = -1, env_group_min = 0;  // ISS_MAIN_GROUP: passes per group of k_main_g (0: k_main; unset: chosen per model); ISS_MAIN_GROUP_MIN: min_round
     double mt_guard = 1e-6;                 // ISS_MT_GUARD: how close to a rounding boundary the device still decides (tests widen it)
     bool light = false;  // reads with an indel are rare (< ISS_LIGHT_INDELS of the reads, default 2e-3): all of them take k_indel_fixup
     double mt_bounce_rate = 0;  // MT mode: expected indel candidates per pair (decides resolver vs. sequential walker)
@@ -347,6 +348,8 @@ void read_switches(iss_ctx *ctx) {
     ctx->mt_guard = (e = getenv("ISS_MT_GUARD")) ? atof(e) : 1e-6;
     ctx->debug_model = getenv("ISS_DEBUG_MODEL") != nullptr;
     ctx->env_chunk_pairs = (e = getenv("ISS_CHUNK_PAIRS")) ? std::max<int64_t>(1, atoll(e)) : 0;
+    ctx->env_group = (e = getenv("ISS_MAIN_GROUP")) ? atoi(e) : -1;
+    ctx->env_group_min = (e = getenv("ISS_MAIN_GROUP_MIN")) ? atoi(e) : 0;
 }
 
 void free_model(iss_ctx *ctx) {
@@ -569,6 +572,33 @@ int mt_prefetch_commit(iss_ctx *ctx, const MtPrefetch &pf) {
 }
 
 // dynamic LDS of k_main: quality rows + deferred-work queues
+// k_main_g: the instantiations (iterations per pass NI, passes per group NP) the library holds -- a group is at most five
+// iterations (8 registers of rows each) -- and the choice of NP for a model.  X(NI, NP) with a trailing separator per entry.
+#define ISS_MAIN_G_LIST(X) X(5, 1) X(4, 1) X(3, 1) X(2, 2) X(2, 1) X(1, 2)
+#define ISS_MAIN_G_PTR(NI_, NP_) reinterpret_cast<const void *>(iss::k_main_g<true, NI_, NP_>),
+constexpr uint32_t MAIN_GROUP_MIN_ROUND = 1;
+// Passes per group (0: k_main).  `want` (ISS_MAIN_GROUP) if the library holds it.  Else by the lane-items a wavefront defers per
+// iteration, E = 64 (1 - (1 - p_defer)^16): a group should end with about one round's worth of entries (64 / E iterations), and a
+// model that defers little gains less from patches in time than a closing round per group costs.  Measured, interleaved on one
+// box (profiles/r06_ab_runs.txt; k_main ms per 5 M pairs, k_main -> k_main_g): HiSeq (E 18) 1.235 -> 1.12 with groups of 2 x 2
+// iterations, 1.17 with 1 x 2; MiSeq (E 29) 4.03 -> 3.44 with 1 x 2, 3.64 with 2 x 2; NextSeq (E 23, four iterations per
+// pass) 2.85 -> 2.60; NovaSeq (E 9, five iterations per pass) 1.155 -> 1.20: k_main stays.
+static int main_group_passes(const iss::DevModel &M, int ni, int want) {
+    const double e = 64.0 * (1.0 - std::pow(1.0 - std::min(std::max((double)M.p_defer, 0.0), 1.0), 16.0));
+    if (want < 0 && e < 15.0) return 0;
+    const int target = want > 0 ? want : std::max(1, (int)std::lround(64.0 / std::max(e, 1.0) / (double)ni));
+    int best = 0;
+#define ISS_MAIN_G_PICK(NI_, NP_) if (ni == NI_ && (want > 0 ? NP_ == want : (NP_ <= target && NP_ > best))) best = NP_;
+    ISS_MAIN_G_LIST(ISS_MAIN_G_PICK)
+#undef ISS_MAIN_G_PICK
+    if (!best && want <= 0) {  // (no instantiation that small: the smallest one for ni)
+#define ISS_MAIN_G_PICK(NI_, NP_) if (ni == NI_ && (!best || NP_ < best)) best = NP_;
+        ISS_MAIN_G_LIST(ISS_MAIN_G_PICK)
+#undef ISS_MAIN_G_PICK
+    }
+    return best;
+}
+
 size_t main_lds_bytes(const iss::DevModel &M) {
     return ((size_t)iss::MAIN_LUT_WORDS + M.tile_words + iss::MAIN_MUT_WORDS + (size_t)2 * M.TP * 4 + (size_t)(iss::MAIN_THREADS / 64) * iss::SLOW_RING * 3) * 4;
 }
@@ -837,6 +867,8 @@ int iss_ctx_create(int device_ordinal, iss_ctx **out) {
                                 reinterpret_cast<const void *>(iss::k_main<false, false, true>), reinterpret_cast<const void *>(iss::k_main<false, true, true>),
                                 reinterpret_cast<const void *>(iss::k_main<true, false, true>), reinterpret_cast<const void *>(iss::k_main<true, true, true>)};
         for (const void *f : mains) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        const void *grouped[] = {ISS_MAIN_G_LIST(ISS_MAIN_G_PTR)};
+        for (const void *f : grouped) HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_mt_walk),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(iss::k_indel_fixup),
@@ -1070,6 +1102,23 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
             if (cost < best - 1e-9) { best = cost; M.GB = gb; }
         }
     }
+    {   // expected share of bases that leave the hot loop for the exact path (k_main_g's grouping, below, is chosen by it): more
+        // than two thresholds of the guide bucket below the digit, or the 8-bit error digit reaching the phred's threshold digit
+        double flag = 0;
+        size_t rows = 0;
+        for (int o = 0; o < 2; ++o)
+            for (int sl = 0; sl < n_slots[o]; ++sl)
+                for (int p = 0; p < RL; p += 3, ++rows) {
+                    const uint64_t *row = t->q_thr + ((size_t)(o * 4 + M.slot_bin[o * 4 + sl]) * RL + p) * nq;
+                    double prev = 0;
+                    for (int q = 0; q <= nq; ++q) {  // P(phred == q) = cdf[q] - cdf[q-1]; phred nq has the rest
+                        const double c = q < nq ? (double)row[q] / 9007199254740992.0 : 1.0;
+                        flag += (c - prev) * (double)(256u - te8(q)) / 256.0;
+                        prev = c;
+                    }
+                }
+        M.p_defer = (float)(more_rate(M.GB) + flag / (double)std::max<size_t>(rows, 1));
+    }
     if (ctx->debug_model) {  // expected share of bases that leave the hot loop
         double err = 0;
         size_t rows = 0;
@@ -1085,8 +1134,8 @@ int iss_model_upload(iss_ctx *ctx, const iss_model_tables *t) {
                     }
                 }
         fprintf(stderr, "[model] per base: P(> 2 thresholds below in the guide bucket) %.5f (GB 6: %.5f, 7: %.5f, 8: %.5f), "
-                        "P(substitution test fires) %.5f, s_max %zu\n", more_rate(M.GB), more_rate(6), more_rate(7), more_rate(8),
-                err / (double)std::max<size_t>(rows, 1), s_max);
+                        "P(substitution test fires) %.5f, P(a base leaves the hot loop) %.5f, s_max %zu\n", more_rate(M.GB), more_rate(6), more_rate(7), more_rate(8),
+                err / (double)std::max<size_t>(rows, 1), (double)M.p_defer, s_max);
     }
     const int gwords = (1 << M.GB) / 4;
     M.stride_w = (int32_t)(gwords + s_max);
@@ -1737,7 +1786,24 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
         if (heavy) hipLaunchKernelGGL((iss::k_main<MUT, PLAIN, true>), grid, block, lds_bytes, s_main, M, dg, A, desc);   \
         else hipLaunchKernelGGL((iss::k_main<MUT, PLAIN, false>), grid, block, lds_bytes, s_main, M, dg, A, desc);        \
     } while (0)
-            if (A.mut) { if (plain) ISS_LAUNCH_MAIN(true, true); else ISS_LAUNCH_MAIN(true, false); }
+            // plain launches of models with a short pass: k_main_g -- the rows of a group of passes wait in registers until the
+            // group's deferred bases are settled, their byte patches follow the rows out in time (iss_kernels.hip.h)
+            bool grouped = false;
+            if (plain && !heavy && !A.mut && ctx->env_group != 0) {
+                const int ni = (M.TS + 3) / 4;
+                const int np = main_group_passes(M, ni, ctx->env_group);
+                const uint64_t span = (uint64_t)(np - 1) * total * iss::MAIN_PAIRS * (uint64_t)M.row + (uint64_t)iss::MAIN_PAIRS * M.row + 4096;
+                const uint32_t min_round = ctx->env_group_min > 0 ? (uint32_t)ctx->env_group_min : MAIN_GROUP_MIN_ROUND;
+#define ISS_MAIN_G_LAUNCH(NI_, NP_)                                                                                                   \
+    if (!grouped && ni == NI_ && np == NP_ && span < ((uint64_t)1 << 32)) {                                                          \
+        hipLaunchKernelGGL((iss::k_main_g<true, NI_, NP_>), grid, block, lds_bytes, s_main, M, dg, A, desc, min_round);                \
+        grouped = true;                                                                                                              \
+    }
+                ISS_MAIN_G_LIST(ISS_MAIN_G_LAUNCH)
+#undef ISS_MAIN_G_LAUNCH
+            }
+            if (grouped) { /* launched */ }
+            else if (A.mut) { if (plain) ISS_LAUNCH_MAIN(true, true); else ISS_LAUNCH_MAIN(true, false); }
             else { if (plain) ISS_LAUNCH_MAIN(false, true); else ISS_LAUNCH_MAIN(false, false); }
 #undef ISS_LAUNCH_MAIN
         }

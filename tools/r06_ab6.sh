@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B of library builds, interleaved: tools/r06_ab6.sh "<bench args>" lib ...
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+ARGS=$1; shift
+for rep in 1 2 3; do for L in "$@"; do
+  ISS_MI355X_LIB=$PWD/$L timeout 120 python bench.py $ARGS --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end --no-other-workloads 2>/dev/null | tail -1 | \
+    python -c "import json,sys; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']; print('$L', 'ms/step %.4f' % (d['ms_per_step']), 'main %.4f' % k['main_ms'], str(d.get('parity_window'))[:9])"
+done; done
