@@ -29,13 +29,17 @@
 extern "C" {
 #endif
 
-/* 6: indels inside k_main (edit scripts): iss_stats_read reports the scripted reads too; iss_build_id.
+/* 8: iss_main_kernel (which instantiation of the hot kernel the last Philox-mode call launched: k_main or k_main_g -- the
+ *    rows of a group of passes wait in registers for their byte patches).
+ * 7: W workers of the reference-identical mode side by side in one context (iss_mt_workers_seed, iss_generate_mt_workers,
+ *    iss_mt_workers_peek); 36-bit coordinates in MT mode and the batch arena.
+ * 6: indels inside k_main (edit scripts): iss_stats_read reports the scripted reads too; iss_build_id.
  * 5: the ErrorModel methods as batched entries (iss_gen_phred_scores, ...), iss_ev_step.
  * 4: device rows interleaved per pair (whole 128-byte lines per store, see iss_output_reserve), iss_output_row;
  *    Philox address map of the hot draws: three blocks per 16 bases.
  * 3: iss_fastq_compress / iss_deflate_code_build (gzip members built on the device), iss_generate_batch,
  *    iss_fastq_emit_batch (a whole work list per call).  2: iss_fastq_emit / iss_fastq_flush, MT-mode path counters. */
-#define ISS_ABI_VERSION 7
+#define ISS_ABI_VERSION 8
 
 #define ISS_E_INVALID (-1)     /* bad argument / model / genome content            */
 #define ISS_E_HIP (-2)         /* HIP runtime failure (message has the hip error)  */
@@ -235,6 +239,12 @@ int iss_timing_read(iss_ctx *ctx, double ms[4], int64_t *n_launches);
 /* Counters since the last read: reads rebuilt by the indel fix-up kernel (one wavefront per read), reads k_main built from an
  * edit script (models whose reads often have indels).  Either pointer may be NULL. */
 int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads, int64_t *n_scripted_reads);
+
+/* Name of the kernel the last iss_generate / iss_generate_batch call launched for the hot path (simulate_read's per-base work,
+ * iss/generator.py:146-180 + iss/error_models/kde.py:52-86): "k_main<mutations, plain, indel>" or "k_main_g<NI, NP>" -- what a
+ * profile of the call lists, so that a measurement can name what it measured.  Returns the name's length (it is cut to
+ * capacity - 1 characters and always closed by a NUL), 0 before the first call. */
+int iss_main_kernel(iss_ctx *ctx, char *name, int capacity);
 
 /*
  * Reference-compatible RNG mode (sequential; for bit-identity with the reference, not throughput).

@@ -23,6 +23,7 @@ EXPORTS = (
     "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush", "iss_fastq_compress", "iss_deflate_code_build",
     "iss_generate_batch", "iss_fastq_emit_batch", "iss_gen_phred_scores", "iss_mut_sequence", "iss_random_insert_size",
     "iss_introduce_indels", "iss_ev_step", "iss_mt_workers_seed", "iss_generate_mt_workers", "iss_mt_workers_peek",
+    "iss_main_kernel",
 )
 
 

@@ -250,6 +250,7 @@ struct iss_ctx {
     std::vector<int64_t> last_first;     // the last call was a batch: its item_first (rows last_row0 + ...), else empty
     std::vector<int64_t> last_off;       // ... and the arena offsets its descriptors carry
     unsigned max_main_grid = 0;
+    std::string main_kernel;             // the hot kernel of the last Philox-mode call (iss_main_kernel)
     uint64_t *stats = nullptr;
     // reference-compatible MT19937 mode (iss_mt_compat.hip.h)
     struct {
@@ -577,6 +578,7 @@ int mt_prefetch_commit(iss_ctx *ctx, const MtPrefetch &pf) {
 #define ISS_MAIN_G_LIST(X) X(5, 1) X(4, 1) X(3, 1) X(2, 2) X(2, 1) X(1, 2)
 #define ISS_MAIN_G_PTR(NI_, NP_) reinterpret_cast<const void *>(iss::k_main_g<true, NI_, NP_>),
 constexpr uint32_t MAIN_GROUP_MIN_ROUND = 1;
+constexpr int64_t MAIN_CHUNK_PAIRS = 12582912;  // pairs per launch of a call at most (generate_core; ISS_CHUNK_PAIRS overrides)
 // Passes per group (0: k_main).  `want` (ISS_MAIN_GROUP) if the library holds it.  Else by the lane-items a wavefront defers per
 // iteration, E = 64 (1 - (1 - p_defer)^16): a group should end with about one round's worth of entries (64 / E iterations), and a
 // model that defers little gains less from patches in time than a closing round per group costs.  Measured, interleaved on one
@@ -1598,7 +1600,12 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
     // and for k_main's pair numbers (row offsets are 64-bit since round 5: 5 M MiSeq pairs of 1 280-byte rows are one launch)
     const int64_t max_chunk = std::max<int64_t>(1, std::min<int64_t>(((int64_t)1 << 31) / std::max(M.n_scan, 1) - iss::MAIN_PAIRS,
                                                                     max_passes * iss::MAIN_PAIRS * min_tile_wg));
-    const int64_t chunk_pairs = ctx->env_chunk_pairs ? std::min(max_chunk, ctx->env_chunk_pairs) : max_chunk;
+    // Pairs per launch.  The address limits above allow 2^31 reads, but k_main's own time per pair rises with the launch: BASELINE
+    // configs[3]'s shape on one GPU (50 M HiSeq pairs per step), interleaved on one box (profiles/r06_ab_runs.txt): ONE launch
+    // 12.9-13.2 ms of k_main (3.7-3.8 x 10^9 pairs/s), launches of 12.5 M or 5 M pairs 11.7-12.0 ms (4.1 x 10^9) -- round 5 had
+    // dropped the <= 4 GB chunks when the row offsets became 64-bit, and that was the 7 % it lost on this shape; k_main_g:
+    // 11.4-11.5 / 10.8 / 10.8 ms.  (k_setup of chunk k + 1 runs beside k_main of chunk k either way.)
+    const int64_t chunk_pairs = std::min(max_chunk, ctx->env_chunk_pairs ? ctx->env_chunk_pairs : MAIN_CHUNK_PAIRS);
     if (ctx->d_pmut) {  // rows of THIS call only
         ctx->d_pmut_count = reinterpret_cast<uint32_t *>(ctx->fix_count) + 60;  // +240 B of the scratch block
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_pmut, 0xff, (size_t)ctx->pmut_cap * sizeof(iss::MutRecord), ctx->stream));
@@ -1797,11 +1804,13 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
 #define ISS_MAIN_G_LAUNCH(NI_, NP_)                                                                                                   \
     if (!grouped && ni == NI_ && np == NP_ && span < ((uint64_t)1 << 32)) {                                                          \
         hipLaunchKernelGGL((iss::k_main_g<true, NI_, NP_>), grid, block, lds_bytes, s_main, M, dg, A, desc, min_round);                \
+        ctx->main_kernel = "k_main_g<" #NI_ ", " #NP_ ">";                                                                           \
         grouped = true;                                                                                                              \
     }
                 ISS_MAIN_G_LIST(ISS_MAIN_G_LAUNCH)
 #undef ISS_MAIN_G_LAUNCH
             }
+            if (!grouped) ctx->main_kernel = std::string("k_main<") + (A.mut ? "true" : "false") + ", " + (plain ? "true" : "false") + ", " + (heavy ? "true" : "false") + ">";
             if (grouped) { /* launched */ }
             else if (A.mut) { if (plain) ISS_LAUNCH_MAIN(true, true); else ISS_LAUNCH_MAIN(true, false); }
             else { if (plain) ISS_LAUNCH_MAIN(false, true); else ISS_LAUNCH_MAIN(false, false); }
@@ -2206,6 +2215,14 @@ int iss_stats_read(iss_ctx *ctx, int64_t *n_fixup_reads, int64_t *n_scripted_rea
     if (n_fixup_reads) *n_fixup_reads = (int64_t)v[0];
     if (n_scripted_reads) *n_scripted_reads = (int64_t)v[1];
     return 0;
+}
+
+int iss_main_kernel(iss_ctx *ctx, char *name, int capacity) {
+    if (!ctx || !name || capacity < 1) return fail(ctx, ISS_E_INVALID, "iss_main_kernel: ctx / name is NULL or capacity < 1");
+    const size_t n = std::min(ctx->main_kernel.size(), (size_t)capacity - 1);
+    memcpy(name, ctx->main_kernel.data(), n);
+    name[n] = 0;
+    return (int)n;
 }
 
 // ------------------------------------------------------------------ reference-compatible MT mode

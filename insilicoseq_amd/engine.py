@@ -374,6 +374,12 @@ class ReadEngine(object):
         return {"setup_ms": ms[0], "main_ms": ms[1], "indel_scan_ms": ms[2], "indel_fixup_ms": ms[3],
                 "launches": n.value}
 
+    def main_kernel(self):
+        """Name of the kernel the last generate() / generate_batch() launched for the hot path ("k_main<...>" / "k_main_g<NI, NP>")."""
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.iss_main_kernel(self._ctx, buf, 64))
+        return buf.value.decode()
+
     def stats_read(self):
         n, m = C.c_int64(0), C.c_int64(0)
         self._check(self._lib.iss_stats_read(self._ctx, C.byref(n), C.byref(m)))

@@ -99,6 +99,27 @@ def test_generate_cli_basic_mode_equals_reference(tmp_path):
     assert open(out + "_R2.fastq", "rb").read() == z["r2"].tobytes()
 
 
+def test_generate_cli_baseline_configs0_as_written(tmp_path):
+    """BASELINE configs[0] as written -- `iss generate --genomes data/ecoli.fasta --mode basic -n 10000 --cpus 1` (seed 42;
+    /root/reference/iss/app.py:333-341, /root/reference/iss/error_models/basic.py:40-63) -- through the device in the
+    byte-identical mode: the reference's own files (tests/golden/tooling/make_golden_configs0.py), byte for byte."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(GOLDEN, "generate", "ecoli_basic_n10000_seed42_cpus1.npz"))
+    fasta = str(tmp_path / "ecoli.fasta")
+    with open(fasta, "wb") as fh:
+        fh.write(z["fasta"].tobytes())
+    out = str(tmp_path / "run")
+    subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes", fasta, "--mode", "basic", "--rng", "mt",
+                           "-n", "10000", "--seed", "42", "--cpus", "1", "--devices", "1", "-o", out, "--quiet"], cwd=root)
+    assert open(out + "_abundance.txt", "rb").read() == z["abundance"].tobytes()
+    for name, key, sha in (("_R1.fastq", "r1", "sha_r1"), ("_R2.fastq", "r2", "sha_r2")):
+        got = open(out + name, "rb").read()
+        assert got.count(b"\n") == 4 * 5000
+        assert got == z[key].tobytes(), name
+        import hashlib
+        assert hashlib.sha256(got).hexdigest() == str(z[sha])
+
+
 @pytest.mark.parametrize("cpus", [1, 2, 3])
 def test_generate_cli_equals_reference(cpus, tmp_path):
     """python -m insilicoseq_amd generate --rng mt == the reference's `iss generate --cpus N` output files."""

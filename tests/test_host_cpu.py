@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(native):
     assert declared == set(native.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.iss_abi_version() == 7
+    assert lib.iss_abi_version() == 8
 
 
 def test_no_gpu_means_loud_failure(native):

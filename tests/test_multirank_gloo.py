@@ -87,6 +87,38 @@ def test_ranks_reproduce_reference_generate(world, tmp_path):
     mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path), GOLDEN), nprocs=world, join=True)
 
 
+def test_baseline_configs0_as_written_on_the_oracle(tmp_path):
+    """BASELINE configs[0] as written (`iss generate --genomes data/ecoli.fasta --mode basic -n 10000 --cpus 1`, seed 42; golden of
+    tests/golden/tooling/make_golden_configs0.py): the reference's divider with one worker, the CPU oracle (MT streams, the
+    BasicErrorModel's legacy-gauss phreds) standing in for the device -- 5 000 pairs, byte for byte."""
+    from insilicoseq_amd import distributed as D
+    from insilicoseq_amd.engine import fastq_write
+    from insilicoseq_amd.generator import lognormal_abundance, parse_fasta
+    from insilicoseq_amd.model import DenseModel
+    from oracle import oracle as O
+
+    z = np.load(os.path.join(GOLDEN, "generate", "ecoli_basic_n10000_seed42_cpus1.npz"))
+    fasta = str(tmp_path / "ecoli.fasta")
+    with open(fasta, "wb") as fh:
+        fh.write(z["fasta"].tobytes())
+    dense = DenseModel.basic()
+    records = list(parse_fasta(fasta))
+    abundance = lognormal_abundance([r.id for r in records], np.random.RandomState(42))
+    output = str(tmp_path / "out")
+    work, _, n_chunks = D.rank_work(records, None, abundance, 10000, None, None, dense, output, 1, 0)
+    orc, rng = O.Oracle(dense), O.Rng().seed_mt(42)
+    prefix = D.temp_prefix(output, 0)
+    with open(prefix + "_R1.fastq", "wb") as f1, open(prefix + "_R2.fastq", "wb") as f2:
+        for rec, n, _ in work:
+            res = orc.simulate(rng, rec.seq, n)
+            assert res["status"] == 0
+            fastq_write(f1.fileno(), f2.fileno(), rec.id, 0, 0, res["n_done"], dense.read_length, dense.read_length,
+                        res["r1_base"], res["r1_qual"], res["r2_base"], res["r2_qual"], 2)
+    D.concatenate_rank_files(output, 1)
+    assert open(output + "_R1.fastq", "rb").read() == z["r1"].tobytes()
+    assert open(output + "_R2.fastq", "rb").read() == z["r2"].tobytes()
+
+
 @pytest.mark.parametrize("case,model,n_reads,seed", [("genomes_hiseq_n1600_seed42", "hiseq", 1600, 42),
                                                      ("syn3_novaseq_n3000_seed7", "novaseq", 3000, 7)])
 def test_eight_workers_reproduce_reference_generate(case, model, n_reads, seed, tmp_path):
