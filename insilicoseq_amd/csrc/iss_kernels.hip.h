@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel 
     struct Sub {  // a pass of the group, per lane
         PairDesc d;
         Addr a;
-        uint32_t rowf, rowr, pfw, prw, pfs, prs, out_b, tag0;
+        uint32_t rowf, rowr, pfw, prw, pfs, prs, out_b, tag0, s_lane;
         bool valid, regular;
     };
     for (uint32_t pass = 0, blk = blk_first; blk < blk_end; pass += NP, blk += (uint32_t)NP * blk_step) {
@@ -1379,6 +1379,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel 
             S.out_b = (wave_pair0 + (lane >> 2)) * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u + (uint32_t)pp * pass_bytes;
             S.regular = PLAIN || !(A.has_frag && (S.d.meta & 64u));
             S.tag0 = ((pass + (uint32_t)pp) << (19u + it_bits)) | (lane << 13) | ((S.d.meta & 15u) << 8);
+            S.s_lane = s_lane;
         }
         uint8_t *const out_pass = A.out[0] + (size_t)blk * (size_t)MAIN_PAIRS * (size_t)(uint32_t)M.row;
         auto request_next = [&]() __attribute__((always_inline)) {  // the descriptors of the next group: behind the first slot's genome windows (k_main)
@@ -1395,13 +1396,8 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel 
             const Sub &S = sub[pp];
             uint32_t rare0 = 0, windows = 0;
             if (S.valid && 4u * it + j4 < T.ts) {
-                // (opaque copies: what a slot derives from the pass's values and its own number is invariant in the group's loop
-                //  below, and hoisted out of it -- the first Philox round, row offsets, window words, addresses -- it costs five
-                //  to eight registers per slot for the whole group)
-                uint32_t s_abs = s_lane + 4u * it, rowf = S.rowf, rowr = S.rowr, pfw_e = S.pfw, prw_e = S.prw;
-                asm volatile("" : "+v"(s_abs), "+v"(rowf), "+v"(rowr), "+v"(pfw_e), "+v"(prw_e));
-                pfw_e += 2u * it;
-                prw_e -= 2u * it;
+                const uint32_t s_abs = S.s_lane + 4u * it, pfw_e = S.pfw + 2u * it, prw_e = S.prw - 2u * it;
+                uint32_t rowf = S.rowf, rowr = S.rowr;
                 uint2 gf = {0u, 0u}, gr = {0u, 0u};
                 if (S.regular) {
                     gf = *reinterpret_cast<const uint2 *>(packed_b + (size_t)(pfw_e << 2));
@@ -1479,15 +1475,19 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel 
             const uint32_t it = (uint32_t)(j % NI);
             const Sub &S = sub[pp];
             if (S.valid && 4u * it + j4 < T.ts) {
-                uint32_t ob = S.out_b;
-                asm volatile("" : "+v"(ob));  // (as in slot())
-                uint4 *dst = reinterpret_cast<uint4 *>(out_pass + (size_t)(ob + it * 128u));
+                uint4 *dst = reinterpret_cast<uint4 *>(out_pass + (size_t)(S.out_b + it * 128u));
                 dst[0] = make_uint4(rows[j][0], rows[j][1], rows[j][2], rows[j][3]);
                 dst[4] = make_uint4(rows[j][4], rows[j][5], rows[j][6], rows[j][7]);
             }
         };
         uint32_t k = 0, first = 0;
         for (;;) {
+            // (opaque re-definitions: what a slot derives from the pass's values and its own number -- the first Philox round,
+            //  row offsets, window words, addresses -- is invariant in this loop; hoisted out of it, it costs five to eight
+            //  registers per slot for the whole group and spills)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp)
+                asm volatile("" : "+v"(sub[pp].s_lane), "+v"(sub[pp].rowf), "+v"(sub[pp].rowr), "+v"(sub[pp].pfw), "+v"(sub[pp].prw), "+v"(sub[pp].out_b));
             bool stop = false;
 #pragma unroll
             for (int j = 0; j < G; ++j) {
