@@ -395,6 +395,8 @@ def main():
             eng.close()  # (the legs below bring their own engines: the rows of the timed region go back to the allocator first)
             eng = None
             e2e_records = [Record(letters[id(r)], id=r.id) for r in records]
+            if isinstance(out.get("other_workloads", {}).get("mt_mode"), dict) and "error" not in out["other_workloads"]["mt_mode"]:
+                out["other_workloads"]["mt_mode"]["end_to_end"] = mt_end_to_end(letters[id(records[0])])
             out["end_to_end"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs)
             out["end_to_end_gzip"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs, compress=True)
             out["end_to_end_4_workers"] = end_to_end(dense, e2e_records, abundance, args.e2e_pairs, workers=4)
@@ -673,6 +675,50 @@ def mt_mode_leg(device, dense, genome, n_pairs=1_000_000, worker_sets=(1, 8, 64,
         return out
     finally:
         eng.close()
+
+
+def mt_end_to_end(genome, pairs=64_000_000, cpus=64):
+    """The byte-identical mode END TO END: wall time of the whole command `python -m insilicoseq_amd generate --rng mt --cpus 64
+    --devices 1` (interpreter start, FASTA parse, engine, the 64 reference workers side by side on one GPU, their text written at
+    its place of the final files) on one 5 Mbp record, NovaSeq, FASTQ on tmpfs -- the files `iss generate --seed 7 --cpus 64`
+    writes, byte for byte (tests/test_gpu_mt_compat.py holds the comparisons).  value = pairs / seconds of the command."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = tempfile.mkdtemp(dir=base)
+    try:
+        need = 2 * 340 * pairs
+        free = shutil.disk_usage(d).free
+        if need > 0.4 * free:
+            pairs = max(cpus * 64, int(pairs * 0.4 * free / need))
+        fasta = os.path.join(d, "g.fasta")
+        with open(fasta, "wb") as fh:
+            fh.write(b">rec0\n" + (genome if isinstance(genome, bytes) else bytes(genome)) + b"\n")
+
+        def run(n_pairs, tag):
+            out = os.path.join(d, tag)
+            t0 = time.perf_counter()
+            subprocess.check_call([sys.executable, "-m", "insilicoseq_amd", "generate", "--genomes", fasta, "--model", "novaseq", "-n",
+                                   str(2 * n_pairs), "--seed", "7", "--cpus", str(cpus), "--devices", "1", "--rng", "mt", "-o", out, "--quiet"],
+                                  cwd=ROOT)
+            dt = time.perf_counter() - t0
+            size = sum(os.path.getsize(out + sfx) for sfx in ("_R1.fastq", "_R2.fastq"))
+            for sfx in ("_R1.fastq", "_R2.fastq", "_abundance.txt"):
+                os.remove(out + sfx)
+            return dt, size
+
+        t_small, _ = run(64 * cpus, "tiny")
+        t_big, size = run(pairs, "big")
+        return {"value": pairs / t_big, "unit": "read-pairs/s", "cpus": cpus, "pairs": pairs, "seconds": t_big, "startup_alone_s": t_small,
+                "written_GB": size / 1e9,
+                "sample": "the whole command `generate --rng mt --cpus %d --devices 1 -n %d` -> %.1f GB of FASTQ on %s in %.2f s "
+                          "(the same command for %d pairs: %.2f s)" % (cpus, 2 * pairs, size / 1e9, base or "the temp dir", t_big, 64 * cpus, t_small)}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "error": repr(e)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def end_to_end(dense, records, abundance, n_pairs, compress=False, workers=1):

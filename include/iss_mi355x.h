@@ -308,6 +308,16 @@ int iss_fastq_emit(iss_ctx *ctx, int fd_r1, int fd_r2, const char *record_id, in
  * appended are those of n_items iss_fastq_emit calls in item order (compressed mode: one gzip member for the call). */
 int iss_fastq_emit_batch(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, const char *const *record_ids,
                          const int64_t *first_i, const int64_t *first_pair, const int64_t *n_pairs, int32_t cpu_number);
+/* The same for items that belong to DIFFERENT workers and go to DIFFERENT places of the two files (text mode only): item k is
+ * worker cpu_numbers[k]'s ("{id}_{i}_{cpu_numbers[k]}/1") and its text is written at byte file_off[k] of fd_r1 and of fd_r2 -- the
+ * two files of a pair hold records of equal lengths.  The reference's parent concatenates its workers' temp files in worker order
+ * (iss/app.py:123-127, iss/util.py:213-234); a worker's text size is arithmetic (constant read length, decimal pair numbers), so
+ * the W workers of a set (iss_generate_mt_workers) write straight into the final files and the concatenation -- a second copy of
+ * every byte under the destination's inode lock -- disappears.  The files' running offsets (iss_fastq_emit) are not moved; the
+ * caller sizes the files (ftruncate) and owns the layout. */
+int iss_fastq_emit_scatter(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, const char *const *record_ids, const int64_t *first_i,
+                           const int64_t *first_pair, const int64_t *n_pairs, const int32_t *cpu_numbers, const int64_t *file_off,
+                           int32_t n_threads);
 int iss_fastq_flush(iss_ctx *ctx);
 
 /*

@@ -23,7 +23,7 @@ EXPORTS = (
     "iss_mt_path_counts", "iss_fastq_emit", "iss_fastq_flush", "iss_fastq_compress", "iss_deflate_code_build",
     "iss_generate_batch", "iss_fastq_emit_batch", "iss_gen_phred_scores", "iss_mut_sequence", "iss_random_insert_size",
     "iss_introduce_indels", "iss_ev_step", "iss_mt_workers_seed", "iss_generate_mt_workers", "iss_mt_workers_peek",
-    "iss_main_kernel",
+    "iss_main_kernel", "iss_fastq_emit_scatter",
 )
 
 
@@ -104,6 +104,8 @@ def lib():
     L.iss_mt_mutations_download.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.iss_fastq_emit.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, i64, i32, i64, i64, i32]
     L.iss_fastq_emit_batch.argtypes = [vp, C.c_int, C.c_int, i32, vp, vp, vp, vp, i32]
+    L.iss_fastq_emit_scatter.argtypes = [vp, C.c_int, C.c_int, i32, vp, vp, vp, vp, vp, vp, i32]
+    L.iss_main_kernel.argtypes = [vp, vp, C.c_int]
     L.iss_fastq_flush.argtypes = [vp]
     L.iss_generate_batch.argtypes = [vp, i32, vp, vp, C.c_uint64, C.c_uint64, i32, i32, i64]
     L.iss_fastq_compress.argtypes = [vp, i32]

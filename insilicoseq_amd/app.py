@@ -254,6 +254,7 @@ def generate_reads(args):
                      temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng, args.store_mutations,
                      (args.fragment_length, args.fragment_length_sd), device_gzip))
     t_gen = time.perf_counter()
+    in_place = False
     if workers == 1:
         for j in jobs:
             _worker(*j, records=records)
@@ -261,13 +262,18 @@ def generate_reads(args):
         # the reference's N workers as N chains side by side on ONE GPU: one workgroup per worker and kernel
         # (worker_set_iterator; the files are those of N worker processes)
         works = [[(records[idx], n, "default") for idx, n in j[3]] for j in jobs]
-        worker_set_iterator(works, error_model, [j[0] for j in jobs], [j[6] for j in jobs], args.seed, args.sequence_type,
-                            args.gc_bias, device=0, compress=device_gzip)
+        # text mode: the workers write at their places of the FINAL files -- the concatenation below has nothing left to do
+        # (fewer chunks than workers: the reference fails on the missing temp file, util.py:233 -- that path keeps the temp files)
+        in_place = worker_set_iterator(works, error_model, [j[0] for j in jobs], [j[6] for j in jobs], args.seed, args.sequence_type,
+                                       args.gc_bias, device=0, compress=device_gzip,
+                                       final_prefix=args.output if len(jobs) == workers and os.environ.get("ISS_SET_TEMP_FILES", "") != "1" else None)
     else:
         with mp.get_context("spawn").Pool(workers) as pool:
             pool.starmap(_worker, jobs)
     t_cat = time.perf_counter()
-    if args.store_mutations:  # app.py:128-133
+    if in_place:
+        pass
+    elif args.store_mutations:  # app.py:128-133
         concatenate_rank_files(args.output, workers, suffixes=("_R1.fastq", "_R2.fastq", ".vcf"),
                                headers={".vcf": VCF_HEADER}, out_suffixes=gz)
     else:

@@ -26,7 +26,7 @@ __host__ __device__ inline uint64_t digits_before(uint64_t x) {
 }
 
 // One emit call formats the rows of several work items (records): item k = rows [first_pair, +n_pairs) with ids
-// "{id_k}_{first_i + j}_{cpu}" and its text at byte `text_off` of the call's text.
+// "{id_k}_{first_i + j}_{cpu_k}" and its text at byte `text_off` of the call's text.
 struct FastqItem {
     uint64_t first_i;        // pair id of the item's first row
     uint64_t before_first;   // digits_before(first_i)
@@ -35,6 +35,8 @@ struct FastqItem {
     int64_t rec_first;       // records of the items before this one
     uint32_t id_off;         // of the record id in `ids`
     int32_t id_len;
+    int32_t cpu_len;         // the worker's number (the items of one call may belong to different workers: iss_fastq_emit_scatter)
+    char cpu[12];            // ... in decimal
 };
 
 struct FastqArgs {
@@ -42,8 +44,7 @@ struct FastqArgs {
     uint8_t *text[2];                  // [mate] output text
     const FastqItem *items;            // [n_items]
     const char *ids;                   // record ids, back to back
-    int32_t n_items, row, RL, cpu_len;
-    char cpu[12];                      // decimal cpu_number
+    int32_t n_items, row, RL;
     int64_t n_records;                 // of all items
 };
 
@@ -65,13 +66,13 @@ __global__ __launch_bounds__(64 * FASTQ_WAVES) void k_fastq_format(FastqArgs A) 
     const uint64_t g = it.first_i + (uint64_t)i;
     int dg = 1;
     for (uint64_t p = 10; dg < 20 && g >= p; p *= 10) ++dg;
-    const uint64_t C = (uint64_t)it.id_len + (uint64_t)A.cpu_len + 2ull * (uint64_t)A.RL + 10ull;
+    const uint64_t C = (uint64_t)it.id_len + (uint64_t)it.cpu_len + 2ull * (uint64_t)A.RL + 10ull;
     uint8_t *w = A.text[mate] + it.text_off + (uint64_t)i * C + (digits_before(g) - it.before_first);
     const char *id = A.ids + it.id_off;
     // ---- "@id_i_cpu/m\n"
     const int h1 = 1 + it.id_len;      // '@' id
     const int h2 = h1 + 1 + dg;        // '_' digits
-    const int hlen = h2 + 1 + A.cpu_len + 3;
+    const int hlen = h2 + 1 + it.cpu_len + 3;
     for (int k = lane; k < hlen; k += 64) {
         char c;
         if (k == 0) c = '@';
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64 * FASTQ_WAVES) void k_fastq_format(FastqArgs A) 
             for (int z = h2 - 1 - k; z > 0; --z) v /= 10;  // digit (h2 - 1 - k) from the right
             c = (char)('0' + (int)(v % 10));
         } else if (k == h2) c = '_';
-        else if (k < h2 + 1 + A.cpu_len) c = A.cpu[k - h2 - 1];
+        else if (k < h2 + 1 + it.cpu_len) c = it.cpu[k - h2 - 1];
         else if (k == hlen - 3) c = '/';
         else if (k == hlen - 2) c = (char)('1' + mate);
         else c = '\n';

@@ -105,6 +105,7 @@ struct FastqJob {
     bool gzip;
     uint32_t n_blocks;
     std::vector<uint64_t> item_off;  // text offsets of the job's work items (the writer checks the record structure there)
+    std::vector<int64_t> item_file_off;  // iss_fastq_emit_scatter: where each item's text goes in BOTH files (empty: the job is one piece at `off`)
 };
 struct FastqPipe {
     bool ready = false;
@@ -722,9 +723,30 @@ void fastq_writer_loop(iss_ctx *ctx) {
                 for (uint64_t at : job.item_off) ok = ok && at < job.bytes && t[at] == '@' && (at == 0 || t[at - 1] == '\n');
                 if (!ok) err = "FASTQ text does not have the record layout its size was computed from";
             }
+            // scattered items (the workers of a set, every one at its own place of the final files): the items dealt to a few
+            // threads per file; the text of item k is [item_off[k], item_off[k + 1])
+            if (err.empty() && !job.item_file_off.empty()) {
+                const size_t n_it = job.item_off.size();
+                const int per_file = std::max(1, std::min<int>(job.threads, 8));
+                std::vector<std::thread> th;
+                std::vector<int> rc((size_t)2 * per_file, 0);
+                for (int mate = 0; mate < 2; ++mate)
+                    for (int t = 0; t < per_file; ++t) {
+                        int *r = &rc[(size_t)mate * per_file + t];
+                        th.emplace_back([&, mate, t, r] {
+                            for (size_t k = (size_t)t; k < n_it && !*r; k += (size_t)per_file) {
+                                const uint64_t a = job.item_off[k], b = k + 1 < n_it ? job.item_off[k + 1] : job.bytes;
+                                if (pwrite_all(job.fd[mate], q.h_text[job.slot][mate] + a, b - a, job.item_file_off[k])) *r = errno ? errno : EIO;
+                            }
+                        });
+                    }
+                for (auto &t : th) t.join();
+                for (int r : rc) if (r) err = std::string("write failed: ") + strerror(r);
+            }
             // both files in parallel, each cut into pieces written with pwrite at their final offsets (a small job --
             // one record of a long work list -- is written by this thread: spawning threads would cost more)
-            const bool small_job = job.bytes <= (1u << 20);
+            const bool small_job = job.bytes <= (1u << 20) || !job.item_file_off.empty();
+            if (!job.item_file_off.empty()) job.bytes = 0;  // (written above)
             for (int mate = 0; small_job && mate < 2 && err.empty(); ++mate)
                 if (err.empty() && pwrite_all(job.fd[mate], q.h_text[job.slot][mate], job.bytes, job.off[mate]))
                     err = std::string("write failed: ") + strerror(errno);
@@ -3318,13 +3340,17 @@ int iss_mt_peek(iss_ctx *ctx, uint32_t *py_words, uint32_t *np_words, int32_t n)
 
 // ------------------------------------------------------------------ FASTQ formatting (host)
 // The rows of n_items work items -> FASTQ text (or gzip members) on their way to the two files.
+// cpu_numbers / file_off (iss_fastq_emit_scatter): per item its worker's number and where its text goes in both files; else every
+// item is worker cpu_number's and the text follows what the files hold.
 static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, const char *const *record_ids, const int64_t *first_i,
-                           const int64_t *first_pair, const int64_t *n_pairs, int32_t cpu_number, int32_t n_threads) {
+                           const int64_t *first_pair, const int64_t *n_pairs, int32_t cpu_number, int32_t n_threads,
+                           const int32_t *cpu_numbers = nullptr, const int64_t *file_off = nullptr) {
     if (!ctx || !ctx->have_model || n_items < 0 || cpu_number < 0 || fd_r1 < 0 || fd_r2 < 0)
         return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: bad argument");
+    if (file_off && ctx->fq.gzip) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit_scatter: text mode only (a gzip member's size is not known up front)");
     const iss::DevModel &M = ctx->M;
     iss::FastqArgs A{};
-    A.cpu_len = (int32_t)snprintf(A.cpu, sizeof A.cpu, "%d", cpu_number);
+    std::vector<int64_t> scatter;
     A.row = M.row;
     A.RL = M.RL;
     std::vector<iss::FastqItem> items;
@@ -3336,8 +3362,12 @@ static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, 
             return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: bad argument");
         const size_t idlen = strlen(record_ids[k]);
         if (idlen > FASTQ_ID_MAX) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: record id longer than 4096 bytes");
+        if (cpu_numbers && cpu_numbers[k] < 0) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: bad argument");
+        if (file_off && file_off[k] < 0) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit: bad argument");
         if (n_pairs[k] == 0) continue;
         iss::FastqItem it{};
+        it.cpu_len = (int32_t)snprintf(it.cpu, sizeof it.cpu, "%d", cpu_numbers ? cpu_numbers[k] : cpu_number);
+        if (file_off) scatter.push_back(file_off[k]);
         it.first_i = (uint64_t)first_i[k];
         it.before_first = iss::digits_before(it.first_i);
         it.text_off = bytes;
@@ -3346,7 +3376,7 @@ static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, 
         it.id_off = (uint32_t)ids.size();
         it.id_len = (int32_t)idlen;
         ids.append(record_ids[k], idlen);
-        const size_t C = idlen + (size_t)A.cpu_len + 2 * (size_t)M.RL + 10;
+        const size_t C = idlen + (size_t)it.cpu_len + 2 * (size_t)M.RL + 10;
         bytes += (size_t)n_pairs[k] * C + (size_t)(iss::digits_before(it.first_i + (uint64_t)n_pairs[k]) - it.before_first);
         n_records += n_pairs[k];
         if (n_pairs[k] > most) {
@@ -3507,7 +3537,9 @@ static int fastq_emit_core(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, 
                      q.gzip != 0, n_blocks, {}};
         if (!q.gzip) {  // (compressed members: the writer thread advances the offsets by what it wrote)
             for (const auto &it : items) job.item_off.push_back(it.text_off);
-            for (int m = 0; m < 2; ++m) { q.off[m] += (int64_t)bytes; q.accounted[m] += (int64_t)bytes; }
+            // (scattered items lie where the caller says: the files' running offsets stay where they are)
+            if (scatter.empty()) for (int m = 0; m < 2; ++m) { q.off[m] += (int64_t)bytes; q.accounted[m] += (int64_t)bytes; }
+            job.item_file_off = std::move(scatter);
         }
         q.jobs.push_back(std::move(job));
         q.busy[slot] = true;
@@ -3527,6 +3559,14 @@ int iss_fastq_emit_batch(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, co
                          const int64_t *first_pair, const int64_t *n_pairs, int32_t cpu_number) {
     if (n_items && (!record_ids || !first_i || !first_pair || !n_pairs)) return fail(ctx, ISS_E_INVALID, "iss_fastq_emit_batch: bad argument");
     return fastq_emit_core(ctx, fd_r1, fd_r2, n_items, record_ids, first_i, first_pair, n_pairs, cpu_number, 1);
+}
+
+int iss_fastq_emit_scatter(iss_ctx *ctx, int fd_r1, int fd_r2, int32_t n_items, const char *const *record_ids, const int64_t *first_i,
+                           const int64_t *first_pair, const int64_t *n_pairs, const int32_t *cpu_numbers, const int64_t *file_off,
+                           int32_t n_threads) {
+    if (n_items && (!record_ids || !first_i || !first_pair || !n_pairs || !cpu_numbers || !file_off))
+        return fail(ctx, ISS_E_INVALID, "iss_fastq_emit_scatter: bad argument");
+    return fastq_emit_core(ctx, fd_r1, fd_r2, n_items, record_ids, first_i, first_pair, n_pairs, 0, n_threads, cpu_numbers, file_off);
 }
 
 int iss_fastq_flush(iss_ctx *ctx) {

@@ -324,6 +324,18 @@ class ReadEngine(object):
         self._check(self._lib.iss_fastq_emit_batch(self._ctx, int(fd_r1), int(fd_r2), n, ids, first_i.ctypes.data,
                                                    first_pair.ctypes.data, n_pairs.ctypes.data, int(cpu_number)))
 
+    def fastq_emit_scatter(self, fd_r1, fd_r2, items, n_threads=4):
+        """items: (record id, first pair id, first output row, pairs, cpu number, byte offset in both files) -- one text job, every
+        item's text written at its own place (the workers of a set straight into the final files; text mode only)."""
+        n = len(items)
+        if not n:
+            return
+        ids = (C.c_char_p * n)(*[str(it[0]).encode() for it in items])
+        cols = [np.array([it[k] for it in items], dtype=np.int64) for k in (1, 2, 3, 5)]
+        cpus = np.array([it[4] for it in items], dtype=np.int32)
+        self._check(self._lib.iss_fastq_emit_scatter(self._ctx, int(fd_r1), int(fd_r2), n, ids, cols[0].ctypes.data, cols[1].ctypes.data,
+                                                     cols[2].ctypes.data, cpus.ctypes.data, cols[3].ctypes.data, int(n_threads)))
+
     def fastq_compress(self, on=True):
         """`--compress` on the device: every fastq_emit appends one gzip member per file instead of text."""
         self._check(self._lib.iss_fastq_compress(self._ctx, 1 if on else 0))

@@ -463,14 +463,36 @@ def worker_iterator(work, error_model, cpu_number, worker_prefix, seed, sequence
         w.close()
 
 
+def _digits_before(x):
+    """Characters of the decimal numbers 0 .. x-1 written one after the other (iss_fastq.hip.h: digits_before)."""
+    total, d, p = 0, 1, 1  # p = 10^(d-1): the numbers with d digits are p .. 10 p - 1 (and 0 has one)
+    while x >= p * 10:
+        total += d * (p * 10 - (p if d > 1 else 0))
+        p *= 10
+        d += 1
+    return total + d * (x - (p if d > 1 else 0))
+
+
+def fastq_text_bytes(record_id, n_pairs, cpu_number, read_length):
+    """Bytes of the FASTQ text of pairs 0 .. n_pairs-1 of one work item in EITHER file: per record "@{id}_{i}_{cpu}/m\n" + SEQ +
+    "\n+\n" + QUAL + "\n" (iss/generator.py:64-65, 150, 181) = len(id) + len(cpu) + 2 RL + 10 + digits(i)."""
+    return n_pairs * (len(str(record_id).encode()) + len(str(int(cpu_number))) + 2 * read_length + 10) + _digits_before(n_pairs)
+
+
 def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, sequence_type, gc_bias, device=None,
-                        compress=False, batch_pairs=None):
+                        compress=False, batch_pairs=None, final_prefix=None):
     """W reference workers (``rng="mt"``) on ONE GPU, side by side: the files of ``worker_iterator(works[k], error_model,
     cpu_numbers[k], worker_prefixes[k], seed, ..., rng="mt")`` for every k -- byte for byte the reference's
     ``iss generate --cpus W`` temp files (iss/app.py:99-106, iss/generator.py:223-251) -- but the workers' chains run in the
     same kernel launches, one workgroup per worker (ReadEngine.generate_mt_workers).  A worker is a sequential chain over its
     two MT19937 streams (seed + cpu_number, generator.py:234-236); W of them are what the reference itself runs in parallel.
-    ``--store_mutations`` rows are per engine: such a run takes one worker after the other through worker_iterator."""
+    ``--store_mutations`` rows are per engine: such a run takes one worker after the other through worker_iterator.
+
+    ``final_prefix`` (text mode): the workers' text goes straight to ``{final_prefix}_R1.fastq`` / ``_R2.fastq`` -- what the
+    parent's concatenation of the temp files in worker order would hold (iss/app.py:123-127, iss/util.py:213-234): a worker's
+    text size is arithmetic (fastq_text_bytes), so worker k starts where workers 0 .. k-1 end, a round is ONE text job whose
+    pieces are written at their places (ReadEngine.fastq_emit_scatter), and no temp file is made.  Returns True when the final
+    files were written, False when the temp files were (the caller concatenates them)."""
     logger = logging.getLogger(__name__)
     W = len(works)
     if not (W == len(cpu_numbers) == len(worker_prefixes)) or W < 1:
@@ -481,18 +503,33 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
         # (unseeded workers draw their seeds from the OS one by one, like the reference's processes)
         for work, cpu, prefix in zip(works, cpu_numbers, worker_prefixes):
             worker_iterator(work, error_model, cpu, prefix, seed, sequence_type, gc_bias, device=device, rng="mt", compress=compress)
-        return
+        return False
+    final = final_prefix is not None and not compress
     handles = []
     try:
-        for prefix in worker_prefixes:
-            handles.append((open("%s_R1.fastq" % prefix, "w"), open("%s_R2.fastq" % prefix, "w"), open("%s.vcf" % prefix, "w")))
+        if final:
+            handles.append((open("%s_R1.fastq" % final_prefix, "w"), open("%s_R2.fastq" % final_prefix, "w")))
+        else:
+            for prefix in worker_prefixes:
+                handles.append((open("%s_R1.fastq" % prefix, "w"), open("%s_R2.fastq" % prefix, "w"), open("%s.vcf" % prefix, "w")))
     except PermissionError as e:
-        logger.error("Failed to write temporary output file(s): %s" % e)
+        logger.error("Failed to write %s output file(s): %s" % ("the" if final else "temporary", e))
         sys.exit(1)
     eng = ReadEngine(0 if device is None else device)
     try:
         dense = _dense_of(error_model)
         eng.load_model(dense)
+        at = [0] * W  # final files: where worker k's next byte goes
+        if final:
+            RL, total = dense.read_length, 0
+            ends = [0] * W
+            for k, (work, cpu) in enumerate(zip(works, cpu_numbers)):
+                at[k] = total
+                total += sum(fastq_text_bytes(rec.id, n, cpu, RL) for rec, n, _m in work if RL < len(rec.seq))
+                ends[k] = total
+            for fh in handles[0]:
+                fh.flush()
+                os.ftruncate(fh.fileno(), total)
         if compress:
             eng.fastq_compress(True)
         eng.seed_mt_workers([worker_seed(seed, c) for c in cpu_numbers])
@@ -546,6 +583,7 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
             n = [c[2] if c else 0 for c in cur]
             row = np.concatenate(([0], np.cumsum(n)[:-1])).astype(np.int64)
             done, status = eng.generate_mt_workers(g, n, row, sequence_type=sequence_type, gc_bias=gc_bias)
+            scattered = []
             for k, c in enumerate(cur):
                 if c is None:
                     continue
@@ -553,9 +591,19 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
                     assert status[k] == _native.E_SHORT_RECORD and done[k] == 0, (k, int(status[k]), int(done[k]))
                     continue
                 assert status[k] == 0 and done[k] == c[2], (k, int(status[k]), int(done[k]), c[2])
-                eng.fastq_emit(handles[k][0].fileno(), handles[k][1].fileno(), c[0].id, c[3], cpu_numbers[k], int(row[k]), c[2],
-                               n_threads=1)
+                if final:  # (the piece's bytes: pairs c[3] .. c[3] + c[2] - 1 of the work item)
+                    scattered.append((c[0].id, c[3], int(row[k]), c[2], cpu_numbers[k], at[k]))
+                    at[k] += fastq_text_bytes(c[0].id, c[3] + c[2], cpu_numbers[k], dense.read_length) - \
+                        fastq_text_bytes(c[0].id, c[3], cpu_numbers[k], dense.read_length)
+                else:
+                    eng.fastq_emit(handles[k][0].fileno(), handles[k][1].fileno(), c[0].id, c[3], cpu_numbers[k], int(row[k]), c[2],
+                                   n_threads=1)
+            if scattered:  # ONE text job per round: the next round's kernels run beside its copy and its writes
+                eng.fastq_emit_scatter(handles[0][0].fileno(), handles[0][1].fileno(), scattered, n_threads=8)
         eng.fastq_flush()
+        if final and at != ends:  # every worker's text ends where the next one's starts
+            raise RuntimeError("worker_set_iterator: a worker's text is not the size computed for it: %r / %r" % (at, ends))
+        return final
     finally:
         eng.close()
         for fh3 in handles:
