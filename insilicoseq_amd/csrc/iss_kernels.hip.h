@@ -942,7 +942,11 @@ __device__ __forceinline__ uint32_t lut_at(uint32_t lds0, uint32_t w) {
     const uint32_t four = 4u;
     if (BYTE == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(a) : "v"(w), "v"(four));
     else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(w), "v"(four));
-    return *reinterpret_cast<lds_u32_t *>(lds0 + OFF + a);
+    // (the kernel's dynamic LDS array is the only LDS it has and stands at address 0 -- k_main / k_main_g check that once --, so the
+    //  table's place is the load's immediate offset; with `lds0 + OFF + a` every lookup paid an addition of a link-time zero)
+    (void)lds0;
+    __builtin_assume(a <= 1020u);
+    return *reinterpret_cast<lds_u32_t *>((uint32_t)OFF + a);
 }
 
 // r = r << 1 | flag in one instruction: the flag's lane mask is the carry-in of v_addc
@@ -992,6 +996,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main(DevModel M,
     __syncthreads();
     // (row offsets below are absolute LDS addresses: ds_read2's offsets are too narrow to skip the letter tables)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_all;
+    if (lds0 != 0u) __builtin_trap();  // (lut_at: the letter tables are addressed from LDS address 0)
     auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     const uint32_t n_iter = sgpr((T.ts + 3u) >> 2);
     const uint32_t it_max = ((uint32_t)M.TS + 3u) / 4u - 1u;  // largest iteration number of a pass
@@ -1288,6 +1293,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel 
     main_stage_tables(M, tile, lds_all);
     __syncthreads();
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_all;
+    if (lds0 != 0u) __builtin_trap();  // (lut_at: the letter tables are addressed from LDS address 0)
     auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     const uint32_t it_max = ((uint32_t)M.TS + 3u) / 4u - 1u;  // (== NI - 1: the host picks the instantiation)
     const uint32_t it_bits = sgpr(it_max ? 32u - (uint32_t)__clz(it_max) : 0u);
