@@ -432,8 +432,6 @@ def headline(out):
     if out.get("n_gpus") == 1:
         drop += ("model_broadcast_s", "model_broadcast_bytes", "genomes_uploaded_per_rank", "backend", "n_ranks_seen")
     h = {k: v for k, v in out.items() if k not in drop}
-    h["value"] = _sig(out["value"], 7)
-    h["ms_per_step"] = _sig(out["ms_per_step"], 6)
     h["config"] = {k: v for k, v in out["config"].items() if k in ("workload", "pairs_per_step_per_gpu", "read_length", "indel_override")}
     h["config"]["workload"] = h["config"]["workload"].split("; sharded")[0]
     h["roofline"] = {k: _sig(v, 6) for k, v in out["roofline"].items() if k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",

@@ -197,6 +197,29 @@ def _worker(rank, device, genome_file, work_spec, npz, seed, prefix, sequence_ty
     worker_iterator(work, model, rank, prefix, seed, sequence_type, gc_bias, device=device, rng=rng, compress=compress)
 
 
+def _run_worker_set(jobs, records, error_model, args, device_gzip, workers):
+    """The reference's N workers as N chains side by side on ONE GPU (worker_set_iterator; up to 1024 of them).  Returns whether
+    the FINAL files were written (else the temp files were), or None when the set cannot be set up -- more workers than the engine takes, not enough memory for their stream buffers (three turns of
+    stream words per worker and buffer: tens of GB from W = 512 on with long reads) -- BEFORE anything was written: the caller
+    then takes the process pool, which has no such limit.  (ISS_HOST_FASTQ=1, the host formatter, is a Worker switch: the pool.)"""
+    from ._native import E_INVALID, E_NOMEM, EngineError
+
+    logger = logging.getLogger(__name__)
+    works = [[(records[idx], n, "default") for idx, n in j[3]] for j in jobs]
+    try:
+        # text mode: the workers write at their places of the FINAL files -- the concatenation has nothing left to do (fewer
+        # chunks than workers: the reference fails on the missing temp file, util.py:233 -- that path keeps the temp files)
+        return worker_set_iterator(
+            works, error_model, [j[0] for j in jobs], [j[6] for j in jobs], args.seed, args.sequence_type, args.gc_bias, device=0,
+            compress=device_gzip,
+            final_prefix=args.output if len(jobs) == workers and os.environ.get("ISS_SET_TEMP_FILES", "") != "1" else None)
+    except EngineError as e:
+        if e.code in (E_INVALID, E_NOMEM) and getattr(e, "before_output", False):
+            logger.warning("%d workers side by side do not fit the device (%s): one process per worker instead" % (workers, e))
+            return None
+        raise
+
+
 def generate_reads(args):
     logger = logging.getLogger(__name__)
     error_model = load_error_model(args.mode, args.seed, args.model, args.fragment_length, args.fragment_length_sd,
@@ -254,20 +277,14 @@ def generate_reads(args):
                      temp_prefix(args.output, rank), args.sequence_type, args.gc_bias, args.rng, args.store_mutations,
                      (args.fragment_length, args.fragment_length_sd), device_gzip))
     t_gen = time.perf_counter()
-    in_place = False
+    in_place = None
     if workers == 1:
         for j in jobs:
             _worker(*j, records=records)
-    elif args.rng == "mt" and args.devices == 1 and not args.store_mutations and args.seed is not None:
-        # the reference's N workers as N chains side by side on ONE GPU: one workgroup per worker and kernel
-        # (worker_set_iterator; the files are those of N worker processes)
-        works = [[(records[idx], n, "default") for idx, n in j[3]] for j in jobs]
-        # text mode: the workers write at their places of the FINAL files -- the concatenation below has nothing left to do
-        # (fewer chunks than workers: the reference fails on the missing temp file, util.py:233 -- that path keeps the temp files)
-        in_place = worker_set_iterator(works, error_model, [j[0] for j in jobs], [j[6] for j in jobs], args.seed, args.sequence_type,
-                                       args.gc_bias, device=0, compress=device_gzip,
-                                       final_prefix=args.output if len(jobs) == workers and os.environ.get("ISS_SET_TEMP_FILES", "") != "1" else None)
-    else:
+    elif args.rng == "mt" and args.devices == 1 and not args.store_mutations and args.seed is not None and workers <= 1024 \
+            and os.environ.get("ISS_HOST_FASTQ", "") != "1":
+        in_place = _run_worker_set(jobs, records, error_model, args, device_gzip, workers)
+    if workers > 1 and in_place is None:  # one process per worker (and what the set could not take)
         with mp.get_context("spawn").Pool(workers) as pool:
             pool.starmap(_worker, jobs)
     t_cat = time.perf_counter()

@@ -1359,7 +1359,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel 
         if (blk_p < blk_end && pair0 < (uint32_t)A.n_pairs) d_next[pp] = desc[pair0];
     }
     struct Sub {  // a pass of the group, per lane
-        PairDesc d;
+        uint32_t meta;  // PairDesc::meta
         Addr a;
         uint32_t rowf, rowr, pfw, prw, pfs, prs, out_b, tag0, s_lane;
         bool valid, regular;
@@ -1373,18 +1373,19 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel 
             const uint32_t blk_p = blk + (uint32_t)pp * blk_step;
             const uint32_t pair = blk_p * MAIN_PAIRS + wave_pair0 + (lane >> 2);
             S.valid = blk_p < blk_end && pair < (uint32_t)A.n_pairs;
-            S.d = d_next[pp];
-            if (tile == 0 && j4 == 0u && S.valid) A.desc_out[pair] = S.d;
-            S.a = make_addr(A.seed, A.first_ordinal + pair, S.d.meta >> 16);
+            const PairDesc d = d_next[pp];
+            S.meta = d.meta;
+            if (tile == 0 && j4 == 0u && S.valid) A.desc_out[pair] = d;
+            S.a = make_addr(A.seed, A.first_ordinal + pair, d.meta >> 16);
             const uint32_t lane_row = j4 * 2u * gs_b + (uint32_t)MAIN_LUT_WORDS * 4u + lds0;
-            S.rowf = __umul24(S.d.meta & 3u, slot_b) + lane_row;
-            S.rowr = __umul24((uint32_t)M.NB + ((S.d.meta >> 2) & 3u), slot_b) + lane_row;
-            const int64_t pf64 = desc_fs(S.d) + (int64_t)(s_lane * 8u), pr64 = desc_re(S.d) - 8 - (int64_t)(s_lane * 8u);
+            S.rowf = __umul24(d.meta & 3u, slot_b) + lane_row;
+            S.rowr = __umul24((uint32_t)M.NB + ((d.meta >> 2) & 3u), slot_b) + lane_row;
+            const int64_t pf64 = desc_fs(d) + (int64_t)(s_lane * 8u), pr64 = desc_re(d) - 8 - (int64_t)(s_lane * 8u);
             S.pfw = (uint32_t)((pf64 >> 4) + 1); S.prw = (uint32_t)((pr64 >> 4) + 1);
             S.pfs = (uint32_t)pf64 & 15u; S.prs = (uint32_t)pr64 & 15u;
             S.out_b = (wave_pair0 + (lane >> 2)) * (uint32_t)M.row + (s_lane >> 2) * 128u + (s_lane & 3u) * 16u + (uint32_t)pp * pass_bytes;
-            S.regular = PLAIN || !(A.has_frag && (S.d.meta & 64u));
-            S.tag0 = ((pass + (uint32_t)pp) << (19u + it_bits)) | (lane << 13) | ((S.d.meta & 15u) << 8);
+            S.regular = PLAIN || !(A.has_frag && (d.meta & 64u));
+            S.tag0 = ((pass + (uint32_t)pp) << (19u + it_bits)) | (lane << 13) | ((d.meta & 15u) << 8);
             S.s_lane = s_lane;
         }
         uint8_t *const out_pass = A.out[0] + (size_t)blk * (size_t)MAIN_PAIRS * (size_t)(uint32_t)M.row;
@@ -1449,7 +1450,7 @@ __global__ __launch_bounds__(MAIN_THREADS, ISS_MAIN_OCC) void k_main_g(DevModel 
                 const uint32_t fb = funnel_r(gf.x, gf.y, S.pfs * 2u);
                 const uint32_t rbr = funnel_r(gr.x, gr.y, S.prs * 2u);
                 windows = __builtin_amdgcn_perm(rbr ^ 0x5555u, fb, 0x05040100u);
-                if (!PLAIN && S.regular && (S.d.meta & 0x30u)) {
+                if (!PLAIN && S.regular && (S.meta & 0x30u)) {
                     const uint32_t *mw = g.mask + ((int32_t)(pfw_e - 1u) >> 1);
                     fm = funnel_r(mw[0], mw[1], ((pfw_e - 1u) & 1u) * 16u + S.pfs) & 0xffu;
                     const uint32_t *nw = g.mask + ((int32_t)(prw_e - 1u) >> 1);

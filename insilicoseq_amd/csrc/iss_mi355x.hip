@@ -279,6 +279,7 @@ struct iss_ctx {
     // iss/generator.py:234-236) as N chains side by side -- one workgroup per worker and kernel, job tables in HBM
     struct MtSet {
         int W = 0;
+        bool started = false, poisoned = false;  // a call that fails after it began leaves streams and rows undefined: re-seed (iss_generate_mt_workers)
         int64_t ch = 0;                      // pairs per worker and turn
         size_t cap[2] = {0, 0};              // words per (worker, stream, ping-pong buffer)
         int buf_turns = 0;                   // ... = this many turns' words (worst case)
@@ -2622,6 +2623,7 @@ int iss_mt_workers_seed(iss_ctx *ctx, int32_t n_workers, const uint64_t *seeds) 
     }
     HIP_TRY(ctx, hipMemcpy(t.d_state, st.data(), st.size() * sizeof(iss::MtState), hipMemcpyHostToDevice));
     t.W = n_workers;
+    t.started = t.poisoned = false;
     t.cur.assign(2 * W, 0);
     t.fill.assign(2 * W, 0);
     t.used.assign(2 * W, 0);
@@ -2772,8 +2774,25 @@ int mt_set_single(iss_ctx *ctx, int w, int32_t genome_id, int64_t n_pairs, int32
 
 }  // namespace
 
+static int mt_workers_generate(iss_ctx *ctx, int32_t n_workers, const int32_t *genome_ids, const int64_t *n_pairs, const int64_t *out_first_pair,
+                               int32_t sequence_type, int32_t gc_bias, int64_t *n_done, int32_t *status);
+
+// A call that fails once it has begun (a HIP error, a draw the side-by-side path cannot take, stream buffers too small) returns in
+// the middle of a turn: some workers' streams have advanced, rows are partly written, n_done / status say nothing for the others.
+// The set is then POISONED -- every later call fails until iss_mt_workers_seed starts the workers anew -- instead of carrying on
+// from undefined stream positions.  (A short record is not a failure: status[w] = ISS_E_SHORT_RECORD, the set goes on.)
 int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *genome_ids, const int64_t *n_pairs, const int64_t *out_first_pair,
                             int32_t sequence_type, int32_t gc_bias, int64_t *n_done, int32_t *status) {
+    if (ctx && ctx->mts.poisoned)
+        return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: an earlier call failed half way (the workers' streams and rows are undefined): call iss_mt_workers_seed again");
+    if (ctx) ctx->mts.started = false;
+    const int rc = mt_workers_generate(ctx, n_workers, genome_ids, n_pairs, out_first_pair, sequence_type, gc_bias, n_done, status);
+    if (rc < 0 && ctx && ctx->mts.started) ctx->mts.poisoned = true;
+    return rc;
+}
+
+static int mt_workers_generate(iss_ctx *ctx, int32_t n_workers, const int32_t *genome_ids, const int64_t *n_pairs, const int64_t *out_first_pair,
+                               int32_t sequence_type, int32_t gc_bias, int64_t *n_done, int32_t *status) {
     if (!ctx || !ctx->have_model) return fail(ctx, ISS_E_INVALID, "iss_generate_mt_workers: upload a model first");
     auto &t = ctx->mts;
     if (n_workers < 1 || n_workers != t.W || !genome_ids || !n_pairs || !out_first_pair)
@@ -2797,6 +2816,7 @@ int iss_generate_mt_workers(iss_ctx *ctx, int32_t n_workers, const int32_t *geno
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc_ = sync_all(ctx); if (rc_) return rc_; }
     { int rc_ = mt_set_reserve(ctx); if (rc_) return rc_; }
+    t.started = true;  // (from here on a failure leaves the set undefined)
     auto &m = ctx->mt;
     const bool basic = M.quality_mode == 1;
     // the resolver (k_mt_resolve_w + k_mt_emit_w) for plain runs, the walker for indel-heavy models and for the single pairs the

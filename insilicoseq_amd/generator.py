@@ -532,12 +532,22 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
                 os.ftruncate(fh.fileno(), total)
         if compress:
             eng.fastq_compress(True)
-        eng.seed_mt_workers([worker_seed(seed, c) for c in cpu_numbers])
+        began = [False]  # (an engine error before the first round's rows exist leaves no output: the caller may take another path)
+        try:
+            eng.seed_mt_workers([worker_seed(seed, c) for c in cpu_numbers])
+        except _native.EngineError as e:
+            e.before_output = True
+            raise
         eng.mt_set_fragment(getattr(error_model, "fragment_length", None), getattr(error_model, "fragment_sd", None))
         # rows per worker and round (2^20 pairs per round for all workers together; 2^22 and 2^24 measured the same end to end:
         # 16 M pairs at W = 64 in 2.6-2.8 s incl. 0.5 s of engine start -- generation and text take turns)
         per = int(batch_pairs or max(1024, min(Worker.BATCH_PAIRS, (1 << 20) // W)))
         gids, resident = {}, [0]
+
+        # letters resident in HBM before all are dropped: Worker's budget less what the set itself holds on the device (stream
+        # buffers, rows of a round -- up to a third of the memory)
+        budget = max(Worker.GENOME_BUDGET // 2, 1 << 30)
+        over = [False]
 
         def gid_of(record):
             hit = gids.get(id(record))
@@ -545,6 +555,8 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
                 seq = record.seq
                 if not isinstance(seq, (str, bytes, bytearray, np.ndarray)):
                     seq = str(seq)
+                if gids and resident[0] + len(seq) > budget:
+                    over[0] = True  # (this round's pieces name the resident records: they go at the round's end)
                 hit = gids[id(record)] = (record, eng.add_genome(seq))
                 resident[0] += len(seq)
             return hit[1]
@@ -571,7 +583,8 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
             for fh in fh3[:2]:
                 fh.flush()
         while True:
-            if resident[0] > Worker.GENOME_BUDGET:
+            if over[0] or resident[0] > budget:
+                over[0] = False
                 # between rounds nothing names an uploaded record: drop them all (a round uploads what its pieces need again)
                 eng.clear_genomes()  # (waits for the device and the FASTQ pipeline first)
                 gids.clear()
@@ -582,7 +595,12 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
             g = [c[1] if c else 0 for c in cur]
             n = [c[2] if c else 0 for c in cur]
             row = np.concatenate(([0], np.cumsum(n)[:-1])).astype(np.int64)
-            done, status = eng.generate_mt_workers(g, n, row, sequence_type=sequence_type, gc_bias=gc_bias)
+            try:
+                done, status = eng.generate_mt_workers(g, n, row, sequence_type=sequence_type, gc_bias=gc_bias)
+            except _native.EngineError as e:
+                e.before_output = not began[0]  # (the first call reserves the stream buffers: ISS_E_NOMEM comes from there)
+                raise
+            began[0] = True
             scattered = []
             for k, c in enumerate(cur):
                 if c is None:
