@@ -429,7 +429,7 @@ def headline(out):
     fraction of the HBM peak, kernel]."""
     drop = ("other_workloads", "end_to_end", "end_to_end_gzip", "end_to_end_4_workers", "cpu_baseline_all_cores", "all_kernels_GBps",
             "indel_fixup_reads_per_step", "indel_scripted_reads_per_step")
-    if out.get("n_gpus") == 1:
+    if out.get("n_gpus") == 1 and out.get("backend") is None:  # (no process group: nothing to say about ranks and broadcasts)
         drop += ("model_broadcast_s", "model_broadcast_bytes", "genomes_uploaded_per_rank", "backend", "n_ranks_seen")
     h = {k: v for k, v in out.items() if k not in drop}
     h["config"] = {k: v for k, v in out["config"].items() if k in ("workload", "pairs_per_step_per_gpu", "read_length", "indel_override")}
