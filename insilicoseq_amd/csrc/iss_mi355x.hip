@@ -231,6 +231,7 @@ struct iss_ctx {
     int env_tiles = 0, env_guide_bits = 0;  // ISS_TILES / ISS_GUIDE_BITS: tuning aids of the tile sweeps (0: the cost model decides)
     bool debug_model = false;               // ISS_DEBUG_MODEL
     int64_t env_chunk_pairs = 0;            // ISS_CHUNK_PAIRS: pairs per launch chunk at most (tests: a call of many chunks)
+    int env_main_wgs = 0;                   // ISS_MAIN_WGS: workgroups of k_main / k_main_g at most (tests: many passes per workgroup from few pairs)
     int env_group = -1, env_group_min = 0;  // ISS_MAIN_GROUP: passes per group of k_main_g (0: k_main; unset: chosen per model); ISS_MAIN_GROUP_MIN: min_round
     double mt_guard = 1e-6;                 // ISS_MT_GUARD: how close to a rounding boundary the device still decides (tests widen it)
     bool light = false;  // reads with an indel are rare (< ISS_LIGHT_INDELS of the reads, default 2e-3): all of them take k_indel_fixup
@@ -351,6 +352,7 @@ void read_switches(iss_ctx *ctx) {
     ctx->mt_guard = (e = getenv("ISS_MT_GUARD")) ? atof(e) : 1e-6;
     ctx->debug_model = getenv("ISS_DEBUG_MODEL") != nullptr;
     ctx->env_chunk_pairs = (e = getenv("ISS_CHUNK_PAIRS")) ? std::max<int64_t>(1, atoll(e)) : 0;
+    ctx->env_main_wgs = (e = getenv("ISS_MAIN_WGS")) ? std::max(1, atoi(e)) : 0;
     ctx->env_group = (e = getenv("ISS_MAIN_GROUP")) ? atoi(e) : -1;
     ctx->env_group_min = (e = getenv("ISS_MAIN_GROUP_MIN")) ? atoi(e) : 0;
 }
@@ -1614,7 +1616,7 @@ static int generate_core(iss_ctx *ctx, const iss::DevGenome &dg, bool any_except
     unsigned it_bits = 0;
     while ((1u << it_bits) <= it_max && it_max) ++it_bits;
     const int64_t max_passes = ((int64_t)1 << (13 - it_bits)) - 1;
-    const unsigned budget_all = std::min((unsigned)ctx->n_cu, ctx->max_main_grid);  // ONE 1024-lane workgroup per CU (k_main: 4 wavefronts / SIMD)
+    const unsigned budget_all = std::min(std::min((unsigned)ctx->n_cu, ctx->max_main_grid), ctx->env_main_wgs ? (unsigned)ctx->env_main_wgs : ~0u);  // ONE 1024-lane workgroup per CU (k_main: 4 wavefronts / SIMD)
     unsigned weight_all = 0;
     for (int t = 0; t < M.n_tiles; ++t) weight_all += 1u + (unsigned)(std::min(M.TS, M.S - t * M.TS) + 3) / 4u;
     const unsigned last_weight = 1u + (unsigned)(M.S - (M.n_tiles - 1) * M.TS + 3) / 4u;
