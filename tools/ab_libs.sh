@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds, interleaved: tools/r06_ab6.sh "<bench args>" lib ...
+# A/B of library builds on the GPU box, interleaved, three passes: tools/ab_libs.sh "<bench args>" lib1.so lib2.so ...  (k_main ms per step from HIP events)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 ARGS=$1; shift
 for rep in 1 2 3; do for L in "$@"; do

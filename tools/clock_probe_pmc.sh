@@ -1,7 +1,7 @@
 #!/bin/bash
 # the chip's clock under k_main: GRBM_GUI_ACTIVE (cycles the GPU is active) per launch / the launch's duration
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r06_clock; mkdir -p $OUT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r06}_clock; mkdir -p $OUT
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads"
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace -d $OUT/grbm -o p --output-format csv -- $BENCH > $OUT/grbm.log 2>&1
 ls $OUT/grbm; head -3 $OUT/grbm/*counter_collection.csv
