@@ -90,8 +90,10 @@ void fastq_writer_loop(iss_ctx *ctx) {
                 for (uint64_t at : job.item_off) ok = ok && at < job.bytes && t[at] == '@' && (at == 0 || t[at - 1] == '\n');
                 if (!ok) err = "FASTQ text does not have the record layout its size was computed from";
             }
-            // scattered items (the workers of a set, every one at its own place of the final files): the items dealt to a few
-            // threads per file; the text of item k is [item_off[k], item_off[k + 1])
+            // scattered items (the workers of a set, every one at its own place of the final files): the text of item k is
+            // [item_off[k], item_off[k + 1]).  ONE thread per file unless the caller asks for more: writes to one tmpfs file
+            // serialise on its inode, and threads that queue there cost more than they add -- 64 M pairs of the whole command
+            // `generate --rng mt --cpus 64`: 4.6 s with one thread per file, 5.8 with two, 7.6-8.0 with four or eight
             if (err.empty() && !job.item_file_off.empty()) {
                 const size_t n_it = job.item_off.size();
                 const int per_file = std::max(1, std::min<int>(job.threads, 8));

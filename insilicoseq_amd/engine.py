@@ -324,7 +324,7 @@ class ReadEngine(object):
         self._check(self._lib.iss_fastq_emit_batch(self._ctx, int(fd_r1), int(fd_r2), n, ids, first_i.ctypes.data,
                                                    first_pair.ctypes.data, n_pairs.ctypes.data, int(cpu_number)))
 
-    def fastq_emit_scatter(self, fd_r1, fd_r2, items, n_threads=4):
+    def fastq_emit_scatter(self, fd_r1, fd_r2, items, n_threads=1):
         """items: (record id, first pair id, first output row, pairs, cpu number, byte offset in both files) -- one text job, every
         item's text written at its own place (the workers of a set straight into the final files; text mode only)."""
         n = len(items)

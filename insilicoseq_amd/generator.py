@@ -617,7 +617,7 @@ def worker_set_iterator(works, error_model, cpu_numbers, worker_prefixes, seed, 
                     eng.fastq_emit(handles[k][0].fileno(), handles[k][1].fileno(), c[0].id, c[3], cpu_numbers[k], int(row[k]), c[2],
                                    n_threads=1)
             if scattered:  # ONE text job per round: the next round's kernels run beside its copy and its writes
-                eng.fastq_emit_scatter(handles[0][0].fileno(), handles[0][1].fileno(), scattered, n_threads=8)
+                eng.fastq_emit_scatter(handles[0][0].fileno(), handles[0][1].fileno(), scattered, n_threads=1)
         eng.fastq_flush()
         if final and at != ends:  # every worker's text ends where the next one's starts
             raise RuntimeError("worker_set_iterator: a worker's text is not the size computed for it: %r / %r" % (at, ends))
