@@ -34,6 +34,10 @@ def derived_summary(src, tag, out_dir, acc, calls, stats_csv, cmd):
     build_id, line = "unknown", None
     for log in glob.glob(src + "/*.log"):
         for ln in open(log, errors="replace"):
+            if ln.startswith("#detail {"):  # (bench.py prints everything behind "#detail ", then the short headline line)
+                ln = ln[len("#detail "):]
+            elif line is not None and "algorithmic_bytes_per_pair" in line.get("roofline", {}):
+                continue  # (the headline line of the same run: the detail line has been read)
             if ln.startswith("{") and "library_build_id" in ln:
                 line = json.loads(ln)
                 build_id = line.get("library_build_id", build_id)
